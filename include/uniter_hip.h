@@ -1,0 +1,277 @@
+/*
+ * libuniter_hip.so -- C ABI of the MI355X-native UNITER fine-tuning hot path.
+ *
+ * The reference (Nithin-Holla/meme_challenge) has no FFI of its own: its hot
+ * path is the nn.Module surface of model/model.py, model/layer.py and
+ * model/meme_uniter.py dispatching to ATen/cuBLAS/Apex kernels.  Every entry
+ * point below names the reference code (file:line, relative to the reference
+ * root) whose device work it replaces.  A maintainer binds them with ctypes
+ * (see INTEGRATION.md); `meme_challenge_amd/_lib.py` is that binding.
+ *
+ * Conventions
+ *  - all pointers are CALLER-OWNED DEVICE pointers (fp32 unless stated), row-major,
+ *    contiguous unless a leading dimension is given; the library never allocates
+ *    or frees user tensors; scratch comes from a caller-provided workspace
+ *  - every call takes the hipStream_t to launch on (as void*) and is asynchronous,
+ *    stream-ordered and re-entrant; no host synchronisation inside
+ *  - return value: 0 = ok, <0 = invalid argument (UNITER_E_*), >0 = hipError_t
+ *  - dropout: counter-based Philox4x32-10 keyed by (seed, offset, site); the same
+ *    (seed, offset) passed to forward and backward regenerates identical masks
+ *    (specification: oracle/philox.py; device code: csrc/philox.h)
+ *  - one process = one device = one rank
+ */
+#ifndef UNITER_HIP_H
+#define UNITER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNITER_ABI_VERSION 1
+
+#define UNITER_E_ARG   (-1)   /* bad pointer / size / alignment            */
+#define UNITER_E_SHAPE (-2)   /* unsupported shape (e.g. head_dim != 64)   */
+#define UNITER_E_WS    (-3)   /* workspace too small                       */
+#define UNITER_E_STATE (-4)   /* call order violated                       */
+
+int         uniter_abi_version(void);
+const char* uniter_last_error(void);          /* thread-local message of the last failure */
+const char* uniter_build_info(void);          /* "gfx950 ..." */
+
+/* ------------------------------------------------------------------------- *
+ * Dense contraction (replaces nn.Linear / torch.matmul dispatch to cuBLAS:
+ * model/layer.py:76-78,112,140,153; model/model.py:267; and their autograd).
+ *   C[M,N] (+)= epilogue( sum_k A(m,k) * B(k,n) )      fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   a_kmajor = 0: A(m,k) = A[m*lda + k]      1: A(m,k) = A[k*lda + m]
+ *   b_kmajor = 0: B(k,n) = B[n*ldb + k]      1: B(k,n) = B[k*ldb + n]
+ *     (a_kmajor=0,b_kmajor=0 is x @ W^T with W stored [out,in] like nn.Linear)
+ *   epilogue: UNITER_EPI_*; beta = 0 overwrite, 1 accumulate into C.
+ * ------------------------------------------------------------------------- */
+enum {
+  UNITER_EPI_NONE      = 0,
+  UNITER_EPI_BIAS      = 1,   /* + bias[n]                                             */
+  UNITER_EPI_BIAS_GELU = 2,   /* u = acc + bias[n]; aux_out = u; C = gelu_erf(u)       */
+  UNITER_EPI_DGELU     = 3,   /* C = acc * gelu_erf'(aux_in[m,n])                      */
+  UNITER_EPI_ADD       = 4    /* C = acc + aux_in[m,n]                                 */
+};
+int uniter_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
+                    const float* A, int lda, const float* B, int ldb,
+                    float* C, int ldc, int epilogue, const float* bias,
+                    const float* aux_in, float* aux_out, int ld_aux,
+                    int beta, void* stream);
+/* tile-configuration override for tuning (0 = heuristic). */
+int uniter_gemm_f32_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K,
+                    const float* A, int lda, const float* B, int ldb,
+                    float* C, int ldc, int epilogue, const float* bias,
+                    const float* aux_in, float* aux_out, int ld_aux,
+                    int beta, void* stream);
+
+/* out[n] (+)= sum_m X[m*ld + n]   (bias gradients of every nn.Linear) */
+int uniter_colsum_f32(const float* X, int M, int N, int ld, float* out, int beta,
+                      void* ws, size_t ws_bytes, void* stream);
+size_t uniter_colsum_ws_bytes(int M, int N);
+
+/* ------------------------------------------------------------------------- *
+ * Fused dropout + residual + LayerNorm (replaces nn.Dropout + add + Apex
+ * FusedLayerNorm: model/layer.py:113-114,154-155; eps=1e-12, biased variance).
+ *   z = dropout_p(x) + res ;  y = LN(z) * gamma + beta
+ * z_out/mean/rstd may be NULL in inference.  res may be NULL.
+ * ------------------------------------------------------------------------- */
+int uniter_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta,
+                  float* z_out, float* y, float* mean, float* rstd, int M, int H,
+                  float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
+                  void* stream);
+/*   dz = dLN(dy) (gradient w.r.t. z, i.e. w.r.t. the residual input)
+ *   dx = dropout-masked dz (gradient w.r.t. x); dx may equal dz when p_drop == 0
+ *   dgamma/dbeta (+)= column reductions (two-stage, deterministic)          */
+int uniter_ln_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
+                  const float* gamma, float* dz, float* dx, float* dgamma, float* dbeta,
+                  int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
+                  void* ws, size_t ws_bytes, void* stream);
+size_t uniter_ln_bwd_ws_bytes(int M, int H);
+
+/* ------------------------------------------------------------------------- *
+ * Fused self-attention over the joint [text|region] sequence (replaces
+ * BertSelfAttention.forward model/layer.py:85-100: QK^T / sqrt(d) + mask,
+ * softmax, dropout on probabilities, P.V, head merge).
+ *   qkv : [B*L, 3*H] rows = (b,l), columns = [Q | K | V], head h at h*64..h*64+63
+ *   attn_mask : [B, L] 1 = attend, 0 = padded (additive (1-m)*-10000 as model/model.py:345)
+ *   ctx : [B*L, H] merged heads;  lse : [B, nh, L] log-sum-exp of the scaled+masked scores
+ * head_dim must be 64.
+ * ------------------------------------------------------------------------- */
+int uniter_attn_fwd(const float* qkv, const float* attn_mask, float* ctx, float* lse,
+                    int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
+                    uint32_t site, void* stream);
+/*   dqkv : [B*L, 3*H] gradients w.r.t. qkv;  delta : [B, nh, L] scratch */
+int uniter_attn_bwd(const float* qkv, const float* attn_mask, const float* ctx,
+                    const float* lse, const float* dctx, float* dqkv, float* delta,
+                    int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
+                    uint32_t site, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Embeddings (replace UniterTextEmbeddings.forward model/model.py:232-245,
+ * UniterImageEmbeddings.forward :261-272 after the img_linear GEMM, and the
+ * cat+gather of :330-333).
+ * ------------------------------------------------------------------------- */
+/* out rows [b, t] of `cat` (row stride: (T+R)*H per sample, text at offset 0):
+ *   LN(word[ids] + pos[position_ids] + type[type_ids or 0]) then dropout      */
+int uniter_txt_embed_fwd(const int64_t* input_ids, const int64_t* position_ids,
+                         const int64_t* type_ids /*NULL=0*/, const float* word, const float* pos,
+                         const float* type, const float* gamma, const float* beta,
+                         float* cat, int B, int T, int S /*rows per sample in cat*/, int H,
+                         int vocab, int max_pos, int type_vocab, int pos_bcast /*position_ids is [1,T]*/,
+                         float p_drop, uint64_t seed, uint32_t offset, void* stream);
+/* image rows: cat[b, T0 + r] = dropout(LN_f(LN_i(imgfc[b,r]) + LN_p(pos7[b,r] @ Wp^T + bp) + type[tid]))
+ * imgfc = img_feat @ W_img^T + b_img is produced by uniter_gemm_f32 beforehand.
+ * stats (optional, training): [B*R, 6] = mean/rstd of LN_i, LN_p, LN_f      */
+int uniter_img_embed_fwd(const float* imgfc, const float* pos7, const int64_t* img_type_ids /*NULL=1*/,
+                         const float* Wp, const float* bp, const float* type,
+                         const float* g_i, const float* b_i, const float* g_p, const float* b_p,
+                         const float* g_f, const float* b_f, float* cat, float* stats,
+                         int B, int R, int T0, int S, int H, int type_vocab,
+                         float p_drop, uint64_t seed, uint32_t offset, void* stream);
+/* out[b, j] = cat[b, gather_index[b, j]]   (gather_index NULL = identity copy) */
+int uniter_gather_rows(const float* cat, const int64_t* gather_index, float* out,
+                       int B, int S, int Lout, int H, void* stream);
+/* dcat[b, s] = sum_{j : gather_index[b,j] == s} dout[b, j]   (deterministic) */
+int uniter_gather_rows_bwd(const float* dout, const int64_t* gather_index, float* dcat,
+                           int B, int S, int Lout, int H, void* stream);
+/* feat_out = feat + mask_emb[img_masks] with mask_emb row 0 treated as zero (model/model.py:262-265) */
+int uniter_img_mask_add(const float* feat, const int64_t* img_masks, const float* mask_emb,
+                        float* feat_out, int rows, int D, void* stream);
+/* backward of the text embedding: accumulates into dword/dpos/dtype/dgamma/dbeta */
+int uniter_txt_embed_bwd(const float* dcat, const int64_t* input_ids, const int64_t* position_ids,
+                         const int64_t* type_ids, const float* word, const float* pos,
+                         const float* type, const float* gamma,
+                         float* dword, float* dpos, float* dtype, float* dgamma, float* dbeta,
+                         int B, int T, int S, int H, int vocab, int max_pos, int type_vocab, int pos_bcast,
+                         float p_drop, uint64_t seed, uint32_t offset,
+                         void* ws, size_t ws_bytes, void* stream);
+/* backward of the image embedding epilogue: writes d_imgfc, d_posfc [B*R,H]; accumulates the
+ * six LN affine grads and dtype; dWp/dbp from d_posfc */
+int uniter_img_embed_bwd(const float* dcat, const float* imgfc, const float* pos7,
+                         const int64_t* img_type_ids, const float* Wp, const float* bp,
+                         const float* type, const float* g_i, const float* b_i,
+                         const float* g_p, const float* b_p, const float* g_f,
+                         const float* stats, float* d_imgfc, float* d_posfc,
+                         float* dWp, float* dbp, float* dtype,
+                         float* dg_i, float* db_i, float* dg_p, float* db_p, float* dg_f, float* db_f,
+                         int B, int R, int T0, int S, int H, int type_vocab,
+                         float p_drop, uint64_t seed, uint32_t offset,
+                         void* ws, size_t ws_bytes, void* stream);
+size_t uniter_embed_bwd_ws_bytes(int rows, int H);
+
+/* ------------------------------------------------------------------------- *
+ * Pooler + classification head (replaces BertPooler.forward model/layer.py:179-185
+ * and MemeUniter.linear model/meme_uniter.py:19-20) and the loss
+ * (nn.BCEWithLogitsLoss(pos_weight), train_template.py:65,98-99).
+ * ------------------------------------------------------------------------- */
+/* pooled[b,:] = tanh(hidden[b,0,:] @ Wp^T + bp) ; hidden row stride per sample = L*H */
+int uniter_pooler_fwd(const float* hidden, const float* Wp, const float* bp, float* pooled,
+                      int B, int L, int H, void* stream);
+/* dpre = dpooled*(1-pooled^2); dWp += dpre^T h0; dbp += colsum(dpre);
+ * dhidden[b,0,:] (+)= dpre @ Wp   (other rows untouched) */
+int uniter_pooler_bwd(const float* dpooled, const float* pooled, const float* hidden,
+                      const float* Wp, float* dWp, float* dbp, float* dhidden,
+                      int B, int L, int H, int beta_dhidden, void* stream);
+/* logits[b,c] = pooled[b,:] . Wc[c,:] + bc[c]   (any small n_classes) */
+int uniter_linear_small_fwd(const float* x, const float* W, const float* b, float* y,
+                            int B, int H, int C, void* stream);
+int uniter_linear_small_bwd(const float* dy, const float* x, const float* W,
+                            float* dx, float* dW, float* db, int B, int H, int C, void* stream);
+/* loss (scalar, mean over B), probs = sigmoid(logits), dlogits = dloss/dlogits * grad_scale */
+int uniter_bce_logits(const float* logits, const int64_t* labels, float pos_weight,
+                      float* loss, float* probs, float* dlogits, float grad_scale,
+                      int B, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Optimizer step over FLAT fp32 buffers (replaces average_gradients +
+ * clip_grad_norm_ + torch.optim.Adam/AdamW.step + zero_grad:
+ * train_template.py:89-92,103-107; utils/optim_utils.py:9-46).
+ *   chunk_flags[i] for elements [64*i, 64*i+64): 0 = skip (no gradient this step),
+ *   1 = no weight decay, 2 = weight decay.
+ * ------------------------------------------------------------------------- */
+/* sumsq[0] = sum g^2 over flagged chunks (device scalar, double) */
+int uniter_grad_sumsq(const float* grads, const uint8_t* chunk_flags, size_t n,
+                      double* sumsq, void* ws, size_t ws_bytes, void* stream);
+size_t uniter_grad_sumsq_ws_bytes(size_t n);
+/* g' = g * grad_scale * min(1, max_norm / (sqrt(sumsq)*grad_scale + 1e-6))   (max_norm<=0: no clip)
+ * adamw = 0: g' += wd*p (torch.optim.Adam L2);  1: p *= 1 - lr*wd (AdamW)
+ * then m,v update, p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps); grads zeroed if zero_grads */
+int uniter_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                     const uint8_t* chunk_flags, size_t n, const double* sumsq,
+                     float grad_scale, float max_norm, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, int adamw, int zero_grads,
+                     void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Whole-model schedule: the library owns the kernel sequence of
+ * UniterModel.forward (model/model.py:336-367) + pooler/head and of its
+ * backward; Python makes a handful of calls per step.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  int32_t hidden_size, num_hidden_layers, num_attention_heads, intermediate_size;
+  int32_t vocab_size, max_position_embeddings, type_vocab_size, img_dim;
+  float   hidden_dropout_prob, attention_probs_dropout_prob;
+} uniter_config_t;
+
+/* canonical parameter order = reference UniterModel.state_dict() order
+ * (see uniter_param_name); query/key/value weights (and biases) of a layer
+ * must be contiguous in memory (they are one [3H,H] operand).           */
+int         uniter_num_params(const uniter_config_t* cfg);
+const char* uniter_param_name(const uniter_config_t* cfg, int i);   /* without prefix */
+int         uniter_param_shape(const uniter_config_t* cfg, int i, int64_t* rows, int64_t* cols);
+
+typedef struct uniter_model uniter_model_t;
+int  uniter_model_create(const uniter_config_t* cfg, float* const* params, float* const* grads,
+                         int n_params, uniter_model_t** out);
+void uniter_model_destroy(uniter_model_t* m);
+
+typedef struct {
+  const int64_t* input_ids;      /* [B,T] or NULL (image only)  */
+  const int64_t* position_ids;   /* [B,T] or [1,T] (pos_bcast=1) */
+  const int64_t* txt_type_ids;   /* [B,T] or NULL */
+  const float*   img_feat;       /* [B,R,img_dim] or NULL (text only) */
+  const float*   img_pos_feat;   /* [B,R,7] */
+  const int64_t* img_type_ids;   /* [B,R] or NULL */
+  const int64_t* img_masks;      /* [B,R] or NULL */
+  const float*   attention_mask; /* [B,L] */
+  const int64_t* gather_index;   /* [B,L] or NULL */
+  int32_t B, T, R, L;            /* L = output sequence length */
+  int32_t pos_bcast;
+} uniter_batch_t;
+
+size_t uniter_model_ws_bytes(const uniter_model_t* m, int B, int T, int R, int L, int train);
+/* hidden_out: [B,L,H] last layer (all_layers = 0) or [nl,B,L,H] (all_layers = 1).
+ * train != 0 applies dropout and keeps activations in `ws` for uniter_model_backward. */
+int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* batch, float* hidden_out,
+                         int all_layers, int train, uint64_t seed, uint32_t offset,
+                         void* ws, size_t ws_bytes, void* stream);
+/* d_hidden: same layout as hidden_out.  Accumulates into the bound gradient buffers.
+ * Stages let the caller interleave gradient all-reduce with backward:
+ *   uniter_model_backward_begin, then layer nl-1 .. 0, then uniter_model_backward_embed. */
+int uniter_model_backward_begin(uniter_model_t* m, const uniter_batch_t* batch, const float* d_hidden,
+                                int all_layers, uint64_t seed, uint32_t offset,
+                                void* ws, size_t ws_bytes, void* stream, void* side_stream);
+int uniter_model_backward_layer(uniter_model_t* m, int layer);
+int uniter_model_backward_embed(uniter_model_t* m);
+/* convenience: begin + all layers + embed */
+int uniter_model_backward(uniter_model_t* m, const uniter_batch_t* batch, const float* d_hidden,
+                          int all_layers, uint64_t seed, uint32_t offset,
+                          void* ws, size_t ws_bytes, void* stream, void* side_stream);
+
+/* per-kernel-kind HIP-event timing of the model schedule (bench.py roofline) */
+enum { UNITER_K_NONE = 0, UNITER_K_GEMM_FFN_UP_FWD = 1, UNITER_K_GEMM_FFN_DOWN_FWD = 2,
+       UNITER_K_GEMM_QKV_FWD = 3, UNITER_K_GEMM_ATTN_OUT_FWD = 4, UNITER_K_ATTN_FWD = 5,
+       UNITER_K_GEMM_DGRAD = 6, UNITER_K_GEMM_WGRAD = 7, UNITER_K_ATTN_BWD = 8,
+       UNITER_K_LN = 9, UNITER_K_COUNT = 10 };
+int uniter_prof_enable(uniter_model_t* m, int kind);             /* 0 disables */
+int uniter_prof_collect(uniter_model_t* m, int* n_launches, double* total_ms);  /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNITER_HIP_H */

@@ -1,0 +1,145 @@
+"""ctypes binding of libuniter_hip.so (include/uniter_hip.h).
+
+Fails loudly if the shared library is missing or a call returns non-zero:
+there is no fallback path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libuniter_hip.so')
+
+c_f32p = C.c_void_p
+c_i64p = C.c_void_p
+c_u8p = C.c_void_p
+
+
+class UniterConfigC(C.Structure):
+    _fields_ = [('hidden_size', C.c_int32), ('num_hidden_layers', C.c_int32),
+                ('num_attention_heads', C.c_int32), ('intermediate_size', C.c_int32),
+                ('vocab_size', C.c_int32), ('max_position_embeddings', C.c_int32),
+                ('type_vocab_size', C.c_int32), ('img_dim', C.c_int32),
+                ('hidden_dropout_prob', C.c_float),
+                ('attention_probs_dropout_prob', C.c_float)]
+
+
+class UniterBatchC(C.Structure):
+    _fields_ = [('input_ids', C.c_void_p), ('position_ids', C.c_void_p),
+                ('txt_type_ids', C.c_void_p), ('img_feat', C.c_void_p),
+                ('img_pos_feat', C.c_void_p), ('img_type_ids', C.c_void_p),
+                ('img_masks', C.c_void_p), ('attention_mask', C.c_void_p),
+                ('gather_index', C.c_void_p),
+                ('B', C.c_int32), ('T', C.c_int32), ('R', C.c_int32), ('L', C.c_int32),
+                ('pos_bcast', C.c_int32)]
+
+
+_I, _F, _P, _SZ, _U64, _U32 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32
+
+# name -> (restype, argtypes)
+_SIGS = {
+    'uniter_abi_version': (_I, []),
+    'uniter_last_error': (C.c_char_p, []),
+    'uniter_build_info': (C.c_char_p, []),
+    'uniter_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
+    'uniter_gemm_f32_cfg': (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
+    'uniter_colsum_f32': (_I, [_P, _I, _I, _I, _P, _I, _P, _SZ, _P]),
+    'uniter_colsum_ws_bytes': (_SZ, [_I, _I]),
+    'uniter_ln_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P]),
+    'uniter_ln_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
+    'uniter_ln_bwd_ws_bytes': (_SZ, [_I, _I]),
+    'uniter_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P]),
+    'uniter_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P]),
+    'uniter_txt_embed_fwd': (_I, [_P] * 9 + [_I] * 8 + [_F, _U64, _U32, _P]),
+    'uniter_img_embed_fwd': (_I, [_P] * 14 + [_I] * 6 + [_F, _U64, _U32, _P]),
+    'uniter_gather_rows': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'uniter_gather_rows_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'uniter_img_mask_add': (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    'uniter_txt_embed_bwd': (_I, [_P] * 13 + [_I] * 8 + [_F, _U64, _U32, _P, _SZ, _P]),
+    'uniter_img_embed_bwd': (_I, [_P] * 24 + [_I] * 6 + [_F, _U64, _U32, _P, _SZ, _P]),
+    'uniter_embed_bwd_ws_bytes': (_SZ, [_I, _I]),
+    'uniter_pooler_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'uniter_pooler_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'uniter_linear_small_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'uniter_linear_small_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'uniter_bce_logits': (_I, [_P, _P, _F, _P, _P, _P, _F, _I, _P]),
+    'uniter_grad_sumsq': (_I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
+    'uniter_grad_sumsq_ws_bytes': (_SZ, [_SZ]),
+    'uniter_adam_step': (_I, [_P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P]),
+    'uniter_num_params': (_I, [C.POINTER(UniterConfigC)]),
+    'uniter_param_name': (C.c_char_p, [C.POINTER(UniterConfigC), _I]),
+    'uniter_param_shape': (_I, [C.POINTER(UniterConfigC), _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'uniter_model_create': (_I, [C.POINTER(UniterConfigC), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p)]),
+    'uniter_model_destroy': (None, [_P]),
+    'uniter_model_ws_bytes': (_SZ, [_P, _I, _I, _I, _I, _I]),
+    'uniter_model_forward': (_I, [_P, C.POINTER(UniterBatchC), _P, _I, _I, _U64, _U32, _P, _SZ, _P]),
+    'uniter_model_backward_begin': (_I, [_P, C.POINTER(UniterBatchC), _P, _I, _U64, _U32, _P, _SZ, _P, _P]),
+    'uniter_model_backward_layer': (_I, [_P, _I]),
+    'uniter_model_backward_embed': (_I, [_P]),
+    'uniter_model_backward': (_I, [_P, C.POINTER(UniterBatchC), _P, _I, _U64, _U32, _P, _SZ, _P, _P]),
+    'uniter_prof_enable': (_I, [_P, _I]),
+    'uniter_prof_collect': (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+class UniterHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UniterHipError(
+                'libuniter_hip.so not found at %s -- build it with '
+                '`python -m meme_challenge_amd.build` (there is no fallback path)' % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        missing = []
+        for name, (res, args) in _SIGS.items():
+            try:
+                fn = getattr(h, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        if missing and not os.environ.get('UNITER_DEV_PARTIAL_LIB'):
+            raise UniterHipError('libuniter_hip.so lacks declared symbols: %s' % ', '.join(missing))
+        if h.uniter_abi_version() != 1:
+            raise UniterHipError('libuniter_hip.so ABI version mismatch')
+        _lib = h
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().uniter_last_error().decode('utf-8', 'replace')
+        raise UniterHipError('%s failed (rc=%d): %s' % (what or 'libuniter_hip call', rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'libuniter_hip needs contiguous tensors'
+    return C.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu_tensor(t, dtype=None, name='tensor'):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise UniterHipError('%s must live on the GPU (cuda/HIP device); got %s' % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise UniterHipError('%s must be %s; got %s' % (name, dtype, t.dtype))

@@ -1,0 +1,359 @@
+// Fused fp32 self-attention forward / backward over the joint [text|region]
+// sequence for gfx950.
+//
+// Replaces BertSelfAttention.forward after the Q/K/V projections
+// (model/layer.py:80-100: transpose_for_scores, QK^T / sqrt(d), + mask, softmax,
+// dropout on the probabilities, P.V, permute+view) and its autograd.  The
+// [B,h,L,L] score tensor never exists in HBM: forward keeps a running
+// (max, sum) per query and stores only the log-sum-exp; backward recomputes the
+// probabilities from Q, K and the LSE and regenerates the dropout mask from the
+// Philox counter.
+//
+// Everything is computed in the TRANSPOSED orientation so that no tile crosses
+// LDS between products (cdna_hip_programming.md 3, "An accumulator tile as the
+// next MFMA's operand"): with v_mfma_f32_32x32x2_f32 the accumulator of
+//     S^T[key][query] = K . Q^T
+// holds, in lane (query j, half h), keys 8g+4h+t in register 4g+t -- exactly the
+// k-slot that lane-half h must feed as the B operand of step (g,t) of
+//     O^T[d][query] = V^T . P^T .
+// One wave owns 32 queries (fwd, dQ) or 32 keys (dK/dV); row max / sum are 15
+// in-register ops plus one cross-half shuffle.  K/V (or Q/dO) tiles of 32 rows
+// are staged in LDS with a 68-dword row stride: row reads are conflict-free
+// ds_read_b128, column reads conflict-free ds_read_b32 off the same image.
+//
+// Layouts: qkv [B*L, 3H] (columns [Q|K|V], head h at h*64), ctx/dctx [B*L, H],
+// lse/delta [B, nh, L].  head_dim == 64.
+#include "common.h"
+#include "philox.h"
+
+namespace {
+
+constexpr int D = 64;        // head dim
+constexpr int LDT = 68;      // LDS row stride (floats) of a 32 x 64 tile
+constexpr int NW = 2;        // waves per workgroup (each owns 32 queries / keys)
+constexpr float NEG_INF = -__builtin_huge_valf();
+
+struct AttnArgs {
+  const float* qkv;
+  const float* mask;    // [B, L]
+  float* ctx;           // fwd out
+  float* lse;           // [B, nh, L]
+  const float* dctx;
+  float* dqkv;
+  float* delta;         // [B, nh, L]
+  int B, L, nh, H, Lp4; // Lp4 = roundup(L,4)/4
+  float scale;
+  DropCfg drop;
+};
+
+// cooperative load of rows [r0, r0+32) x 64 floats (row stride ld) into s[32][LDT]; rows >= L zeroed
+__device__ __forceinline__ void stage_tile(float* s, const float* __restrict__ base, int ld, int r0,
+                                           int L, int tid) {
+  // 32 rows x 16 float4 = 512 float4 over NW*64 = 128 threads -> 4 each
+#pragma unroll
+  for (int p = 0; p < 512 / (NW * 64); ++p) {
+    const int idx = tid + p * NW * 64;
+    const int r = idx >> 4, c4 = idx & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r0 + r < L) v = *reinterpret_cast<const f32x4*>(base + (size_t)(r0 + r) * ld + c4 * 4);
+    *reinterpret_cast<f32x4*>(s + r * LDT + c4 * 4) = v;
+  }
+}
+
+// per-lane operand fragments of one row (64 floats): element kb holds k = 8kb+4h .. +3
+__device__ __forceinline__ void load_row_frags(f32x4 (&f)[8], const float* __restrict__ row, bool valid, int h) {
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb)
+    f[kb] = valid ? *reinterpret_cast<const f32x4*>(row + kb * 8 + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// acc[rows of tile s][lane's column] = sum_d tile[row][d] * frag[d]
+__device__ __forceinline__ f32x16 tile_times_frag(const float* s, const f32x4 (&f)[8], int i, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(s + i * LDT + kb * 8 + 4 * h);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], f[kb][t], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// out{0,1}[d][lane's column] += sum_rows tile[row][d] * w[row]   (w in accumulator layout)
+__device__ __forceinline__ void tileT_times_acc(const float* s, const f32x16& w, f32x16& out0, f32x16& out1,
+                                                int i, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float* p = s + (8 * g + 4 * h + t) * LDT + i;
+      out0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p[0], w[4 * g + t], out0, 0, 0, 0);
+      out1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p[32], w[4 * g + t], out1, 0, 0, 0);
+    }
+  }
+}
+
+// store a transposed accumulator pair (rows = d, column = lane's row of the output matrix)
+__device__ __forceinline__ void store_rowT(float* __restrict__ row, const f32x16& a0, const f32x16& a1,
+                                           float mul, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v0 = {a0[4 * g] * mul, a0[4 * g + 1] * mul, a0[4 * g + 2] * mul, a0[4 * g + 3] * mul};
+    f32x4 v1 = {a1[4 * g] * mul, a1[4 * g + 1] * mul, a1[4 * g + 2] * mul, a1[4 * g + 3] * mul};
+    *reinterpret_cast<f32x4*>(row + 8 * g + 4 * h) = v0;
+    *reinterpret_cast<f32x4*>(row + 32 + 8 * g + 4 * h) = v1;
+  }
+}
+
+__device__ __forceinline__ void stage_mask_bias(float* mb, const float* __restrict__ mask_row, int k0, int L, int tid) {
+  if (tid < 32) {
+    const int k = k0 + tid;
+    mb[tid] = k < L ? (1.0f - mask_row[k]) * -10000.0f : NEG_INF;
+  }
+}
+
+// ---------------------------------------------------------------- forward ---
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[32 * LDT];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * LDT];
+  __shared__ __attribute__((aligned(16))) float mb[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.nh, head = bh - b * a.nh;
+  const int ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
+  const int q = (blockIdx.x * NW + wave) * 32 + i;
+  const bool vq = q < a.L;
+
+  f32x4 qf[8];
+  load_row_frags(qf, base + (size_t)q * ld, vq, h);
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = NEG_INF, l_run = 0.f;
+
+  for (int k0 = 0; k0 < a.L; k0 += 32) {
+    __syncthreads();
+    stage_tile(Ks, base + a.H, ld, k0, a.L, tid);
+    stage_tile(Vs, base + 2 * a.H, ld, k0, a.L, tid);
+    stage_mask_bias(mb, a.mask + (size_t)b * a.L, k0, a.L, tid);
+    __syncthreads();
+
+    f32x16 s = tile_times_frag(Ks, qf, i, h);     // S^T[key][query]
+    float mx = NEG_INF;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + 8 * g + 4 * h);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s[4 * g + t] = s[4 * g + t] * a.scale + bias[t];
+        mx = fmaxf(mx, s[4 * g + t]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_new); ls += s[r]; }
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    if (a.drop.active && vq) {
+      const uint64_t grow = ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float m4[4];
+        drop_mult4(a.drop, grow + 2 * g + h, m4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[4 * g + t] *= m4[t];
+      }
+    }
+    tileT_times_acc(Vs, s, o0, o1, i, h);         // O^T[d][query] += V^T . Pd^T
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (vq) {
+    store_rowT(a.ctx + ((size_t)b * a.L + q) * a.H + head * D, o0, o1, 1.0f / l_tot, h);
+    if (h == 0 && a.lse) a.lse[(size_t)bh * a.L + q] = m_run + __logf(l_tot);
+  }
+}
+
+// ------------------------------------------------------- backward: dQ, delta ---
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[32 * LDT];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * LDT];
+  __shared__ __attribute__((aligned(16))) float mb[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.nh, head = bh - b * a.nh;
+  const int ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
+  const int q = (blockIdx.x * NW + wave) * 32 + i;
+  const bool vq = q < a.L;
+
+  f32x4 qf[8], dof[8];
+  load_row_frags(qf, base + (size_t)q * ld, vq, h);
+  load_row_frags(dof, a.dctx + ((size_t)b * a.L + q) * a.H + head * D, vq, h);
+  float delta = 0.f;
+  {
+    f32x4 of[8];
+    load_row_frags(of, a.ctx + ((size_t)b * a.L + q) * a.H + head * D, vq, h);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) delta += of[kb][t] * dof[kb][t];
+    delta += __shfl_xor(delta, 32, 64);
+    if (vq && h == 0) a.delta[(size_t)bh * a.L + q] = delta;
+  }
+  const float lse = vq ? a.lse[(size_t)bh * a.L + q] : 0.f;
+
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+
+  for (int k0 = 0; k0 < a.L; k0 += 32) {
+    __syncthreads();
+    stage_tile(Ks, base + a.H, ld, k0, a.L, tid);
+    stage_tile(Vs, base + 2 * a.H, ld, k0, a.L, tid);
+    stage_mask_bias(mb, a.mask + (size_t)b * a.L, k0, a.L, tid);
+    __syncthreads();
+
+    f32x16 s = tile_times_frag(Ks, qf, i, h);      // S^T[key][query]
+    f32x16 dp = tile_times_frag(Vs, dof, i, h);    // dPd^T[key][query] = V . dO^T
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + 8 * g + 4 * h);
+      float m4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.drop.active && vq)
+        drop_mult4(a.drop, ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2) + 2 * g + h, m4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float p = __expf(s[4 * g + t] * a.scale + bias[t] - lse);
+        s[4 * g + t] = p * (dp[4 * g + t] * m4[t] - delta) * a.scale;   // dS^T * scale
+      }
+    }
+    tileT_times_acc(Ks, s, dq0, dq1, i, h);        // dQ^T[d][query] += K^T . dS^T
+  }
+  if (vq) store_rowT(a.dqkv + ((size_t)b * a.L + q) * ld + head * D, dq0, dq1, 1.0f, h);
+}
+
+// ------------------------------------------------------ backward: dK, dV ---
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Qs[32 * LDT];
+  __shared__ __attribute__((aligned(16))) float dOs[32 * LDT];
+  __shared__ __attribute__((aligned(16))) float lse_s[32];
+  __shared__ __attribute__((aligned(16))) float del_s[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5, u = lane & 3;
+  const int bh = blockIdx.y, b = bh / a.nh, head = bh - b * a.nh;
+  const int ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
+  const int key = (blockIdx.x * NW + wave) * 32 + i;
+  const bool vk = key < a.L;
+
+  f32x4 kf[8], vf[8];
+  load_row_frags(kf, base + a.H + (size_t)key * ld, vk, h);
+  load_row_frags(vf, base + 2 * a.H + (size_t)key * ld, vk, h);
+  const float bias = vk ? (1.0f - a.mask[(size_t)b * a.L + key]) * -10000.0f : NEG_INF;
+
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+
+  for (int q0 = 0; q0 < a.L; q0 += 32) {
+    __syncthreads();
+    stage_tile(Qs, base, ld, q0, a.L, tid);
+    stage_tile(dOs, a.dctx + (size_t)b * a.L * a.H + head * D, a.H, q0, a.L, tid);
+    if (tid < 32) {
+      const int qq = q0 + tid;
+      lse_s[tid] = qq < a.L ? a.lse[(size_t)bh * a.L + qq] : -NEG_INF;   // +inf -> p = 0
+      del_s[tid] = qq < a.L ? a.delta[(size_t)bh * a.L + qq] : 0.f;
+    }
+    __syncthreads();
+
+    f32x16 s = tile_times_frag(Qs, kf, i, h);      // S[query][key]
+    f32x16 dp = tile_times_frag(dOs, vf, i, h);    // dPd[query][key] = dO . V^T
+    f32x16 pd;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + 8 * g + 4 * h);
+      const f32x4 del4 = *reinterpret_cast<const f32x4*>(del_s + 8 * g + 4 * h);
+      float m4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.drop.active) {
+        // the 4 lanes of a quad hold keys 4c..4c+3; quad-lane u draws the Philox group of
+        // (query 8g+4h+u, keys 4c..4c+3) and the keep bits are exchanged across the quad
+        const int qq = q0 + 8 * g + 4 * h + u;
+        const u32x4 w = drop_words(a.drop, ((uint64_t)bh * a.L + qq) * a.Lp4 + (key >> 2));
+        const int bits = (w.x >= a.drop.thresh ? 1 : 0) | (w.y >= a.drop.thresh ? 2 : 0) |
+                         (w.z >= a.drop.thresh ? 4 : 0) | (w.w >= a.drop.thresh ? 8 : 0);
+        const int b0 = __builtin_amdgcn_mov_dpp(bits, 0x00, 0xf, 0xf, true);
+        const int b1 = __builtin_amdgcn_mov_dpp(bits, 0x55, 0xf, 0xf, true);
+        const int b2 = __builtin_amdgcn_mov_dpp(bits, 0xAA, 0xf, 0xf, true);
+        const int b3 = __builtin_amdgcn_mov_dpp(bits, 0xFF, 0xf, 0xf, true);
+        m4[0] = ((b0 >> u) & 1) ? a.drop.scale : 0.f;
+        m4[1] = ((b1 >> u) & 1) ? a.drop.scale : 0.f;
+        m4[2] = ((b2 >> u) & 1) ? a.drop.scale : 0.f;
+        m4[3] = ((b3 >> u) & 1) ? a.drop.scale : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float p = __expf(s[4 * g + t] * a.scale + bias - lse4[t]);
+        pd[4 * g + t] = p * m4[t];
+        s[4 * g + t] = p * (dp[4 * g + t] * m4[t] - del4[t]) * a.scale;   // dS * scale
+      }
+    }
+    tileT_times_acc(dOs, pd, dv0, dv1, i, h);      // dV^T[d][key] += dO^T . Pd
+    tileT_times_acc(Qs, s, dk0, dk1, i, h);        // dK^T[d][key] += Q^T . dS
+  }
+  if (vk) {
+    float* row = a.dqkv + ((size_t)b * a.L + key) * ld + head * D;
+    store_rowT(row + a.H, dk0, dk1, 1.0f, h);
+    store_rowT(row + 2 * a.H, dv0, dv1, 1.0f, h);
+  }
+}
+
+int make_args(AttnArgs& a, int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
+              uint32_t site) {
+  UCHECK_ARG(B > 0 && L > 0 && nh > 0, "attention: bad dims B=%d L=%d nh=%d", B, L, nh);
+  UCHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "attention: bad dropout p");
+  a.B = B; a.L = L; a.nh = nh; a.H = nh * D; a.Lp4 = (L + 3) / 4;
+  a.scale = 0.125f;   // 1/sqrt(64), model/layer.py:86
+  a.drop = make_drop(p_drop, seed, offset, site);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int uniter_attn_fwd(const float* qkv, const float* attn_mask, float* ctx, float* lse, int B,
+                               int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
+                               uint32_t site, void* stream) {
+  UCHECK_ARG(qkv && attn_mask && ctx, "attn_fwd: null pointer");
+  AttnArgs a = {};
+  UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
+  a.qkv = qkv; a.mask = attn_mask; a.ctx = ctx; a.lse = lse;
+  dim3 grid((L + 32 * NW - 1) / (32 * NW), B * nh);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_attn_bwd(const float* qkv, const float* attn_mask, const float* ctx,
+                               const float* lse, const float* dctx, float* dqkv, float* delta, int B,
+                               int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
+                               uint32_t site, void* stream) {
+  UCHECK_ARG(qkv && attn_mask && ctx && lse && dctx && dqkv && delta, "attn_bwd: null pointer");
+  AttnArgs a = {};
+  UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
+  a.qkv = qkv; a.mask = attn_mask; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
+  a.dctx = dctx; a.dqkv = dqkv; a.delta = delta;
+  dim3 grid((L + 32 * NW - 1) / (32 * NW), B * nh);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);
+  UCHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);
+  UCHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,281 @@
+// fp32 MFMA GEMM for gfx950:  C[M,N] (+)= epi( sum_k A(m,k) B(k,n) ).
+//
+// Replaces the cuBLAS sgemm calls behind nn.Linear / its autograd in the
+// reference (model/layer.py:76-78,112,140,153; model/model.py:267).
+//
+// Design (MI355X_MICROARCH.md "Matrix cores", cdna_hip_programming.md 3):
+//  * v_mfma_f32_32x32x2_f32: exact fp32, 64 cycles/SIMD per instruction, peak
+//    157.3 TFLOP/s -- 1/16 of the bf16 rate, so the kernel is matrix-pipe bound
+//    and LDS / L2 traffic is secondary.  One wave per SIMD per workgroup,
+//    two workgroups per CU so that a barrier in one does not idle the pipe.
+//  * the MFMA K index is a free permutation: lane-half h of instruction t in an
+//    8-deep k-block takes k = 8*kb + 4*h + t for BOTH operands.  A k-contiguous
+//    operand fragment is then ONE ds_read_b128 (4 consecutive k) per 4 MFMAs.
+//  * k-contiguous tiles sit in LDS as [rows][32+4] floats: the 36-dword stride
+//    maps the 16 lanes of every ds_read_b128 lane group to 16 distinct 4-bank
+//    slots (9*i mod 16 is a bijection) -> conflict free.
+//  * k-major tiles (dgrad's W, wgrad's dY and X) sit as [32][cols+4]; a fragment
+//    is 4 ds_read_b32 with lanes 0..31 on consecutive dwords -> conflict free.
+//  * global -> registers -> LDS staging, double buffered, next tile's global
+//    loads issued before the MFMA block of the current one (T14), one
+//    __syncthreads per k-tile.
+//  * blockIdx -> tile map is XCD-aware (bijective chunking): blocks that share an
+//    XCD's L2 work on adjacent tiles.
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+  int M, N, K;
+  const float* A; int lda;
+  const float* B; int ldb;
+  float* C; int ldc;
+  int epi;
+  const float* bias;
+  const float* aux_in;
+  float* aux_out;
+  int ld_aux;
+  int beta;
+  int tiles_m, tiles_n;
+};
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;   // row stride (floats) of a k-contiguous tile
+
+template <int R, bool KM> struct TileSize {
+  static constexpr int value = KM ? BK * (R + 4) : R * LDK;
+};
+
+// issue the global loads of one operand tile into registers
+template <int R, bool KM>
+__device__ __forceinline__ void tile_load(f32x4 (&reg)[R / 32], const float* __restrict__ P,
+                                          int ld, int row0, int rows, int k0, int K, int tid) {
+  if constexpr (!KM) {
+    const int c4 = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < R / 32; ++p) {
+      const int r = row0 + rr + 32 * p;
+      const int k = k0 + c4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows && k < K) v = *reinterpret_cast<const f32x4*>(P + (size_t)r * ld + k);
+      reg[p] = v;
+    }
+  } else {
+    constexpr int TPR = R / 4;          // threads per k-row
+    constexpr int RPP = 256 / TPR;      // k-rows per pass
+    const int c4 = tid % TPR, kk0 = tid / TPR;
+#pragma unroll
+    for (int p = 0; p < R / 32; ++p) {
+      const int k = k0 + kk0 + RPP * p;
+      const int c = row0 + c4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (k < K && c < rows) v = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + c);
+      reg[p] = v;
+    }
+  }
+}
+
+template <int R, bool KM>
+__device__ __forceinline__ void tile_store(const f32x4 (&reg)[R / 32], float* s, int tid) {
+  if constexpr (!KM) {
+    const int c4 = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < R / 32; ++p)
+      *reinterpret_cast<f32x4*>(s + (rr + 32 * p) * LDK + c4 * 4) = reg[p];
+  } else {
+    constexpr int TPR = R / 4;
+    constexpr int RPP = 256 / TPR;
+    const int c4 = tid % TPR, kk0 = tid / TPR;
+#pragma unroll
+    for (int p = 0; p < R / 32; ++p)
+      *reinterpret_cast<f32x4*>(s + (kk0 + RPP * p) * (R + 4) + c4 * 4) = reg[p];
+  }
+}
+
+// fragment of the 32-row sub-tile starting at row `r0` for k-block kb
+template <int R, bool KM>
+__device__ __forceinline__ f32x4 frag_read(const float* s, int r0, int kb, int i, int h) {
+  if constexpr (!KM) {
+    return *reinterpret_cast<const f32x4*>(s + (r0 + i) * LDK + kb * 8 + 4 * h);
+  } else {
+    const float* p = s + (kb * 8 + 4 * h) * (R + 4) + r0 + i;
+    f32x4 v;
+    v[0] = p[0];
+    v[1] = p[R + 4];
+    v[2] = p[2 * (R + 4)];
+    v[3] = p[3 * (R + 4)];
+    return v;
+  }
+}
+
+template <int BM, int BN, bool AKM, bool BKM, int TAG>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int SA = TileSize<BM, AKM>::value, SB = TileSize<BN, BKM>::value;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
+
+  // XCD-aware bijective remap: blocks b, b+8, ... share an XCD -> contiguous tile chunk
+  const int nwg = gridDim.x;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = tile / g.tiles_n, tile_n = tile - tile_m * g.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  f32x4 ra[BM / 32], rb[BN / 32];
+  const int nk = (g.K + BK - 1) / BK;
+
+  tile_load<BM, AKM>(ra, g.A, g.lda, m0, g.M, 0, g.K, tid);
+  tile_load<BN, BKM>(rb, g.B, g.ldb, n0, g.N, 0, g.K, tid);
+  tile_store<BM, AKM>(ra, smem, tid);
+  tile_store<BN, BKM>(rb, smem + SA, tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* sA = smem + (kt & 1) * (SA + SB);
+    const float* sB = sA + SA;
+    if (kt + 1 < nk) {
+      tile_load<BM, AKM>(ra, g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, tid);
+      tile_load<BN, BKM>(rb, g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, tid);
+    }
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[a] = frag_read<BM, AKM>(sA, wm * WM + a * 32, kb, i, h);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[b] = frag_read<BN, BKM>(sB, wn * WN + b * 32, kb, i, h);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][t], fb[b][t], acc[a][b], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      float* dA = smem + ((kt + 1) & 1) * (SA + SB);
+      tile_store<BM, AKM>(ra, dA, tid);
+      tile_store<BN, BKM>(rb, dA + SA, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + wn * WN + b * 32 + i;
+      if (col >= g.N) continue;
+      const float bv = (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        float v = acc[a][b][r] + bv;
+        if (g.epi == UNITER_EPI_BIAS_GELU) {
+          if (g.aux_out) g.aux_out[(size_t)row * g.ld_aux + col] = v;
+          v = gelu_erf(v);
+        } else if (g.epi == UNITER_EPI_DGELU) {
+          v *= dgelu_erf(g.aux_in[(size_t)row * g.ld_aux + col]);
+        } else if (g.epi == UNITER_EPI_ADD) {
+          v += g.aux_in[(size_t)row * g.ld_aux + col];
+        }
+        float* c = g.C + (size_t)row * g.ldc + col;
+        if (g.beta) v += *c;
+        *c = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool AKM, bool BKM, int TAG>
+int launch(GemmArgs g, hipStream_t st) {
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  const int tiles = g.tiles_m * g.tiles_n;
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AKM, BKM, TAG>), dim3(tiles), dim3(256), 0, st, g);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+template <bool AKM, bool BKM>
+int dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
+  switch (cfg) {
+    case 1: return launch<128, 128, AKM, BKM, 0>(g, st);
+    case 2: return launch<64, 128, AKM, BKM, 0>(g, st);
+    case 3: return launch<128, 64, AKM, BKM, 0>(g, st);
+    case 4: return launch<64, 64, AKM, BKM, 0>(g, st);
+    default: uniter_set_error("gemm: bad cfg %d", cfg); return UNITER_E_ARG;
+  }
+}
+
+// pick the tile shape that minimises (rounds over 256 CUs) x (tile work / efficiency)
+int choose_cfg(int M, int N) {
+  static const int bm[5] = {0, 128, 64, 128, 64}, bn[5] = {0, 128, 128, 64, 64};
+  static const double eff[5] = {0, 1.00, 0.95, 0.95, 0.88};
+  int best = 1;
+  double best_cost = 1e300;
+  for (int c = 1; c <= 4; ++c) {
+    const long tiles = (long)((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
+    const long rounds = (tiles + 255) / 256;
+    const double cost = (double)rounds * bm[c] * bn[c] / eff[c];
+    if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+}  // namespace
+
+extern "C" int uniter_gemm_f32_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K,
+                                   const float* A, int lda, const float* B, int ldb, float* C,
+                                   int ldc, int epilogue, const float* bias, const float* aux_in,
+                                   float* aux_out, int ld_aux, int beta, void* stream) {
+  UCHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad dims %d %d %d", M, N, K);
+  UCHECK_ARG(A && B && C, "gemm: null operand");
+  UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_ADD, "gemm: bad epilogue %d", epilogue);
+  UCHECK_ARG(!(epilogue == UNITER_EPI_BIAS || epilogue == UNITER_EPI_BIAS_GELU) || bias,
+             "gemm: epilogue needs bias");
+  UCHECK_ARG(!(epilogue == UNITER_EPI_DGELU || epilogue == UNITER_EPI_ADD) || aux_in,
+             "gemm: epilogue needs aux_in");
+  // 16-byte vector loads along the contiguous dimension
+  if (!a_kmajor) UCHECK_SHAPE(K % 4 == 0 && lda % 4 == 0, "gemm: K/lda must be multiples of 4 (A k-contiguous)");
+  else           UCHECK_SHAPE(M % 4 == 0 && lda % 4 == 0, "gemm: M/lda must be multiples of 4 (A k-major)");
+  if (!b_kmajor) UCHECK_SHAPE(K % 4 == 0 && ldb % 4 == 0, "gemm: K/ldb must be multiples of 4 (B k-contiguous)");
+  else           UCHECK_SHAPE(N % 4 == 0 && ldb % 4 == 0, "gemm: N/ldb must be multiples of 4 (B k-major)");
+  UCHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm: operands must be 16-byte aligned");
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux;
+  g.beta = beta; g.tiles_m = g.tiles_n = 0;
+  if (cfg == 0) cfg = choose_cfg(M, N);
+  hipStream_t st = (hipStream_t)stream;
+  if (!a_kmajor && !b_kmajor) return dispatch_cfg<false, false>(cfg, g, st);
+  if (!a_kmajor && b_kmajor) return dispatch_cfg<false, true>(cfg, g, st);
+  if (a_kmajor && b_kmajor) return dispatch_cfg<true, true>(cfg, g, st);
+  return dispatch_cfg<true, false>(cfg, g, st);
+}
+
+extern "C" int uniter_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,
+                               int lda, const float* B, int ldb, float* C, int ldc, int epilogue,
+                               const float* bias, const float* aux_in, float* aux_out, int ld_aux,
+                               int beta, void* stream) {
+  return uniter_gemm_f32_cfg(0, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, epilogue, bias,
+                             aux_in, aux_out, ld_aux, beta, stream);
+}

@@ -1,0 +1,211 @@
+// Fused dropout + residual + LayerNorm forward / backward, and column sums.
+//
+// Replaces nn.Dropout + residual add + Apex FusedLayerNorm(eps=1e-12) of
+// BertSelfOutput / BertOutput (model/layer.py:113-114,154-155) and their
+// autograd, and the bias-gradient reductions of every nn.Linear.
+//
+// HBM-bound row kernels: one 64-lane wave owns one row, 16-byte loads, fp32
+// statistics with a two-pass variance held in registers, wave-shuffle reduces.
+// Column reductions (dgamma, dbeta, bias grads) are two-stage and deterministic:
+// per-workgroup partial rows in a workspace, then a finalize kernel.
+#include "common.h"
+#include "philox.h"
+#include "rowops.h"
+
+namespace {
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x,
+                                                     const float* __restrict__ res,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     float* __restrict__ z_out, float* __restrict__ y,
+                                                     float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int M, int H,
+                                                     DropCfg drop) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int H4 = H >> 2;
+  f32x4 v[NV];
+  row_load<NV>(v, x + (size_t)row * H, H4, lane);
+  if (drop.active) row_dropout<NV>(v, drop, (uint64_t)row * H4, H4, lane);
+  if (res) {
+    f32x4 r[NV];
+    row_load<NV>(r, res + (size_t)row * H, H4, lane);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] += r[k];
+  }
+  if (z_out) row_store<NV>(v, z_out + (size_t)row * H, H4, lane);
+  float mean, rstd;
+  row_stats<NV>(v, H, H4, lane, mean, rstd);
+  if (mean_out && lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  row_affine<NV>(v, gamma, beta, mean, rstd, H4, lane);
+  row_store<NV>(v, y + (size_t)row * H, H4, lane);
+}
+
+// grid: nblk workgroups of 4 waves; wave w of block b walks rows b*4+w, +4*nblk, ...
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy,
+                                                     const float* __restrict__ z,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma,
+                                                     float* __restrict__ dz, float* __restrict__ dx,
+                                                     float* __restrict__ part, int M, int H,
+                                                     DropCfg drop) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 2 * NV * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H4 = H >> 2;
+  f32x4 g[NV], dg[NV], db[NV];
+  row_load<NV>(g, gamma, H4, lane);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) { dg[k] = f32x4{0, 0, 0, 0}; db[k] = f32x4{0, 0, 0, 0}; }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    f32x4 d[NV], xh[NV];
+    row_load<NV>(d, dy + (size_t)row * H, H4, lane);
+    row_load<NV>(xh, z + (size_t)row * H, H4, lane);
+    const float mu = mean[row], rs = rstd[row];
+    row_ln_bwd<NV>(d, xh, g, mu, rs, dg, db, H, H4, lane);      // d <- dz, accumulates dg/db
+    if (dz) row_store<NV>(d, dz + (size_t)row * H, H4, lane);
+    if (dx && (dx != dz || drop.active)) {
+      if (drop.active) row_dropout<NV>(d, drop, (uint64_t)row * H4, H4, lane);
+      row_store<NV>(d, dx + (size_t)row * H, H4, lane);
+    }
+  }
+  // cross-wave reduce of the column partials, then one partial row per workgroup
+  block_col_reduce_store<NV>(dg, red, part + (size_t)blockIdx.x * 2 * H, H4, lane, wave);
+  block_col_reduce_store<NV>(db, red, part + (size_t)blockIdx.x * 2 * H + H, H4, lane, wave);
+}
+
+// out[n] (+)= sum_p part[p*stride + n]
+__global__ void finalize_partials_kernel(const float* __restrict__ part, int nparts, size_t stride,
+                                         float* __restrict__ out, int N, int beta) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * stride + n];
+  out[n] = beta ? out[n] + s : s;
+}
+
+// column sums: block (bx, by) covers columns [bx*256, bx*256+256) and rows by, by+gridDim.y, ...
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ld,
+                                                     float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  f32x4 s = {0, 0, 0, 0};
+  if (c < N) {
+    for (int r = blockIdx.y * 4 + wave; r < M; r += gridDim.y * 4)
+      s += *reinterpret_cast<const f32x4*>(X + (size_t)r * ld + c);
+  }
+  *reinterpret_cast<f32x4*>(red + wave * 256 + lane * 4) = s;
+  __syncthreads();
+  if (wave == 0 && c < N) {
+    f32x4 t = s;
+#pragma unroll
+    for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + w * 256 + lane * 4);
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.y * N + c) = t;
+  }
+}
+
+__global__ void add_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+}
+
+inline int ln_bwd_blocks(int M) {
+  int b = (M + 3) / 4;
+  return b < 512 ? b : 512;
+}
+inline int colsum_splits(int M) {
+  int s = (M + 31) / 32;
+  return s < 64 ? (s < 1 ? 1 : s) : 64;
+}
+
+}  // namespace
+
+// out = a + b (n multiple of 4)
+int launch_add_f32(float* out, const float* a, const float* b, size_t n, hipStream_t st) {
+  const size_t n4 = n / 4;
+  if (n4 == 0) return 0;
+  hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, out, a, b, n4);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(finalize_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, nparts,
+                     stride, out, N, beta);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t uniter_colsum_ws_bytes(int M, int N) {
+  return (size_t)colsum_splits(M) * N * sizeof(float);
+}
+
+extern "C" int uniter_colsum_f32(const float* X, int M, int N, int ld, float* out, int beta, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  UCHECK_ARG(X && out && ws, "colsum: null pointer");
+  UCHECK_SHAPE(N % 4 == 0 && ld % 4 == 0, "colsum: N and ld must be multiples of 4");
+  UCHECK_ARG(ws_bytes >= uniter_colsum_ws_bytes(M, N), "colsum: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int splits = colsum_splits(M);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, splits), dim3(256), 0, st, X, M, N, ld,
+                     (float*)ws);
+  UCHECK_LAUNCH();
+  return finalize_partials((const float*)ws, splits, (size_t)N, out, N, beta, st);
+}
+
+#define LN_DISPATCH(NVv, KERNEL, GRID, ...)                                                      \
+  switch (NVv) {                                                                                 \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(256), 0, st, __VA_ARGS__); break;         \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(256), 0, st, __VA_ARGS__); break;         \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), GRID, dim3(256), 0, st, __VA_ARGS__); break;         \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(256), 0, st, __VA_ARGS__); break;         \
+    default: uniter_set_error("layernorm: hidden size %d unsupported (max 1024)", H);            \
+             return UNITER_E_SHAPE;                                                              \
+  }
+
+extern "C" int uniter_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta,
+                             float* z_out, float* y, float* mean, float* rstd, int M, int H,
+                             float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
+                             void* stream) {
+  UCHECK_ARG(x && gamma && beta && y, "ln_fwd: null pointer");
+  UCHECK_ARG((mean == nullptr) == (rstd == nullptr), "ln_fwd: mean/rstd must both be given or NULL");
+  UCHECK_SHAPE(H % 4 == 0 && H >= 4, "ln_fwd: H must be a multiple of 4");
+  UCHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "ln_fwd: bad dropout p");
+  if (M <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const DropCfg drop = make_drop(p_drop, seed, offset, site);
+  const int nv = (H / 4 + 63) / 64;
+  LN_DISPATCH(nv, ln_fwd_kernel, dim3((M + 3) / 4), x, res, gamma, beta, z_out, y, mean, rstd, M, H, drop);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t uniter_ln_bwd_ws_bytes(int M, int H) {
+  return (size_t)ln_bwd_blocks(M) * 2 * H * sizeof(float);
+}
+
+extern "C" int uniter_ln_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
+                             const float* gamma, float* dz, float* dx, float* dgamma, float* dbeta,
+                             int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
+                             void* ws, size_t ws_bytes, void* stream) {
+  UCHECK_ARG(dy && z && mean && rstd && gamma && dgamma && dbeta && ws, "ln_bwd: null pointer");
+  UCHECK_ARG(dz || dx, "ln_bwd: need dz or dx");
+  UCHECK_SHAPE(H % 4 == 0 && H >= 4, "ln_bwd: H must be a multiple of 4");
+  UCHECK_ARG(ws_bytes >= uniter_ln_bwd_ws_bytes(M, H), "ln_bwd: workspace too small");
+  if (M <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const DropCfg drop = make_drop(p_drop, seed, offset, site);
+  const int nv = (H / 4 + 63) / 64;
+  const int nblk = ln_bwd_blocks(M);
+  float* part = (float*)ws;
+  LN_DISPATCH(nv, ln_bwd_kernel, dim3(nblk), dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop);
+  UCHECK_LAUNCH();
+  UCHECK_RC(finalize_partials(part, nblk, (size_t)2 * H, dgamma, H, 1, st));
+  return finalize_partials(part + H, nblk, (size_t)2 * H, dbeta, H, 1, st);
+}

@@ -1,0 +1,571 @@
+// Whole-model kernel schedule of the UNITER encoder: the library owns the
+// sequence of launches for UniterModel.forward (model/model.py:336-367,
+// BertLayer.forward model/layer.py:166-170) and for its backward, so the host
+// makes a handful of calls per training step instead of ~60 framework
+// dispatches per layer.
+//
+// Streams: the forward and the backward dgrad chain run on `stream`; weight /
+// bias gradient GEMMs of layer l run on `side_stream` behind an event, so they
+// overlap layer l-1's dgrad chain and fill the CUs that the partial last wave
+// of each GEMM leaves idle.  Every layer owns its backward scratch, so the two
+// streams never race on a buffer (288 GB of HBM: ~3 GB for UNITER-base B=16).
+#include <string.h>
+#include <string>
+#include <vector>
+#include "common.h"
+#include "philox.h"
+
+// internal helpers implemented in other translation units
+int launch_add_f32(float* out, const float* a, const float* b, size_t n, hipStream_t st);
+int launch_masked_rowsum(const float* x, const int64_t* masks, float* out, int rows, int D, hipStream_t st);
+
+namespace {
+
+enum { P_WORD = 0, P_POS, P_TYPE, P_ELN_G, P_ELN_B, P_IMG_W, P_IMG_B, P_ILN_G, P_ILN_B, P_PLN_G, P_PLN_B,
+       P_POSL_W, P_POSL_B, P_MASK_EMB, P_FLN_G, P_FLN_B, P_LAYER0 };
+enum { L_QW = 0, L_QB, L_KW, L_KB, L_VW, L_VB, L_OW, L_OB, L_LN1_G, L_LN1_B, L_W1, L_B1, L_W2, L_B2, L_LN2_G,
+       L_LN2_B, L_COUNT };
+
+const char* kEmbNames[P_LAYER0] = {
+    "embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+    "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias",
+    "img_embeddings.img_linear.weight", "img_embeddings.img_linear.bias",
+    "img_embeddings.img_layer_norm.weight", "img_embeddings.img_layer_norm.bias",
+    "img_embeddings.pos_layer_norm.weight", "img_embeddings.pos_layer_norm.bias",
+    "img_embeddings.pos_linear.weight", "img_embeddings.pos_linear.bias",
+    "img_embeddings.mask_embedding.weight", "img_embeddings.LayerNorm.weight", "img_embeddings.LayerNorm.bias"};
+const char* kLayerNames[L_COUNT] = {
+    "attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight",
+    "attention.self.key.bias", "attention.self.value.weight", "attention.self.value.bias",
+    "attention.output.dense.weight", "attention.output.dense.bias", "attention.output.LayerNorm.weight",
+    "attention.output.LayerNorm.bias", "intermediate.dense.weight", "intermediate.dense.bias",
+    "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias"};
+
+struct Carver {
+  char* base; size_t off;
+  explicit Carver(void* b) : base((char*)b), off(0) {}
+  float* f(size_t n) { float* p = (float*)(base + off); off += align_up(n * sizeof(float), 256); return p; }
+  void* raw(size_t n) { void* p = base + off; off += align_up(n, 256); return p; }
+};
+
+struct LayerBufs {   // saved activations + backward scratch of one layer
+  float *qkv, *lse, *ctx, *t1, *z1, *mean1, *rstd1, *y1, *u, *hact, *t2, *z2, *mean2, *rstd2, *y2;
+  float *dz2, *g2, *du, *dy1, *dz1, *g1, *dctx, *dqkv, *delta, *dx;
+};
+
+struct Plan {
+  int B, T, R, L, S, T0, M, mode;
+  bool has_txt, has_img;
+  float *feat_eff, *imgfc, *img_stats, *cat, *emb;
+  std::vector<LayerBufs> layers;
+  float *dcat, *d_imgfc, *d_posfc, *d_feat, *dsum;
+  void *ln_ws, *col_ws, *emb_ws;
+  size_t ln_ws_bytes, col_ws_bytes, emb_ws_bytes;
+  size_t total;
+};
+
+}  // namespace
+
+struct uniter_model {
+  uniter_config_t cfg;
+  int n_params;
+  std::vector<float*> p, g;
+  std::vector<std::string> names;
+  std::vector<hipEvent_t> ev_main, ev_side;
+  // profiling
+  int prof_kind = 0;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0;
+  // state carried from forward to backward
+  Plan plan;
+  uniter_batch_t batch;
+  float* hidden_out = nullptr;
+  const float* d_hidden = nullptr;
+  int all_layers = 0;
+  uint64_t seed = 0;
+  uint32_t offset = 0;
+  hipStream_t st = nullptr, side = nullptr;
+  bool bwd_open = false;
+
+  float* P(int i) const { return p[i]; }
+  float* G(int i) const { return g[i]; }
+  float* LP(int l, int k) const { return p[P_LAYER0 + l * L_COUNT + k]; }
+  float* LG(int l, int k) const { return g[P_LAYER0 + l * L_COUNT + k]; }
+  int pooler_w() const { return P_LAYER0 + cfg.num_hidden_layers * L_COUNT; }
+};
+
+namespace {
+
+int check_cfg(const uniter_config_t* c) {
+  UCHECK_ARG(c, "config is NULL");
+  UCHECK_SHAPE(c->hidden_size > 0 && c->num_attention_heads > 0 &&
+               c->hidden_size == 64 * c->num_attention_heads,
+               "hidden_size (%d) must be 64 * num_attention_heads (%d): head_dim 64 only", c->hidden_size,
+               c->num_attention_heads);
+  UCHECK_SHAPE(c->hidden_size <= 1024, "hidden_size %d > 1024 unsupported", c->hidden_size);
+  UCHECK_SHAPE(c->intermediate_size % 4 == 0 && c->img_dim % 4 == 0, "intermediate_size / img_dim must be multiples of 4");
+  UCHECK_SHAPE(c->num_hidden_layers >= 1 && c->vocab_size > 0 && c->max_position_embeddings > 0 &&
+               c->type_vocab_size >= 2, "bad config");
+  return 0;
+}
+
+void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, int L, bool has_txt,
+               bool has_img, bool has_masks, int mode) {
+  const uniter_config_t& c = m->cfg;
+  const int H = c.hidden_size, I = c.intermediate_size, nl = c.num_hidden_layers, nh = c.num_attention_heads;
+  pl.B = B; pl.T = T; pl.R = R; pl.L = L; pl.mode = mode; pl.has_txt = has_txt; pl.has_img = has_img;
+  pl.T0 = has_txt ? T : 0;
+  pl.S = pl.T0 + (has_img ? R : 0);
+  pl.M = B * L;
+  const size_t M = (size_t)pl.M;
+  Carver cv(ws);
+  const size_t BR = (size_t)B * (has_img ? R : 0);
+  pl.feat_eff = has_masks ? cv.f(BR * c.img_dim) : nullptr;
+  pl.imgfc = cv.f(BR * H);
+  pl.img_stats = cv.f(BR * 6);
+  pl.cat = cv.f((size_t)B * pl.S * H);
+  pl.emb = cv.f(M * H);
+  pl.layers.resize(nl);
+  const bool save = mode != 0;
+  auto alloc_fwd = [&](LayerBufs& b) {
+    b.qkv = cv.f(M * 3 * H); b.lse = cv.f((size_t)B * nh * L); b.ctx = cv.f(M * H); b.t1 = cv.f(M * H);
+    b.z1 = save ? cv.f(M * H) : nullptr; b.mean1 = cv.f(M); b.rstd1 = cv.f(M); b.y1 = cv.f(M * H);
+    b.u = save ? cv.f(M * I) : nullptr; b.hact = cv.f(M * I); b.t2 = cv.f(M * H);
+    b.z2 = save ? cv.f(M * H) : nullptr; b.mean2 = cv.f(M); b.rstd2 = cv.f(M); b.y2 = cv.f(M * H);
+  };
+  if (save) {
+    for (int l = 0; l < nl; ++l) {
+      LayerBufs& b = pl.layers[l];
+      b = LayerBufs();
+      alloc_fwd(b);
+      b.dz2 = cv.f(M * H); b.g2 = cv.f(M * H); b.du = cv.f(M * I); b.dy1 = cv.f(M * H); b.dz1 = cv.f(M * H);
+      b.g1 = cv.f(M * H); b.dctx = cv.f(M * H); b.dqkv = cv.f(M * 3 * H); b.delta = cv.f((size_t)B * nh * L);
+      b.dx = cv.f(M * H);
+    }
+  } else {
+    // inference: every layer reuses one set of buffers; the layer output ping-pongs
+    LayerBufs base = LayerBufs();
+    alloc_fwd(base);
+    float* yB = cv.f(M * H);
+    for (int l = 0; l < nl; ++l) {
+      pl.layers[l] = base;
+      if (l & 1) pl.layers[l].y2 = yB;
+    }
+  }
+  if (save) {
+    pl.dcat = cv.f((size_t)B * pl.S * H);
+    pl.d_imgfc = cv.f(BR * H);
+    pl.d_posfc = cv.f(BR * H);
+    pl.d_feat = has_masks ? cv.f(BR * c.img_dim) : nullptr;
+    pl.dsum = cv.f(M * H);
+    pl.ln_ws_bytes = uniter_ln_bwd_ws_bytes(pl.M, H);
+    pl.ln_ws = cv.raw(pl.ln_ws_bytes);
+    const int maxN = 3 * H > I ? 3 * H : I;
+    pl.col_ws_bytes = uniter_colsum_ws_bytes(pl.M, maxN);
+    pl.col_ws = cv.raw(pl.col_ws_bytes);
+    const int rows = B * (T > R ? T : R);
+    pl.emb_ws_bytes = uniter_embed_bwd_ws_bytes(rows, H);
+    pl.emb_ws = cv.raw(pl.emb_ws_bytes);
+  }
+  pl.total = cv.off;
+}
+
+struct ProfScope {
+  uniter_model* m; hipStream_t st; bool on;
+  ProfScope(uniter_model* m_, int kind, hipStream_t st_) : m(m_), st(st_), on(false) {
+    if (m->prof_kind && m->prof_kind == kind && m->prof_used + 2 <= m->prof_ev.size()) {
+      on = true;
+      hipEventRecord(m->prof_ev[m->prof_used], st);
+    }
+  }
+  ~ProfScope() {
+    if (on) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
+  }
+};
+
+int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int N, int K, const float* A,
+         int lda, const float* B, int ldb, float* C, int ldc, int epi, const float* bias, const float* aux_in,
+         float* aux_out, int ld_aux, int beta) {
+  ProfScope ps(m, kind, st);
+  return uniter_gemm_f32(akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux_in, aux_out, ld_aux, beta, st);
+}
+
+int validate_batch(const uniter_model* m, const uniter_batch_t* b) {
+  UCHECK_ARG(b, "batch is NULL");
+  UCHECK_ARG(b->B > 0 && b->L > 0, "batch: B and L must be positive");
+  UCHECK_ARG(b->input_ids || b->img_feat, "batch: need input_ids and/or img_feat");
+  UCHECK_ARG(b->attention_mask, "batch: attention_mask is NULL");
+  if (b->input_ids) UCHECK_ARG(b->position_ids && b->T > 0, "batch: text needs position_ids and T > 0");
+  if (b->img_feat) UCHECK_ARG(b->img_pos_feat && b->R > 0, "batch: image needs img_pos_feat and R > 0");
+  const int S = (b->input_ids ? b->T : 0) + (b->img_feat ? b->R : 0);
+  if (!(b->input_ids && b->img_feat && b->gather_index))
+    UCHECK_SHAPE(b->L == S || (b->input_ids && b->img_feat && b->L <= S),
+                 "batch: without gather_index L (%d) must equal T+R (%d)", b->L, S);
+  UCHECK_SHAPE(b->T <= m->cfg.max_position_embeddings || !b->input_ids, "batch: T exceeds max_position_embeddings");
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI ---
+extern "C" int uniter_num_params(const uniter_config_t* cfg) {
+  if (!cfg) return 0;
+  return P_LAYER0 + cfg->num_hidden_layers * L_COUNT + 2;
+}
+
+extern "C" const char* uniter_param_name(const uniter_config_t* cfg, int i) {
+  static thread_local char buf[128];
+  if (!cfg || i < 0 || i >= uniter_num_params(cfg)) return nullptr;
+  if (i < P_LAYER0) return kEmbNames[i];
+  const int nl = cfg->num_hidden_layers;
+  if (i < P_LAYER0 + nl * L_COUNT) {
+    const int l = (i - P_LAYER0) / L_COUNT, k = (i - P_LAYER0) % L_COUNT;
+    snprintf(buf, sizeof(buf), "encoder.layer.%d.%s", l, kLayerNames[k]);
+    return buf;
+  }
+  return i == P_LAYER0 + nl * L_COUNT ? "pooler.dense.weight" : "pooler.dense.bias";
+}
+
+extern "C" int uniter_param_shape(const uniter_config_t* c, int i, int64_t* rows, int64_t* cols) {
+  if (!c || !rows || !cols || i < 0 || i >= uniter_num_params(c)) return UNITER_E_ARG;
+  const int64_t H = c->hidden_size, I = c->intermediate_size, D = c->img_dim;
+  int64_t r = H, cc = 0;   // cols == 0 -> 1-D of length rows
+  if (i < P_LAYER0) {
+    switch (i) {
+      case P_WORD: r = c->vocab_size; cc = H; break;
+      case P_POS: r = c->max_position_embeddings; cc = H; break;
+      case P_TYPE: r = c->type_vocab_size; cc = H; break;
+      case P_IMG_W: r = H; cc = D; break;
+      case P_POSL_W: r = H; cc = 7; break;
+      case P_MASK_EMB: r = 2; cc = D; break;
+      default: break;
+    }
+  } else if (i < P_LAYER0 + c->num_hidden_layers * L_COUNT) {
+    switch ((i - P_LAYER0) % L_COUNT) {
+      case L_QW: case L_KW: case L_VW: case L_OW: cc = H; break;
+      case L_W1: r = I; cc = H; break;
+      case L_B1: r = I; break;
+      case L_W2: r = H; cc = I; break;
+      default: break;
+    }
+  } else if (i == P_LAYER0 + c->num_hidden_layers * L_COUNT) {
+    cc = H;
+  }
+  *rows = r; *cols = cc;
+  return 0;
+}
+
+extern "C" int uniter_model_create(const uniter_config_t* cfg, float* const* params, float* const* grads,
+                                   int n_params, uniter_model_t** out) {
+  UCHECK_RC(check_cfg(cfg));
+  UCHECK_ARG(params && out, "model_create: null pointer");
+  UCHECK_ARG(n_params == uniter_num_params(cfg), "model_create: expected %d parameters, got %d",
+             uniter_num_params(cfg), n_params);
+  uniter_model* m = new uniter_model();
+  m->cfg = *cfg;
+  m->n_params = n_params;
+  m->p.assign(params, params + n_params);
+  if (grads) m->g.assign(grads, grads + n_params); else m->g.assign(n_params, nullptr);
+  const size_t H = cfg->hidden_size;
+  for (int i = 0; i < n_params; ++i) {
+    if (!m->p[i] || ((uintptr_t)m->p[i] & 15)) {
+      uniter_set_error("model_create: parameter %d (%s) is NULL or not 16-byte aligned", i, uniter_param_name(cfg, i));
+      delete m; return UNITER_E_ARG;
+    }
+  }
+  for (int l = 0; l < cfg->num_hidden_layers; ++l) {
+    const bool ok = m->LP(l, L_KW) == m->LP(l, L_QW) + H * H && m->LP(l, L_VW) == m->LP(l, L_QW) + 2 * H * H &&
+                    m->LP(l, L_KB) == m->LP(l, L_QB) + H && m->LP(l, L_VB) == m->LP(l, L_QB) + 2 * H;
+    const bool gok = !grads || (m->LG(l, L_KW) == m->LG(l, L_QW) + H * H && m->LG(l, L_VW) == m->LG(l, L_QW) + 2 * H * H &&
+                                m->LG(l, L_KB) == m->LG(l, L_QB) + H && m->LG(l, L_VB) == m->LG(l, L_QB) + 2 * H);
+    if (!ok || !gok) {
+      uniter_set_error("model_create: layer %d query/key/value weights (and biases, and their grads) must be contiguous", l);
+      delete m; return UNITER_E_ARG;
+    }
+  }
+  const int nl = cfg->num_hidden_layers;
+  m->ev_main.resize(nl + 1); m->ev_side.resize(nl + 1);
+  for (int i = 0; i <= nl; ++i) {
+    hipError_t e1 = hipEventCreateWithFlags(&m->ev_main[i], hipEventDisableTiming);
+    hipError_t e2 = hipEventCreateWithFlags(&m->ev_side[i], hipEventDisableTiming);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      uniter_set_error("model_create: hipEventCreate failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+      delete m; return (int)(e1 != hipSuccess ? e1 : e2);
+    }
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" void uniter_model_destroy(uniter_model_t* m) {
+  if (!m) return;
+  for (auto e : m->ev_main) if (e) hipEventDestroy(e);
+  for (auto e : m->ev_side) if (e) hipEventDestroy(e);
+  for (auto e : m->prof_ev) if (e) hipEventDestroy(e);
+  delete m;
+}
+
+extern "C" size_t uniter_model_ws_bytes(const uniter_model_t* m, int B, int T, int R, int L, int train) {
+  if (!m) return 0;
+  Plan pl;
+  // sizes do not depend on pointers: carve from address 0; assume both modalities + masks (upper bound)
+  make_plan(m, pl, nullptr, B, T > 0 ? T : 0, R > 0 ? R : 0, L, T > 0, R > 0, true, train);
+  return pl.total + 256;
+}
+
+extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, float* hidden_out,
+                                    int all_layers, int train, uint64_t seed, uint32_t offset, void* ws,
+                                    size_t ws_bytes, void* stream) {
+  UCHECK_ARG(m && hidden_out && ws, "model_forward: null pointer");
+  UCHECK_ARG(train >= 0 && train <= 2, "model_forward: train must be 0, 1 or 2");
+  UCHECK_RC(validate_batch(m, b));
+  UCHECK_ARG(((uintptr_t)ws & 255) == 0, "model_forward: workspace must be 256-byte aligned");
+  const uniter_config_t& c = m->cfg;
+  const int H = c.hidden_size, I = c.intermediate_size, nl = c.num_hidden_layers, nh = c.num_attention_heads;
+  const bool has_txt = b->input_ids != nullptr, has_img = b->img_feat != nullptr;
+  Plan& pl = m->plan;
+  make_plan(m, pl, ws, b->B, b->T, b->R, b->L, has_txt, has_img, b->img_masks != nullptr, train);
+  if (pl.total > ws_bytes) {
+    uniter_set_error("model_forward: workspace too small (%zu < %zu)", ws_bytes, pl.total);
+    return UNITER_E_WS;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const float ph = train == 1 ? c.hidden_dropout_prob : 0.f;
+  const float pa = train == 1 ? c.attention_probs_dropout_prob : 0.f;
+  const int B = b->B, T = b->T, R = b->R, L = b->L, S = pl.S, M = pl.M;
+  const bool save = train != 0;
+  m->batch = *b; m->hidden_out = hidden_out; m->all_layers = all_layers; m->seed = seed; m->offset = offset;
+  m->bwd_open = false;
+
+  // ---- embeddings (model/model.py:321-334) ----
+  if (has_txt)
+    UCHECK_RC(uniter_txt_embed_fwd(b->input_ids, b->position_ids, b->txt_type_ids, m->P(P_WORD), m->P(P_POS),
+                                   m->P(P_TYPE), m->P(P_ELN_G), m->P(P_ELN_B), pl.cat, B, T, S, H,
+                                   c.vocab_size, c.max_position_embeddings, c.type_vocab_size, b->pos_bcast,
+                                   ph, seed, offset, st));
+  if (has_img) {
+    const float* feat = b->img_feat;
+    if (b->img_masks) {
+      UCHECK_RC(uniter_img_mask_add(b->img_feat, b->img_masks, m->P(P_MASK_EMB), pl.feat_eff, B * R, c.img_dim, st));
+      feat = pl.feat_eff;
+    }
+    UCHECK_RC(gemm(m, 0, st, 0, 0, B * R, H, c.img_dim, feat, c.img_dim, m->P(P_IMG_W), c.img_dim, pl.imgfc, H,
+                   UNITER_EPI_BIAS, m->P(P_IMG_B), nullptr, nullptr, 0, 0));
+    UCHECK_RC(uniter_img_embed_fwd(pl.imgfc, b->img_pos_feat, b->img_type_ids, m->P(P_POSL_W), m->P(P_POSL_B),
+                                   m->P(P_TYPE), m->P(P_ILN_G), m->P(P_ILN_B), m->P(P_PLN_G), m->P(P_PLN_B),
+                                   m->P(P_FLN_G), m->P(P_FLN_B), pl.cat, save ? pl.img_stats : nullptr, B, R,
+                                   pl.T0, S, H, c.type_vocab_size, ph, seed, offset, st));
+  }
+  const bool joint = has_txt && has_img;
+  UCHECK_RC(uniter_gather_rows(pl.cat, joint ? b->gather_index : nullptr, pl.emb, B, S, L, H, st));
+
+  // ---- encoder (model/model.py:282-292; model/layer.py:166-170) ----
+  const float* x = pl.emb;
+  for (int l = 0; l < nl; ++l) {
+    LayerBufs& lb = pl.layers[l];
+    float* y2 = all_layers ? hidden_out + (size_t)l * M * H : (l == nl - 1 ? hidden_out : lb.y2);
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, x, H, m->LP(l, L_QW), H, lb.qkv, 3 * H,
+                   UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
+    {
+      ProfScope ps(m, UNITER_K_ATTN_FWD, st);
+      UCHECK_RC(uniter_attn_fwd(lb.qkv, b->attention_mask, lb.ctx, lb.lse, B, L, nh, pa, seed, offset,
+                                SITE_ATTN_PROBS(l), st));
+    }
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, 0, M, H, H, lb.ctx, H, m->LP(l, L_OW), H, lb.t1, H,
+                   UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, nullptr, 0, 0));
+    {
+      ProfScope ps(m, UNITER_K_LN, st);
+      UCHECK_RC(uniter_ln_fwd(lb.t1, x, m->LP(l, L_LN1_G), m->LP(l, L_LN1_B), lb.z1, lb.y1,
+                              save ? lb.mean1 : nullptr, save ? lb.rstd1 : nullptr, M, H, ph, seed, offset,
+                              SITE_ATTN_OUT(l), st));
+    }
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_FFN_UP_FWD, st, 0, 0, M, I, H, lb.y1, H, m->LP(l, L_W1), H, lb.hact, I,
+                   UNITER_EPI_BIAS_GELU, m->LP(l, L_B1), nullptr, lb.u, I, 0));
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_FFN_DOWN_FWD, st, 0, 0, M, H, I, lb.hact, I, m->LP(l, L_W2), I, lb.t2, H,
+                   UNITER_EPI_BIAS, m->LP(l, L_B2), nullptr, nullptr, 0, 0));
+    {
+      ProfScope ps(m, UNITER_K_LN, st);
+      UCHECK_RC(uniter_ln_fwd(lb.t2, lb.y1, m->LP(l, L_LN2_G), m->LP(l, L_LN2_B), lb.z2, y2,
+                              save ? lb.mean2 : nullptr, save ? lb.rstd2 : nullptr, M, H, ph, seed, offset,
+                              SITE_FFN_OUT(l), st));
+    }
+    lb.y2 = y2;
+    x = y2;
+  }
+  return 0;
+}
+
+extern "C" int uniter_model_backward_begin(uniter_model_t* m, const uniter_batch_t* b, const float* d_hidden,
+                                           int all_layers, uint64_t seed, uint32_t offset, void* ws,
+                                           size_t ws_bytes, void* stream, void* side_stream) {
+  UCHECK_ARG(m && d_hidden && ws, "backward_begin: null pointer");
+  if (m->plan.mode == 0 || m->hidden_out == nullptr) {
+    uniter_set_error("backward_begin: no training-mode forward precedes this call");
+    return UNITER_E_STATE;
+  }
+  UCHECK_ARG(m->seed == seed && m->offset == offset && m->all_layers == all_layers,
+             "backward_begin: seed/offset/all_layers differ from the forward call");
+  for (int i = 0; i < m->n_params; ++i)
+    UCHECK_ARG(m->g[i] != nullptr, "backward: gradient buffer %d (%s) is NULL", i, uniter_param_name(&m->cfg, i));
+  (void)ws_bytes; (void)b;
+  m->d_hidden = d_hidden;
+  m->st = (hipStream_t)stream;
+  m->side = side_stream ? (hipStream_t)side_stream : (hipStream_t)stream;
+  m->bwd_open = true;
+  return 0;
+}
+
+extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
+  UCHECK_ARG(m, "backward_layer: null model");
+  if (!m->bwd_open) { uniter_set_error("backward_layer: call uniter_model_backward_begin first"); return UNITER_E_STATE; }
+  const uniter_config_t& c = m->cfg;
+  const int H = c.hidden_size, I = c.intermediate_size, nl = c.num_hidden_layers, nh = c.num_attention_heads;
+  UCHECK_ARG(l >= 0 && l < nl, "backward_layer: bad layer %d", l);
+  Plan& pl = m->plan;
+  const int B = pl.B, L = pl.L, M = pl.M;
+  const float ph = pl.mode == 1 ? c.hidden_dropout_prob : 0.f;
+  const float pa = pl.mode == 1 ? c.attention_probs_dropout_prob : 0.f;
+  hipStream_t st = m->st, sd = m->side;
+  LayerBufs& lb = pl.layers[l];
+  const float* x = l == 0 ? pl.emb : pl.layers[l - 1].y2;
+  const size_t MH = (size_t)M * H;
+
+  // upstream gradient w.r.t. this layer's output
+  const float* dy;
+  if (l == nl - 1) {
+    dy = m->all_layers ? m->d_hidden + (size_t)l * MH : m->d_hidden;
+  } else if (m->all_layers) {
+    UCHECK_RC(launch_add_f32(pl.dsum, pl.layers[l + 1].dx, m->d_hidden + (size_t)l * MH, MH, st));
+    dy = pl.dsum;
+  } else {
+    dy = pl.layers[l + 1].dx;
+  }
+  float* g2 = ph > 0.f ? lb.g2 : lb.dz2;
+  float* g1 = ph > 0.f ? lb.g1 : lb.dz1;
+  {
+    ProfScope ps(m, UNITER_K_LN, st);
+    UCHECK_RC(uniter_ln_bwd(dy, lb.z2, lb.mean2, lb.rstd2, m->LP(l, L_LN2_G), lb.dz2, g2, m->LG(l, L_LN2_G),
+                            m->LG(l, L_LN2_B), M, H, ph, m->seed, m->offset, SITE_FFN_OUT(l), pl.ln_ws,
+                            pl.ln_ws_bytes, st));
+  }
+  // FFN down dgrad (+ GELU'), FFN up dgrad (+ residual grad)
+  UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, g2, H, m->LP(l, L_W2), I, lb.du, I, UNITER_EPI_DGELU,
+                 nullptr, lb.u, nullptr, I, 0));
+  UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, I, lb.du, I, m->LP(l, L_W1), H, lb.dy1, H, UNITER_EPI_ADD,
+                 nullptr, lb.dz2, nullptr, H, 0));
+  {
+    ProfScope ps(m, UNITER_K_LN, st);
+    UCHECK_RC(uniter_ln_bwd(lb.dy1, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1, g1, m->LG(l, L_LN1_G),
+                            m->LG(l, L_LN1_B), M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l), pl.ln_ws,
+                            pl.ln_ws_bytes, st));
+  }
+  UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, H, g1, H, m->LP(l, L_OW), H, lb.dctx, H, UNITER_EPI_NONE,
+                 nullptr, nullptr, nullptr, 0, 0));
+  {
+    ProfScope ps(m, UNITER_K_ATTN_BWD, st);
+    UCHECK_RC(uniter_attn_bwd(lb.qkv, m->batch.attention_mask, lb.ctx, lb.lse, lb.dctx, lb.dqkv, lb.delta, B, L,
+                              nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), st));
+  }
+  UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, 3 * H, lb.dqkv, 3 * H, m->LP(l, L_QW), H, lb.dx, H,
+                 UNITER_EPI_ADD, nullptr, lb.dz1, nullptr, H, 0));
+
+  // weight / bias gradients on the side stream (accumulate into the bound grad buffers)
+  if (sd != st) {
+    UCHECK_HIP(hipEventRecord(m->ev_main[l], st));
+    UCHECK_HIP(hipStreamWaitEvent(sd, m->ev_main[l], 0));
+  }
+  UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, g2, H, lb.hact, I, m->LG(l, L_W2), I, UNITER_EPI_NONE,
+                 nullptr, nullptr, nullptr, 0, 1));
+  UCHECK_RC(uniter_colsum_f32(g2, M, H, H, m->LG(l, L_B2), 1, pl.col_ws, pl.col_ws_bytes, sd));
+  UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, I, H, M, lb.du, I, lb.y1, H, m->LG(l, L_W1), H, UNITER_EPI_NONE,
+                 nullptr, nullptr, nullptr, 0, 1));
+  UCHECK_RC(uniter_colsum_f32(lb.du, M, I, I, m->LG(l, L_B1), 1, pl.col_ws, pl.col_ws_bytes, sd));
+  UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, H, M, g1, H, lb.ctx, H, m->LG(l, L_OW), H, UNITER_EPI_NONE,
+                 nullptr, nullptr, nullptr, 0, 1));
+  UCHECK_RC(uniter_colsum_f32(g1, M, H, H, m->LG(l, L_OB), 1, pl.col_ws, pl.col_ws_bytes, sd));
+  UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkv, 3 * H, x, H, m->LG(l, L_QW), H,
+                 UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+  UCHECK_RC(uniter_colsum_f32(lb.dqkv, M, 3 * H, 3 * H, m->LG(l, L_QB), 1, pl.col_ws, pl.col_ws_bytes, sd));
+  if (sd != st) UCHECK_HIP(hipEventRecord(m->ev_side[l], sd));
+  return 0;
+}
+
+extern "C" int uniter_model_backward_embed(uniter_model_t* m) {
+  UCHECK_ARG(m, "backward_embed: null model");
+  if (!m->bwd_open) { uniter_set_error("backward_embed: call uniter_model_backward_begin first"); return UNITER_E_STATE; }
+  const uniter_config_t& c = m->cfg;
+  const int H = c.hidden_size;
+  Plan& pl = m->plan;
+  const uniter_batch_t& b = m->batch;
+  const int B = pl.B, T = pl.T, R = pl.R, L = pl.L, S = pl.S;
+  const float ph = pl.mode == 1 ? c.hidden_dropout_prob : 0.f;
+  hipStream_t st = m->st, sd = m->side;
+  const float* demb = pl.layers[0].dx;
+  const bool joint = pl.has_txt && pl.has_img;
+  UCHECK_RC(uniter_gather_rows_bwd(demb, joint ? b.gather_index : nullptr, pl.dcat, B, S, L, H, st));
+  if (pl.has_txt)
+    UCHECK_RC(uniter_txt_embed_bwd(pl.dcat, b.input_ids, b.position_ids, b.txt_type_ids, m->P(P_WORD),
+                                   m->P(P_POS), m->P(P_TYPE), m->P(P_ELN_G), m->G(P_WORD), m->G(P_POS),
+                                   m->G(P_TYPE), m->G(P_ELN_G), m->G(P_ELN_B), B, T, S, H, c.vocab_size,
+                                   c.max_position_embeddings, c.type_vocab_size, b.pos_bcast, ph, m->seed,
+                                   m->offset, pl.emb_ws, pl.emb_ws_bytes, st));
+  if (pl.has_img) {
+    UCHECK_RC(uniter_img_embed_bwd(pl.dcat, pl.imgfc, b.img_pos_feat, b.img_type_ids, m->P(P_POSL_W),
+                                   m->P(P_POSL_B), m->P(P_TYPE), m->P(P_ILN_G), m->P(P_ILN_B), m->P(P_PLN_G),
+                                   m->P(P_PLN_B), m->P(P_FLN_G), pl.img_stats, pl.d_imgfc, pl.d_posfc,
+                                   m->G(P_POSL_W), m->G(P_POSL_B), m->G(P_TYPE), m->G(P_ILN_G), m->G(P_ILN_B),
+                                   m->G(P_PLN_G), m->G(P_PLN_B), m->G(P_FLN_G), m->G(P_FLN_B), B, R, pl.T0, S, H,
+                                   c.type_vocab_size, ph, m->seed, m->offset, pl.emb_ws, pl.emb_ws_bytes, st));
+    const float* feat = b.img_masks ? pl.feat_eff : b.img_feat;
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, st, 1, 1, H, c.img_dim, B * R, pl.d_imgfc, H, feat, c.img_dim,
+                   m->G(P_IMG_W), c.img_dim, UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+    UCHECK_RC(uniter_colsum_f32(pl.d_imgfc, B * R, H, H, m->G(P_IMG_B), 1, pl.col_ws, pl.col_ws_bytes, st));
+    if (b.img_masks) {
+      // d(img_feat + mask_emb[img_masks]) = d_imgfc @ W_img; row 1 of mask_embedding sums the masked rows
+      UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, B * R, c.img_dim, H, pl.d_imgfc, H, m->P(P_IMG_W),
+                     c.img_dim, pl.d_feat, c.img_dim, UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 0));
+      UCHECK_RC(launch_masked_rowsum(pl.d_feat, b.img_masks, m->G(P_MASK_EMB) + c.img_dim, B * R, c.img_dim, st));
+    }
+  }
+  if (sd != st) {   // join: everything the caller does next on `stream` sees all gradients
+    UCHECK_HIP(hipEventRecord(m->ev_side[c.num_hidden_layers], sd));
+    UCHECK_HIP(hipStreamWaitEvent(st, m->ev_side[c.num_hidden_layers], 0));
+  }
+  m->bwd_open = false;
+  return 0;
+}
+
+extern "C" int uniter_model_backward(uniter_model_t* m, const uniter_batch_t* b, const float* d_hidden,
+                                     int all_layers, uint64_t seed, uint32_t offset, void* ws, size_t ws_bytes,
+                                     void* stream, void* side_stream) {
+  UCHECK_RC(uniter_model_backward_begin(m, b, d_hidden, all_layers, seed, offset, ws, ws_bytes, stream, side_stream));
+  for (int l = m->cfg.num_hidden_layers - 1; l >= 0; --l) UCHECK_RC(uniter_model_backward_layer(m, l));
+  return uniter_model_backward_embed(m);
+}
+
+extern "C" int uniter_prof_enable(uniter_model_t* m, int kind) {
+  UCHECK_ARG(m && kind >= 0 && kind < UNITER_K_COUNT, "prof_enable: bad argument");
+  m->prof_kind = kind;
+  m->prof_used = 0;
+  if (kind && m->prof_ev.empty()) {
+    m->prof_ev.resize(8192);
+    for (auto& e : m->prof_ev) UCHECK_HIP(hipEventCreate(&e));
+  }
+  return 0;
+}
+
+extern "C" int uniter_prof_collect(uniter_model_t* m, int* n_launches, double* total_ms) {
+  UCHECK_ARG(m && n_launches && total_ms, "prof_collect: null pointer");
+  double tot = 0.0;
+  int n = 0;
+  for (size_t i = 0; i + 1 < m->prof_used; i += 2) {
+    UCHECK_HIP(hipEventSynchronize(m->prof_ev[i + 1]));
+    float ms = 0.f;
+    UCHECK_HIP(hipEventElapsedTime(&ms, m->prof_ev[i], m->prof_ev[i + 1]));
+    tot += ms;
+    ++n;
+  }
+  *n_launches = n; *total_ms = tot;
+  m->prof_used = 0;
+  return 0;
+}

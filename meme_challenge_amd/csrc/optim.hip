@@ -1,0 +1,135 @@
+// Fused optimizer step over flat fp32 buffers.
+//
+// Replaces, in one HBM pass, TrainerTemplate.average_gradients
+// (train_template.py:89-92), torch.nn.utils.clip_grad_norm_ (:104), the
+// per-tensor torch.optim.Adam / AdamW step configured by get_optimizer
+// (utils/optim_utils.py:9-46) and optimizer.zero_grad (:107): 212 tensors x ~5
+// elementwise launches in the reference.  Algorithmic traffic: read p,g,m,v +
+// write p,m,v (+ zeroed g) = 32 B per parameter.
+//
+// The global gradient norm is reduced on the device into a double and consumed
+// by the step kernel from device memory: no host synchronisation.
+// Per-64-element chunk flags carry the parameter-group split:
+//   0 = parameter received no gradient this step (torch skips grad=None params),
+//   1 = no weight decay ('bias' / 'LayerNorm.*' names), 2 = weight decay.
+#include "common.h"
+
+namespace {
+
+constexpr int CHUNK = 64;
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
+                                                    const uint8_t* __restrict__ flags, size_t n4,
+                                                    double* __restrict__ part) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    if (flags[(i * 4) / CHUNK] == 0) continue;
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    acc += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ part, int n,
+                                                          double* __restrict__ out) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+struct AdamArgs {
+  float* p; float* g; float* m; float* v;
+  const uint8_t* flags;
+  size_t n4;
+  const double* sumsq;
+  float gscale, max_norm, lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2;
+  int adamw, zero_grads;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
+  float coef = a.gscale;
+  if (a.max_norm > 0.f && a.sumsq) {
+    const float total = (float)sqrt(a.sumsq[0]) * a.gscale;         // norm of the averaged grads
+    const float c = a.max_norm / (total + 1e-6f);                   // clip_grad_norm_
+    coef *= c < 1.0f ? c : 1.0f;
+  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) {
+    const uint8_t f = a.flags[(i * 4) / CHUNK];
+    if (f == 0) continue;
+    const float wd = f == 2 ? a.wd : 0.f;
+    f32x4 p = reinterpret_cast<f32x4*>(a.p)[i];
+    f32x4 g = reinterpret_cast<f32x4*>(a.g)[i];
+    f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
+    f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gg = g[e] * coef;
+      float pp = p[e];
+      if (a.adamw) pp *= 1.0f - a.lr * wd;
+      else gg += wd * pp;
+      m[e] = a.b1 * m[e] + (1.0f - a.b1) * gg;
+      v[e] = a.b2 * v[e] + (1.0f - a.b2) * gg * gg;
+      const float denom = sqrtf(v[e]) * a.inv_sqrt_bc2 + a.eps;
+      p[e] = pp - a.step_size * (m[e] / denom);
+    }
+    reinterpret_cast<f32x4*>(a.p)[i] = p;
+    reinterpret_cast<f32x4*>(a.m)[i] = m;
+    reinterpret_cast<f32x4*>(a.v)[i] = v;
+    if (a.zero_grads) reinterpret_cast<f32x4*>(a.g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+inline int sumsq_blocks(size_t n) {
+  size_t b = (n / 4 + 255) / 256;
+  return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
+}
+
+}  // namespace
+
+extern "C" size_t uniter_grad_sumsq_ws_bytes(size_t n) { return (size_t)sumsq_blocks(n) * sizeof(double); }
+
+extern "C" int uniter_grad_sumsq(const float* grads, const uint8_t* chunk_flags, size_t n, double* sumsq,
+                                 void* ws, size_t ws_bytes, void* stream) {
+  UCHECK_ARG(grads && chunk_flags && sumsq && ws, "grad_sumsq: null pointer");
+  UCHECK_SHAPE(n % CHUNK == 0, "grad_sumsq: n must be a multiple of 64");
+  UCHECK_ARG(ws_bytes >= uniter_grad_sumsq_ws_bytes(n), "grad_sumsq: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = sumsq_blocks(n);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, grads, chunk_flags, n / 4, (double*)ws);
+  UCHECK_LAUNCH();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, sumsq);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale,
+                                float max_norm, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, int step, int adamw, int zero_grads, void* stream) {
+  UCHECK_ARG(params && grads && exp_avg && exp_avg_sq && chunk_flags, "adam_step: null pointer");
+  UCHECK_SHAPE(n % CHUNK == 0, "adam_step: n must be a multiple of 64");
+  UCHECK_ARG(step >= 1, "adam_step: step must be >= 1");
+  UCHECK_ARG(max_norm <= 0.f || sumsq, "adam_step: clipping needs sumsq");
+  AdamArgs a;
+  a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.flags = chunk_flags; a.n4 = n / 4;
+  a.sumsq = sumsq; a.gscale = grad_scale; a.max_norm = max_norm; a.lr = lr; a.b1 = beta1; a.b2 = beta2;
+  a.eps = eps; a.wd = weight_decay; a.adamw = adamw; a.zero_grads = zero_grads;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.step_size = (float)((double)lr / bc1);
+  a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const int nb = sumsq_blocks(n);
+  hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+  UCHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,765 @@
+"""Host-side mirror of the reference's UNITER module surface, executing on
+libuniter_hip.so.
+
+Mirrors (same names, constructor / forward signatures, state_dict keys, error
+behaviour):
+  UniterConfig               model/model.py:24-114
+  UniterPreTrainedModel      model/model.py:117-214  (init_weights, from_pretrained)
+  UniterTextEmbeddings       model/model.py:217-245
+  UniterImageEmbeddings      model/model.py:248-272
+  UniterEncoder / BertLayer… model/model.py:275-292, model/layer.py:53-170
+  BertPooler                 model/layer.py:173-185
+  UniterModel                model/model.py:295-367
+
+The nn.Module tree exists to own parameters under the reference's names; the
+arithmetic of ``UniterModel.forward`` and of its backward is one kernel schedule
+inside the library (csrc/model.cpp).  All parameters (and gradients) live in one
+flat fp32 device buffer each (``ParamStore``) so that the optimizer step and the
+data-parallel gradient exchange are single-buffer operations; the
+``nn.Parameter`` objects are views into it.
+
+There is no CPU / eager fallback: tensors must be on the GPU and the library
+must be built, otherwise a ``UniterHipError`` is raised.
+"""
+import copy
+import ctypes as C
+import json
+import logging
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import UniterBatchC, UniterConfigC, UniterHipError, check, ptr
+
+logger = logging.getLogger(__name__)
+
+CHUNK = 64          # floats; granularity of the optimizer's per-chunk flags
+
+
+class UniterConfig(object):
+    """Configuration of a `UniterModel` (mirror of model/model.py:24-114)."""
+
+    def __init__(self, vocab_size_or_config_json_file, hidden_size=768,
+                 num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, hidden_act="gelu",
+                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                 max_position_embeddings=512, type_vocab_size=2,
+                 initializer_range=0.02):
+        if isinstance(vocab_size_or_config_json_file, str):
+            with open(vocab_size_or_config_json_file, "r", encoding='utf-8') as reader:
+                json_config = json.loads(reader.read())
+            for key, value in json_config.items():
+                self.__dict__[key] = value
+        elif isinstance(vocab_size_or_config_json_file, int):
+            self.vocab_size = vocab_size_or_config_json_file
+            self.hidden_size = hidden_size
+            self.num_hidden_layers = num_hidden_layers
+            self.num_attention_heads = num_attention_heads
+            self.hidden_act = hidden_act
+            self.intermediate_size = intermediate_size
+            self.hidden_dropout_prob = hidden_dropout_prob
+            self.attention_probs_dropout_prob = attention_probs_dropout_prob
+            self.max_position_embeddings = max_position_embeddings
+            self.type_vocab_size = type_vocab_size
+            self.initializer_range = initializer_range
+        else:
+            raise ValueError("First argument must be either a vocabulary size "
+                             "(int) or the path to a pretrained model config "
+                             "file (str)")
+
+    @classmethod
+    def from_dict(cls, json_object):
+        config = UniterConfig(vocab_size_or_config_json_file=-1)
+        for key, value in json_object.items():
+            config.__dict__[key] = value
+        return config
+
+    @classmethod
+    def from_json_file(cls, json_file):
+        with open(json_file, "r", encoding='utf-8') as reader:
+            text = reader.read()
+        return cls.from_dict(json.loads(text))
+
+    def __repr__(self):
+        return str(self.to_json_string())
+
+    def to_dict(self):
+        return copy.deepcopy(self.__dict__)
+
+    def to_json_string(self):
+        return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
+
+
+# --------------------------------------------------------------------------- #
+# flat parameter / gradient storage
+# --------------------------------------------------------------------------- #
+def _round_up(x, a):
+    return (x + a - 1) // a * a
+
+
+class ParamStore(object):
+    """One flat fp32 buffer for parameters and one for gradients.
+
+    Layout (backward-completion order, so that a gradient bucket is a contiguous
+    slice): [head & pooler | layer nl-1 | ... | layer 0 | embeddings].  Inside a
+    layer query/key/value weights are adjacent (one [3H,H] GEMM operand), as are
+    their biases.  Every tensor starts on a 64-float boundary (optimizer flag
+    granularity).
+    """
+
+    def __init__(self, module):
+        named = list(module.named_parameters())
+        if not named:
+            raise UniterHipError('module has no parameters')
+        dev = named[0][1].device
+        if dev.type != 'cuda':
+            raise UniterHipError('parameters must be on the GPU before the first forward '
+                                 '(model.cuda()); got %s' % dev)
+        for n, p in named:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise UniterHipError('parameter %s must be float32 on %s' % (n, dev))
+        self.device = dev
+        order, self.buckets = self._order(named)
+        self.names = [n for n, _ in order]
+        offs, off = {}, 0
+        for n, p in order:
+            offs[n] = off
+            off += _round_up(p.numel(), CHUNK)
+        self.numel = off
+        self.offsets = offs
+        self.flat_params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.params = {}
+        with torch.no_grad():
+            for n, p in order:
+                o, k = offs[n], p.numel()
+                view = self.flat_params[o:o + k].view(p.shape)
+                view.copy_(p.data)
+                old_grad = p.grad
+                p.data = view
+                gview = self.flat_grads[o:o + k].view(p.shape)
+                if old_grad is not None:
+                    gview.copy_(old_grad)
+                p.grad = gview
+                self.params[n] = p
+        # bucket boundaries as (start, end) element offsets
+        self.bucket_ranges = []
+        for names in self.buckets:
+            s = min(offs[n] for n in names)
+            e = max(offs[n] + _round_up(self.params[n].numel(), CHUNK) for n in names)
+            self.bucket_ranges.append((s, e))
+        self.touched = set()
+
+    @staticmethod
+    def _order(named):
+        """Group parameter names into backward-order buckets."""
+        import re
+        by = dict(named)
+        head, layers, emb = [], {}, []
+        for n, _ in named:
+            m = re.search(r'encoder\.layer\.(\d+)\.', n)
+            if m:
+                layers.setdefault(int(m.group(1)), []).append(n)
+            elif 'embeddings.' in n:
+                emb.append(n)
+            else:
+                head.append(n)
+
+        def layer_key(n):
+            ranks = ['attention.self.query.weight', 'attention.self.key.weight',
+                     'attention.self.value.weight', 'attention.self.query.bias',
+                     'attention.self.key.bias', 'attention.self.value.bias']
+            for i, r in enumerate(ranks):
+                if n.endswith(r):
+                    return (0, i)
+            return (1, 0)
+        buckets, order = [], []
+        if head:
+            buckets.append(head)
+        for l in sorted(layers, reverse=True):
+            names = layers[l]
+            fused = sorted([n for n in names if layer_key(n)[0] == 0], key=layer_key)
+            rest = [n for n in names if layer_key(n)[0] == 1]
+            buckets.append(fused + rest)
+        if emb:
+            buckets.append(emb)
+        for b in buckets:
+            order += [(n, by[n]) for n in b]
+        return order, buckets
+
+    def is_current(self):
+        for n, p in self.params.items():
+            o = self.offsets[n]
+            if p.data_ptr() != self.flat_params.data_ptr() + 4 * o:
+                return False
+        return True
+
+    def reattach_grads(self):
+        for n, p in self.params.items():
+            o, k = self.offsets[n], p.numel()
+            g = p.grad
+            if g is None or g.data_ptr() != self.flat_grads.data_ptr() + 4 * o:
+                p.grad = self.flat_grads[o:o + k].view(p.shape)
+
+    def touch(self, names):
+        self.touched.update(names)
+
+    def zero_grads(self):
+        self.flat_grads.zero_()
+        self.touched.clear()
+        self.reattach_grads()
+
+
+def _find_store(module):
+    return getattr(module, '_param_store', None)
+
+
+def ensure_store(root):
+    """(Re)build the flat store of `root` if parameters were moved / replaced."""
+    st = _find_store(root)
+    if st is None or not st.is_current():
+        st = ParamStore(root)
+        object.__setattr__(root, '_param_store', st)
+        for m in root.modules():
+            if m is not root and hasattr(m, '_param_store'):
+                object.__setattr__(m, '_param_store', None)
+            if isinstance(m, UniterModel):
+                m._destroy_handle()
+                object.__setattr__(m, '_store_root', root)
+    else:
+        st.reattach_grads()
+    return st
+
+
+# --------------------------------------------------------------------------- #
+# parameter containers (reference module names => identical state_dict keys)
+# --------------------------------------------------------------------------- #
+class _ParamLayerNorm(nn.Module):
+    """Parameter holder for a LayerNorm(eps=1e-12) (Apex FusedLayerNorm in the
+    reference: model/model.py:229,252,253,258; model/layer.py:108,149)."""
+
+    def __init__(self, hidden_size, eps=1e-12):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.bias = nn.Parameter(torch.zeros(hidden_size))
+        self.eps = eps
+
+
+class _ParamLinear(nn.Module):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.zeros(out_features))
+
+
+class _ParamEmbedding(nn.Module):
+    def __init__(self, num_embeddings, embedding_dim, padding_idx=None):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+        self.padding_idx = padding_idx
+        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim))
+
+
+class UniterTextEmbeddings(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = _ParamEmbedding(config.vocab_size, config.hidden_size, padding_idx=0)
+        self.position_embeddings = _ParamEmbedding(config.max_position_embeddings, config.hidden_size)
+        self.token_type_embeddings = _ParamEmbedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = _ParamLayerNorm(config.hidden_size)
+
+
+class UniterImageEmbeddings(nn.Module):
+    def __init__(self, config, img_dim):
+        super().__init__()
+        self.img_linear = _ParamLinear(img_dim, config.hidden_size)
+        self.img_layer_norm = _ParamLayerNorm(config.hidden_size)
+        self.pos_layer_norm = _ParamLayerNorm(config.hidden_size)
+        self.pos_linear = _ParamLinear(7, config.hidden_size)
+        self.mask_embedding = _ParamEmbedding(2, img_dim, padding_idx=0)
+        self.LayerNorm = _ParamLayerNorm(config.hidden_size)
+
+
+class BertSelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError(
+                "The hidden size (%d) is not a multiple of the number of attention "
+                "heads (%d)" % (config.hidden_size, config.num_attention_heads))
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = int(config.hidden_size / config.num_attention_heads)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query = _ParamLinear(config.hidden_size, self.all_head_size)
+        self.key = _ParamLinear(config.hidden_size, self.all_head_size)
+        self.value = _ParamLinear(config.hidden_size, self.all_head_size)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = _ParamLinear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = _ParamLayerNorm(config.hidden_size)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_act != 'gelu':
+            raise ValueError('only hidden_act="gelu" (erf form, model/layer.py:31-37) is built')
+        self.dense = _ParamLinear(config.hidden_size, config.intermediate_size)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = _ParamLinear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = _ParamLayerNorm(config.hidden_size)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.attention = BertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+
+class UniterEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(config) for _ in range(config.num_hidden_layers)])
+
+
+# --------------------------------------------------------------------------- #
+# small autograd bridges (pooler, head)
+# --------------------------------------------------------------------------- #
+class _PoolerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hidden, weight, bias, module):
+        _lib.require_gpu_tensor(hidden, torch.float32, 'hidden')
+        hidden = hidden.contiguous()
+        B, L, H = hidden.shape
+        pooled = torch.empty(B, H, dtype=torch.float32, device=hidden.device)
+        check(_lib.lib().uniter_pooler_fwd(ptr(hidden), ptr(weight), ptr(bias), ptr(pooled),
+                                           B, L, H, _lib.cur_stream()), 'uniter_pooler_fwd')
+        ctx.save_for_backward(hidden, pooled)
+        ctx.module = module
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        hidden, pooled = ctx.saved_tensors
+        mod = ctx.module
+        B, L, H = hidden.shape
+        dpooled = dpooled.contiguous()
+        w, b = mod.dense.weight, mod.dense.bias
+        _ensure_grad(w)
+        _ensure_grad(b)
+        dhidden = None
+        if ctx.needs_input_grad[0]:
+            dhidden = torch.zeros_like(hidden)
+        check(_lib.lib().uniter_pooler_bwd(ptr(dpooled), ptr(pooled), ptr(hidden), ptr(w),
+                                           ptr(w.grad), ptr(b.grad), ptr(dhidden), B, L, H, 0,
+                                           _lib.cur_stream()), 'uniter_pooler_bwd')
+        _mark_touched(mod, (w, b))
+        return dhidden, None, None, None
+
+
+class _LinearSmallFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, module):
+        _lib.require_gpu_tensor(x, torch.float32, 'input')
+        x = x.contiguous()
+        B, H = x.shape
+        Cn = weight.shape[0]
+        y = torch.empty(B, Cn, dtype=torch.float32, device=x.device)
+        check(_lib.lib().uniter_linear_small_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), B, H, Cn,
+                                                 _lib.cur_stream()), 'uniter_linear_small_fwd')
+        ctx.save_for_backward(x)
+        ctx.module = module
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        mod = ctx.module
+        dy = dy.contiguous()
+        B, H = x.shape
+        w, b = mod.weight, mod.bias
+        Cn = w.shape[0]
+        _ensure_grad(w)
+        _ensure_grad(b)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().uniter_linear_small_bwd(ptr(dy), ptr(x), ptr(w), ptr(dx), ptr(w.grad),
+                                                 ptr(b.grad), B, H, Cn, _lib.cur_stream()),
+              'uniter_linear_small_bwd')
+        _mark_touched(mod, (w, b))
+        return dx, None, None, None
+
+
+def _ensure_grad(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+
+
+def _mark_touched(module, params):
+    root = getattr(module, '_store_root_ref', None)
+    st = _find_store(root) if root is not None else None
+    if st is not None:
+        ids = {id(p) for p in params}
+        st.touch([n for n, p in st.params.items() if id(p) in ids])
+
+
+class BertPooler(nn.Module):
+    """model/layer.py:173-185: tanh(dense(hidden[:, 0]))."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = _ParamLinear(config.hidden_size, config.hidden_size)
+
+    def forward(self, hidden_states):
+        anchor = self.dense.weight if torch.is_grad_enabled() else self.dense.weight.detach()
+        return _PoolerFn.apply(hidden_states, anchor, self.dense.bias, self)
+
+
+class HipLinear(nn.Module):
+    """nn.Linear(hidden, n_classes) for tiny n_classes (model/meme_uniter.py:15,20)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        # nn.Linear default init (kaiming_uniform(a=sqrt(5)) / uniform bias)
+        import math
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_features)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return _LinearSmallFn.apply(x, self.weight, self.bias, self)
+
+
+# --------------------------------------------------------------------------- #
+# the encoder as one autograd node
+# --------------------------------------------------------------------------- #
+class _UniterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, batch, keep, all_layers, mode, seed, offset):
+        lib = _lib.lib()
+        cfg = model.config
+        B, L = batch.B, batch.L
+        nl, H = cfg.num_hidden_layers, cfg.hidden_size
+        dev = anchor.device
+        shape = (nl, B, L, H) if all_layers else (B, L, H)
+        hidden = torch.empty(shape, dtype=torch.float32, device=dev)
+        nbytes = lib.uniter_model_ws_bytes(model._handle, B, batch.T if batch.input_ids else 0,
+                                           batch.R if batch.img_feat else 0, L, mode)
+        ws = model._get_ws(nbytes, mode)
+        check(lib.uniter_model_forward(model._handle, C.byref(batch), ptr(hidden), int(all_layers),
+                                       mode, seed, offset, ptr(ws), nbytes, _lib.cur_stream()),
+              'uniter_model_forward')
+        ctx.model, ctx.batch, ctx.keep, ctx.ws, ctx.nbytes = model, batch, keep, ws, nbytes
+        ctx.all_layers, ctx.seed, ctx.offset = all_layers, seed, offset
+        return hidden
+
+    @staticmethod
+    def backward(ctx, d_hidden):
+        model = ctx.model
+        d_hidden = d_hidden.contiguous()
+        model._run_backward(ctx.batch, d_hidden, ctx.all_layers, ctx.seed, ctx.offset, ctx.ws,
+                            ctx.nbytes)
+        ctx.ws = None
+        return (None,) * 8
+
+
+class UniterPreTrainedModel(nn.Module):
+    """Weights initialisation + pretrained loading (mirror of model/model.py:117-214)."""
+
+    def __init__(self, config, *inputs, **kwargs):
+        super().__init__()
+        if not isinstance(config, UniterConfig):
+            raise ValueError(
+                "Parameter config in `{}(config)` should be an instance of "
+                "class `UniterConfig`. To create a model from a Google "
+                "pretrained model use "
+                "`model = {}.from_pretrained(PRETRAINED_MODEL_NAME)`".format(
+                    self.__class__.__name__, self.__class__.__name__))
+        self.config = config
+
+    def init_weights(self, module):
+        """Linear/Embedding weights ~ N(0, initializer_range); biases 0; LN 1/0
+        (model/model.py:133-146)."""
+        if isinstance(module, (_ParamLinear, _ParamEmbedding, HipLinear)):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        elif isinstance(module, _ParamLayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, (_ParamLinear, HipLinear)) and module.bias is not None:
+            module.bias.data.zero_()
+
+    @classmethod
+    def from_pretrained(cls, config_file, state_dict, *inputs, **kwargs):
+        """Instantiate from a config json and a state dict (model/model.py:148-214):
+        gamma/beta -> weight/bias renames, optional 'bert.' prefix, missing /
+        unexpected keys logged, shape errors raise RuntimeError."""
+        config = UniterConfig.from_json_file(config_file)
+        logger.info("Model config {}".format(config))
+        model = cls(config, *inputs, **kwargs)
+        old_keys, new_keys = [], []
+        for key in state_dict.keys():
+            new_key = None
+            if 'gamma' in key:
+                new_key = key.replace('gamma', 'weight')
+            if 'beta' in key:
+                new_key = key.replace('beta', 'bias')
+            if new_key:
+                old_keys.append(key)
+                new_keys.append(new_key)
+        for old_key, new_key in zip(old_keys, new_keys):
+            state_dict[new_key] = state_dict.pop(old_key)
+        missing_keys, unexpected_keys, error_msgs = [], [], []
+        metadata = getattr(state_dict, '_metadata', None)
+        state_dict = state_dict.copy()
+        if metadata is not None:
+            state_dict._metadata = metadata
+
+        def load(module, prefix=''):
+            local_metadata = ({} if metadata is None else metadata.get(prefix[:-1], {}))
+            module._load_from_state_dict(state_dict, prefix, local_metadata, True, missing_keys,
+                                         unexpected_keys, error_msgs)
+            for name, child in module._modules.items():
+                if child is not None:
+                    load(child, prefix + name + '.')
+        start_prefix = ''
+        if not hasattr(model, 'bert') and any(s.startswith('bert.') for s in state_dict.keys()):
+            start_prefix = 'bert.'
+        load(model, prefix=start_prefix)
+        if len(missing_keys) > 0:
+            logger.info("Weights of {} not initialized from pretrained model: {}".format(
+                model.__class__.__name__, missing_keys))
+        if len(unexpected_keys) > 0:
+            logger.info("Weights from pretrained model not used in {}: {}".format(
+                model.__class__.__name__, unexpected_keys))
+        if len(error_msgs) > 0:
+            raise RuntimeError('Error(s) in loading state_dict for {}:\n\t{}'.format(
+                model.__class__.__name__, "\n\t".join(error_msgs)))
+        return model
+
+
+class UniterModel(UniterPreTrainedModel):
+    """Joint vision-language encoder (mirror of model/model.py:295-367)."""
+
+    def __init__(self, config, img_dim):
+        super().__init__(config)
+        self.img_dim = img_dim
+        self.embeddings = UniterTextEmbeddings(config)
+        self.img_embeddings = UniterImageEmbeddings(config, img_dim)
+        self.encoder = UniterEncoder(config)
+        self.pooler = BertPooler(config)
+        self.apply(self.init_weights)
+        self._handle = None
+        self._prefix_names = None
+        object.__setattr__(self, '_store_root', None)
+        self._ws_cache = {}
+        self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self._offset = 0
+        self._grad_hook = None       # callable(kind, index) used by the DP gradient exchange
+        self._side_stream = None
+        self.use_side_stream = True
+
+    # -- plumbing ------------------------------------------------------------
+    def set_dropout_seed(self, seed, offset=0):
+        self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._offset = int(offset)
+
+    def _c_config(self):
+        c = self.config
+        return UniterConfigC(c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
+                             c.intermediate_size, c.vocab_size, c.max_position_embeddings,
+                             c.type_vocab_size, self.img_dim, float(c.hidden_dropout_prob),
+                             float(c.attention_probs_dropout_prob))
+
+    def _root(self):
+        return self._store_root if self._store_root is not None else self
+
+    def _ensure_handle(self):
+        root = self._root()
+        st = _find_store(root)
+        if st is None or not st.is_current() or self._handle is None:
+            # the outermost module that owns this model decides the flat layout
+            st = ensure_store(root)
+            for m in root.modules():
+                object.__setattr__(m, '_store_root_ref', root)
+            lib = _lib.lib()
+            cc = self._c_config()
+            n = lib.uniter_num_params(C.byref(cc))
+            mine = dict(self.named_parameters())
+            pa, ga = (C.c_void_p * n)(), (C.c_void_p * n)()
+            for i in range(n):
+                name = lib.uniter_param_name(C.byref(cc), i).decode()
+                p = mine[name]
+                pa[i] = p.data_ptr()
+                ga[i] = p.grad.data_ptr()
+            h = C.c_void_p()
+            check(lib.uniter_model_create(C.byref(cc), pa, ga, n, C.byref(h)), 'uniter_model_create')
+            self._destroy_handle()
+            self._handle = h
+            self._prefix_names = None
+        return st
+
+    def _destroy_handle(self):
+        if getattr(self, '_handle', None) is not None:
+            try:
+                _lib.lib().uniter_model_destroy(self._handle)
+            except Exception:       # interpreter shutdown
+                pass
+            self._handle = None
+
+    def __del__(self):
+        self._destroy_handle()
+
+    def _get_ws(self, nbytes, mode):
+        if mode != 0:
+            # activations must survive until backward: fresh buffer per training forward
+            return torch.empty(nbytes, dtype=torch.uint8, device=self.embeddings.LayerNorm.weight.device)
+        ws = self._ws_cache.get(0)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.embeddings.LayerNorm.weight.device)
+            self._ws_cache[0] = ws
+        return ws
+
+    def _touched_names(self, batch):
+        """Parameter names (in the root's namespace) that receive a gradient."""
+        root = self._root()
+        if self._prefix_names is None:
+            ids = {id(p): n for n, p in root.named_parameters()}
+            self._prefix_names = {n: ids[id(p)] for n, p in self.named_parameters()}
+        out = []
+        for local, full in self._prefix_names.items():
+            if local.startswith('pooler.'):
+                continue
+            if local.startswith('img_embeddings.'):
+                if not batch.img_feat:
+                    continue
+                if 'mask_embedding' in local and not batch.img_masks:
+                    continue
+            if local.startswith('embeddings.') and 'token_type' not in local and not batch.input_ids:
+                continue
+            out.append(full)
+        return out
+
+    def _run_backward(self, batch, d_hidden, all_layers, seed, offset, ws, nbytes):
+        lib = _lib.lib()
+        nl = self.config.num_hidden_layers
+        st = _find_store(self._root())
+        st.reattach_grads()
+        main = torch.cuda.current_stream()
+        side = None
+        if self.use_side_stream:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=d_hidden.device)
+            side = self._side_stream
+            side.wait_stream(main)
+        side_ptr = C.c_void_p(side.cuda_stream) if side is not None else None
+        check(lib.uniter_model_backward_begin(self._handle, C.byref(batch), ptr(d_hidden),
+                                              int(all_layers), seed, offset, ptr(ws), nbytes,
+                                              _lib.cur_stream(), side_ptr), 'uniter_model_backward_begin')
+        hook = self._grad_hook
+        if hook is not None:
+            hook('begin', None, side or main)
+        for l in range(nl - 1, -1, -1):
+            check(lib.uniter_model_backward_layer(self._handle, l), 'uniter_model_backward_layer')
+            if hook is not None:
+                hook('layer', l, side or main)
+        check(lib.uniter_model_backward_embed(self._handle), 'uniter_model_backward_embed')
+        st.touch(self._touched_names(batch))
+        if hook is not None:
+            hook('embed', None, main)
+
+    # -- the reference's public surface ---------------------------------------
+    def forward(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
+                gather_index=None, img_masks=None, output_all_encoded_layers=True,
+                txt_type_ids=None, img_type_ids=None):
+        """Same signature / return as model/model.py:336-367: list of per-layer
+        hidden states, or the last layer's [B, L, H] tensor."""
+        self._ensure_handle()
+        dev = self.embeddings.LayerNorm.weight.device
+        keep = []
+
+        def prep(t, dtype, name):
+            if t is None:
+                return None
+            if not torch.is_tensor(t):
+                raise UniterHipError('%s must be a tensor' % name)
+            if t.device != dev:
+                raise UniterHipError('%s is on %s but the model is on %s (no implicit transfers: '
+                                     'move the batch with batch_to_device)' % (name, t.device, dev))
+            if t.dtype != dtype:
+                t = t.to(dtype)
+            t = t.contiguous()
+            keep.append(t)
+            return t
+
+        if input_ids is None and img_feat is None:
+            raise ValueError('need input_ids and/or img_feat')
+        input_ids = prep(input_ids, torch.int64, 'input_ids')
+        position_ids = prep(position_ids, torch.int64, 'position_ids')
+        txt_type_ids = prep(txt_type_ids, torch.int64, 'txt_type_ids')
+        img_feat = prep(img_feat, torch.float32, 'img_feat')
+        img_pos_feat = prep(img_pos_feat, torch.float32, 'img_pos_feat')
+        img_type_ids = prep(img_type_ids, torch.int64, 'img_type_ids')
+        img_masks = prep(img_masks, torch.int64, 'img_masks')
+        attention_mask = prep(attention_mask, torch.float32, 'attention_mask')
+        gather_index = prep(gather_index, torch.int64, 'gather_index')
+        if input_ids is not None and img_feat is not None and gather_index is None:
+            raise ValueError('joint text+image input needs gather_index (model/model.py:327-333)')
+
+        b = UniterBatchC()
+        B = (input_ids if input_ids is not None else img_feat).shape[0]
+        b.B = B
+        b.T = input_ids.shape[1] if input_ids is not None else 0
+        b.R = img_feat.shape[1] if img_feat is not None else 0
+        b.L = attention_mask.shape[1]
+        if attention_mask.shape[0] != B:
+            raise ValueError('attention_mask batch size mismatch')
+        if input_ids is not None:
+            if position_ids is None:
+                raise ValueError('position_ids required with input_ids')
+            b.pos_bcast = 1 if (position_ids.shape[0] == 1 and B != 1) else 0
+            if position_ids.shape[-1] != b.T:
+                raise ValueError('position_ids length mismatch')
+        if img_feat is not None:
+            if img_feat.shape[2] != self.img_dim:
+                raise ValueError('img_feat last dim %d != img_dim %d' % (img_feat.shape[2], self.img_dim))
+            if img_pos_feat is None or tuple(img_pos_feat.shape) != (B, b.R, 7):
+                raise ValueError('img_pos_feat must be [B, R, 7]')
+        if gather_index is not None and tuple(gather_index.shape) != (B, b.L):
+            raise ValueError('gather_index must be [B, L] with L = attention_mask.shape[1]')
+        for fld, t in (('input_ids', input_ids), ('position_ids', position_ids),
+                       ('txt_type_ids', txt_type_ids), ('img_feat', img_feat),
+                       ('img_pos_feat', img_pos_feat), ('img_type_ids', img_type_ids),
+                       ('img_masks', img_masks), ('attention_mask', attention_mask),
+                       ('gather_index', gather_index)):
+            setattr(b, fld, t.data_ptr() if t is not None else None)
+
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        mode = 0 if not grad else (1 if self.training else 2)
+        seed, offset = self._seed, self._offset
+        if mode == 1:
+            self._offset = (self._offset + 1) & 0xFFFFFFFF
+        anchor = self.embeddings.LayerNorm.weight if grad else self.embeddings.LayerNorm.weight.detach()
+        hidden = _UniterFn.apply(anchor, self, b, keep, bool(output_all_encoded_layers), mode, seed, offset)
+        if output_all_encoded_layers:
+            return [hidden[i] for i in range(self.config.num_hidden_layers)]
+        return hidden

@@ -1,0 +1,87 @@
+"""Host helpers that define the hot path's inputs (mirror of utils/utils.py:111-141
+and of the loss / batch plumbing in train_template.py)."""
+import random
+
+import numpy as np
+import torch
+
+
+def get_gather_index(txt_lens, num_bbs, batch_size, max_len, out_size):
+    """utils/utils.py:111-117: identity, with [tl, tl+nbb) redirected to the
+    image rows (offset max_len) of cat([txt, img])."""
+    assert len(txt_lens) == len(num_bbs) == batch_size
+    gather_index = torch.arange(0, out_size, dtype=torch.long).unsqueeze(0).repeat(batch_size, 1)
+    for i, (tl, nbb) in enumerate(zip(txt_lens, num_bbs)):
+        gather_index.data[i, tl:tl + nbb] = torch.arange(max_len, max_len + nbb, dtype=torch.long).data
+    return gather_index
+
+
+def get_attention_mask(text_len, img_len):
+    """utils/utils.py:120-125: ones(tl+nbb) right-padded with zeros."""
+    n = [int(t) + int(i) for t, i in zip(text_len, img_len)]
+    mask = torch.zeros(len(n), max(n))
+    for r, k in enumerate(n):
+        mask[r, :k] = 1
+    return mask
+
+
+def pad_tensors(tensors, lens=None, pad=0):
+    """B x [T, ...] -> [B, max_len, hid] (utils/utils.py:128-141)."""
+    if lens is None:
+        lens = [t.size(0) for t in tensors]
+    max_len = max(lens)
+    bs = len(tensors)
+    hid = tensors[0].size(-1)
+    dtype = tensors[0].dtype
+    output = torch.zeros(bs, max_len, hid, dtype=dtype)
+    if pad:
+        output.data.fill_(pad)
+    for i, (t, l) in enumerate(zip(tensors, lens)):
+        output.data[i, :l, ...] = t.data
+    return output
+
+
+def set_seed(seed):
+    """utils/utils.py:100-107."""
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def make_synthetic_batch(B, T, R, seed=1234, vocab=28996, img_dim=2048, txt_lens=None,
+                         num_bbs=None, pos_label_prob=0.36, device=None):
+    """Synthetic batch with the layout of the reference collate_fn
+    (data/meme_dataset.py:152-214): input_ids ~ U{1..V-1}
+    with [CLS]=101 first, position_ids = arange(T), img_feat ~ |N(0,1)|,
+    7-d box features (x1,y1,x2,y2,w,h,w*h), compact attention mask and
+    gather_index, labels ~ Bernoulli(0.36).  Same PCG64 stream as the oracle's
+    generator so fixtures can be rebuilt anywhere."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ids = rng.integers(1, vocab, size=(B, T), dtype=np.int64)
+    ids[:, 0] = 101 if vocab > 101 else 1
+    feat = np.abs(rng.standard_normal((B, R, img_dim), dtype=np.float32))
+    xy = rng.random((B, R, 2), dtype=np.float32) * np.float32(0.7)
+    wh = rng.random((B, R, 2), dtype=np.float32) * np.float32(0.25) + np.float32(0.05)
+    pos = np.concatenate([xy, xy + wh, wh, wh[..., :1] * wh[..., 1:]], axis=-1)
+    labels = (rng.random(B) < pos_label_prob).astype(np.int64)
+    if txt_lens is None:
+        txt_lens = [T] * B
+    if num_bbs is None:
+        num_bbs = [R] * B
+    for b in range(B):
+        ids[b, txt_lens[b]:] = 0
+        feat[b, num_bbs[b]:] = 0
+        pos[b, num_bbs[b]:] = 0
+    attn = get_attention_mask(txt_lens, num_bbs)
+    gi = get_gather_index(txt_lens, num_bbs, B, T, attn.shape[1])
+    batch = {'input_ids': torch.from_numpy(ids),
+             'position_ids': torch.arange(T, dtype=torch.int64).unsqueeze(0).repeat(B, 1),
+             'img_feat': torch.from_numpy(feat),
+             'img_pos_feat': torch.from_numpy(pos.astype(np.float32)),
+             'attn_mask': attn, 'gather_index': gi,
+             'labels': torch.from_numpy(labels)}
+    if device is not None:
+        batch = {k: v.to(device) for k, v in batch.items()}
+    return batch

@@ -1,0 +1,79 @@
+"""GPU: fp32 MFMA GEMM (uniter_gemm_f32) against a float64 host product."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(lib, L, cfg, akm, bkm, M, N, K, epi, beta, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn((K, M) if akm else (M, K), generator=g)
+    B = torch.randn((K, N) if bkm else (N, K), generator=g)
+    bias = torch.randn(N, generator=g)
+    aux = torch.randn(M, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    Am = A.t() if akm else A
+    Bm = B if bkm else B.t()
+    ref = Am.double() @ Bm.double()
+    aux_out_ref = None
+    if epi in (1, 2):
+        ref = ref + bias.double()
+    if epi == 2:
+        aux_out_ref = ref.clone()
+        ref = ref * 0.5 * (1.0 + torch.erf(ref / math.sqrt(2.0)))
+    if epi == 3:
+        x = aux.double()
+        ref = ref * (0.5 * (1 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi))
+    if epi == 4:
+        ref = ref + aux.double()
+    if beta:
+        ref = ref + C0.double()
+    dA, dB, dbias, daux, dC = (t.cuda().contiguous() for t in (A, B, bias, aux, C0))
+    daux_out = torch.empty(M, N, device='cuda')
+    rc = lib.uniter_gemm_f32_cfg(cfg, int(akm), int(bkm), M, N, K, L.ptr(dA), dA.shape[1],
+                                 L.ptr(dB), dB.shape[1], L.ptr(dC), N, epi, L.ptr(dbias),
+                                 L.ptr(daux), L.ptr(daux_out), N, beta, L.cur_stream())
+    L.check(rc, 'gemm')
+    torch.cuda.synchronize()
+    scale = math.sqrt(K)
+    err = (dC.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5 * scale * 4, (cfg, akm, bkm, M, N, K, epi, beta, err)
+    if epi == 2:
+        assert (daux_out.cpu().double() - aux_out_ref).abs().max().item() < 2e-5 * scale * 4
+
+
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_layouts_and_edges(cfg, layout):
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    akm, bkm = layout
+    # ragged M (not a tile multiple), K not a multiple of the 32-deep k-tile
+    _run(lib, L, cfg, akm, bkm, M=164, N=192, K=72, epi=0, beta=0)
+    _run(lib, L, cfg, akm, bkm, M=48, N=128, K=48 if (akm or bkm) else 64, epi=0, beta=1)
+
+
+@pytest.mark.parametrize('epi', [1, 2, 3, 4])
+def test_gemm_epilogues(epi):
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    _run(lib, L, 0, 0, 0 if epi in (1, 2) else 1, M=300, N=256, K=128, epi=epi, beta=0)
+
+
+def test_gemm_model_shapes():
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    _run(lib, L, 0, 0, 0, M=2624, N=3072, K=768, epi=2, beta=0)     # FFN up
+    _run(lib, L, 0, 0, 1, M=2624, N=768, K=3072, epi=4, beta=0)     # dgrad
+    _run(lib, L, 0, 1, 1, M=768, N=3072, K=2624, epi=0, beta=1)     # wgrad (accumulate)
+
+
+def test_gemm_rejects_bad_args():
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    x = torch.zeros(64, 64, device='cuda')
+    rc = lib.uniter_gemm_f32(0, 0, 64, 64, 62, L.ptr(x), 64, L.ptr(x), 64, L.ptr(x), 64, 0,
+                             None, None, None, 0, 0, L.cur_stream())
+    assert rc == -2 and b'multiples of 4' in lib.uniter_last_error()
