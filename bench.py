@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Headline benchmark: train samples/sec of UNITER-base fine-tuning
+(BASELINE.json: batch 16 per GPU, 36 regions x 2048-d, 128 text tokens,
+12 layers, fp32) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = forward + BCE loss + backward (+ RCCL gradient all-reduce for N>1)
++ global-norm clip + Adam + LR schedule, dropout ON (p=0.1), synthetic inputs
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+BASE = dict(attention_probs_dropout_prob=0.1, hidden_act='gelu', hidden_dropout_prob=0.1,
+            hidden_size=768, initializer_range=0.02, intermediate_size=3072,
+            max_position_embeddings=512, num_attention_heads=12, num_hidden_layers=12,
+            type_vocab_size=2, vocab_size=28996)       # == reference config/uniter-base.json
+LARGE = dict(BASE, hidden_size=1024, intermediate_size=4096, num_attention_heads=16, num_hidden_layers=24)
+
+PEAK_TFLOPS = {'f32': 157.3}       # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32)
+
+
+def flops_per_step(cfg, B, T, R):
+    """Algorithmic FLOPs: 2MNK per GEMM, bwd = 2x fwd, attention
+    QK^T and PV included, elementwise excluded.  Returns (total, ffn_only, ffn_up_fwd)."""
+    H, I, nl = cfg['hidden_size'], cfg['intermediate_size'], cfg['num_hidden_layers']
+    L = T + R
+    M = B * L
+    per_layer = 2 * M * H * 3 * H + 2 * M * H * H + 2 * 2 * M * H * I + 2 * 2 * B * L * L * H
+    fwd = nl * per_layer + 2 * B * R * 2048 * H + 2 * B * H * H + 2 * B * H
+    ffn_up_fwd = 2 * M * H * I
+    return 3 * fwd, 3 * nl * 2 * ffn_up_fwd, ffn_up_fwd
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Reported baseline only: the CPU oracle (port of the reference forward; autograd
+    backward) on BASELINE config 1 (B=4, T=64, R=36, UNITER-base, dropout on), timed on this
+    box's host cores.  A bounded sample: 1 warm-up + up to 10 steps within the budget."""
+    from oracle import uniter_oracle as O
+    from oracle import step_oracle as S
+    nthreads = torch.get_num_threads()
+    sd = {k: v.requires_grad_(True) for k, v in O.synth_state_dict(BASE, seed=0).items()}
+    b = O.synth_batch(4, 64, 36, seed=1234)
+    kw = dict(img_feat=b['img_feat'], img_pos_feat=b['img_pos_feat'], input_ids=b['input_ids'],
+              position_ids=b['position_ids'], attention_mask=b['attn_mask'],
+              gather_index=b['gather_index'], output_all_encoded_layers=False)
+
+    def step(i):
+        drop = O.DropSpec(1234, i, 0.1, 0.1)
+        loss = S.bce_with_logits(O.meme_uniter_forward(sd, BASE, drop=drop, **kw), b['labels'], 1.8)
+        grads = torch.autograd.grad(loss, [v for v in sd.values()], allow_unused=True)
+        return grads
+    step(0)
+    t0 = time.perf_counter()
+    n = 0
+    while n < 10 and (time.perf_counter() - t0) < seconds_budget:
+        step(n + 1)
+        n += 1
+    dt = (time.perf_counter() - t0) / max(n, 1)
+    return {'value': round(4.0 / dt, 3), 'unit': 'samples/s', 'cores': nthreads, 'kind': 'port',
+            'sample': 'config 1: UNITER-base B=4 T=64 R=36 fwd+bwd, %d steps after 1 warm-up, '
+                      'oracle/uniter_oracle.py (torch CPU fp32, dropout on), %.3f s/step' % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
+    ap.add_argument('--txt_len', type=int, default=128)
+    ap.add_argument('--num_bb', type=int, default=36)
+    ap.add_argument('--model', choices=['base', 'large'], default='base')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_side_stream', action='store_true')
+    ap.add_argument('--prof_kind', type=int, default=1, help='UNITER_K_* kind timed with HIP events (1 = FFN-up fwd GEMM)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if rank == 0:
+            print('warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from meme_challenge_amd import _lib
+    from meme_challenge_amd.model import UniterConfig, UniterModel
+    from meme_challenge_amd.meme_uniter import MemeUniter
+    from meme_challenge_amd.trainer import FusedAdam, TrainStep, get_scheduler
+    from meme_challenge_amd.utils import make_synthetic_batch
+    from meme_challenge_amd import dp
+    import ctypes as C
+
+    cfgd = BASE if args.model == 'base' else LARGE
+    torch.manual_seed(0)                                   # identical init on every rank
+    cfg = UniterConfig.from_dict(cfgd)
+    model = MemeUniter(UniterModel(cfg, img_dim=2048), cfg.hidden_size, 1).to(dev).train()
+    model.uniter_model.use_side_stream = not args.no_side_stream
+    model.uniter_model.set_dropout_seed(1234 + rank, 0)
+    B, T, R = args.batch, args.txt_len, args.num_bb
+    batch = make_synthetic_batch(B, T, R, seed=1234 + rank, device=dev)
+    config = dict(optimizer='adam', lr=3e-5, beta1=0.9, beta2=0.999, weight_decay=1e-3,
+                  gradient_accumulation=1, max_grad_norm=5, pos_wt=1.8, loss_func='bce_logits',
+                  scheduler='warmup_cosine', warmup_steps=500, max_epoch=30)
+    opt = FusedAdam(model, lr=config['lr'], weight_decay=config['weight_decay'])
+    sched = get_scheduler(opt, config, steps_per_epoch=1000)
+    sync = None
+    if world > 1:
+        dp.broadcast_parameters(model)
+        sync = dp.attach(model)
+    step = TrainStep(model, opt, sched, config, grad_sync=sync)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step.train_iter(batch, iters=0)
+    lib = _lib.lib()
+    handle = model.uniter_model._handle
+    barrier()
+    if args.prof_kind:
+        _lib.check(lib.uniter_prof_enable(handle, args.prof_kind))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.train_iter(batch, iters=0)
+    barrier()
+    dt = time.perf_counter() - t0
+    n_launch, tot_ms = C.c_int(0), C.c_double(0.0)
+    if args.prof_kind:
+        _lib.check(lib.uniter_prof_collect(handle, C.byref(n_launch), C.byref(tot_ms)))
+        _lib.check(lib.uniter_prof_enable(handle, 0))
+    loss = float(step.last_loss.item())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = B * world * args.steps / dt
+        total, ffn, ffn_up = flops_per_step(cfgd, B, T, R)
+        peak = PEAK_TFLOPS['f32']
+        out = {
+            'metric': 'train samples/sec UNITER-%s (36 regions, 128 tok)' % args.model,
+            'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'UNITER-%s fine-tune step (fwd + BCE + bwd + clip + Adam, dropout 0.1), '
+                                   'batch %d per GPU, %d regions x 2048, %d text tokens, fp32 (BASELINE configs[1])'
+                                   % (args.model, B, R, T),
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                       'side_stream_wgrad': not args.no_side_stream},
+            'step_mfma_frac': round(total / (ms * 1e-3) / world * world / (peak * 1e12), 4),
+            'ffn_roofline_frac': round(ffn / (ms * 1e-3) / (peak * 1e12), 4),
+            'final_loss': round(loss, 5),
+        }
+        if args.prof_kind and n_launch.value > 0:
+            avg_ms = tot_ms.value / n_launch.value
+            ach = ffn_up / (avg_ms * 1e-3) / 1e12 if args.prof_kind == 1 else None
+            out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2) if ach else None, 'peak': peak,
+                               'unit': 'TFLOP/s', 'frac': round(ach / peak, 4) if ach else None,
+                               'traffic': None,
+                               'kernel': 'gemm_f32_kernel<...,TAG=1> (FFN-up fwd: M=%d N=%d K=%d, bias+GELU epilogue)'
+                                         % (B * (T + R), cfgd['intermediate_size'], cfgd['hidden_size']),
+                               'launches': n_launch.value, 'avg_ms': round(avg_ms, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

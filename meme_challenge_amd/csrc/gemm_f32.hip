@@ -75,6 +75,35 @@ __device__ __forceinline__ void tile_load(f32x4 (&reg)[R / 32], const float* __r
   }
 }
 
+// Branch-free variant: raw buffer loads with hardware range checking (out-of-range rows of
+// a k-contiguous operand and out-of-range k-rows of a k-major operand read as 0).  Needs
+// K % 32 == 0 for k-contiguous operands (no in-row k tail).  voff[] holds the per-pass byte
+// offsets for k0 = 0; the k advance goes in the scalar offset.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int R, bool KM>
+__device__ __forceinline__ void tile_offsets(int (&voff)[R / 32], int ld, int row0, int tid) {
+  if constexpr (!KM) {
+    const int c4 = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < R / 32; ++p) voff[p] = ((row0 + rr + 32 * p) * ld + c4 * 4) * 4;
+  } else {
+    constexpr int TPR = R / 4;
+    constexpr int RPP = 256 / TPR;
+    const int c4 = tid % TPR, kk0 = tid / TPR;
+#pragma unroll
+    for (int p = 0; p < R / 32; ++p) voff[p] = ((kk0 + RPP * p) * ld + row0 + c4 * 4) * 4;
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void tile_load_buf(f32x4 (&reg)[R / 32], __amdgpu_buffer_rsrc_t rsrc,
+                                              const int (&voff)[R / 32], int soff) {
+#pragma unroll
+  for (int p = 0; p < R / 32; ++p)
+    reg[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[p], soff, 0));
+}
+
 template <int R, bool KM>
 __device__ __forceinline__ void tile_store(const f32x4 (&reg)[R / 32], float* s, int tid) {
   if constexpr (!KM) {
@@ -215,38 +244,234 @@ int launch(GemmArgs g, hipStream_t st) {
   return 0;
 }
 
-template <bool AKM, bool BKM>
+
+// ---------------------------------------------------------------------------
+// v2: persistent, software-pipelined across the barrier.
+//   * each workgroup walks a static sequence of output tiles; the first k-tile
+//     of the NEXT output tile is fetched during the last k-iteration of the
+//     current one, so the epilogue stores overlap the next tile's prologue
+//   * per k-iteration the four 8-deep k-blocks are issued as
+//         [kb0 MFMAs | read kb1] [kb1 MFMAs | read kb2] [write next tile -> LDS]
+//         [kb2 MFMAs | read kb3] [barrier] [kb3 MFMAs | read next tile's kb0]
+//     so fragment reads always have a 16-MFMA (1024-cycle) shadow, the
+//     ds_writes complete under kb2's MFMAs, and the first MFMA after the barrier
+//     never waits for LDS.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, bool AKM, bool BKM, int TAG, bool BUF>
+__global__ __launch_bounds__(256, 2) void gemm_f32_v2_kernel(const GemmArgs g) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int SA = TileSize<BM, AKM>::value, SB = TileSize<BN, BKM>::value;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int nk = (g.K + BK - 1) / BK;
+
+  // XCD-aware static schedule: the blocks of one XCD (b = x, x+8, ...) share a contiguous
+  // chunk of tiles and stride through it.
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int chunk_n = q + (xcd < r ? 1 : 0);
+  if (idx >= chunk_n) return;
+
+  f32x4 ra[BM / 32], rb[BN / 32];
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  int t_local = idx;
+  int tile = chunk0 + t_local;
+  int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+  int it = 0;   // running k-iteration counter: LDS buffer parity
+
+  // buffer descriptors (wave-uniform: kernel arguments only) and per-thread offsets
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.A), 0, (AKM ? g.K : g.M) * g.lda * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.B), 0, (BKM ? g.K : g.N) * g.ldb * 4, 0x00020000);
+  const int kstepA = (AKM ? BK * g.lda : BK) * 4, kstepB = (BKM ? BK * g.ldb : BK) * 4;
+  int voA[BM / 32], voB[BN / 32], nvoA[BM / 32], nvoB[BN / 32];
+  if constexpr (BUF) {
+    tile_offsets<BM, AKM>(voA, g.lda, m0, tid);
+    tile_offsets<BN, BKM>(voB, g.ldb, n0, tid);
+    tile_load_buf<BM>(ra, rsA, voA, 0);
+    tile_load_buf<BN>(rb, rsB, voB, 0);
+  } else {
+    tile_load<BM, AKM>(ra, g.A, g.lda, m0, g.M, 0, g.K, tid);
+    tile_load<BN, BKM>(rb, g.B, g.ldb, n0, g.N, 0, g.K, tid);
+  }
+  tile_store<BM, AKM>(ra, smem, tid);
+  tile_store<BN, BKM>(rb, smem + SA, tid);
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < TM; ++a) fa0[a] = frag_read<BM, AKM>(smem, wm * WM + a * 32, 0, i, h);
+#pragma unroll
+  for (int b = 0; b < TN; ++b) fb0[b] = frag_read<BN, BKM>(smem + SA, wn * WN + b * 32, 0, i, h);
+
+  while (true) {
+    const int t_next = t_local + per_xcd;
+    const bool has_next_tile = t_next < chunk_n;
+    const int ntile = chunk0 + t_next;
+    const int nm0 = (ntile / g.tiles_n) * BM, nn0 = (ntile % g.tiles_n) * BN;
+    if constexpr (BUF) {
+      if (has_next_tile) {
+        tile_offsets<BM, AKM>(nvoA, g.lda, nm0, tid);
+        tile_offsets<BN, BKM>(nvoB, g.ldb, nn0, tid);
+      }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) acc[a][b][rr] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt, ++it) {
+      const float* sA = smem + (it & 1) * (SA + SB);
+      const float* sB = sA + SA;
+      float* dA = smem + ((it + 1) & 1) * (SA + SB);
+      const bool last = kt + 1 == nk;
+      const bool more = !last || has_next_tile;
+      if constexpr (BUF) {
+        if (!last) {
+          tile_load_buf<BM>(ra, rsA, voA, (kt + 1) * kstepA);
+          tile_load_buf<BN>(rb, rsB, voB, (kt + 1) * kstepB);
+        } else if (has_next_tile) {
+          tile_load_buf<BM>(ra, rsA, nvoA, 0);
+          tile_load_buf<BN>(rb, rsB, nvoB, 0);
+        }
+      } else {
+        if (!last) {
+          tile_load<BM, AKM>(ra, g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, tid);
+          tile_load<BN, BKM>(rb, g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, tid);
+        } else if (has_next_tile) {
+          tile_load<BM, AKM>(ra, g.A, g.lda, nm0, g.M, 0, g.K, tid);
+          tile_load<BN, BKM>(rb, g.B, g.ldb, nn0, g.N, 0, g.K, tid);
+        }
+      }
+#define MFMA_BLOCK(FA, FB)                                                                              \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
+  _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                        \
+  _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                        \
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a][t], FB[b][t], acc[a][b], 0, 0, 0);
+#define READ_FRAGS(FA, FB, SAp, SBp, KB)                                                                \
+  _Pragma("unroll") for (int a = 0; a < TM; ++a) FA[a] = frag_read<BM, AKM>(SAp, wm * WM + a * 32, KB, i, h); \
+  _Pragma("unroll") for (int b = 0; b < TN; ++b) FB[b] = frag_read<BN, BKM>(SBp, wn * WN + b * 32, KB, i, h);
+
+      __builtin_amdgcn_sched_barrier(0);
+      READ_FRAGS(fa1, fb1, sA, sB, 1)
+      MFMA_BLOCK(fa0, fb0)
+      __builtin_amdgcn_sched_barrier(0);
+      READ_FRAGS(fa0, fb0, sA, sB, 2)
+      MFMA_BLOCK(fa1, fb1)
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        tile_store<BM, AKM>(ra, dA, tid);
+        tile_store<BN, BKM>(rb, dA + SA, tid);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      READ_FRAGS(fa1, fb1, sA, sB, 3)
+      MFMA_BLOCK(fa0, fb0)
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) { READ_FRAGS(fa0, fb0, dA, (dA + SA), 0) }
+      MFMA_BLOCK(fa1, fb1)
+      __builtin_amdgcn_sched_barrier(0);
+#undef MFMA_BLOCK
+#undef READ_FRAGS
+    }
+
+    // epilogue of the finished tile (next tile's first k-tile is already in LDS / registers)
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn * WN + b * 32 + i;
+        if (col >= g.N) continue;
+        const float bv = (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int row = m0 + wm * WM + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+          if (row >= g.M) continue;
+          float v = acc[a][b][rr] + bv;
+          if (g.epi == UNITER_EPI_BIAS_GELU) {
+            if (g.aux_out) g.aux_out[(size_t)row * g.ld_aux + col] = v;
+            v = gelu_erf(v);
+          } else if (g.epi == UNITER_EPI_DGELU) {
+            v *= dgelu_erf(g.aux_in[(size_t)row * g.ld_aux + col]);
+          } else if (g.epi == UNITER_EPI_ADD) {
+            v += g.aux_in[(size_t)row * g.ld_aux + col];
+          }
+          float* c = g.C + (size_t)row * g.ldc + col;
+          if (g.beta) v += *c;
+          *c = v;
+        }
+      }
+    }
+    if (!has_next_tile) break;
+    t_local = t_next; tile = ntile; m0 = nm0; n0 = nn0;
+    if constexpr (BUF) {
+#pragma unroll
+      for (int p = 0; p < BM / 32; ++p) voA[p] = nvoA[p];
+#pragma unroll
+      for (int p = 0; p < BN / 32; ++p) voB[p] = nvoB[p];
+    }
+  }
+}
+
+template <int BM, int BN, bool AKM, bool BKM, int TAG>
+int launch_v2(GemmArgs g, hipStream_t st) {
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  const int tiles = g.tiles_m * g.tiles_n;
+  // persistent grid: up to `slots` resident workgroups (multiple of 8 for the XCD schedule)
+  constexpr int SLOTS = (BM * BN >= 128 * 128) ? 512 : (BM * BN >= 64 * 128 ? 512 : 1024);
+  int grid = tiles < SLOTS ? (tiles + 7) / 8 * 8 : SLOTS;
+  // branch-free buffer-load path: no in-row k tail, and byte offsets must fit the 32-bit voffset
+  const bool fast = g.K % BK == 0 && (size_t)(AKM ? g.K : g.M) * g.lda * 4 < (1ull << 31) &&
+                    (size_t)(BKM ? g.K : g.N) * g.ldb * 4 < (1ull << 31);
+  if (fast)
+    hipLaunchKernelGGL((gemm_f32_v2_kernel<BM, BN, AKM, BKM, TAG, true>), dim3(grid), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_f32_v2_kernel<BM, BN, AKM, BKM, TAG, false>), dim3(grid), dim3(256), 0, st, g);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+template <bool AKM, bool BKM, int TAG>
 int dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
   switch (cfg) {
-    case 1: return launch<128, 128, AKM, BKM, 0>(g, st);
-    case 2: return launch<64, 128, AKM, BKM, 0>(g, st);
-    case 3: return launch<128, 64, AKM, BKM, 0>(g, st);
-    case 4: return launch<64, 64, AKM, BKM, 0>(g, st);
+    case 1: return launch<128, 128, AKM, BKM, TAG>(g, st);
+    case 2: return launch<64, 128, AKM, BKM, TAG>(g, st);
+    case 3: return launch<128, 64, AKM, BKM, TAG>(g, st);
+    case 4: return launch<64, 64, AKM, BKM, TAG>(g, st);
+    case 11: return launch_v2<128, 128, AKM, BKM, TAG>(g, st);
+    case 12: return launch_v2<64, 128, AKM, BKM, TAG>(g, st);
+    case 13: return launch_v2<128, 64, AKM, BKM, TAG>(g, st);
+    case 14: return launch_v2<64, 64, AKM, BKM, TAG>(g, st);
     default: uniter_set_error("gemm: bad cfg %d", cfg); return UNITER_E_ARG;
   }
 }
 
-// pick the tile shape that minimises (rounds over 256 CUs) x (tile work / efficiency)
+// Tile choice, from measurements on MI355X (tests/bench_gemm_gpu.py): the persistent 64x64
+// kernel (4 workgroups per CU, tiles finish out of phase so epilogues overlap other tiles' MFMAs)
+// wins on every model shape (M = 2624 / 576, N,K in {768, 2304, 3072, 2048}); 128x128 wins once
+// there are >= ~3000 64x64 tiles (e.g. 4096^3: 137 vs 128 TFLOP/s).
 int choose_cfg(int M, int N) {
-  static const int bm[5] = {0, 128, 64, 128, 64}, bn[5] = {0, 128, 128, 64, 64};
-  static const double eff[5] = {0, 1.00, 0.95, 0.95, 0.88};
-  int best = 1;
-  double best_cost = 1e300;
-  for (int c = 1; c <= 4; ++c) {
-    const long tiles = (long)((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
-    const long rounds = (tiles + 255) / 256;
-    const double cost = (double)rounds * bm[c] * bn[c] / eff[c];
-    if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
-  }
-  return best;
+  const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+  return t64 >= 3072 ? 11 : 14;
 }
 
 }  // namespace
 
-extern "C" int uniter_gemm_f32_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K,
-                                   const float* A, int lda, const float* B, int ldb, float* C,
-                                   int ldc, int epilogue, const float* bias, const float* aux_in,
-                                   float* aux_out, int ld_aux, int beta, void* stream) {
+// tag != 0 selects a separately named instantiation of the x @ W^T kernel (TAG template
+// argument) so that one call site (the FFN-up forward GEMM) is its own row in rocprofv3 --stats.
+int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,
+                 int lda, const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
+                 const float* aux_in, float* aux_out, int ld_aux, int beta, void* stream) {
   UCHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad dims %d %d %d", M, N, K);
   UCHECK_ARG(A && B && C, "gemm: null operand");
   UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_ADD, "gemm: bad epilogue %d", epilogue);
@@ -266,10 +491,19 @@ extern "C" int uniter_gemm_f32_cfg(int cfg, int a_kmajor, int b_kmajor, int M, i
   g.beta = beta; g.tiles_m = g.tiles_n = 0;
   if (cfg == 0) cfg = choose_cfg(M, N);
   hipStream_t st = (hipStream_t)stream;
-  if (!a_kmajor && !b_kmajor) return dispatch_cfg<false, false>(cfg, g, st);
-  if (!a_kmajor && b_kmajor) return dispatch_cfg<false, true>(cfg, g, st);
-  if (a_kmajor && b_kmajor) return dispatch_cfg<true, true>(cfg, g, st);
-  return dispatch_cfg<true, false>(cfg, g, st);
+  if (!a_kmajor && !b_kmajor)
+    return tag ? dispatch_cfg<false, false, 1>(cfg, g, st) : dispatch_cfg<false, false, 0>(cfg, g, st);
+  if (!a_kmajor && b_kmajor) return dispatch_cfg<false, true, 0>(cfg, g, st);
+  if (a_kmajor && b_kmajor) return dispatch_cfg<true, true, 0>(cfg, g, st);
+  return dispatch_cfg<true, false, 0>(cfg, g, st);
+}
+
+extern "C" int uniter_gemm_f32_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K,
+                                   const float* A, int lda, const float* B, int ldb, float* C,
+                                   int ldc, int epilogue, const float* bias, const float* aux_in,
+                                   float* aux_out, int ld_aux, int beta, void* stream) {
+  return gemm_f32_run(cfg, 0, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, epilogue, bias, aux_in,
+                      aux_out, ld_aux, beta, stream);
 }
 
 extern "C" int uniter_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,

@@ -78,14 +78,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   block_col_reduce_store<NV>(db, red, part + (size_t)blockIdx.x * 2 * H + H, H4, lane, wave);
 }
 
-// out[n] (+)= sum_p part[p*stride + n]
-__global__ void finalize_partials_kernel(const float* __restrict__ part, int nparts, size_t stride,
-                                         float* __restrict__ out, int N, int beta) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// out[n] (+)= sum_p part[p*stride + n].  Block = 32 columns x 8 partial-slices: the slices
+// stride through the partial rows in parallel and meet in LDS (a single thread per column
+// walking 512 partial rows serially cost 80 us; this shape costs a few).
+__global__ __launch_bounds__(256) void finalize_partials_kernel(const float* __restrict__ part, int nparts,
+                                                                size_t stride, float* __restrict__ out, int N,
+                                                                int beta) {
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + cx;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * stride + n];
-  out[n] = beta ? out[n] + s : s;
+  if (n < N)
+    for (int p = sl; p < nparts; p += 8) s += part[(size_t)p * stride + n];
+  red[sl][cx] = s;
+  __syncthreads();
+  if (sl == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    out[n] = beta ? out[n] + t : t;
+  }
 }
 
 // column sums: block (bx, by) covers columns [bx*256, bx*256+256) and rows by, by+gridDim.y, ...
@@ -115,8 +127,8 @@ __global__ void add_kernel(float* __restrict__ out, const float* __restrict__ a,
 }
 
 inline int ln_bwd_blocks(int M) {
-  int b = (M + 3) / 4;
-  return b < 512 ? b : 512;
+  int b = (M + 15) / 16;      // ~4 rows per wave: enough waves in flight for HBM, few partial rows
+  return b < 256 ? (b < 1 ? 1 : b) : 256;
 }
 inline int colsum_splits(int M) {
   int s = (M + 31) / 32;
@@ -136,7 +148,7 @@ int launch_add_f32(float* out, const float* a, const float* b, size_t n, hipStre
 
 int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta,
                       hipStream_t st) {
-  hipLaunchKernelGGL(finalize_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, nparts,
+  hipLaunchKernelGGL(finalize_partials_kernel, dim3((N + 31) / 32), dim3(256), 0, st, part, nparts,
                      stride, out, N, beta);
   UCHECK_LAUNCH();
   return 0;

@@ -17,6 +17,9 @@
 
 // internal helpers implemented in other translation units
 int launch_add_f32(float* out, const float* a, const float* b, size_t n, hipStream_t st);
+int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda,
+                 const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
+                 const float* aux_in, float* aux_out, int ld_aux, int beta, void* stream);
 int launch_masked_rowsum(const float* x, const int64_t* masks, float* out, int rows, int D, hipStream_t st);
 
 namespace {
@@ -187,7 +190,8 @@ int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int
          int lda, const float* B, int ldb, float* C, int ldc, int epi, const float* bias, const float* aux_in,
          float* aux_out, int ld_aux, int beta) {
   ProfScope ps(m, kind, st);
-  return uniter_gemm_f32(akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux_in, aux_out, ld_aux, beta, st);
+  return gemm_f32_run(0, kind == UNITER_K_GEMM_FFN_UP_FWD, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias,
+                      aux_in, aux_out, ld_aux, beta, st);
 }
 
 int validate_batch(const uniter_model* m, const uniter_batch_t* b) {
@@ -519,7 +523,8 @@ extern "C" int uniter_model_backward_embed(uniter_model_t* m) {
     const float* feat = b.img_masks ? pl.feat_eff : b.img_feat;
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, st, 1, 1, H, c.img_dim, B * R, pl.d_imgfc, H, feat, c.img_dim,
                    m->G(P_IMG_W), c.img_dim, UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
-    UCHECK_RC(uniter_colsum_f32(pl.d_imgfc, B * R, H, H, m->G(P_IMG_B), 1, pl.col_ws, pl.col_ws_bytes, st));
+    // NOT pl.col_ws: the side stream's bias-gradient reductions of layer 0 may still be using it
+    UCHECK_RC(uniter_colsum_f32(pl.d_imgfc, B * R, H, H, m->G(P_IMG_B), 1, pl.emb_ws, pl.emb_ws_bytes, st));
     if (b.img_masks) {
       // d(img_feat + mask_emb[img_masks]) = d_imgfc @ W_img; row 1 of mask_embedding sums the masked rows
       UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, B * R, c.img_dim, H, pl.d_imgfc, H, m->P(P_IMG_W),

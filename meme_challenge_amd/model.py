@@ -188,18 +188,32 @@ class ParamStore(object):
             order += [(n, by[n]) for n in b]
         return order, buckets
 
-    def is_current(self):
-        for n, p in self.params.items():
-            o = self.offsets[n]
-            if p.data_ptr() != self.flat_params.data_ptr() + 4 * o:
+    def is_current(self, full=False):
+        """Are the module's parameters still views of the flat buffer?  The per-step check
+        looks at three sentinels (.to()/.cuda() re-home every parameter at once); `full`
+        checks all of them."""
+        names = self.names if full else (self.names[0], self.names[len(self.names) // 2], self.names[-1])
+        base = self.flat_params.data_ptr()
+        for n in names:
+            if self.params[n].data_ptr() != base + 4 * self.offsets[n]:
                 return False
         return True
 
-    def reattach_grads(self):
+    def reattach_grads(self, full=False):
+        names = self.names if full else (self.names[0], self.names[len(self.names) // 2], self.names[-1])
+        base = self.flat_grads.data_ptr()
+        ok = True
+        for n in names:
+            g = self.params[n].grad
+            if g is None or g.data_ptr() != base + 4 * self.offsets[n]:
+                ok = False
+                break
+        if ok and not full:
+            return
         for n, p in self.params.items():
             o, k = self.offsets[n], p.numel()
             g = p.grad
-            if g is None or g.data_ptr() != self.flat_grads.data_ptr() + 4 * o:
+            if g is None or g.data_ptr() != base + 4 * o:
                 p.grad = self.flat_grads[o:o + k].view(p.shape)
 
     def touch(self, names):
@@ -208,7 +222,7 @@ class ParamStore(object):
     def zero_grads(self):
         self.flat_grads.zero_()
         self.touched.clear()
-        self.reattach_grads()
+        self.reattach_grads(full=True)
 
 
 def _find_store(module):
@@ -416,8 +430,12 @@ def _mark_touched(module, params):
     root = getattr(module, '_store_root_ref', None)
     st = _find_store(root) if root is not None else None
     if st is not None:
-        ids = {id(p) for p in params}
-        st.touch([n for n, p in st.params.items() if id(p) in ids])
+        cache = module.__dict__.get('_touch_cache')
+        if cache is None or cache[0] is not st:
+            ids = {id(p) for p in params}
+            cache = (st, [n for n, p in st.params.items() if id(p) in ids])
+            object.__setattr__(module, '_touch_cache', cache)
+        st.touch(cache[1])
 
 
 class BertPooler(nn.Module):
@@ -645,6 +663,10 @@ class UniterModel(UniterPreTrainedModel):
         if self._prefix_names is None:
             ids = {id(p): n for n, p in root.named_parameters()}
             self._prefix_names = {n: ids[id(p)] for n, p in self.named_parameters()}
+            self._touch_lists = {}
+        key = (bool(batch.input_ids), bool(batch.img_feat), bool(batch.img_masks))
+        if key in self._touch_lists:
+            return self._touch_lists[key]
         out = []
         for local, full in self._prefix_names.items():
             if local.startswith('pooler.'):
@@ -657,6 +679,7 @@ class UniterModel(UniterPreTrainedModel):
             if local.startswith('embeddings.') and 'token_type' not in local and not batch.input_ids:
                 continue
             out.append(full)
+        self._touch_lists[key] = out
         return out
 
     def _run_backward(self, batch, d_hidden, all_layers, seed, offset, ws, nbytes):

@@ -146,8 +146,7 @@ class FusedAdam(torch.optim.Optimizer):
                                    int(self.adamw), int(bool(zero_grads)), _lib.cur_stream()),
               'uniter_adam_step')
         if zero_grads:
-            st.touched.clear()
-            self._flags_key = None
+            st.touched.clear()      # flags stay cached: the same set is touched again next step
 
     def zero_grad(self, set_to_none=False):
         self.store.zero_grads()
@@ -246,7 +245,8 @@ class TrainStep(object):
         if stepping:
             if self.grad_sync is not None:
                 self.grad_sync.finish()
-            self.optimizer.step(grad_scale=1.0 / accum, max_grad_norm=cfg['max_grad_norm'],
+            world = self.grad_sync.world if self.grad_sync is not None else 1
+            self.optimizer.step(grad_scale=1.0 / (accum * world), max_grad_norm=cfg['max_grad_norm'],
                                 zero_grads=True)
             self.scheduler.step()
         self.last_loss, self.last_probs = loss.detach(), probs

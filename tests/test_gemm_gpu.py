@@ -44,7 +44,7 @@ def _run(lib, L, cfg, akm, bkm, M, N, K, epi, beta, seed=0):
         assert (daux_out.cpu().double() - aux_out_ref).abs().max().item() < 2e-5 * scale * 4
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 11, 12, 13, 14])
 @pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_layouts_and_edges(cfg, layout):
     from meme_challenge_amd import _lib as L
@@ -62,12 +62,14 @@ def test_gemm_epilogues(epi):
     _run(lib, L, 0, 0, 0 if epi in (1, 2) else 1, M=300, N=256, K=128, epi=epi, beta=0)
 
 
-def test_gemm_model_shapes():
+@pytest.mark.parametrize('cfg', [0, 11, 14])
+def test_gemm_model_shapes(cfg):
     from meme_challenge_amd import _lib as L
     lib = L.lib()
-    _run(lib, L, 0, 0, 0, M=2624, N=3072, K=768, epi=2, beta=0)     # FFN up
-    _run(lib, L, 0, 0, 1, M=2624, N=768, K=3072, epi=4, beta=0)     # dgrad
-    _run(lib, L, 0, 1, 1, M=768, N=3072, K=2624, epi=0, beta=1)     # wgrad (accumulate)
+    _run(lib, L, cfg, 0, 0, M=2624, N=3072, K=768, epi=2, beta=0)     # FFN up
+    _run(lib, L, cfg, 0, 1, M=2624, N=768, K=3072, epi=4, beta=0)     # dgrad
+    _run(lib, L, cfg, 1, 1, M=768, N=3072, K=2624, epi=0, beta=1)     # wgrad (accumulate)
+    _run(lib, L, cfg, 0, 0, M=576, N=768, K=2048, epi=1, beta=0)      # img_linear
 
 
 def test_gemm_rejects_bad_args():
