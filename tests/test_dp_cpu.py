@@ -1,0 +1,140 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient exchange (meme_challenge_amd/dp.py).
+Invariant: summed-then-averaged per-rank gradients equal the
+single-process gradients on the concatenated batch, every rank ends with identical
+buffers, buckets are contiguous slices issued in backward order, and non-stepping
+micro-batches do not communicate."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+
+from common import TINY, TINY_IMG_DIM      # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _layout(sd):
+    from meme_challenge_amd.model import ParamStore, CHUNK
+    named = [(k, v) for k, v in sd.items()]
+    order, buckets = ParamStore._order(named)
+    offs, off = {}, 0
+    for n, p in order:
+        offs[n] = off
+        off += (p.numel() + CHUNK - 1) // CHUNK * CHUNK
+    ranges = []
+    for names in buckets:
+        s = min(offs[n] for n in names)
+        e = max(offs[n] + (sd[n].numel() + CHUNK - 1) // CHUNK * CHUNK for n in names)
+        ranges.append((s, e))
+    return offs, off, ranges, buckets
+
+
+def _grads(sd, batch):
+    from oracle import uniter_oracle as O
+    from oracle import step_oracle as S
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    kw = dict(img_feat=batch['img_feat'], img_pos_feat=batch['img_pos_feat'], input_ids=batch['input_ids'],
+              position_ids=batch['position_ids'], attention_mask=batch['attn_mask'],
+              gather_index=batch['gather_index'], output_all_encoded_layers=False)
+    loss = S.bce_with_logits(O.meme_uniter_forward(leaf, TINY, **kw), batch['labels'], 1.8)
+    loss.backward()
+    return {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import uniter_oracle as O
+    from meme_challenge_amd.dp import GradSync
+    torch.set_num_threads(2)
+    sd = O.synth_state_dict(TINY, seed=3, img_dim=TINY_IMG_DIM, ln_jitter=0.05)
+    offs, numel, ranges, buckets = _layout(sd)
+    nl = TINY['num_hidden_layers']
+    assert len(ranges) == nl + 2
+    # buckets are contiguous, ordered head | layer nl-1 .. 0 | embeddings, and tile the buffer
+    assert ranges[0][0] == 0 and ranges[-1][1] == numel
+    for (s0, e0), (s1, e1) in zip(ranges, ranges[1:]):
+        assert e0 == s1
+    assert any('linear.weight' in n for n in buckets[0]) and any('layer.%d.' % (nl - 1) in n for n in buckets[1])
+    assert any('word_embeddings' in n for n in buckets[-1])
+    batch = O.synth_batch(3, 10, 6, seed=50 + rank, vocab=TINY['vocab_size'], img_dim=TINY_IMG_DIM,
+                          txt_lens=[10, 5, 7], num_bbs=[6, 3, 6])
+    g = _grads(sd, batch)
+    flat = torch.zeros(numel)
+    for n, t in g.items():
+        flat[offs[n]:offs[n] + t.numel()] = t.reshape(-1)
+    local = flat.clone()
+
+    sync = GradSync(flat, ranges, bucket_bytes=1)       # every bucket its own collective
+    # (1) a non-stepping micro-batch must not communicate
+    sync.prepare(will_step=False)
+    sync.hook('begin', None, None)
+    for l in range(nl - 1, -1, -1):
+        sync.hook('layer', l, None)
+    sync.hook('embed', None, None)
+    sync.finish()
+    assert torch.equal(flat, local) and sync.launched == []
+    # (2) the stepping micro-batch: bucketed all-reduce in backward order
+    sync.prepare(will_step=True)
+    sync.hook('begin', None, None)
+    for l in range(nl - 1, -1, -1):
+        sync.hook('layer', l, None)
+    sync.hook('embed', None, None)
+    sync.finish()
+    assert sync.launched == ranges
+    # (3) coalescing: one big bucket -> a single collective covering everything
+    flat2 = local.clone()
+    sync2 = GradSync(flat2, ranges, bucket_bytes=1 << 40)
+    sync2.prepare(True)
+    sync2.hook('begin', None, None)
+    for l in range(nl - 1, -1, -1):
+        sync2.hook('layer', l, None)
+    sync2.hook('embed', None, None)
+    sync2.finish()
+    assert sync2.launched == [(0, numel)]
+    assert torch.equal(flat2, flat)
+    # (4) finish() without hooks (e.g. frozen encoder) still reduces everything
+    flat3 = local.clone()
+    sync3 = GradSync(flat3, ranges, bucket_bytes=1)
+    sync3.prepare(True)
+    sync3.finish()
+    assert torch.equal(flat3, flat)
+    if rank == 0:
+        torch.save({'reduced': flat, 'offs': offs}, out)
+    # every rank holds identical reduced gradients
+    chk = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(chk, flat)
+    assert all(torch.equal(c, chk[0]) for c in chk)
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_big_batch_gradients(tmp_path):
+    from oracle import uniter_oracle as O
+    world, port, out = 2, _free_port(), str(tmp_path / 'r0.pt')
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    r = torch.load(out)
+    sd = O.synth_state_dict(TINY, seed=3, img_dim=TINY_IMG_DIM, ln_jitter=0.05)
+    bs = [O.synth_batch(3, 10, 6, seed=50 + k, vocab=TINY['vocab_size'], img_dim=TINY_IMG_DIM,
+                        txt_lens=[10, 5, 7], num_bbs=[6, 3, 6]) for k in range(world)]
+    big = {k: torch.cat([b[k] for b in bs], 0) for k in bs[0]}
+    g = _grads(sd, big)
+    for n, t in g.items():
+        o = r['offs'][n]
+        got = r['reduced'][o:o + t.numel()].view(t.shape) / world      # grad_scale = 1/world
+        assert (got - t).abs().max().item() <= 1e-6 + 1e-4 * t.abs().max().item(), n

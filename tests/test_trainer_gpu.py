@@ -1,0 +1,74 @@
+"""GPU: optimizer-step semantics of the reference trainer (driven by the REAL
+TrainerTemplate.calculate_loss when the golden was made): gradient-accumulation
+quirk, averaging, clipping, Adam / AdamW with the name-based decay split, cosine
+warm-up, skipped no-grad parameters."""
+import numpy as np
+import pytest
+import torch
+
+from common import TINY, TINY_IMG_DIM, sd_from_npz, batch_from_npz, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('optname', ['adam', 'adamw'])
+def test_trainer_steps_match_reference(trainer_steps, optname):
+    from meme_challenge_amd.model import UniterConfig, UniterModel
+    from meme_challenge_amd.meme_uniter import MemeUniter
+    from meme_challenge_amd.trainer import get_optimizer, TrainStep, cosine_warmup_lambda
+    z = trainer_steps
+    cfg = UniterConfig.from_dict(TINY)
+    m = MemeUniter(UniterModel(cfg, img_dim=TINY_IMG_DIM), cfg.hidden_size, 1)
+    m.load_state_dict(sd_from_npz(z, 'sd0/'))
+    m = m.cuda().eval()          # the golden run had dropout off
+    config = dict(optimizer=optname, lr=1e-3, beta1=0.9, beta2=0.999, weight_decay=1e-3,
+                  gradient_accumulation=2, max_grad_norm=1, pos_wt=1.8, loss_func='bce_logits')
+    opt = get_optimizer(m, config)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, cosine_warmup_lambda(1, 6))
+    step = TrainStep(m, opt, sched, config)
+    n_it = len(z[optname + '/losses'])
+    for it in range(n_it):
+        b = {k: v.cuda() for k, v in batch_from_npz(z, 'batch%d/' % it).items()}
+        loss = step.train_iter(b, iters=it)
+        assert abs(loss.item() - z[optname + '/losses'][it]) < 2e-5, it
+        assert abs(opt.param_groups[0]['lr'] - float(z['%s/it%d/lr' % (optname, it)])) < 1e-12
+        sd = m.state_dict()
+        for k in z.files:
+            pre = '%s/it%d/' % (optname, it)
+            if k.startswith(pre) and not k.endswith('/lr'):
+                assert maxdiff(sd[k[len(pre):]], z[k]) < 2e-5, (it, k)
+    assert maxdiff(step.last_probs, z[optname + '/probs'][-3:]) < 2e-5
+    if optname == 'adam':
+        sd = m.state_dict()
+        for k in z.files:
+            if k.startswith('adam/final/'):
+                assert maxdiff(sd[k[len('adam/final/'):]], z[k]) < 2e-5, k
+        # mask_embedding never receives a gradient -> torch skips it (no decay either)
+        assert torch.equal(sd['uniter_model.img_embeddings.mask_embedding.weight'].cpu(),
+                           torch.from_numpy(z['sd0/uniter_model.img_embeddings.mask_embedding.weight']))
+
+
+def test_grad_norm_and_clip_coefficient():
+    from meme_challenge_amd.model import UniterConfig, UniterModel
+    from meme_challenge_amd.meme_uniter import MemeUniter
+    from meme_challenge_amd.trainer import FusedAdam
+    torch.manual_seed(1)
+    cfg = UniterConfig.from_dict(TINY)
+    m = MemeUniter(UniterModel(cfg, img_dim=TINY_IMG_DIM), cfg.hidden_size, 1).cuda()
+    opt = FusedAdam(m, lr=1e-2, weight_decay=0.0)
+    st = opt.store
+    for p in m.parameters():             # (padding between tensors stays zero, as in real use)
+        p.grad.copy_(torch.randn_like(p))
+    g = st.flat_grads.clone()
+    st.touch(st.names)
+    ref = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())).item()
+    assert abs(opt.grad_norm().item() - ref) < 1e-6 * ref
+    p0 = st.flat_params.clone()
+    opt.step(grad_scale=0.5, max_grad_norm=1.0)
+    # first Adam step moves every touched parameter by lr * sign(g) (bias-corrected), whatever the clip
+    moved = (st.flat_params - p0)
+    for n in ('linear.weight', 'uniter_model.encoder.layer.0.output.dense.weight'):
+        o, k = st.offsets[n], st.params[n].numel()
+        big = g[o:o + k].abs() > 0.1          # (eps=1e-8 matters only for vanishing gradients)
+        assert torch.allclose(moved[o:o + k][big], -1e-2 * torch.sign(g[o:o + k][big]), atol=5e-6)
+    assert st.flat_grads.abs().max().item() == 0      # zero_grad fused into the step
