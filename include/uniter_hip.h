@@ -86,11 +86,13 @@ int uniter_ln_fwd(const float* x, const float* res, const float* gamma, const fl
                   void* stream);
 /*   dz = dLN(dy) (gradient w.r.t. z, i.e. w.r.t. the residual input)
  *   dx = dropout-masked dz (gradient w.r.t. x); dx may equal dz when p_drop == 0
- *   dgamma/dbeta (+)= column reductions (two-stage, deterministic)          */
+ *   dgamma/dbeta += column reductions (two-stage, deterministic)
+ *   dbias (optional) += column sum of dx = bias gradient of the Linear that produced x
+ *   (model/layer.py:112,153), fused here to save a pass over dx                         */
 int uniter_ln_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
                   const float* gamma, float* dz, float* dx, float* dgamma, float* dbeta,
-                  int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
-                  void* ws, size_t ws_bytes, void* stream);
+                  float* dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
+                  uint32_t site, void* ws, size_t ws_bytes, void* stream);
 size_t uniter_ln_bwd_ws_bytes(int M, int H);
 
 /* ------------------------------------------------------------------------- *

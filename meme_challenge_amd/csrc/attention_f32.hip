@@ -316,6 +316,223 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Resident variants (L <= 256): one workgroup per (batch, head) with one wave per 32-row block.
+// The whole K and V (or Q and dO) of the head -- 2 x L x 64 fp32 = 84 KB at L = 164 -- are staged
+// ONCE into the 160 KB LDS; the key/query loop then runs without a single barrier or global load.
+// The streaming kernels above (32-row tiles re-staged per block, two barriers each) remain the
+// general path for longer sequences.
+// ---------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) float dyn_smem[];
+
+__device__ __forceinline__ void stage_rows(float* s, const float* __restrict__ base, int ld, int L, int Lr,
+                                           int tid, int nthr) {
+  for (int idx = tid; idx < Lr * 16; idx += nthr) {
+    const int r = idx >> 4, c4 = idx & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < L) v = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c4 * 4);
+    *reinterpret_cast<f32x4*>(s + r * LDT + c4 * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs a, int Lr) {
+  float* Ks = dyn_smem;
+  float* Vs = Ks + Lr * LDT;
+  float* mb = Vs + Lr * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int i = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const int ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
+  stage_rows(Ks, base + a.H, ld, a.L, Lr, tid, nthr);
+  stage_rows(Vs, base + 2 * a.H, ld, a.L, Lr, tid, nthr);
+  for (int k = tid; k < Lr; k += nthr)
+    mb[k] = k < a.L ? (1.0f - a.mask[(size_t)b * a.L + k]) * -10000.0f : NEG_INF;
+  const int q = wave * 32 + i;
+  const bool vq = q < a.L;
+  f32x4 qf[8];
+  load_row_frags(qf, base + (size_t)q * ld, vq, h);
+  __syncthreads();
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = NEG_INF, l_run = 0.f;
+  for (int k0 = 0; k0 < a.L; k0 += 32) {
+    f32x16 s = tile_times_frag(Ks + k0 * LDT, qf, i, h);
+    float mx = NEG_INF;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + k0 + 8 * g + 4 * h);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s[4 * g + t] = s[4 * g + t] * a.scale + bias[t];
+        mx = fmaxf(mx, s[4 * g + t]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_new); ls += s[r]; }
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    if (a.drop.active && vq) {
+      const uint64_t grow = ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float m4[4];
+        drop_mult4(a.drop, grow + 2 * g + h, m4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[4 * g + t] *= m4[t];
+      }
+    }
+    tileT_times_acc(Vs + k0 * LDT, s, o0, o1, i, h);
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (vq) {
+    store_rowT(a.ctx + ((size_t)b * a.L + q) * a.H + head * D, o0, o1, 1.0f / l_tot, h);
+    if (h == 0 && a.lse) a.lse[(size_t)bh * a.L + q] = m_run + __logf(l_tot);
+  }
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs a, int Lr) {
+  float* Ks = dyn_smem;
+  float* Vs = Ks + Lr * LDT;
+  float* mb = Vs + Lr * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int i = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const int ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
+  stage_rows(Ks, base + a.H, ld, a.L, Lr, tid, nthr);
+  stage_rows(Vs, base + 2 * a.H, ld, a.L, Lr, tid, nthr);
+  for (int k = tid; k < Lr; k += nthr)
+    mb[k] = k < a.L ? (1.0f - a.mask[(size_t)b * a.L + k]) * -10000.0f : NEG_INF;
+  const int q = wave * 32 + i;
+  const bool vq = q < a.L;
+  f32x4 qf[8], dof[8];
+  load_row_frags(qf, base + (size_t)q * ld, vq, h);
+  load_row_frags(dof, a.dctx + ((size_t)b * a.L + q) * a.H + head * D, vq, h);
+  float delta = 0.f;
+  {
+    f32x4 of[8];
+    load_row_frags(of, a.ctx + ((size_t)b * a.L + q) * a.H + head * D, vq, h);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) delta += of[kb][t] * dof[kb][t];
+    delta += __shfl_xor(delta, 32, 64);
+    if (vq && h == 0) a.delta[(size_t)bh * a.L + q] = delta;
+  }
+  const float lse = vq ? a.lse[(size_t)bh * a.L + q] : 0.f;
+  __syncthreads();
+
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+  for (int k0 = 0; k0 < a.L; k0 += 32) {
+    f32x16 s = tile_times_frag(Ks + k0 * LDT, qf, i, h);
+    f32x16 dp = tile_times_frag(Vs + k0 * LDT, dof, i, h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + k0 + 8 * g + 4 * h);
+      float m4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.drop.active && vq)
+        drop_mult4(a.drop, ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2) + 2 * g + h, m4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float p = __expf(s[4 * g + t] * a.scale + bias[t] - lse);
+        s[4 * g + t] = p * (dp[4 * g + t] * m4[t] - delta) * a.scale;
+      }
+    }
+    tileT_times_acc(Ks + k0 * LDT, s, dq0, dq1, i, h);
+  }
+  if (vq) store_rowT(a.dqkv + ((size_t)b * a.L + q) * ld + head * D, dq0, dq1, 1.0f, h);
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnArgs a, int Lr) {
+  float* Qs = dyn_smem;
+  float* dOs = Qs + Lr * LDT;
+  float* lse_s = dOs + Lr * LDT;
+  float* del_s = lse_s + Lr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int i = lane & 31, h = lane >> 5, u = lane & 3;
+  const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const int ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
+  stage_rows(Qs, base, ld, a.L, Lr, tid, nthr);
+  stage_rows(dOs, a.dctx + (size_t)b * a.L * a.H + head * D, a.H, a.L, Lr, tid, nthr);
+  for (int k = tid; k < Lr; k += nthr) {
+    lse_s[k] = k < a.L ? a.lse[(size_t)bh * a.L + k] : -NEG_INF;
+    del_s[k] = k < a.L ? a.delta[(size_t)bh * a.L + k] : 0.f;
+  }
+  const int key = wave * 32 + i;
+  const bool vk = key < a.L;
+  f32x4 kf[8], vf[8];
+  load_row_frags(kf, base + a.H + (size_t)key * ld, vk, h);
+  load_row_frags(vf, base + 2 * a.H + (size_t)key * ld, vk, h);
+  const float bias = vk ? (1.0f - a.mask[(size_t)b * a.L + key]) * -10000.0f : NEG_INF;
+  __syncthreads();
+
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+  for (int q0 = 0; q0 < a.L; q0 += 32) {
+    f32x16 s = tile_times_frag(Qs + q0 * LDT, kf, i, h);
+    f32x16 dp = tile_times_frag(dOs + q0 * LDT, vf, i, h);
+    f32x16 pd;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + q0 + 8 * g + 4 * h);
+      const f32x4 del4 = *reinterpret_cast<const f32x4*>(del_s + q0 + 8 * g + 4 * h);
+      float m4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.drop.active) {
+        const int qq = q0 + 8 * g + 4 * h + u;
+        const u32x4 w = drop_words(a.drop, ((uint64_t)bh * a.L + qq) * a.Lp4 + (key >> 2));
+        const int bits = (w.x >= a.drop.thresh ? 1 : 0) | (w.y >= a.drop.thresh ? 2 : 0) |
+                         (w.z >= a.drop.thresh ? 4 : 0) | (w.w >= a.drop.thresh ? 8 : 0);
+        const int b0 = __builtin_amdgcn_mov_dpp(bits, 0x00, 0xf, 0xf, true);
+        const int b1 = __builtin_amdgcn_mov_dpp(bits, 0x55, 0xf, 0xf, true);
+        const int b2 = __builtin_amdgcn_mov_dpp(bits, 0xAA, 0xf, 0xf, true);
+        const int b3 = __builtin_amdgcn_mov_dpp(bits, 0xFF, 0xf, 0xf, true);
+        m4[0] = ((b0 >> u) & 1) ? a.drop.scale : 0.f;
+        m4[1] = ((b1 >> u) & 1) ? a.drop.scale : 0.f;
+        m4[2] = ((b2 >> u) & 1) ? a.drop.scale : 0.f;
+        m4[3] = ((b3 >> u) & 1) ? a.drop.scale : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float p = __expf(s[4 * g + t] * a.scale + bias - lse4[t]);
+        pd[4 * g + t] = p * m4[t];
+        s[4 * g + t] = p * (dp[4 * g + t] * m4[t] - del4[t]) * a.scale;
+      }
+    }
+    tileT_times_acc(dOs + q0 * LDT, pd, dv0, dv1, i, h);
+    tileT_times_acc(Qs + q0 * LDT, s, dk0, dk1, i, h);
+  }
+  if (vk) {
+    float* row = a.dqkv + ((size_t)b * a.L + key) * ld + head * D;
+    store_rowT(row + a.H, dk0, dk1, 1.0f, h);
+    store_rowT(row + 2 * a.H, dv0, dv1, 1.0f, h);
+  }
+}
+
+constexpr int RES_MAX_LR = 256;      // 8 waves (2 per SIMD: 256 VGPRs each); 2*256*68*4 B = 139 KB LDS
+
+inline size_t res_lds_bytes(int Lr) { return (size_t)(2 * Lr * LDT + 2 * Lr) * sizeof(float); }
+
+template <typename K>
+int set_dyn_lds(K kernel, size_t bytes) {
+  UCHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
+
 int make_args(AttnArgs& a, int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
               uint32_t site) {
   UCHECK_ARG(B > 0 && L > 0 && nh > 0, "attention: bad dims B=%d L=%d nh=%d", B, L, nh);
@@ -335,8 +552,15 @@ extern "C" int uniter_attn_fwd(const float* qkv, const float* attn_mask, float* 
   AttnArgs a = {};
   UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.ctx = ctx; a.lse = lse;
-  dim3 grid((L + 32 * NW - 1) / (32 * NW), B * nh);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);
+  const int Lr = (L + 31) / 32 * 32;
+  if (Lr <= RES_MAX_LR) {
+    const size_t lds = res_lds_bytes(Lr);
+    UCHECK_RC(set_dyn_lds(attn_fwd_res_kernel, lds));
+    hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(B * nh), dim3(Lr * 2), lds, (hipStream_t)stream, a, Lr);
+  } else {
+    dim3 grid((L + 32 * NW - 1) / (32 * NW), B * nh);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);
+  }
   UCHECK_LAUNCH();
   return 0;
 }
@@ -350,6 +574,17 @@ extern "C" int uniter_attn_bwd(const float* qkv, const float* attn_mask, const f
   UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
   a.dctx = dctx; a.dqkv = dqkv; a.delta = delta;
+  const int Lr = (L + 31) / 32 * 32;
+  if (Lr <= RES_MAX_LR) {
+    const size_t lds = res_lds_bytes(Lr);
+    UCHECK_RC(set_dyn_lds(attn_bwd_dq_res_kernel, lds));
+    UCHECK_RC(set_dyn_lds(attn_bwd_dkv_res_kernel, lds));
+    hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * nh), dim3(Lr * 2), lds, (hipStream_t)stream, a, Lr);
+    UCHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_dkv_res_kernel, dim3(B * nh), dim3(Lr * 2), lds, (hipStream_t)stream, a, Lr);
+    UCHECK_LAUNCH();
+    return 0;
+  }
   dim3 grid((L + 32 * NW - 1) / (32 * NW), B * nh);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);
   UCHECK_LAUNCH();

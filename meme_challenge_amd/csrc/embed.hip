@@ -385,10 +385,8 @@ extern "C" int uniter_txt_embed_bwd(const float* dcat, const int64_t* input_ids,
   const int nblk = bwd_blocks(B * T);
   NV_DISPATCH(txt_embed_bwd_kernel, dim3(nblk), a);
   UCHECK_LAUNCH();
-  UCHECK_RC(finalize_partials(a.part, nblk, (size_t)3 * H, dgamma, H, 1, st));
-  UCHECK_RC(finalize_partials(a.part + H, nblk, (size_t)3 * H, dbeta, H, 1, st));
-  if (!type_ids) UCHECK_RC(finalize_partials(a.part + 2 * H, nblk, (size_t)3 * H, dtype, H, 1, st));
-  return 0;
+  float* outs[3] = {dgamma, dbeta, type_ids ? nullptr : dtype};
+  return finalize_partials_multi(a.part, nblk, (size_t)3 * H, outs, 3, H, st);
 }
 
 extern "C" int uniter_img_embed_fwd(const float* imgfc, const float* pos7, const int64_t* img_type_ids,
@@ -437,8 +435,7 @@ extern "C" int uniter_img_embed_bwd(const float* dcat, const float* imgfc, const
   NV_DISPATCH(img_embed_bwd_kernel, dim3(nblk), a);
   UCHECK_LAUNCH();
   float* outs[7] = {dg_f, db_f, dg_i, db_i, dg_p, db_p, img_type_ids ? nullptr : dtype + H};
-  for (int s = 0; s < 7; ++s)
-    if (outs[s]) UCHECK_RC(finalize_partials(a.part + (size_t)s * H, nblk, (size_t)7 * H, outs[s], H, 1, st));
+  UCHECK_RC(finalize_partials_multi(a.part, nblk, (size_t)7 * H, outs, 7, H, st));
   hipLaunchKernelGGL(pos_linear_wgrad_kernel, dim3((H + 255) / 256, (B * R + 31) / 32), dim3(256), 0, st,
                      d_posfc, pos7, dWp, dbp, B * R, H);
   UCHECK_LAUNCH();

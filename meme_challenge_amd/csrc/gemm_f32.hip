@@ -37,6 +37,7 @@ struct GemmArgs {
   int ld_aux;
   int beta;
   int tiles_m, tiles_n;
+  int band_h;
 };
 
 constexpr int BK = 32;
@@ -257,6 +258,21 @@ int launch(GemmArgs g, hipStream_t st) {
 //     ds_writes complete under kb2's MFMAs, and the first MFMA after the barrier
 //     never waits for LDS.
 // ---------------------------------------------------------------------------
+// L2-aware tile order.  The workgroups of one XCD run ~128 consecutive tiles of the linear
+// order at once (32 CUs x 4 resident workgroups).  Row-major order makes that window 2-3 tile
+// rows x all tile columns: the whole B operand streams through the 4 MiB L2 again for every few
+// rows (measured on FFN-up: 68 % L2 hit rate, ~250 MB fetched beyond L2 for 17 MB of operands).
+// Banded order: bands of `band_h` tile rows whose A panel stays L2-resident, tile columns swept
+// inside a band with the row index fastest, so the window is band_h x ~(128/band_h) tiles.
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int band_h, int& tm, int& tn) {
+  const int full = band_h * tiles_n;
+  const int band = t / full;
+  const int rem = t - band * full;
+  const int bh = min(band_h, tiles_m - band * band_h);
+  tn = rem / bh;
+  tm = band * band_h + (rem - tn * bh);
+}
+
 template <int BM, int BN, bool AKM, bool BKM, int TAG, bool BUF>
 __global__ __launch_bounds__(256, 2) void gemm_f32_v2_kernel(const GemmArgs g) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -281,7 +297,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v2_kernel(const GemmArgs g) {
   f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
   int t_local = idx;
   int tile = chunk0 + t_local;
-  int m0 = (tile / g.tiles_n) * BM, n0 = (tile % g.tiles_n) * BN;
+  int tmi, tni;
+  tile_coords(tile, g.tiles_m, g.tiles_n, g.band_h, tmi, tni);
+  int m0 = tmi * BM, n0 = tni * BN;
   int it = 0;   // running k-iteration counter: LDS buffer parity
 
   // buffer descriptors (wave-uniform: kernel arguments only) and per-thread offsets
@@ -312,7 +330,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v2_kernel(const GemmArgs g) {
     const int t_next = t_local + per_xcd;
     const bool has_next_tile = t_next < chunk_n;
     const int ntile = chunk0 + t_next;
-    const int nm0 = (ntile / g.tiles_n) * BM, nn0 = (ntile % g.tiles_n) * BN;
+    tile_coords(has_next_tile ? ntile : tile, g.tiles_m, g.tiles_n, g.band_h, tmi, tni);
+    const int nm0 = tmi * BM, nn0 = tni * BN;
     if constexpr (BUF) {
       if (has_next_tile) {
         tile_offsets<BM, AKM>(nvoA, g.lda, nm0, tid);
@@ -427,6 +446,12 @@ int launch_v2(GemmArgs g, hipStream_t st) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   const int tiles = g.tiles_m * g.tiles_n;
+  {  // band height: keep the band's A panel (band_h x BM x K floats) around 1.5 MB of the 4 MiB L2
+    const long panel = (long)BM * g.K * 4;
+    long bh = (3l << 19) / (panel > 0 ? panel : 1);
+    g.band_h = (int)(bh < 1 ? 1 : (bh > 16 ? 16 : bh));
+    if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
+  }
   // persistent grid: up to `slots` resident workgroups (multiple of 8 for the XCD schedule)
   constexpr int SLOTS = (BM * BN >= 128 * 128) ? 512 : (BM * BN >= 64 * 128 ? 512 : 1024);
   int grid = tiles < SLOTS ? (tiles + 7) / 8 * 8 : SLOTS;
@@ -488,7 +513,7 @@ int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int
   GemmArgs g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux;
-  g.beta = beta; g.tiles_m = g.tiles_n = 0;
+  g.beta = beta; g.tiles_m = g.tiles_n = 0; g.band_h = 1;
   if (cfg == 0) cfg = choose_cfg(M, N);
   hipStream_t st = (hipStream_t)stream;
   if (!a_kmajor && !b_kmajor)

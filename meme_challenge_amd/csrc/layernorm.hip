@@ -53,14 +53,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma,
                                                      float* __restrict__ dz, float* __restrict__ dx,
                                                      float* __restrict__ part, int M, int H,
-                                                     DropCfg drop) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 2 * NV * 256];
+                                                     DropCfg drop, int want_dbias) {
+  __shared__ __attribute__((aligned(16))) float red[4 * NV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H4 = H >> 2;
-  f32x4 g[NV], dg[NV], db[NV];
+  f32x4 g[NV], dg[NV], db[NV], dbx[NV];     // dbx: column sum of dx = bias gradient of the producing Linear
   row_load<NV>(g, gamma, H4, lane);
 #pragma unroll
-  for (int k = 0; k < NV; ++k) { dg[k] = f32x4{0, 0, 0, 0}; db[k] = f32x4{0, 0, 0, 0}; }
+  for (int k = 0; k < NV; ++k) { dg[k] = f32x4{0, 0, 0, 0}; db[k] = f32x4{0, 0, 0, 0}; dbx[k] = f32x4{0, 0, 0, 0}; }
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     f32x4 d[NV], xh[NV];
     row_load<NV>(d, dy + (size_t)row * H, H4, lane);
@@ -68,14 +68,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const float mu = mean[row], rs = rstd[row];
     row_ln_bwd<NV>(d, xh, g, mu, rs, dg, db, H, H4, lane);      // d <- dz, accumulates dg/db
     if (dz) row_store<NV>(d, dz + (size_t)row * H, H4, lane);
-    if (dx && (dx != dz || drop.active)) {
-      if (drop.active) row_dropout<NV>(d, drop, (uint64_t)row * H4, H4, lane);
-      row_store<NV>(d, dx + (size_t)row * H, H4, lane);
+    if (drop.active) row_dropout<NV>(d, drop, (uint64_t)row * H4, H4, lane);
+    if (dx && (dx != dz || drop.active)) row_store<NV>(d, dx + (size_t)row * H, H4, lane);
+    if (want_dbias) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) if (lane + 64 * k < H4) dbx[k] += d[k];
     }
   }
   // cross-wave reduce of the column partials, then one partial row per workgroup
-  block_col_reduce_store<NV>(dg, red, part + (size_t)blockIdx.x * 2 * H, H4, lane, wave);
-  block_col_reduce_store<NV>(db, red, part + (size_t)blockIdx.x * 2 * H + H, H4, lane, wave);
+  block_col_reduce_store<NV>(dg, red, part + (size_t)blockIdx.x * 3 * H, H4, lane, wave);
+  block_col_reduce_store<NV>(db, red, part + (size_t)blockIdx.x * 3 * H + H, H4, lane, wave);
+  if (want_dbias) block_col_reduce_store<NV>(dbx, red, part + (size_t)blockIdx.x * 3 * H + 2 * H, H4, lane, wave);
 }
 
 // out[n] (+)= sum_p part[p*stride + n].  Block = 32 columns x 8 partial-slices: the slices
@@ -97,6 +100,28 @@ __global__ __launch_bounds__(256) void finalize_partials_kernel(const float* __r
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][cx];
     out[n] = beta ? out[n] + t : t;
+  }
+}
+
+// several outputs of H columns each out of one partial buffer whose rows are [nout][H]:
+// outs[j][c] += sum_p part[p*stride + j*H + c]   (one launch instead of one per output)
+struct MultiOut { float* out[8]; };
+__global__ __launch_bounds__(256) void finalize_multi_kernel(const float* __restrict__ part, int nparts,
+                                                             size_t stride, MultiOut outs, int nout, int H) {
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + cx, N = nout * H;
+  float s = 0.f;
+  if (n < N)
+    for (int p = sl; p < nparts; p += 8) s += part[(size_t)p * stride + n];
+  red[sl][cx] = s;
+  __syncthreads();
+  if (sl == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    float* o = outs.out[n / H];
+    if (o) o[n % H] += t;
   }
 }
 
@@ -142,6 +167,17 @@ int launch_add_f32(float* out, const float* a, const float* b, size_t n, hipStre
   const size_t n4 = n / 4;
   if (n4 == 0) return 0;
   hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, out, a, b, n4);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+// accumulate nout (<= 8) outputs of H columns each; NULL outputs are skipped
+int finalize_partials_multi(const float* part, int nparts, size_t stride, float* const* outs, int nout, int H,
+                            hipStream_t st) {
+  MultiOut mo = {};
+  for (int j = 0; j < nout && j < 8; ++j) mo.out[j] = outs[j];
+  hipLaunchKernelGGL(finalize_multi_kernel, dim3((nout * H + 31) / 32), dim3(256), 0, st, part, nparts, stride,
+                     mo, nout, H);
   UCHECK_LAUNCH();
   return 0;
 }
@@ -199,13 +235,13 @@ extern "C" int uniter_ln_fwd(const float* x, const float* res, const float* gamm
 }
 
 extern "C" size_t uniter_ln_bwd_ws_bytes(int M, int H) {
-  return (size_t)ln_bwd_blocks(M) * 2 * H * sizeof(float);
+  return (size_t)ln_bwd_blocks(M) * 3 * H * sizeof(float);
 }
 
 extern "C" int uniter_ln_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
                              const float* gamma, float* dz, float* dx, float* dgamma, float* dbeta,
-                             int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
-                             void* ws, size_t ws_bytes, void* stream) {
+                             float* dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
+                             uint32_t site, void* ws, size_t ws_bytes, void* stream) {
   UCHECK_ARG(dy && z && mean && rstd && gamma && dgamma && dbeta && ws, "ln_bwd: null pointer");
   UCHECK_ARG(dz || dx, "ln_bwd: need dz or dx");
   UCHECK_SHAPE(H % 4 == 0 && H >= 4, "ln_bwd: H must be a multiple of 4");
@@ -216,8 +252,8 @@ extern "C" int uniter_ln_bwd(const float* dy, const float* z, const float* mean,
   const int nv = (H / 4 + 63) / 64;
   const int nblk = ln_bwd_blocks(M);
   float* part = (float*)ws;
-  LN_DISPATCH(nv, ln_bwd_kernel, dim3(nblk), dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop);
+  LN_DISPATCH(nv, ln_bwd_kernel, dim3(nblk), dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop, dbias != nullptr);
   UCHECK_LAUNCH();
-  UCHECK_RC(finalize_partials(part, nblk, (size_t)2 * H, dgamma, H, 1, st));
-  return finalize_partials(part + H, nblk, (size_t)2 * H, dbeta, H, 1, st);
+  float* outs[3] = {dgamma, dbeta, dbias};
+  return finalize_partials_multi(part, nblk, (size_t)3 * H, outs, dbias ? 3 : 2, H, st);
 }

@@ -449,7 +449,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   {
     ProfScope ps(m, UNITER_K_LN, st);
     UCHECK_RC(uniter_ln_bwd(dy, lb.z2, lb.mean2, lb.rstd2, m->LP(l, L_LN2_G), lb.dz2, g2, m->LG(l, L_LN2_G),
-                            m->LG(l, L_LN2_B), M, H, ph, m->seed, m->offset, SITE_FFN_OUT(l), pl.ln_ws,
+                            m->LG(l, L_LN2_B), m->LG(l, L_B2), M, H, ph, m->seed, m->offset, SITE_FFN_OUT(l), pl.ln_ws,
                             pl.ln_ws_bytes, st));
   }
   // FFN down dgrad (+ GELU'), FFN up dgrad (+ residual grad)
@@ -460,7 +460,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   {
     ProfScope ps(m, UNITER_K_LN, st);
     UCHECK_RC(uniter_ln_bwd(lb.dy1, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1, g1, m->LG(l, L_LN1_G),
-                            m->LG(l, L_LN1_B), M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l), pl.ln_ws,
+                            m->LG(l, L_LN1_B), m->LG(l, L_OB), M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l), pl.ln_ws,
                             pl.ln_ws_bytes, st));
   }
   UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, H, g1, H, m->LP(l, L_OW), H, lb.dctx, H, UNITER_EPI_NONE,
@@ -480,13 +480,11 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, g2, H, lb.hact, I, m->LG(l, L_W2), I, UNITER_EPI_NONE,
                  nullptr, nullptr, nullptr, 0, 1));
-  UCHECK_RC(uniter_colsum_f32(g2, M, H, H, m->LG(l, L_B2), 1, pl.col_ws, pl.col_ws_bytes, sd));
   UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, I, H, M, lb.du, I, lb.y1, H, m->LG(l, L_W1), H, UNITER_EPI_NONE,
                  nullptr, nullptr, nullptr, 0, 1));
   UCHECK_RC(uniter_colsum_f32(lb.du, M, I, I, m->LG(l, L_B1), 1, pl.col_ws, pl.col_ws_bytes, sd));
   UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, H, M, g1, H, lb.ctx, H, m->LG(l, L_OW), H, UNITER_EPI_NONE,
                  nullptr, nullptr, nullptr, 0, 1));
-  UCHECK_RC(uniter_colsum_f32(g1, M, H, H, m->LG(l, L_OB), 1, pl.col_ws, pl.col_ws_bytes, sd));
   UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkv, 3 * H, x, H, m->LG(l, L_QW), H,
                  UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
   UCHECK_RC(uniter_colsum_f32(lb.dqkv, M, 3 * H, 3 * H, m->LG(l, L_QB), 1, pl.col_ws, pl.col_ws_bytes, sd));

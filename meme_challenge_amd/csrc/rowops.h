@@ -126,3 +126,6 @@ __device__ __forceinline__ void block_col_reduce_store(const f32x4 (&acc)[NV], f
 // host: out[n] (+)= sum_p part[p*stride + n]   (layernorm.hip)
 int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta,
                       hipStream_t st);
+// outs[j][c] += sum_p part[p*stride + j*H + c] for j < nout (<= 8); NULL outputs skipped
+int finalize_partials_multi(const float* part, int nparts, size_t stride, float* const* outs, int nout, int H,
+                            hipStream_t st);

@@ -28,7 +28,7 @@ def _ref(qkv, mask, B, L, nh, p, seed, offset, site):
 
 
 @pytest.mark.parametrize('B,L,nh,p', [(2, 164, 2, 0.0), (2, 164, 2, 0.1), (3, 16, 2, 0.1), (1, 33, 1, 0.25),
-                                       (2, 100, 12, 0.1), (1, 178, 16, 0.0)])
+                                       (2, 100, 12, 0.1), (1, 178, 16, 0.0), (1, 288, 1, 0.1), (1, 300, 2, 0.1)])
 def test_attention_fwd_bwd(B, L, nh, p):
     from meme_challenge_amd import _lib as Lb
     lib = Lb.lib()

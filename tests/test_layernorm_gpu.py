@@ -58,10 +58,12 @@ def test_ln_fwd_bwd(M, H, p):
     dbet = torch.full((H,), -0.25, device='cuda')
     ws_n = lib.uniter_ln_bwd_ws_bytes(M, H)
     ws = torch.empty(ws_n, dtype=torch.uint8, device='cuda')
+    dbias = torch.full((H,), 0.125, device='cuda')
     L.check(lib.uniter_ln_bwd(L.ptr(ddy), L.ptr(z), L.ptr(mu), L.ptr(rstd), L.ptr(dg_), L.ptr(dz),
-                              L.ptr(dxo), L.ptr(dgam), L.ptr(dbet), M, H, p, seed, offset, site,
+                              L.ptr(dxo), L.ptr(dgam), L.ptr(dbet), L.ptr(dbias), M, H, p, seed, offset, site,
                               L.ptr(ws), ws_n, L.cur_stream()))
     torch.cuda.synchronize()
+    assert (dbias.cpu().double() - 0.125 - xr.grad.sum(0)).abs().max() < 1e-4
     assert (dz.cpu().double() - rr.grad).abs().max() < 5e-5
     assert (dxo.cpu().double() - xr.grad).abs().max() < 5e-5
     assert (dgam.cpu().double() - 0.5 - gr.grad).abs().max() < 1e-4
