@@ -21,6 +21,7 @@
 //    __syncthreads per k-tile.
 //  * blockIdx -> tile map is XCD-aware (bijective chunking): blocks that share an
 //    XCD's L2 work on adjacent tiles.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -38,7 +39,13 @@ struct GemmArgs {
   int beta;
   int tiles_m, tiles_n;
   int band_h;
+  int prio_mode;
 };
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;   // row stride (floats) of a k-contiguous tile
@@ -292,6 +299,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v2_kernel(const GemmArgs g) {
   const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int chunk_n = q + (xcd < r ? 1 : 0);
   if (idx >= chunk_n) return;
+  if (g.prio_mode == 1) {          // experiment: distinct priorities for (probably) co-resident workgroups
+    const int pr = (blockIdx.x >> 8) & 3;
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
 
   f32x4 ra[BM / 32], rb[BN / 32];
   f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
@@ -454,7 +467,11 @@ int launch_v2(GemmArgs g, hipStream_t st) {
   }
   // persistent grid: up to `slots` resident workgroups (multiple of 8 for the XCD schedule)
   constexpr int SLOTS = (BM * BN >= 128 * 128) ? 512 : (BM * BN >= 64 * 128 ? 512 : 1024);
-  int grid = tiles < SLOTS ? (tiles + 7) / 8 * 8 : SLOTS;
+  static const int slots_override = env_int("UNITER_GEMM_SLOTS", 0);     // tuning experiments only
+  static const int prio_mode = env_int("UNITER_GEMM_PRIO", 0);
+  const int slots = slots_override > 0 ? slots_override : SLOTS;
+  g.prio_mode = prio_mode;
+  int grid = tiles < slots ? (tiles + 7) / 8 * 8 : slots;
   // branch-free buffer-load path: no in-row k tail, and byte offsets must fit the 32-bit voffset
   const bool fast = g.K % BK == 0 && (size_t)(AKM ? g.K : g.M) * g.lda * 4 < (1ull << 31) &&
                     (size_t)(BKM ? g.K : g.N) * g.ldb * 4 < (1ull << 31);
@@ -462,6 +479,207 @@ int launch_v2(GemmArgs g, hipStream_t st) {
     hipLaunchKernelGGL((gemm_f32_v2_kernel<BM, BN, AKM, BKM, TAG, true>), dim3(grid), dim3(256), 0, st, g);
   else
     hipLaunchKernelGGL((gemm_f32_v2_kernel<BM, BN, AKM, BKM, TAG, false>), dim3(grid), dim3(256), 0, st, g);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// v3: v2's schedule with a full-iteration prefetch distance.  The k-tiles a workgroup will consume
+// (across all of its output tiles) form one flat sequence of "units"; in the middle of iteration u
+// the staging registers (unit u+1, fetched during iteration u-1) are written to LDS and at once
+// refilled with unit u+2, so every global load has a full k-iteration (>= 64 MFMAs of this wave,
+// times the waves sharing the SIMD) to land instead of half of one.  A lone wave per SIMD lost ~19 % to vmcnt stalls with
+// the one-deep version.  Needs the branch-free buffer-load path (K % 32 == 0).
+// ---------------------------------------------------------------------------
+template <int BM, int BN, bool AKM, bool BKM, int TAG>
+__global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int SA = TileSize<BM, AKM>::value, SB = TileSize<BN, BKM>::value;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int nk = g.K / BK;
+
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int chunk_n = q + (xcd < r ? 1 : 0);
+  if (idx >= chunk_n) return;
+  const int my_tiles = (chunk_n - idx + per_xcd - 1) / per_xcd;
+  const int total_units = my_tiles * nk;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.A), 0, (AKM ? g.K : g.M) * g.lda * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.B), 0, (BKM ? g.K : g.N) * g.ldb * 4, 0x00020000);
+  const int kstepA = (AKM ? BK * g.lda : BK) * 4, kstepB = (BKM ? BK * g.ldb : BK) * 4;
+
+  // load cursor: (tile, k) of the next unit to fetch
+  int lt = idx, lk = 0, lm0, ln0;
+  int voA[BM / 32], voB[BN / 32];
+  {
+    int tmi, tni;
+    tile_coords(chunk0 + lt, g.tiles_m, g.tiles_n, g.band_h, tmi, tni);
+    lm0 = tmi * BM; ln0 = tni * BN;
+    tile_offsets<BM, AKM>(voA, g.lda, lm0, tid);
+    tile_offsets<BN, BKM>(voB, g.ldb, ln0, tid);
+  }
+  int loaded = 0;     // units fetched so far
+#define ADVANCE_LOAD_CURSOR()                                                            \
+  do {                                                                                   \
+    ++loaded;                                                                            \
+    if (++lk == nk) {                                                                    \
+      lk = 0; lt += per_xcd;                                                             \
+      if (loaded < total_units) {                                                        \
+        int tmi_, tni_;                                                                  \
+        tile_coords(chunk0 + lt, g.tiles_m, g.tiles_n, g.band_h, tmi_, tni_);            \
+        lm0 = tmi_ * BM; ln0 = tni_ * BN;                                                \
+        tile_offsets<BM, AKM>(voA, g.lda, lm0, tid);                                     \
+        tile_offsets<BN, BKM>(voB, g.ldb, ln0, tid);                                     \
+      }                                                                                  \
+    }                                                                                    \
+  } while (0)
+#define LOAD_UNIT(RA, RB)                                                                \
+  do {                                                                                   \
+    if (loaded < total_units) {                                                          \
+      tile_load_buf<BM>(RA, rsA, voA, lk * kstepA);                                      \
+      tile_load_buf<BN>(RB, rsB, voB, lk * kstepB);                                      \
+      ADVANCE_LOAD_CURSOR();                                                             \
+    }                                                                                    \
+  } while (0)
+
+  f32x4 ra0[BM / 32], rb0[BN / 32], ra1[BM / 32], rb1[BN / 32];
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+
+  LOAD_UNIT(ra0, rb0);                       // unit 0
+  tile_store<BM, AKM>(ra0, smem, tid);
+  tile_store<BN, BKM>(rb0, smem + SA, tid);
+  LOAD_UNIT(ra1, rb1);                       // unit 1 (stays in registers until iteration 0 stores it)
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < TM; ++a) fa0[a] = frag_read<BM, AKM>(smem, wm * WM + a * 32, 0, i, h);
+#pragma unroll
+  for (int b = 0; b < TN; ++b) fb0[b] = frag_read<BN, BKM>(smem + SA, wn * WN + b * 32, 0, i, h);
+
+  // compute cursor
+  int ct = idx, ck = 0;
+  int tmi0, tni0;
+  tile_coords(chunk0 + ct, g.tiles_m, g.tiles_n, g.band_h, tmi0, tni0);
+  int m0 = tmi0 * BM, n0 = tni0 * BN;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) acc[a][b][rr] = 0.f;
+
+#define MFMA_BLOCK(FA, FB)                                                                              \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
+  _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                        \
+  _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                        \
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a][t], FB[b][t], acc[a][b], 0, 0, 0);
+#define READ_FRAGS(FA, FB, SAp, SBp, KB)                                                                \
+  _Pragma("unroll") for (int a = 0; a < TM; ++a) FA[a] = frag_read<BM, AKM>(SAp, wm * WM + a * 32, KB, i, h); \
+  _Pragma("unroll") for (int b = 0; b < TN; ++b) FB[b] = frag_read<BN, BKM>(SBp, wn * WN + b * 32, KB, i, h);
+
+// one k-iteration: unit u is in LDS stage (u&1); RS* = registers holding unit u+1 (stored now);
+// RL* = registers that receive unit u+2
+#define K_ITERATION(U, RSA, RSB, RLA, RLB)                                                              \
+  {                                                                                                     \
+    const float* sA = smem + ((U) & 1) * (SA + SB);                                                     \
+    const float* sB = sA + SA;                                                                          \
+    float* dA = smem + (((U) + 1) & 1) * (SA + SB);                                                     \
+    const bool more = (U) + 1 < total_units;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    READ_FRAGS(fa1, fb1, sA, sB, 1)                                                                     \
+    MFMA_BLOCK(fa0, fb0)                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    READ_FRAGS(fa0, fb0, sA, sB, 2)                                                                     \
+    MFMA_BLOCK(fa1, fb1)                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (more) {                                                                                         \
+      tile_store<BM, AKM>(RSA, dA, tid);                                                                \
+      tile_store<BN, BKM>(RSB, dA + SA, tid);                                                           \
+    }                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    LOAD_UNIT(RSA, RSB);   /* registers just stored are free: fetch unit u+3 ... */                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    READ_FRAGS(fa1, fb1, sA, sB, 3)                                                                     \
+    MFMA_BLOCK(fa0, fb0)                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    __syncthreads();                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (more) { READ_FRAGS(fa0, fb0, dA, (dA + SA), 0) }                                                \
+    MFMA_BLOCK(fa1, fb1)                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (++ck == nk) {                                                                                   \
+      EPILOGUE();                                                                                       \
+      ck = 0; ct += per_xcd;                                                                            \
+      if (more) {                                                                                       \
+        tile_coords(chunk0 + ct, g.tiles_m, g.tiles_n, g.band_h, tmi0, tni0);                          \
+        m0 = tmi0 * BM; n0 = tni0 * BN;                                                                 \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+
+#define EPILOGUE()                                                                                      \
+  _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                      \
+    _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                    \
+      const int col = n0 + wn * WN + b * 32 + i;                                                        \
+      const bool cok = col < g.N;                                                                       \
+      const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU)) ? g.bias[col] : 0.f; \
+      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                               \
+        const int row = m0 + wm * WM + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;                       \
+        if (cok && row < g.M) {                                                                         \
+          float v = acc[a][b][rr] + bv;                                                                 \
+          if (g.epi == UNITER_EPI_BIAS_GELU) {                                                          \
+            if (g.aux_out) g.aux_out[(size_t)row * g.ld_aux + col] = v;                                 \
+            v = gelu_erf(v);                                                                            \
+          } else if (g.epi == UNITER_EPI_DGELU) {                                                       \
+            v *= dgelu_erf(g.aux_in[(size_t)row * g.ld_aux + col]);                                     \
+          } else if (g.epi == UNITER_EPI_ADD) {                                                         \
+            v += g.aux_in[(size_t)row * g.ld_aux + col];                                                \
+          }                                                                                             \
+          float* c = g.C + (size_t)row * g.ldc + col;                                                   \
+          if (g.beta) v += *c;                                                                          \
+          *c = v;                                                                                       \
+        }                                                                                               \
+        acc[a][b][rr] = 0.f;                                                                            \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+
+  // One register set suffices: the set is written to LDS in the middle of iteration u and refilled
+  // immediately, and is not needed again until the middle of iteration u+1.
+  for (int u = 0; u < total_units; ++u) K_ITERATION(u, ra1, rb1, ra1, rb1)
+#undef K_ITERATION
+#undef EPILOGUE
+#undef MFMA_BLOCK
+#undef READ_FRAGS
+#undef LOAD_UNIT
+#undef ADVANCE_LOAD_CURSOR
+}
+
+template <int BM, int BN, bool AKM, bool BKM, int TAG>
+int launch_v3(GemmArgs g, hipStream_t st, int slots) {
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  const int tiles = g.tiles_m * g.tiles_n;
+  {
+    const long panel = (long)BM * g.K * 4;
+    long bh = (3l << 19) / (panel > 0 ? panel : 1);
+    g.band_h = (int)(bh < 1 ? 1 : (bh > 16 ? 16 : bh));
+    if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
+  }
+  static const int slots_override = env_int("UNITER_GEMM_SLOTS", 0);
+  if (slots_override > 0) slots = slots_override;
+  int grid = tiles < slots ? (tiles + 7) / 8 * 8 : slots;
+  hipLaunchKernelGGL((gemm_f32_v3_kernel<BM, BN, AKM, BKM, TAG>), dim3(grid), dim3(256), 0, st, g);
   UCHECK_LAUNCH();
   return 0;
 }
@@ -477,6 +695,15 @@ int dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
     case 12: return launch_v2<64, 128, AKM, BKM, TAG>(g, st);
     case 13: return launch_v2<128, 64, AKM, BKM, TAG>(g, st);
     case 14: return launch_v2<64, 64, AKM, BKM, TAG>(g, st);
+    case 21: case 22: case 23: case 24: {
+      const bool fast = g.K % BK == 0 && (size_t)(AKM ? g.K : g.M) * g.lda * 4 < (1ull << 31) &&
+                        (size_t)(BKM ? g.K : g.N) * g.ldb * 4 < (1ull << 31);
+      if (!fast) return dispatch_cfg<AKM, BKM, TAG>(cfg - 10, g, st);
+      if (cfg == 21) return launch_v3<128, 128, AKM, BKM, TAG>(g, st, 512);
+      if (cfg == 22) return launch_v3<64, 128, AKM, BKM, TAG>(g, st, 512);
+      if (cfg == 23) return launch_v3<128, 64, AKM, BKM, TAG>(g, st, 512);
+      return launch_v3<64, 64, AKM, BKM, TAG>(g, st, 1024);
+    }
     default: uniter_set_error("gemm: bad cfg %d", cfg); return UNITER_E_ARG;
   }
 }
@@ -487,7 +714,7 @@ int dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
 // there are >= ~3000 64x64 tiles (e.g. 4096^3: 137 vs 128 TFLOP/s).
 int choose_cfg(int M, int N) {
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
-  return t64 >= 3072 ? 11 : 14;
+  return t64 >= 3072 ? 21 : 24;      // v3 kernels; they fall back to v2 / v1 when K % 32 != 0
 }
 
 }  // namespace
@@ -513,7 +740,7 @@ int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int
   GemmArgs g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux;
-  g.beta = beta; g.tiles_m = g.tiles_n = 0; g.band_h = 1;
+  g.beta = beta; g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.prio_mode = 0;
   if (cfg == 0) cfg = choose_cfg(M, N);
   hipStream_t st = (hipStream_t)stream;
   if (!a_kmajor && !b_kmajor)

@@ -152,8 +152,8 @@ __global__ void add_kernel(float* __restrict__ out, const float* __restrict__ a,
 }
 
 inline int ln_bwd_blocks(int M) {
-  int b = (M + 15) / 16;      // ~4 rows per wave: enough waves in flight for HBM, few partial rows
-  return b < 256 ? (b < 1 ? 1 : b) : 256;
+  int b = (M + 7) / 8;        // ~2 rows per wave: enough waves in flight for HBM, few partial rows
+  return b < 512 ? (b < 1 ? 1 : b) : 512;
 }
 inline int colsum_splits(int M) {
   int s = (M + 31) / 32;
