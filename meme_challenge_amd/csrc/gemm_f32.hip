@@ -40,6 +40,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int band_h;
   int prio_mode;
+  float* colsum_part;   // optional [ceil(M/32)][N]: per-32-row-block column sums of the stored C (v3 only)
 };
 
 static int env_int(const char* name, int dflt) {
@@ -633,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
       const int col = n0 + wn * WN + b * 32 + i;                                                        \
       const bool cok = col < g.N;                                                                       \
       const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU)) ? g.bias[col] : 0.f; \
+      float csum = 0.f;                                                                                 \
       _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                               \
         const int row = m0 + wm * WM + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;                       \
         if (cok && row < g.M) {                                                                         \
@@ -645,11 +647,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
           } else if (g.epi == UNITER_EPI_ADD) {                                                         \
             v += g.aux_in[(size_t)row * g.ld_aux + col];                                                \
           }                                                                                             \
+          csum += v;                                                                                    \
           float* c = g.C + (size_t)row * g.ldc + col;                                                   \
           if (g.beta) v += *c;                                                                          \
           *c = v;                                                                                       \
         }                                                                                               \
         acc[a][b][rr] = 0.f;                                                                            \
+      }                                                                                                 \
+      if (g.colsum_part) {                                                                              \
+        csum += __shfl_xor(csum, 32, 64);                                                               \
+        if (h == 0 && cok && (m0 + wm * WM + a * 32) < g.M)                                             \
+          g.colsum_part[(size_t)((m0 + wm * WM + a * 32) >> 5) * g.N + col] = csum;                     \
       }                                                                                                 \
     }                                                                                                   \
   }
@@ -723,7 +731,8 @@ int choose_cfg(int M, int N) {
 // argument) so that one call site (the FFN-up forward GEMM) is its own row in rocprofv3 --stats.
 int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,
                  int lda, const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
-                 const float* aux_in, float* aux_out, int ld_aux, int beta, void* stream) {
+                 const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part,
+                 void* stream) {
   UCHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad dims %d %d %d", M, N, K);
   UCHECK_ARG(A && B && C, "gemm: null operand");
   UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_ADD, "gemm: bad epilogue %d", epilogue);
@@ -740,8 +749,13 @@ int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int
   GemmArgs g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux;
-  g.beta = beta; g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.prio_mode = 0;
+  g.beta = beta; g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.prio_mode = 0; g.colsum_part = colsum_part;
   if (cfg == 0) cfg = choose_cfg(M, N);
+  if (colsum_part) {
+    const bool fast = K % BK == 0 && (size_t)(a_kmajor ? K : M) * lda * 4 < (1ull << 31) &&
+                      (size_t)(b_kmajor ? K : N) * ldb * 4 < (1ull << 31);
+    UCHECK_SHAPE(fast && cfg >= 21 && cfg <= 24 && beta == 0, "gemm: fused column sums need the v3 kernel (K %% 32 == 0)");
+  }
   hipStream_t st = (hipStream_t)stream;
   if (!a_kmajor && !b_kmajor)
     return tag ? dispatch_cfg<false, false, 1>(cfg, g, st) : dispatch_cfg<false, false, 0>(cfg, g, st);
@@ -755,7 +769,7 @@ extern "C" int uniter_gemm_f32_cfg(int cfg, int a_kmajor, int b_kmajor, int M, i
                                    int ldc, int epilogue, const float* bias, const float* aux_in,
                                    float* aux_out, int ld_aux, int beta, void* stream) {
   return gemm_f32_run(cfg, 0, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, epilogue, bias, aux_in,
-                      aux_out, ld_aux, beta, stream);
+                      aux_out, ld_aux, beta, nullptr, stream);
 }
 
 extern "C" int uniter_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,

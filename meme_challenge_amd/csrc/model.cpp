@@ -19,7 +19,8 @@
 int launch_add_f32(float* out, const float* a, const float* b, size_t n, hipStream_t st);
 int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda,
                  const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
-                 const float* aux_in, float* aux_out, int ld_aux, int beta, void* stream);
+                 const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part, void* stream);
+int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta, hipStream_t st);
 int launch_masked_rowsum(const float* x, const int64_t* masks, float* out, int rows, int D, hipStream_t st);
 
 namespace {
@@ -53,7 +54,7 @@ struct Carver {
 
 struct LayerBufs {   // saved activations + backward scratch of one layer
   float *qkv, *lse, *ctx, *t1, *z1, *mean1, *rstd1, *y1, *u, *hact, *t2, *z2, *mean2, *rstd2, *y2;
-  float *dz2, *g2, *du, *dy1, *dz1, *g1, *dctx, *dqkv, *delta, *dx;
+  float *dz2, *g2, *du, *dy1, *dz1, *g1, *dctx, *dqkv, *delta, *dx, *du_csum;
 };
 
 struct Plan {
@@ -144,6 +145,7 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
       b.dz2 = cv.f(M * H); b.g2 = cv.f(M * H); b.du = cv.f(M * I); b.dy1 = cv.f(M * H); b.dz1 = cv.f(M * H);
       b.g1 = cv.f(M * H); b.dctx = cv.f(M * H); b.dqkv = cv.f(M * 3 * H); b.delta = cv.f((size_t)B * nh * L);
       b.dx = cv.f(M * H);
+      b.du_csum = cv.f((size_t)((M + 31) / 32) * I);
     }
   } else {
     // inference: every layer reuses one set of buffers; the layer output ping-pongs
@@ -188,10 +190,10 @@ struct ProfScope {
 
 int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int N, int K, const float* A,
          int lda, const float* B, int ldb, float* C, int ldc, int epi, const float* bias, const float* aux_in,
-         float* aux_out, int ld_aux, int beta) {
+         float* aux_out, int ld_aux, int beta, float* colsum_part = nullptr) {
   ProfScope ps(m, kind, st);
   return gemm_f32_run(0, kind == UNITER_K_GEMM_FFN_UP_FWD, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias,
-                      aux_in, aux_out, ld_aux, beta, st);
+                      aux_in, aux_out, ld_aux, beta, colsum_part, st);
 }
 
 int validate_batch(const uniter_model* m, const uniter_batch_t* b) {
@@ -453,8 +455,11 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                             pl.ln_ws_bytes, st));
   }
   // FFN down dgrad (+ GELU'), FFN up dgrad (+ residual grad)
+  // the GEMM's epilogue also emits per-32-row column sums of du (= partial bias gradients of
+  // intermediate.dense): saves a 32 MB re-read of du
+  const bool fuse_db1 = H % 32 == 0;
   UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, g2, H, m->LP(l, L_W2), I, lb.du, I, UNITER_EPI_DGELU,
-                 nullptr, lb.u, nullptr, I, 0));
+                 nullptr, lb.u, nullptr, I, 0, fuse_db1 ? lb.du_csum : nullptr));
   UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, I, lb.du, I, m->LP(l, L_W1), H, lb.dy1, H, UNITER_EPI_ADD,
                  nullptr, lb.dz2, nullptr, H, 0));
   {
@@ -482,7 +487,8 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                  nullptr, nullptr, nullptr, 0, 1));
   UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, I, H, M, lb.du, I, lb.y1, H, m->LG(l, L_W1), H, UNITER_EPI_NONE,
                  nullptr, nullptr, nullptr, 0, 1));
-  UCHECK_RC(uniter_colsum_f32(lb.du, M, I, I, m->LG(l, L_B1), 1, pl.col_ws, pl.col_ws_bytes, sd));
+  if (fuse_db1) UCHECK_RC(finalize_partials(lb.du_csum, (M + 31) / 32, (size_t)I, m->LG(l, L_B1), I, 1, sd));
+  else UCHECK_RC(uniter_colsum_f32(lb.du, M, I, I, m->LG(l, L_B1), 1, pl.col_ws, pl.col_ws_bytes, sd));
   UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, H, M, g1, H, lb.ctx, H, m->LG(l, L_OW), H, UNITER_EPI_NONE,
                  nullptr, nullptr, nullptr, 0, 1));
   UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkv, 3 * H, x, H, m->LG(l, L_QW), H,

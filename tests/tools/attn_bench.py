@@ -1,0 +1,20 @@
+import sys, torch
+sys.path.insert(0, '.')
+from meme_challenge_amd import _lib as L
+lib = L.lib()
+B, Lq, nh = 16, 164, 12
+H = nh * 64
+for p in (0.0, 0.1):
+    qkv = torch.randn(B * Lq, 3 * H, device='cuda'); mask = torch.ones(B, Lq, device='cuda')
+    ctx = torch.empty(B * Lq, H, device='cuda'); lse = torch.empty(B, nh, Lq, device='cuda')
+    dctx = torch.randn(B * Lq, H, device='cuda'); dqkv = torch.empty(B * Lq, 3 * H, device='cuda'); delta = torch.empty(B, nh, Lq, device='cuda')
+    def fwd(): L.check(lib.uniter_attn_fwd(L.ptr(qkv), L.ptr(mask), L.ptr(ctx), L.ptr(lse), B, Lq, nh, p, 1, 2, 3, L.cur_stream()))
+    def bwd(): L.check(lib.uniter_attn_bwd(L.ptr(qkv), L.ptr(mask), L.ptr(ctx), L.ptr(lse), L.ptr(dctx), L.ptr(dqkv), L.ptr(delta), B, Lq, nh, p, 1, 2, 3, L.cur_stream()))
+    for name, f in (('fwd', fwd), ('bwd(dq+dkv)', bwd)):
+        for _ in range(3): f()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): f()
+        e1.record(); torch.cuda.synchronize()
+        print('p=%.1f %-12s %.1f us' % (p, name, e0.elapsed_time(e1) / 20 * 1e3), flush=True)
