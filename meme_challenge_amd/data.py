@@ -1,0 +1,197 @@
+"""Input side of the hot path: the batch dict the model consumes.
+
+Counterpart of data/dataset_template.py:92-114 (`_load_img_feature`: `<id>.npy` fp32
+[nbb,2048] + `<id>_info.npy` pickled dict with bbox / image_width / image_height / objects /
+objects_conf|cls_prob -> 7-d box features (x1,y1,x2,y2,w,h,w*h), normalised), of
+data/meme_dataset.py:27-214 (jsonl list, `__getitem__`, `collate_fn` with compact batches) and
+of `ConfounderSampler` (:221-271).  Same file formats, same batch keys:
+  input_ids, position_ids, img_feat, img_pos_feat, token_type_ids, attn_mask, gather_index,
+  labels, ids.
+"""
+import json
+import os
+from random import shuffle
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.utils.data as data
+from torch.nn.utils.rnn import pad_sequence
+
+from .utils import get_attention_mask, get_gather_index
+
+
+def expand_id(img_id):
+    return str(img_id).zfill(5)
+
+
+def load_img_feature(feature_dir, img_id, normalize=True):
+    """-> (feat [nbb, D] fp32, pos [nbb, 7] fp32, objects, objects_conf)"""
+    sid = expand_id(img_id)
+    feat = torch.from_numpy(np.load(os.path.join(feature_dir, '%s.npy' % sid)))
+    info = np.load(os.path.join(feature_dir, '%s_info.npy' % sid), allow_pickle=True).item()
+    x1, y1, x2, y2 = [c.astype(np.float32).copy() for c in np.split(info['bbox'], 4, axis=1)]
+    conf = info['objects_conf'] if 'objects_conf' in info else info['cls_prob'].max(axis=-1)
+    if normalize:
+        x1 /= info['image_width']; x2 /= info['image_width']
+        y1 /= info['image_height']; y2 /= info['image_height']
+    w, h = x2 - x1, y2 - y1
+    pos = torch.from_numpy(np.concatenate((x1, y1, x2, y2, w, h, w * h), axis=1).astype(np.float32))
+    return feat.float(), pos, info['objects'], conf
+
+
+class MemeDataset(data.Dataset):
+    def __init__(self, filepath, feature_dir=None, text_padding=None, return_ids=False, compact_batch=True,
+                 confidence_threshold=0.0, preload_images=False, text_only=False, debug=False, **unused):
+        assert os.path.isfile(filepath), "Dataset file cannot be found: \"%s\"." % filepath
+        assert filepath.endswith(".jsonl"), "The filepath requires a JSON list file (\".jsonl\")."
+        self.filepath, self.feature_dir = filepath, feature_dir
+        self.name = filepath.split("/")[-1].split(".")[0]
+        self.text_padding, self.return_ids, self.compact_batch = text_padding, return_ids, compact_batch
+        self.confidence_threshold, self.text_only = confidence_threshold, text_only
+        with open(filepath, "r") as f:
+            js = [json.loads(l) for l in f if l.strip()]
+        self.data = SimpleNamespace(
+            ids=torch.LongTensor([int(j["id"]) for j in js]),
+            labels=torch.LongTensor([j.get("label", -1) for j in js]),
+            text=[j["text"] for j in js],
+            imgs=[os.path.join(os.path.dirname(filepath), j.get("img", "")) for j in js])
+        if not text_only:
+            for i in self.data.ids.tolist():
+                for suffix in ('.npy', '_info.npy'):
+                    p = os.path.join(feature_dir, expand_id(i) + suffix)
+                    assert os.path.isfile(p), "Feature file %s does not exist." % p
+        self._cache = None
+        if preload_images and not text_only:
+            self._cache = [load_img_feature(feature_dir, i) for i in self.data.ids.tolist()]
+
+    def __len__(self):
+        return len(self.data.ids)
+
+    def __getitem__(self, idx):
+        data_id, label = self.data.ids[idx], self.data.labels[idx]
+        feat = pos = None
+        if not self.text_only:
+            feat, pos, _, conf = self._cache[idx] if self._cache is not None else \
+                load_img_feature(self.feature_dir, data_id.item())
+            if self.confidence_threshold > 0.0:
+                keep = torch.from_numpy(np.asarray(conf) > self.confidence_threshold)
+                feat, pos = feat[keep], pos[keep]
+        return {'img_feat': feat, 'img_pos_feat': pos, 'text': self.data.text[idx], 'label': label,
+                'data_id': data_id}
+
+    def get_collate_fn(self):
+        def collate_fn(samples):
+            texts = self.text_padding([s['text'] for s in samples])
+            input_ids = texts['input_ids']
+            text_len = [int(x) for x in (texts['length'].tolist() if torch.is_tensor(texts['length'])
+                                         else texts['length'])]
+            B, T = input_ids.shape
+            batch = {'input_ids': input_ids,
+                     'position_ids': torch.arange(T, dtype=torch.long).unsqueeze(0).repeat(B, 1),
+                     'token_type_ids': texts.get('token_type_ids') if hasattr(texts, 'get') else None,
+                     'labels': torch.stack([s['label'] for s in samples]),
+                     'ids': torch.stack([s['data_id'] for s in samples])}
+            if self.text_only:
+                batch.update(img_feat=None, img_pos_feat=None, attn_mask=texts['attention_mask'], gather_index=None)
+                return batch
+            img_feat = pad_sequence([s['img_feat'] for s in samples], batch_first=True, padding_value=0)
+            img_pos = pad_sequence([s['img_pos_feat'] for s in samples], batch_first=True, padding_value=0)
+            img_len = [s['img_feat'].size(0) for s in samples]
+            if self.compact_batch:
+                attn = get_attention_mask(text_len, img_len)
+            else:
+                attn = torch.cat((texts['attention_mask'].float(), get_attention_mask([0] * B, img_len)), dim=1)
+            gi = get_gather_index(text_len, img_len, B, T, attn.shape[1])
+            batch.update(img_feat=img_feat, img_pos_feat=img_pos, attn_mask=attn, gather_index=gi)
+            return batch
+        return collate_fn
+
+
+class ConfounderSampler(data.Sampler):
+    """Repeats the text confounders (same text, both labels) `repeat_factor` times per epoch
+    (data/meme_dataset.py:221-271)."""
+
+    def __init__(self, dataset, repeat_factor=1):
+        self.dataset, self.repeat_factor = dataset, repeat_factor
+        labels_of = {}
+        for idx, text in enumerate(dataset.data.text):
+            labels_of.setdefault(text, set()).add(int(dataset.data.labels[idx]))
+        conf_text = {t for t, ls in labels_of.items() if ls == {0, 1}}
+        self.confounders = [i for i, t in enumerate(dataset.data.text) if t in conf_text]
+        self.non_confounders = [i for i, t in enumerate(dataset.data.text) if t not in conf_text]
+        self._generate()
+
+    def _generate(self):
+        plain = self.non_confounders[:]
+        shuffle(plain)
+        n, k = len(plain), self.repeat_factor
+        splits = [(n // k) * i for i in range(k)] + [n]
+        out = []
+        for i in range(k):
+            sub = plain[splits[i]:splits[i + 1]] + self.confounders
+            shuffle(sub)
+            out += sub
+        self.sample_list = out
+
+    def __iter__(self):
+        self._generate()
+        return iter(self.sample_list)
+
+    def __len__(self):
+        return len(self.sample_list)
+
+
+class HashTokenizer(object):
+    """Offline stand-in for `BertTokenizer('bert-base-cased')` (which needs the hub): lower-cased
+    whitespace tokens hashed into the vocabulary, [CLS]=101 / [SEP]=102 / [PAD]=0, same call
+    signature and return fields as the partial built at train_uniter.py:124-126."""
+
+    def __init__(self, vocab_size=28996, max_length=60):
+        self.vocab_size, self.max_length = vocab_size, max_length
+
+    def __call__(self, texts, **kw):
+        T = kw.get('max_length', self.max_length)
+        ids = torch.zeros(len(texts), T, dtype=torch.long)
+        lens = []
+        for b, t in enumerate(texts):
+            toks = [101] + [1000 + (hash_str(w) % (self.vocab_size - 1000)) for w in str(t).lower().split()][:T - 2] + [102]
+            ids[b, :len(toks)] = torch.tensor(toks)
+            lens.append(len(toks))
+        return {'input_ids': ids, 'length': torch.tensor(lens), 'attention_mask': (ids != 0).long(),
+                'token_type_ids': torch.zeros_like(ids)}
+
+
+def hash_str(s):
+    h = 2166136261
+    for c in s.encode('utf-8'):
+        h = ((h ^ c) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+def write_synthetic_dataset(root, n=64, num_bb=(10, 36), img_dim=2048, seed=0, splits=('train', 'dev_seen')):
+    """Create a dataset in the reference's ON-DISK FORMAT (jsonl + per-image .npy feature files) with
+    a learnable signal: label 1 memes have a shifted feature mean and contain a marker word."""
+    rng = np.random.default_rng(seed)
+    feat_dir = os.path.join(root, 'img_feats')
+    os.makedirs(feat_dir, exist_ok=True)
+    words = ['cat', 'dog', 'meme', 'funny', 'sky', 'tree', 'car', 'look', 'when', 'you', 'me', 'nobody']
+    idx = 0
+    for split in splits:
+        with open(os.path.join(root, split + '.jsonl'), 'w') as f:
+            for _ in range(n):
+                label = int(rng.random() < 0.4)
+                nbb = int(rng.integers(num_bb[0], num_bb[1] + 1))
+                feat = np.abs(rng.standard_normal((nbb, img_dim))).astype(np.float32) + 0.5 * label
+                W, H = 640, 480
+                x1 = rng.random((nbb, 1)) * 0.7 * W; y1 = rng.random((nbb, 1)) * 0.7 * H
+                bw = (rng.random((nbb, 1)) * 0.25 + 0.05) * W; bh = (rng.random((nbb, 1)) * 0.25 + 0.05) * H
+                info = {'bbox': np.concatenate([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32),
+                        'image_width': W, 'image_height': H,
+                        'objects': rng.integers(0, 1600, nbb), 'objects_conf': rng.random(nbb).astype(np.float32)}
+                np.save(os.path.join(feat_dir, expand_id(idx) + '.npy'), feat)
+                np.save(os.path.join(feat_dir, expand_id(idx) + '_info.npy'), info, allow_pickle=True)
+                text = ' '.join(rng.choice(words, int(rng.integers(3, 9)))) + (' hateful' if label else ' nice')
+                f.write(json.dumps({'id': idx, 'img': 'img/%s.png' % expand_id(idx), 'label': label, 'text': text}) + '\n')
+                idx += 1
+    return feat_dir

@@ -91,6 +91,31 @@ class UniterConfig(object):
         return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
 
 
+# hyper-parameters of the two published UNITER sizes (the reference ships them as
+# config/uniter-base.json and config/uniter-large.json); `UniterConfig.from_name('uniter-base')`
+BUILTIN_CONFIGS = {
+    'uniter-base': dict(vocab_size=28996, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                        intermediate_size=3072, hidden_act='gelu', hidden_dropout_prob=0.1,
+                        attention_probs_dropout_prob=0.1, max_position_embeddings=512, type_vocab_size=2,
+                        initializer_range=0.02),
+}
+BUILTIN_CONFIGS['uniter-large'] = dict(BUILTIN_CONFIGS['uniter-base'], hidden_size=1024, num_hidden_layers=24,
+                                       num_attention_heads=16, intermediate_size=4096)
+
+
+def resolve_config(path_or_name):
+    """A json path, or the name of a built-in size ('uniter-base' / 'uniter-large',
+    with or without a directory prefix and '.json')."""
+    import os
+    if os.path.isfile(path_or_name):
+        return UniterConfig.from_json_file(path_or_name)
+    key = os.path.basename(path_or_name)
+    key = key[:-5] if key.endswith('.json') else key
+    if key in BUILTIN_CONFIGS:
+        return UniterConfig.from_dict(BUILTIN_CONFIGS[key])
+    raise ValueError("[!] ERROR: config JSON path does not exist: %r" % path_or_name)
+
+
 # --------------------------------------------------------------------------- #
 # flat parameter / gradient storage
 # --------------------------------------------------------------------------- #
@@ -531,7 +556,7 @@ class UniterPreTrainedModel(nn.Module):
         """Instantiate from a config json and a state dict (model/model.py:148-214):
         gamma/beta -> weight/bias renames, optional 'bert.' prefix, missing /
         unexpected keys logged, shape errors raise RuntimeError."""
-        config = UniterConfig.from_json_file(config_file)
+        config = config_file if isinstance(config_file, UniterConfig) else resolve_config(config_file)
         logger.info("Model config {}".format(config))
         model = cls(config, *inputs, **kwargs)
         old_keys, new_keys = [], []

@@ -251,6 +251,20 @@ def gen_host_helpers():
             s.step()
             lrs.append(o.param_groups[0]['lr'])
         out['lr/' + nm] = np.array(lrs, np.float64)
+    # data/metrics.py: standard_metrics (binary) incl. optimal threshold, on seeded probabilities
+    from data import metrics as RM
+    rng = np.random.default_rng(0)
+    cases = [(10, 0.4), (57, 0.3), (300, 0.5), (8, 0.9)]
+    out['metrics/n'] = np.array(len(cases))
+    for k, (n, pr) in enumerate(cases):
+        p = rng.random(n).astype(np.float32)
+        p[::7] = p[0]                                   # ties
+        y = (rng.random(n) < pr).astype(np.int64)
+        y[0], y[1] = 0, 1
+        m = RM.standard_metrics(torch.from_numpy(p), torch.from_numpy(y), add_optimal_acc=True)
+        out['metrics/%d/probs' % k] = p
+        out['metrics/%d/labels' % k] = y
+        out['metrics/%d/ref' % k] = np.array(json.dumps({kk: float(vv) for kk, vv in m.items()}))
     np.savez_compressed(os.path.join(HERE, 'host_helpers.npz'), **out)
     print('host_helpers.npz written;', len(out['state_dict_keys']), 'keys')
 

@@ -1,0 +1,79 @@
+"""CPU: input pipeline (on-disk feature format -> batch dict), sampler, metrics, CLI surface."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_dataset_reads_reference_disk_format_and_collates(tmp_path):
+    from meme_challenge_amd.data import MemeDataset, HashTokenizer, write_synthetic_dataset, ConfounderSampler
+    from functools import partial
+    root = str(tmp_path)
+    feat_dir = write_synthetic_dataset(root, n=9, num_bb=(3, 7), img_dim=16, seed=1, splits=('train',))
+    tok = partial(HashTokenizer(vocab_size=2000), max_length=12, padding='max_length', truncation=True,
+                  return_tensors='pt', return_length=True)
+    ds = MemeDataset(os.path.join(root, 'train.jsonl'), feature_dir=feat_dir, text_padding=tok, return_ids=True)
+    assert len(ds) == 9 and ds.name == 'train'
+    s = ds[0]
+    info = np.load(os.path.join(feat_dir, '00000_info.npy'), allow_pickle=True).item()
+    bb = info['bbox'][0]
+    exp = np.array([bb[0] / 640, bb[1] / 480, bb[2] / 640, bb[3] / 480, (bb[2] - bb[0]) / 640, (bb[3] - bb[1]) / 480,
+                    (bb[2] - bb[0]) / 640 * (bb[3] - bb[1]) / 480], np.float32)
+    assert np.allclose(s['img_pos_feat'][0].numpy(), exp, atol=1e-6)      # dataset_template.py:98-113
+    batch = ds.get_collate_fn()([ds[i] for i in range(4)])
+    B, T = batch['input_ids'].shape
+    nbb = [ds[i]['img_feat'].shape[0] for i in range(4)]
+    tl = [int((batch['input_ids'][i] != 0).sum()) for i in range(4)]
+    L = max(t + n for t, n in zip(tl, nbb))
+    assert batch['attn_mask'].shape == (4, L) and batch['gather_index'].shape == (4, L)
+    for i in range(4):
+        assert batch['attn_mask'][i].sum().item() == tl[i] + nbb[i]
+        assert batch['gather_index'][i, tl[i]:tl[i] + nbb[i]].tolist() == list(range(T, T + nbb[i]))
+        assert torch.equal(batch['img_feat'][i, nbb[i]:], torch.zeros_like(batch['img_feat'][i, nbb[i]:]))
+    assert batch['position_ids'].tolist() == [list(range(T))] * 4
+    assert set(batch) >= {'input_ids', 'position_ids', 'img_feat', 'img_pos_feat', 'attn_mask', 'gather_index',
+                          'labels', 'ids'}
+    # confounders: same text with both labels is repeated repeat_factor times
+    ds.data.text[0] = ds.data.text[1] = 'same text'
+    ds.data.labels[0], ds.data.labels[1] = 0, 1
+    smp = ConfounderSampler(ds, repeat_factor=3)
+    order = list(iter(smp))
+    assert order.count(0) == 3 and order.count(1) == 3 and len(order) == 7 + 6
+
+
+def test_metrics_against_reference_golden(host_helpers):
+    from meme_challenge_amd.metrics import standard_metrics, find_optimal_threshold, aucroc
+    z = host_helpers
+    for k in range(int(z['metrics/n'])):
+        p, y = torch.from_numpy(z['metrics/%d/probs' % k]), torch.from_numpy(z['metrics/%d/labels' % k])
+        m = standard_metrics(p, y, add_optimal_acc=True)
+        ref = json.loads(str(z['metrics/%d/ref' % k]))
+        for key, v in ref.items():
+            assert abs(m[key] - v) < 1e-6, (k, key, m[key], v)
+    assert aucroc(torch.tensor([0.2, 0.9]), torch.tensor([1, 1])) == 0.0
+
+
+def test_cli_flags_match_reference_surface():
+    import train_uniter
+    from meme_challenge_amd.model import resolve_config
+    p = train_uniter.build_parser()
+    a = p.parse_args([])
+    ref_defaults = dict(data_path='./dataset', model_path='./model_checkpoints', vis_path='./vis_checkpoints',
+                        model_save_name='best_model.pt', optimizer='adam', loss_func='bce_logits',
+                        optimize_for='aucroc', scheduler='warmup_cosine', confounder_repeat=1,
+                        object_conf_thresh=0.0, num_folds=0, crossval_dev_size=300, beta1=0.9, beta2=0.999,
+                        batch_size=8, num_workers=0, gradient_accumulation=1, max_grad_norm=5, pos_wt=1,
+                        lr=1e-4, warmup_steps=50, weight_decay=1e-3, max_epoch=20, lr_decay_step=3,
+                        lr_decay_factor=0.8, patience=5, early_stop_thresh=1e-3, seed=42, log_every=2000,
+                        parallel_computing=False, config='./config/uniter-base.json',
+                        feature_path='./dataset/img_feats', max_txt_len=60, conf_th=0.2, max_bb=100, min_bb=10,
+                        num_bb=36, fc_dim=64, dropout=0.2)
+    for k, v in ref_defaults.items():
+        assert getattr(a, k) == v, k
+    c = resolve_config('./config/uniter-base.json')
+    assert (c.hidden_size, c.num_hidden_layers, c.vocab_size) == (768, 12, 28996)
+    assert resolve_config('uniter-large').intermediate_size == 4096
+    with pytest.raises(ValueError):
+        resolve_config('./config/nope.json')

@@ -1,0 +1,128 @@
+#!/usr/bin/env python
+"""CLI of the UNITER fine-tuning path on MI355X: counterpart of the reference's
+train_uniter.py (same flags, same hooks, same model/kwargs plumbing), running on
+libuniter_hip.so.
+
+    python train_uniter.py --config config/uniter-base.json --data_path ./dataset --feature_path ./dataset/img_feats \
+        --pretrained_model_file uniter-base.pt --lr 3e-5 --scheduler warmup_cosine --warmup_steps 500 \
+        --max_epoch 30 --batch_size 16 --gradient_accumulation 2 --pos_wt 1.8 --seed 43
+    torchrun --nproc-per-node 8 train_uniter.py ... --parallel_computing True      # DP over RCCL
+
+Additive flags (not in the reference): --synthetic N (write a synthetic dataset in the reference's
+on-disk format under --data_path and train on it), --hash_tokenizer (offline tokenizer).
+"""
+import argparse
+import os
+from functools import partial
+
+import torch
+from torch.utils import data
+
+from meme_challenge_amd.data import MemeDataset, ConfounderSampler, HashTokenizer, write_synthetic_dataset
+from meme_challenge_amd.meme_uniter import MemeUniter
+from meme_challenge_amd.model import UniterModel, UniterConfig, resolve_config
+from meme_challenge_amd.train_template import TrainerTemplate, LOGGER
+
+IMG_DIM = 2048            # utils/const.py
+
+
+class TrainerUniter(TrainerTemplate):
+
+    def init_model(self):
+        if self.pretrained_model_file:
+            checkpoint = torch.load(self.pretrained_model_file, map_location='cpu')
+            LOGGER.info('Using pretrained UNITER base model {}'.format(self.pretrained_model_file))
+            # the reference goes through UniterForPretraining and keeps `.uniter` (train_uniter.py:26-33)
+            sd = {k[len('uniter.'):]: v for k, v in checkpoint['model_state_dict'].items() if k.startswith('uniter.')}
+            base = UniterModel.from_pretrained(self.config['config'], state_dict=sd, img_dim=IMG_DIM)
+            self.model = MemeUniter(uniter_model=base, hidden_size=base.config.hidden_size,
+                                    n_classes=self.config['n_classes'])
+        else:
+            self.load_model()
+
+    def load_model(self):
+        uniter_config = resolve_config(self.config['config'])
+        uniter_model = UniterModel(uniter_config, img_dim=IMG_DIM)
+        self.model = MemeUniter(uniter_model=uniter_model, hidden_size=uniter_model.config.hidden_size,
+                                n_classes=self.config['n_classes'])
+        if self.model_file and os.path.isfile(self.model_file):
+            checkpoint = torch.load(self.model_file, map_location='cpu')
+            LOGGER.info('Using UNITER model {}'.format(self.model_file))
+            self.model.load_state_dict(checkpoint['model_state_dict'])
+
+    def _forward(self, batch):
+        return self.model(img_feat=batch['img_feat'], img_pos_feat=batch['img_pos_feat'],
+                          input_ids=batch['input_ids'], position_ids=batch['position_ids'],
+                          attention_mask=batch['attn_mask'], gather_index=batch['gather_index'],
+                          output_all_encoded_layers=False)
+
+    def eval_iter_step(self, iters, batch, test):
+        self.calculate_loss(self._forward(batch), batch['labels'], grad_step=False)
+
+    def train_iter_step(self):
+        self.preds = self._forward(self.batch)
+        self.calculate_loss(self.preds, self.batch['labels'], grad_step=True)
+
+    def test_iter_step(self, batch):
+        return self._forward(batch).squeeze()
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    TrainerTemplate.add_default_argparse(parser)
+    parser.add_argument('--config', type=str, default='./config/uniter-base.json')
+    parser.add_argument('--feature_path', type=str, default='./dataset/img_feats')
+    parser.add_argument('--max_txt_len', type=int, default=60)
+    parser.add_argument('--conf_th', type=float, default=0.2)
+    parser.add_argument('--max_bb', type=int, default=100)
+    parser.add_argument('--min_bb', type=int, default=10)
+    parser.add_argument('--num_bb', type=int, default=36)
+    parser.add_argument('--fc_dim', type=int, default=64)
+    parser.add_argument('--dropout', type=float, default=0.2)
+    # additive
+    parser.add_argument('--synthetic', type=int, default=0, help='write + use a synthetic dataset of N samples per split')
+    parser.add_argument('--hash_tokenizer', action='store_true', help='offline tokenizer instead of bert-base-cased')
+    return parser
+
+
+def main(argv=None):
+    args, _ = build_parser().parse_known_args(argv)
+    config = args.__dict__
+    if config['parallel_computing'] and 'RANK' in os.environ and not torch.distributed.is_initialized():
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        torch.distributed.init_process_group('nccl')
+    if config['synthetic'] > 0:
+        os.makedirs(config['data_path'], exist_ok=True)
+        if not os.path.isfile(os.path.join(config['data_path'], 'train.jsonl')):
+            config['feature_path'] = write_synthetic_dataset(config['data_path'], n=config['synthetic'],
+                                                             splits=('train', 'dev_seen', 'test_seen'))
+        else:
+            config['feature_path'] = os.path.join(config['data_path'], 'img_feats')
+    config = TrainerTemplate.preprocess_args(config)
+    if config['hash_tokenizer'] or config['synthetic'] > 0:
+        tokenizer = HashTokenizer(max_length=config['max_txt_len'])
+    else:
+        from transformers import BertTokenizer
+        tokenizer = BertTokenizer.from_pretrained('bert-base-cased')      # needs the hub cache
+    tokenizer_func = partial(tokenizer, max_length=config['max_txt_len'], padding='max_length', truncation=True,
+                             return_tensors='pt', return_length=True)
+
+    def make(fname, train=False, ids=False):
+        ds = MemeDataset(filepath=os.path.join(config['data_path'], fname), feature_dir=config['feature_path'],
+                         text_padding=tokenizer_func, return_ids=ids, confidence_threshold=config['object_conf_thresh'])
+        kw = dict(batch_size=config['batch_size'], num_workers=config['num_workers'], collate_fn=ds.get_collate_fn())
+        if train:
+            return data.DataLoader(ds, pin_memory=True, sampler=ConfounderSampler(ds, config['confounder_repeat']), **kw)
+        return data.DataLoader(ds, **kw)
+
+    config['train_loader'] = make('train.jsonl', train=True)
+    config['val_loader'] = make('dev_seen.jsonl')
+    config['test_loader'] = [make(f, ids=True) for f in ('test_seen.jsonl', 'test_unseen.jsonl', 'dev_seen.jsonl',
+                                                        'dev_unseen.jsonl')
+                             if os.path.isfile(os.path.join(config['data_path'], f))]
+    trainer = TrainerUniter(config)
+    return trainer.train_main()
+
+
+if __name__ == '__main__':
+    main()
