@@ -20,6 +20,7 @@ norm for clipping is computed on the reduced buffer, identical on every rank,
 so no second collective is needed.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -42,7 +43,8 @@ class GradSync(object):
     def prepare(self, will_step=True):
         """Call before backward.  Gradients are exchanged only on the micro-batch that
         steps; earlier micro-batches accumulate locally."""
-        self.active = bool(will_step) and self.world > 1
+        # UNITER_DP_FORCE=1 exercises the collective path on a single rank (testing only)
+        self.active = bool(will_step) and (self.world > 1 or os.environ.get('UNITER_DP_FORCE') == '1')
         self._works, self._pending, self._next, self.launched = [], None, 0, []
 
     def finish(self):
