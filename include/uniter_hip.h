@@ -190,6 +190,28 @@ int uniter_bce_logits(const float* logits, const int64_t* labels, float pos_weig
                       int B, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Pretraining heads (BASELINE config 5: UniterForPretraining.forward_{mlm,mrfr,itm},
+ * model/pretrain.py:107-203).  Dense / tied-decoder products are uniter_gemm_f32, the
+ * LayerNorm uniter_ln_*; these are the remaining pieces.
+ * ------------------------------------------------------------------------- */
+/* dst[r,:] = src[idx[r],:]           (_compute_masked_hidden, model/pretrain.py:129-133) */
+int uniter_row_gather(const float* src, const int64_t* idx, float* dst, int n, int H, int nsrc, void* stream);
+/* dst[idx[r],:] += src[r,:]          (its backward; idx must be unique) */
+int uniter_row_scatter_add(const float* src, const int64_t* idx, float* dst, int n, int H, int ndst, void* stream);
+/* F.cross_entropy(logits, targets, reduction='none'): loss[r] = lse[r] - logits[r,targets[r]] */
+int uniter_cross_entropy_fwd(const float* logits, const int64_t* targets, float* loss, float* lse,
+                             int n, int C, int ld, void* stream);
+/* dlogits[r,c] = (softmax(logits[r])[c] - [c == targets[r]]) * dloss[r]   (dlogits may alias logits) */
+int uniter_cross_entropy_bwd(const float* logits, const int64_t* targets, const float* lse,
+                             const float* dloss, float* dlogits, int n, int C, int ld, void* stream);
+/* F.mse_loss(pred, target, reduction='none') and its backward dpred = 2 (pred - target) dloss */
+int uniter_mse_fwd(const float* pred, const float* target, float* loss, size_t n, void* stream);
+int uniter_mse_bwd(const float* pred, const float* target, const float* dloss, float* dpred, size_t n,
+                   void* stream);
+/* out = dy * gelu_erf'(u)   (backward through the heads' GELU, model/layer.py:31-37) */
+int uniter_dgelu_mul(const float* dy, const float* u, float* out, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Optimizer step over FLAT fp32 buffers (replaces average_gradients +
  * clip_grad_norm_ + torch.optim.Adam/AdamW.step + zero_grad:
  * train_template.py:89-92,103-107; utils/optim_utils.py:9-46).

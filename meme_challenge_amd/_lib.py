@@ -64,6 +64,13 @@ _SIGS = {
     'uniter_linear_small_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'uniter_linear_small_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'uniter_bce_logits': (_I, [_P, _P, _F, _P, _P, _P, _F, _I, _P]),
+    'uniter_row_gather': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'uniter_row_scatter_add': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'uniter_cross_entropy_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'uniter_cross_entropy_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'uniter_mse_fwd': (_I, [_P, _P, _P, _SZ, _P]),
+    'uniter_mse_bwd': (_I, [_P, _P, _P, _P, _SZ, _P]),
+    'uniter_dgelu_mul': (_I, [_P, _P, _P, _SZ, _P]),
     'uniter_grad_sumsq': (_I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
     'uniter_grad_sumsq_ws_bytes': (_SZ, [_SZ]),
     'uniter_adam_step': (_I, [_P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P]),

@@ -106,20 +106,21 @@ __global__ __launch_bounds__(256) void finalize_partials_kernel(const float* __r
 // several outputs of H columns each out of one partial buffer whose rows are [nout][H]:
 // outs[j][c] += sum_p part[p*stride + j*H + c]   (one launch instead of one per output)
 struct MultiOut { float* out[8]; };
-__global__ __launch_bounds__(256) void finalize_multi_kernel(const float* __restrict__ part, int nparts,
-                                                             size_t stride, MultiOut outs, int nout, int H) {
-  __shared__ float red[8][33];
+// block = 32 columns x 32 partial-slices (1024 threads): ~10 dependent loads per thread for 328 partial rows
+__global__ __launch_bounds__(1024) void finalize_multi_kernel(const float* __restrict__ part, int nparts,
+                                                              size_t stride, MultiOut outs, int nout, int H) {
+  __shared__ float red[32][33];
   const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int n = blockIdx.x * 32 + cx, N = nout * H;
   float s = 0.f;
   if (n < N)
-    for (int p = sl; p < nparts; p += 8) s += part[(size_t)p * stride + n];
+    for (int p = sl; p < nparts; p += 32) s += part[(size_t)p * stride + n];
   red[sl][cx] = s;
   __syncthreads();
   if (sl == 0 && n < N) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    for (int k = 0; k < 32; ++k) t += red[k][cx];
     float* o = outs.out[n / H];
     if (o) o[n % H] += t;
   }
@@ -176,7 +177,7 @@ int finalize_partials_multi(const float* part, int nparts, size_t stride, float*
                             hipStream_t st) {
   MultiOut mo = {};
   for (int j = 0; j < nout && j < 8; ++j) mo.out[j] = outs[j];
-  hipLaunchKernelGGL(finalize_multi_kernel, dim3((nout * H + 31) / 32), dim3(256), 0, st, part, nparts, stride,
+  hipLaunchKernelGGL(finalize_multi_kernel, dim3((nout * H + 31) / 32), dim3(1024), 0, st, part, nparts, stride,
                      mo, nout, H);
   UCHECK_LAUNCH();
   return 0;

@@ -455,12 +455,16 @@ def _mark_touched(module, params):
     root = getattr(module, '_store_root_ref', None)
     st = _find_store(root) if root is not None else None
     if st is not None:
+        key = tuple(id(p) for p in params)
         cache = module.__dict__.get('_touch_cache')
         if cache is None or cache[0] is not st:
-            ids = {id(p) for p in params}
-            cache = (st, [n for n, p in st.params.items() if id(p) in ids])
+            cache = (st, {})
             object.__setattr__(module, '_touch_cache', cache)
-        st.touch(cache[1])
+        names = cache[1].get(key)
+        if names is None:
+            ids = set(key)
+            names = cache[1][key] = [n for n, p in st.params.items() if id(p) in ids]
+        st.touch(names)
 
 
 class BertPooler(nn.Module):

@@ -1,0 +1,350 @@
+"""UNITER pretraining heads on the HIP path (BASELINE config 5: ITM / MLM / MRFR).
+
+Mirror of model/pretrain.py:19-203 and model/layer.py:188-233: `UniterForPretraining(config,
+img_dim, img_label_dim)` with the reference's module / state_dict names (`uniter.*`,
+`cls.predictions.*` with the decoder tied to `word_embeddings.weight`, `feat_regress.*` tied to
+`img_linear.weight` used transposed, `region_classifier.*`, `itm_output.*`) and
+`forward(batch, task, compute_loss=True)` for task in {'mlm', 'mrfr', 'itm'}.  The MRC tasks and
+the OT loss are out of scope and raise.
+
+The heads are composed from small autograd nodes whose forward / backward are C-ABI calls
+(GEMM, LayerNorm, row gather, cross-entropy, MSE); parameter gradients accumulate directly into
+the flat gradient buffer, including both tied weights.
+"""
+from collections import defaultdict
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import check, ptr, UniterHipError
+from .model import (UniterModel, UniterPreTrainedModel, HipLinear, ensure_store, _ensure_grad,
+                    _mark_touched, _ParamLinear, _ParamLayerNorm)
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_ADD = range(5)
+
+
+def _gemm(akm, bkm, M, N, K, A, lda, B, ldb, Cc, ldc, epi=EPI_NONE, bias=None, aux_in=None, aux_out=None,
+          ld_aux=0, beta=0):
+    if M == 0 or N == 0 or K == 0:
+        return
+    check(_lib.lib().uniter_gemm_f32(akm, bkm, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(Cc), ldc, epi, ptr(bias),
+                                     ptr(aux_in), ptr(aux_out), ld_aux, beta, _lib.cur_stream()), 'uniter_gemm_f32')
+
+
+def _colsum(X, M, N, out):
+    if M == 0:
+        return
+    lib = _lib.lib()
+    n = lib.uniter_colsum_ws_bytes(M, N)
+    ws = torch.empty(n, dtype=torch.uint8, device=X.device)
+    check(lib.uniter_colsum_f32(ptr(X), M, N, N, ptr(out), 1, ptr(ws), n, _lib.cur_stream()), 'uniter_colsum_f32')
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b)  (w_t=False, W stored [out,in]) or x @ W + b (w_t=True, W stored [in,out]:
+    the MRFR output layer uses img_linear.weight transposed, model/pretrain.py:27,32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, owner, names, gelu, w_t):
+        x = x.contiguous()
+        M, K = x.shape
+        N = weight.shape[1] if w_t else weight.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        u = torch.empty_like(y) if gelu else None
+        if w_t:
+            _gemm(0, 1, M, N, K, x, K, weight, N, y, N, EPI_BIAS, bias)
+        else:
+            _gemm(0, 0, M, N, K, x, K, weight, K, y, N, EPI_BIAS_GELU if gelu else EPI_BIAS, bias,
+                  aux_out=u, ld_aux=N)
+        ctx.save_for_backward(x, u)
+        ctx.owner, ctx.names, ctx.w_t = owner, names, w_t
+        ctx.wb = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, u = ctx.saved_tensors
+        weight, bias = ctx.wb
+        w_t = ctx.w_t
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = dy.shape[1]
+        _ensure_grad(weight)
+        _ensure_grad(bias)
+        if u is not None:       # through the activation: dy <- dy * gelu'(u)
+            g = torch.empty_like(dy)
+            check(_lib.lib().uniter_dgelu_mul(ptr(dy), ptr(u), ptr(g), dy.numel(), _lib.cur_stream()),
+                  'uniter_dgelu_mul')
+            dy = g
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            if w_t:      # dx[m,k] = sum_n dy[m,n] W[k,n]
+                _gemm(0, 0, M, K, N, dy, N, weight, N, dx, K)
+            else:        # dx[m,k] = sum_n dy[m,n] W[n,k]
+                _gemm(0, 1, M, K, N, dy, N, weight, K, dx, K)
+        if w_t:          # dW[k,n] += sum_m x[m,k] dy[m,n]
+            _gemm(1, 1, K, N, M, x, K, dy, N, weight.grad, N, beta=1)
+        else:            # dW[n,k] += sum_m dy[m,n] x[m,k]
+            _gemm(1, 1, N, K, M, dy, N, x, K, weight.grad, K, beta=1)
+        _colsum(dy, M, N, bias.grad)
+        _mark_touched_names(ctx.owner, ctx.names)
+        return dx, None, None, None, None, None, None
+
+
+def _mark_touched_names(owner, params):
+    _mark_touched(owner, params)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, owner):
+        x = x.contiguous()
+        M, H = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        check(_lib.lib().uniter_ln_fwd(ptr(x), None, ptr(weight), ptr(bias), None, ptr(y), ptr(mean), ptr(rstd),
+                                       M, H, 0.0, 0, 0, 0, _lib.cur_stream()), 'uniter_ln_fwd')
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.owner, ctx.wb = owner, (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        weight, bias = ctx.wb
+        dy = dy.contiguous()
+        M, H = x.shape
+        _ensure_grad(weight)
+        _ensure_grad(bias)
+        dx = torch.empty_like(x)
+        lib = _lib.lib()
+        n = lib.uniter_ln_bwd_ws_bytes(M, H)
+        ws = torch.empty(n, dtype=torch.uint8, device=x.device)
+        if M > 0:
+            check(lib.uniter_ln_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(weight), ptr(dx), ptr(dx),
+                                    ptr(weight.grad), ptr(bias.grad), None, M, H, 0.0, 0, 0, 0, ptr(ws), n,
+                                    _lib.cur_stream()), 'uniter_ln_bwd')
+        _mark_touched(ctx.owner, (weight, bias))
+        return dx, None, None, None
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, idx):
+        src2 = src.contiguous().view(-1, src.shape[-1])
+        n, H = idx.numel(), src2.shape[1]
+        out = torch.empty(n, H, dtype=torch.float32, device=src.device)
+        check(_lib.lib().uniter_row_gather(ptr(src2), ptr(idx), ptr(out), n, H, src2.shape[0], _lib.cur_stream()),
+              'uniter_row_gather')
+        ctx.save_for_backward(idx)
+        ctx.shape = src.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dsrc = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
+        d2 = dsrc.view(-1, ctx.shape[-1])
+        dout = dout.contiguous()
+        check(_lib.lib().uniter_row_scatter_add(ptr(dout), ptr(idx), ptr(d2), idx.numel(), d2.shape[1], d2.shape[0],
+                                                _lib.cur_stream()), 'uniter_row_scatter_add')
+        return dsrc, None
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets):
+        logits = logits.contiguous()
+        targets = targets.contiguous().to(torch.int64)
+        n, Cn = logits.shape
+        loss = torch.empty(n, dtype=torch.float32, device=logits.device)
+        lse = torch.empty_like(loss)
+        check(_lib.lib().uniter_cross_entropy_fwd(ptr(logits), ptr(targets), ptr(loss), ptr(lse), n, Cn, Cn,
+                                                  _lib.cur_stream()), 'uniter_cross_entropy_fwd')
+        ctx.save_for_backward(logits, targets, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, targets, lse = ctx.saved_tensors
+        n, Cn = logits.shape
+        dl = torch.empty_like(logits)
+        check(_lib.lib().uniter_cross_entropy_bwd(ptr(logits), ptr(targets), ptr(lse), ptr(dloss.contiguous()),
+                                                  ptr(dl), n, Cn, Cn, _lib.cur_stream()), 'uniter_cross_entropy_bwd')
+        return dl, None
+
+
+class _MseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred, target = pred.contiguous(), target.contiguous().to(torch.float32)
+        if pred.shape != target.shape:
+            raise ValueError('mse_loss: shape mismatch %s vs %s' % (tuple(pred.shape), tuple(target.shape)))
+        loss = torch.empty_like(pred)
+        check(_lib.lib().uniter_mse_fwd(ptr(pred), ptr(target), ptr(loss), pred.numel(), _lib.cur_stream()),
+              'uniter_mse_fwd')
+        ctx.save_for_backward(pred, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        pred, target = ctx.saved_tensors
+        dp = torch.empty_like(pred)
+        check(_lib.lib().uniter_mse_bwd(ptr(pred), ptr(target), ptr(dloss.contiguous()), ptr(dp), pred.numel(),
+                                        _lib.cur_stream()), 'uniter_mse_bwd')
+        return dp, None
+
+
+def hip_linear(x, lin, owner, gelu=False):
+    return _LinearFn.apply(x, lin.weight, lin.bias, owner, (lin.weight, lin.bias), gelu, False)
+
+
+# --------------------------------------------------------------------------- #
+# modules (reference names)
+# --------------------------------------------------------------------------- #
+class GELU(nn.Module):
+    pass            # placeholder so that nn.Sequential indices match (net.0 / net.1 / net.2)
+
+
+class BertPredictionHeadTransform(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = _ParamLinear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = _ParamLayerNorm(config.hidden_size)
+
+    def forward(self, h):
+        h = hip_linear(h, self.dense, self, gelu=True)
+        return _LayerNormFn.apply(h, self.LayerNorm.weight, self.LayerNorm.bias, self)
+
+
+class _TiedDecoder(nn.Module):
+    def __init__(self, weight):
+        super().__init__()
+        self.weight = weight            # the SAME Parameter as word_embeddings.weight (model/layer.py:212-215)
+
+
+class BertLMPredictionHead(nn.Module):
+    def __init__(self, config, bert_model_embedding_weights):
+        super().__init__()
+        self.transform = BertPredictionHeadTransform(config)
+        self.decoder = _TiedDecoder(bert_model_embedding_weights)
+        self.bias = nn.Parameter(torch.zeros(bert_model_embedding_weights.size(0)))
+
+    def forward(self, h):
+        h = self.transform(h)
+        return _LinearFn.apply(h, self.decoder.weight, self.bias, self, (self.decoder.weight, self.bias), False, False)
+
+
+class BertOnlyMLMHead(nn.Module):
+    def __init__(self, config, bert_model_embedding_weights):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config, bert_model_embedding_weights)
+
+    def forward(self, sequence_output):
+        return self.predictions(sequence_output)
+
+
+class RegionFeatureRegression(nn.Module):
+    """model/pretrain.py:19-33: Linear -> GELU -> LN, then F.linear(h, img_linear.weight.t(), bias)."""
+
+    def __init__(self, hidden_size, feat_dim, img_linear_weight):
+        super().__init__()
+        self.net = nn.Sequential(_ParamLinear(hidden_size, hidden_size), GELU(), _ParamLayerNorm(hidden_size))
+        self.weight = img_linear_weight        # tied (registers as feat_regress.weight, shared storage)
+        self.bias = nn.Parameter(torch.zeros(feat_dim))
+
+    def forward(self, x):
+        h = hip_linear(x, self.net[0], self, gelu=True)
+        h = _LayerNormFn.apply(h, self.net[2].weight, self.net[2].bias, self)
+        return _LinearFn.apply(h, self.weight, self.bias, self, (self.weight, self.bias), False, True)
+
+
+class RegionClassification(nn.Module):
+    """Parameter holder only (MRC is out of scope); keeps checkpoints loadable (model/pretrain.py:36-47)."""
+
+    def __init__(self, hidden_size, label_dim):
+        super().__init__()
+        self.net = nn.Sequential(_ParamLinear(hidden_size, hidden_size), GELU(), _ParamLayerNorm(hidden_size),
+                                 _ParamLinear(hidden_size, label_dim))
+
+
+class UniterForPretraining(UniterPreTrainedModel):
+    def __init__(self, config, img_dim, img_label_dim):
+        super().__init__(config)
+        self.uniter = UniterModel(config, img_dim)
+        self.cls = BertOnlyMLMHead(config, self.uniter.embeddings.word_embeddings.weight)
+        self.feat_regress = RegionFeatureRegression(config.hidden_size, img_dim,
+                                                    self.uniter.img_embeddings.img_linear.weight)
+        self.region_classifier = RegionClassification(config.hidden_size, img_label_dim)
+        self.itm_output = HipLinear(config.hidden_size, 2)
+        self.apply(self.init_weights)
+
+    def param_store(self):
+        st = ensure_store(self)
+        self.uniter._ensure_handle()
+        return st
+
+    def forward(self, batch, task, compute_loss=True):
+        ensure_store(self)
+        batch = defaultdict(lambda: None, batch)
+        common = (batch['input_ids'], batch['position_ids'], batch['img_feat'], batch['img_pos_feat'],
+                  batch['attn_masks'], batch['gather_index'])
+        if task == 'mlm':
+            return self.forward_mlm(*common, batch['txt_labels'], compute_loss)
+        elif task == 'mrfr':
+            return self.forward_mrfr(*common, batch['img_masks'], batch['img_mask_tgt'], batch['feat_targets'],
+                                     compute_loss)
+        elif task == 'itm':
+            return self.forward_itm(*common, batch['targets'], batch['ot_inputs'], compute_loss)
+        elif task.startswith('mrc'):
+            raise NotImplementedError('MRC / MRC-kl are outside the built scope (SURVEY.md 2.1 row 4)')
+        raise ValueError('invalid task')
+
+    @staticmethod
+    def _masked_rows(hidden, mask):
+        """_compute_masked_hidden (model/pretrain.py:129-133): rows of `hidden` [B,L,H] where
+        `mask` [B,L'] (L' <= L) is set, in row-major order."""
+        B, L, _ = hidden.shape
+        mask = mask.bool()
+        nz = torch.nonzero(mask, as_tuple=False)                 # (host sync, as the reference's boolean indexing)
+        idx = (nz[:, 0] * L + nz[:, 1]).contiguous()
+        return _GatherRowsFn.apply(hidden, idx)
+
+    def forward_mlm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                    txt_labels, compute_loss=True):
+        seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                          output_all_encoded_layers=False)
+        T = input_ids.size(1)
+        if seq.shape[1] < T:
+            raise ValueError('sequence output shorter than the text length (model/pretrain.py:116)')
+        masked = self._masked_rows(seq, txt_labels != -1)       # == seq[:, :T][mask]
+        scores = self.cls(masked)
+        if not compute_loss:
+            return scores
+        return _CrossEntropyFn.apply(scores, txt_labels[txt_labels != -1])
+
+    def forward_mrfr(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                     img_masks, img_mask_tgt, feat_targets, compute_loss=True):
+        seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                          output_all_encoded_layers=False, img_masks=img_masks)
+        masked = self._masked_rows(seq, img_mask_tgt)
+        pred = self.feat_regress(masked)
+        if not compute_loss:
+            return pred
+        return _MseFn.apply(pred, feat_targets)
+
+    def forward_itm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                    targets, ot_inputs=None, compute_loss=True):
+        if ot_inputs is not None:
+            raise NotImplementedError('the OT branch computes a value the reference discards '
+                                      '(model/pretrain.py:197-203); it is outside the built scope')
+        seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                          output_all_encoded_layers=False)
+        pooled = self.uniter.pooler(seq)
+        scores = self.itm_output(pooled)
+        if not compute_loss:
+            return scores
+        return _CrossEntropyFn.apply(scores, targets)

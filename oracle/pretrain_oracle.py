@@ -1,0 +1,101 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+CPU restatement of the pretraining heads used by BASELINE config 5 (ITM / MLM / MRFR):
+UniterForPretraining.forward_{mlm,mrfr,itm} (model/pretrain.py:107-203),
+RegionFeatureRegression (model/pretrain.py:19-33), BertOnlyMLMHead (model/layer.py:188-233).
+Weights use the reference's UniterForPretraining.state_dict() key names ("uniter." prefix)."""
+import torch
+import torch.nn.functional as F
+
+from . import uniter_oracle as O
+
+
+def _masked_hidden(hidden, mask):
+    # _compute_masked_hidden, model/pretrain.py:129-133
+    m = mask.bool().unsqueeze(-1).expand_as(hidden)
+    return hidden[m].contiguous().view(-1, hidden.size(-1))
+
+
+def _head_transform(sd, p, x):
+    # dense -> erf-GELU -> LayerNorm(eps 1e-12)   (model/layer.py:188-204; model/pretrain.py:22-25)
+    return O.layer_norm(O.gelu(F.linear(x, sd[p[0] + 'weight'], sd[p[0] + 'bias'])),
+                        sd[p[1] + 'weight'], sd[p[1] + 'bias'])
+
+
+def _encode(sd, cfg, batch, drop, img_masks=None):
+    return O.uniter_forward(sd, cfg, batch['input_ids'], batch['position_ids'], batch['img_feat'],
+                            batch['img_pos_feat'], batch['attn_masks'], batch['gather_index'],
+                            img_masks=img_masks, output_all_encoded_layers=False, drop=drop, prefix='uniter.')
+
+
+def forward_mlm(sd, cfg, batch, compute_loss=True, drop=None):
+    seq = _encode(sd, cfg, batch, drop)
+    seq = seq[:, :batch['input_ids'].size(1), :]
+    h = _masked_hidden(seq, batch['txt_labels'] != -1)
+    h = _head_transform(sd, ('cls.predictions.transform.dense.', 'cls.predictions.transform.LayerNorm.'), h)
+    # tied decoder (model/layer.py:212-226): word_embeddings.weight + separate bias
+    scores = F.linear(h, sd['uniter.embeddings.word_embeddings.weight']) + sd['cls.predictions.bias']
+    if not compute_loss:
+        return scores
+    tl = batch['txt_labels']
+    return F.cross_entropy(scores, tl[tl != -1], reduction='none')
+
+
+def forward_mrfr(sd, cfg, batch, compute_loss=True, drop=None):
+    seq = _encode(sd, cfg, batch, drop, img_masks=batch['img_masks'])
+    h = _masked_hidden(seq, batch['img_mask_tgt'])
+    h = _head_transform(sd, ('feat_regress.net.0.', 'feat_regress.net.2.'), h)
+    # F.linear(hidden, img_linear.weight.t(), bias), model/pretrain.py:27,32
+    pred = F.linear(h, sd['uniter.img_embeddings.img_linear.weight'].t(), sd['feat_regress.bias'])
+    if not compute_loss:
+        return pred
+    return F.mse_loss(pred, batch['feat_targets'], reduction='none')
+
+
+def forward_itm(sd, cfg, batch, compute_loss=True, drop=None):
+    seq = _encode(sd, cfg, batch, drop)
+    pooled = O.pooler(sd, 'uniter.', seq)
+    scores = F.linear(pooled, sd['itm_output.weight'], sd['itm_output.bias'])
+    if not compute_loss:
+        return scores
+    return F.cross_entropy(scores, batch['targets'], reduction='none')
+
+
+def synth_pretrain_batch(B, T, R, seed, vocab, img_dim, txt_lens, num_bbs, mask_prob=0.3):
+    """A config-5 style batch (data/pretrain_mlm.py:95-131, pretrain_mrfr.py:88-131,
+    pretrain_itm.py): MLM labels, region masks + regression targets, ITM targets."""
+    import numpy as np
+    b = O.synth_batch(B, T, R, seed=seed, vocab=vocab, img_dim=img_dim, txt_lens=txt_lens, num_bbs=num_bbs)
+    rng = np.random.Generator(np.random.PCG64(seed + 7))
+    ids = b['input_ids'].clone()
+    txt_labels = torch.full_like(ids, -1)
+    for i in range(B):
+        picked = False
+        for t in range(1, txt_lens[i]):
+            if rng.random() < mask_prob:
+                txt_labels[i, t] = ids[i, t]
+                ids[i, t] = 3            # [MASK]-like id
+                picked = True
+        if not picked:
+            txt_labels[i, 1] = ids[i, 1]
+            ids[i, 1] = 3
+    img_masks = torch.zeros(B, R, dtype=torch.bool)
+    for i in range(B):
+        for r in range(num_bbs[i]):
+            img_masks[i, r] = rng.random() < mask_prob
+        if not img_masks[i].any():
+            img_masks[i, 0] = True
+    L = b['attn_mask'].shape[1]
+    img_mask_tgt = torch.zeros(B, L, dtype=torch.bool)
+    for i in range(B):
+        img_mask_tgt[i, txt_lens[i]:txt_lens[i] + R] = img_masks[i][:max(0, min(R, L - txt_lens[i]))]
+    feat = b['img_feat']
+    feat_targets = feat[img_masks.unsqueeze(-1).expand_as(feat)].contiguous().view(-1, feat.size(-1))
+    out = {'input_ids': ids, 'input_ids_unmasked': b['input_ids'],
+           'position_ids': torch.arange(T, dtype=torch.long).unsqueeze(0),
+           'img_feat': feat, 'img_feat_masked': feat.masked_fill(img_masks.unsqueeze(-1), 0),
+           'img_pos_feat': b['img_pos_feat'], 'attn_masks': b['attn_mask'], 'gather_index': b['gather_index'],
+           'txt_labels': txt_labels, 'img_masks': img_masks, 'img_mask_tgt': img_mask_tgt,
+           'feat_targets': feat_targets,
+           'targets': torch.from_numpy((rng.random(B) < 0.5).astype('int64'))}
+    return out

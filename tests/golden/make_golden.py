@@ -334,8 +334,55 @@ def gen_trainer_steps():
     np.savez_compressed(os.path.join(HERE, 'trainer_steps.npz'), **out)
 
 
+def gen_pretrain():
+    """UniterForPretraining (model/pretrain.py) on the tiny config: mlm / mrfr / itm outputs,
+    per-sample losses and selected gradients (incl. both tied weights)."""
+    from model.pretrain import UniterForPretraining
+    from oracle import pretrain_oracle as PO
+    TINY_PRE = dict(TINY, vocab_size=100)      # the HIP MLM decoder needs vocab % 4 == 0 (28996 is)
+    cfg = UniterConfig.from_dict(TINY_PRE)
+    torch.manual_seed(21)
+    m = UniterForPretraining(cfg, img_dim=TINY_IMG_DIM, img_label_dim=11)
+    jitter_(m, 5)
+    m.eval()
+    out = {}
+    for k, v in m.state_dict().items():
+        out['sd/' + k] = v.detach().numpy().copy()
+    B, T, R = 3, 10, 6
+    tl, nbb = [10, 4, 7], [6, 6, 3]
+    b = PO.synth_pretrain_batch(B, T, R, seed=9, vocab=TINY_PRE['vocab_size'], img_dim=TINY_IMG_DIM,
+                                txt_lens=tl, num_bbs=nbb)
+    for k, v in b.items():
+        out['in/' + k] = v.numpy()
+    keep = ['uniter.embeddings.word_embeddings.weight', 'uniter.img_embeddings.img_linear.weight',
+            'uniter.img_embeddings.mask_embedding.weight', 'cls.predictions.bias',
+            'cls.predictions.transform.dense.weight', 'cls.predictions.transform.LayerNorm.weight',
+            'feat_regress.bias', 'feat_regress.net.0.weight', 'feat_regress.net.2.bias', 'itm_output.weight',
+            'itm_output.bias', 'uniter.pooler.dense.weight', 'uniter.encoder.layer.0.attention.self.query.weight',
+            'uniter.encoder.layer.1.output.LayerNorm.bias', 'uniter.embeddings.position_embeddings.weight']
+    params = dict(m.named_parameters())
+    for task in ('mlm', 'mrfr', 'itm'):
+        batch = dict(b)
+        if task == 'mrfr':
+            batch['img_feat'] = b['img_feat_masked']
+        scores = m(batch, task, compute_loss=False)
+        m.zero_grad()
+        loss = m(batch, task, compute_loss=True)
+        loss.mean().backward()
+        out['%s/scores' % task] = scores.detach().numpy().copy()
+        out['%s/loss' % task] = loss.detach().numpy().copy()
+        for n in keep:
+            g = params[n].grad
+            out['%s/grad/%s' % (task, n)] = (g if g is not None else torch.zeros_like(params[n])).numpy().copy()
+        print('pretrain', task, 'loss mean', loss.mean().item(), tuple(scores.shape))
+    out['state_dict_keys'] = np.array(list(m.state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, 'pretrain_tiny.npz'), **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiny', 'host', 'trainer', 'base', 'large']
+    which = sys.argv[1:] or ['tiny', 'host', 'trainer', 'base', 'large', 'pretrain']
+    if 'pretrain' in which:
+        gen_pretrain()
     if 'tiny' in which:
         gen_tiny()
     if 'host' in which:
