@@ -28,7 +28,7 @@ BASE = dict(attention_probs_dropout_prob=0.1, hidden_act='gelu', hidden_dropout_
             type_vocab_size=2, vocab_size=28996)       # == reference config/uniter-base.json
 LARGE = dict(BASE, hidden_size=1024, intermediate_size=4096, num_attention_heads=16, num_hidden_layers=24)
 
-PEAK_TFLOPS = {'f32': 157.3}       # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32)
+PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}       # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32)
 
 
 def flops_per_step(cfg, B, T, R):
@@ -83,6 +83,8 @@ def main():
     ap.add_argument('--txt_len', type=int, default=128)
     ap.add_argument('--num_bb', type=int, default=36)
     ap.add_argument('--model', choices=['base', 'large'], default='base')
+    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
+                    help="fp32 (BASELINE configs[1], default) or bf16: bf16 MFMA for the dense GEMMs, fp32 elsewhere (configs[2])")
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_side_stream', action='store_true')
     ap.add_argument('--prof_kind', type=int, default=1, help='UNITER_K_* kind timed with HIP events (1 = FFN-up fwd GEMM)')
@@ -116,6 +118,7 @@ def main():
     cfg = UniterConfig.from_dict(cfgd)
     model = MemeUniter(UniterModel(cfg, img_dim=2048), cfg.hidden_size, 1).to(dev).train()
     model.uniter_model.use_side_stream = not args.no_side_stream
+    model.uniter_model.precision = args.precision
     model.uniter_model.set_dropout_seed(1234 + rank, 0)
     B, T, R = args.batch, args.txt_len, args.num_bb
     batch = make_synthetic_batch(B, T, R, seed=1234 + rank, device=dev)
@@ -161,15 +164,17 @@ def main():
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt
         total, ffn, ffn_up = flops_per_step(cfgd, B, T, R)
-        peak = PEAK_TFLOPS['f32']
+        dt_name = 'f32' if args.precision == 'fp32' else 'bf16'
+        peak = PEAK_TFLOPS[dt_name]
         out = {
             'metric': 'train samples/sec UNITER-%s (36 regions, 128 tok)' % args.model,
             'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': dt_name, 'data': 'synthetic',
             'config': {'workload': 'UNITER-%s fine-tune step (fwd + BCE + bwd + clip + Adam, dropout 0.1), '
-                                   'batch %d per GPU, %d regions x 2048, %d text tokens, fp32 (BASELINE configs[1])'
-                                   % (args.model, B, R, T),
+                                   'batch %d per GPU, %d regions x 2048, %d text tokens, %s'
+                                   % (args.model, B, R, T, 'fp32 (BASELINE configs[1])' if args.precision == 'fp32'
+                                      else 'bf16 MFMA GEMMs / fp32 storage (BASELINE configs[2])'),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        'side_stream_wgrad': not args.no_side_stream},
             'step_mfma_frac': round(total / (ms * 1e-3) / world * world / (peak * 1e12), 4),
@@ -182,7 +187,9 @@ def main():
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2) if ach else None, 'peak': peak,
                                'unit': 'TFLOP/s', 'frac': round(ach / peak, 4) if ach else None,
                                'traffic': None,
-                               'kernel': 'gemm_f32_v3_kernel<64,64,false,false,TAG=1> (FFN-up fwd: M=%d N=%d K=%d, bias+GELU epilogue)'
+                               'kernel': ('gemm_f32_v3_kernel<64,64,false,false,TAG=1>' if args.precision == 'fp32'
+                                          else 'gemm_bf16_kernel<...,false,false>') +
+                                         ' (FFN-up fwd: M=%d N=%d K=%d, bias+GELU epilogue)'
                                          % (B * (T + R), cfgd['intermediate_size'], cfgd['hidden_size']),
                                'launches': n_launch.value, 'avg_ms': round(avg_ms, 4)}
         if world == 1 and not args.no_cpu_baseline:

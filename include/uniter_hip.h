@@ -69,6 +69,16 @@ int uniter_gemm_f32_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K
                     const float* aux_in, float* aux_out, int ld_aux,
                     int beta, void* stream);
 
+/* Mixed precision (BASELINE config 3, "bf16 MFMA for the dense GEMMs"): same contract and fp32
+ * operands/outputs as uniter_gemm_f32_cfg, but A and B are rounded to bf16 (RNE) on their way
+ * into LDS and multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Shapes with
+ * K % 64 != 0 run on the exact fp32 kernel. */
+int uniter_gemm_bf16_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K,
+                    const float* A, int lda, const float* B, int ldb,
+                    float* C, int ldc, int epilogue, const float* bias,
+                    const float* aux_in, float* aux_out, int ld_aux,
+                    int beta, void* stream);
+
 /* out[n] (+)= sum_m X[m*ld + n]   (bias gradients of every nn.Linear) */
 int uniter_colsum_f32(const float* X, int M, int N, int ld, float* out, int beta,
                       void* ws, size_t ws_bytes, void* stream);
@@ -268,6 +278,9 @@ typedef struct {
   int32_t pos_bcast;
 } uniter_batch_t;
 
+/* 0 (default): exact fp32 MFMA GEMMs.  1: bf16 MFMA for the dense GEMMs of the schedule (operands
+ * rounded to bf16 in flight; storage, LayerNorm, softmax, attention, loss and optimizer stay fp32) */
+int  uniter_model_set_precision(uniter_model_t* m, int precision);
 size_t uniter_model_ws_bytes(const uniter_model_t* m, int B, int T, int R, int L, int train);
 /* hidden_out: [B,L,H] last layer (all_layers = 0) or [nl,B,L,H] (all_layers = 1).
  * train != 0 applies dropout and keeps activations in `ws` for uniter_model_backward. */

@@ -44,6 +44,7 @@ _SIGS = {
     'uniter_build_info': (C.c_char_p, []),
     'uniter_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     'uniter_gemm_f32_cfg': (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
+    'uniter_gemm_bf16_cfg': (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     'uniter_colsum_f32': (_I, [_P, _I, _I, _I, _P, _I, _P, _SZ, _P]),
     'uniter_colsum_ws_bytes': (_SZ, [_I, _I]),
     'uniter_ln_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P]),
@@ -79,6 +80,7 @@ _SIGS = {
     'uniter_param_shape': (_I, [C.POINTER(UniterConfigC), _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'uniter_model_create': (_I, [C.POINTER(UniterConfigC), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p)]),
     'uniter_model_destroy': (None, [_P]),
+    'uniter_model_set_precision': (_I, [_P, _I]),
     'uniter_model_ws_bytes': (_SZ, [_P, _I, _I, _I, _I, _I]),
     'uniter_model_forward': (_I, [_P, C.POINTER(UniterBatchC), _P, _I, _I, _U64, _U32, _P, _SZ, _P]),
     'uniter_model_backward_begin': (_I, [_P, C.POINTER(UniterBatchC), _P, _I, _U64, _U32, _P, _SZ, _P, _P]),

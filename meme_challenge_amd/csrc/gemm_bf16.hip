@@ -1,0 +1,348 @@
+// Mixed-precision GEMM for gfx950: fp32 operands in HBM, converted to bf16 while they are
+// staged into LDS, multiplied on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32
+// accumulate), fp32 epilogue and output.
+//
+// This is the "bf16 MFMA used only for the dense QKV / FFN GEMMs" mode of BASELINE config 3: all
+// tensors stay fp32 in memory (master weights, activations, gradients, LayerNorm / softmax / loss
+// arithmetic), only the contraction inputs are rounded to bf16 (round-to-nearest-even,
+// v_cvt_pk_bf16_f32).  The bf16 pipe is 16x the fp32 one, so unlike gemm_f32 this kernel is bound
+// by operand delivery (L2 -> LDS), not by the matrix pipe: tiles are large (128 x 128 x 64) and
+// the schedule is v3's (persistent workgroups, banded L2-aware tile order, branch-free
+// buffer loads with a full-iteration prefetch distance, LDS written mid-iteration).
+//
+// LDS image: every operand tile is [rows][64 k] bf16 with a 144-byte row stride (conflict-free
+// ds_read_b128 of 8 consecutive k per lane).  Operands whose k index is the slow memory index
+// (dgrad's W, wgrad's dY and X) are TRANSPOSED ON THE WAY IN: a thread loads 2 k-rows x 4
+// consecutive columns, packs (k, k+1) pairs and issues 4 ds_write_b32 -- so the MFMA loop is
+// identical for all three layouts and no transposed LDS read is needed.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+struct GemmArgsB {
+  int M, N, K;
+  const float* A; int lda;
+  const float* B; int ldb;
+  float* C; int ldc;
+  int epi;
+  const float* bias;
+  const float* aux_in;
+  float* aux_out;
+  int ld_aux;
+  int beta;
+  int tiles_m, tiles_n, band_h;
+  float* colsum_part;
+};
+
+constexpr int BKB = 64;            // k-tile depth
+constexpr int LDB16 = 72;          // LDS row stride in bf16 elements (144 B)
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+__device__ __forceinline__ void tile_coords_b(int t, int tiles_m, int tiles_n, int band_h, int& tm, int& tn) {
+  const int full = band_h * tiles_n;
+  const int band = t / full;
+  const int rem = t - band * full;
+  const int bh = min(band_h, tiles_m - band * band_h);
+  tn = rem / bh;
+  tm = band * band_h + (rem - tn * bh);
+}
+
+// per-thread byte offsets of the float4 loads of one tile (k0 = 0)
+template <int R, bool KM>
+__device__ __forceinline__ void tile_offsets_b(int (&voff)[R / 16], int ld, int row0, int tid) {
+  if constexpr (!KM) {
+    const int c4 = tid & 15, rr = tid >> 4;          // 16 threads cover one row's 64 k
+#pragma unroll
+    for (int p = 0; p < R / 16; ++p) voff[p] = ((row0 + rr + 16 * p) * ld + c4 * 4) * 4;
+  } else {
+    // item = (4 columns, k-pair): id = tid + 256*pass; columns fastest over 4 lanes, then 32 k-pairs
+#pragma unroll
+    for (int p = 0; p < R / 32; ++p) {
+      const int id = tid + 256 * p;
+      const int c4 = ((id >> 7) << 2) | (id & 3), kp = (id >> 2) & 31;
+      voff[2 * p] = ((2 * kp) * ld + row0 + c4 * 4) * 4;
+      voff[2 * p + 1] = voff[2 * p] + ld * 4;
+    }
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void tile_load_b(f32x4 (&reg)[R / 16], __amdgpu_buffer_rsrc_t rsrc,
+                                            const int (&voff)[R / 16], int soff) {
+#pragma unroll
+  for (int p = 0; p < R / 16; ++p)
+    reg[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[p], soff, 0));
+}
+
+// convert + write one staged tile into its LDS image [R][LDB16] bf16
+template <int R, bool KM>
+__device__ __forceinline__ void tile_store_b(const f32x4 (&reg)[R / 16], unsigned short* s, int tid) {
+  if constexpr (!KM) {
+    const int c4 = tid & 15, rr = tid >> 4;
+#pragma unroll
+    for (int p = 0; p < R / 16; ++p) {
+      u32x2_t v = {pack_bf16(reg[p][0], reg[p][1]), pack_bf16(reg[p][2], reg[p][3])};
+      *reinterpret_cast<u32x2_t*>(s + (rr + 16 * p) * LDB16 + c4 * 4) = v;
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < R / 32; ++p) {
+      const int id = tid + 256 * p;
+      const int c4 = ((id >> 7) << 2) | (id & 3), kp = (id >> 2) & 31;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<unsigned*>(s + (c4 * 4 + e) * LDB16 + 2 * kp) = pack_bf16(reg[2 * p][e], reg[2 * p + 1][e]);
+    }
+  }
+}
+
+// operand fragment of the 32-row sub-tile at r0 for k16-step ks: 8 consecutive k of row r0 + (lane&31)
+__device__ __forceinline__ bf16x8 frag_read_b(const unsigned short* s, int r0, int ks, int i, int h) {
+  return *reinterpret_cast<const bf16x8*>(s + (r0 + i) * LDB16 + ks * 16 + 8 * h);
+}
+
+template <int BM, int BN, bool AKM, bool BKM, int TAG>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int SA = BM * LDB16, SB = BN * LDB16;              // bf16 elements
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (SA + SB)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int nk = g.K / BKB;
+
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int chunk_n = q + (xcd < r ? 1 : 0);
+  if (idx >= chunk_n) return;
+  const int my_tiles = (chunk_n - idx + per_xcd - 1) / per_xcd;
+  const int total_units = my_tiles * nk;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.A), 0, (AKM ? g.K : g.M) * g.lda * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.B), 0, (BKM ? g.K : g.N) * g.ldb * 4, 0x00020000);
+  const int kstepA = (AKM ? BKB * g.lda : BKB) * 4, kstepB = (BKM ? BKB * g.ldb : BKB) * 4;
+
+  int lt = idx, lk = 0;
+  int voA[BM / 16], voB[BN / 16];
+  {
+    int tmi, tni;
+    tile_coords_b(chunk0 + lt, g.tiles_m, g.tiles_n, g.band_h, tmi, tni);
+    tile_offsets_b<BM, AKM>(voA, g.lda, tmi * BM, tid);
+    tile_offsets_b<BN, BKM>(voB, g.ldb, tni * BN, tid);
+  }
+  int loaded = 0;
+#define LOAD_UNIT(RA, RB)                                                                \
+  do {                                                                                   \
+    if (loaded < total_units) {                                                          \
+      tile_load_b<BM>(RA, rsA, voA, lk * kstepA);                                        \
+      tile_load_b<BN>(RB, rsB, voB, lk * kstepB);                                        \
+      ++loaded;                                                                          \
+      if (++lk == nk) {                                                                  \
+        lk = 0; lt += per_xcd;                                                           \
+        if (loaded < total_units) {                                                      \
+          int tmi_, tni_;                                                                \
+          tile_coords_b(chunk0 + lt, g.tiles_m, g.tiles_n, g.band_h, tmi_, tni_);        \
+          tile_offsets_b<BM, AKM>(voA, g.lda, tmi_ * BM, tid);                           \
+          tile_offsets_b<BN, BKM>(voB, g.ldb, tni_ * BN, tid);                           \
+        }                                                                                \
+      }                                                                                  \
+    }                                                                                    \
+  } while (0)
+
+  f32x4 ra[BM / 16], rb[BN / 16];
+  bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+
+  LOAD_UNIT(ra, rb);
+  tile_store_b<BM, AKM>(ra, smem, tid);
+  tile_store_b<BN, BKM>(rb, smem + SA, tid);
+  LOAD_UNIT(ra, rb);
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < TM; ++a) fa0[a] = frag_read_b(smem, wm * WM + a * 32, 0, i, h);
+#pragma unroll
+  for (int b = 0; b < TN; ++b) fb0[b] = frag_read_b(smem + SA, wn * WN + b * 32, 0, i, h);
+
+  int ct = idx, ck = 0;
+  int tmi0, tni0;
+  tile_coords_b(chunk0 + ct, g.tiles_m, g.tiles_n, g.band_h, tmi0, tni0);
+  int m0 = tmi0 * BM, n0 = tni0 * BN;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) acc[a][b][rr] = 0.f;
+
+#define MFMA_BLOCK(FA, FB)                                                                              \
+  _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                        \
+  _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                        \
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[a], FB[b], acc[a][b], 0, 0, 0);
+#define READ_FRAGS(FA, FB, SAp, SBp, KS)                                                                \
+  _Pragma("unroll") for (int a = 0; a < TM; ++a) FA[a] = frag_read_b(SAp, wm * WM + a * 32, KS, i, h);  \
+  _Pragma("unroll") for (int b = 0; b < TN; ++b) FB[b] = frag_read_b(SBp, wn * WN + b * 32, KS, i, h);
+
+  for (int u = 0; u < total_units; ++u) {
+    const unsigned short* sA = smem + (u & 1) * (SA + SB);
+    const unsigned short* sB = sA + SA;
+    unsigned short* dA = smem + ((u + 1) & 1) * (SA + SB);
+    const bool more = u + 1 < total_units;
+    __builtin_amdgcn_sched_barrier(0);
+    READ_FRAGS(fa1, fb1, sA, sB, 1)
+    MFMA_BLOCK(fa0, fb0)
+    __builtin_amdgcn_sched_barrier(0);
+    READ_FRAGS(fa0, fb0, sA, sB, 2)
+    MFMA_BLOCK(fa1, fb1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      tile_store_b<BM, AKM>(ra, dA, tid);
+      tile_store_b<BN, BKM>(rb, dA + SA, tid);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LOAD_UNIT(ra, rb);
+    __builtin_amdgcn_sched_barrier(0);
+    READ_FRAGS(fa1, fb1, sA, sB, 3)
+    MFMA_BLOCK(fa0, fb0)
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) { READ_FRAGS(fa0, fb0, dA, (dA + SA), 0) }
+    MFMA_BLOCK(fa1, fb1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (++ck == nk) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int col = n0 + wn * WN + b * 32 + i;
+          const bool cok = col < g.N;
+          const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU)) ? g.bias[col] : 0.f;
+          float csum = 0.f;
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const int row = m0 + wm * WM + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+            if (cok && row < g.M) {
+              float v = acc[a][b][rr] + bv;
+              if (g.epi == UNITER_EPI_BIAS_GELU) {
+                if (g.aux_out) g.aux_out[(size_t)row * g.ld_aux + col] = v;
+                v = gelu_erf(v);
+              } else if (g.epi == UNITER_EPI_DGELU) {
+                v *= dgelu_erf(g.aux_in[(size_t)row * g.ld_aux + col]);
+              } else if (g.epi == UNITER_EPI_ADD) {
+                v += g.aux_in[(size_t)row * g.ld_aux + col];
+              }
+              csum += v;
+              float* c = g.C + (size_t)row * g.ldc + col;
+              if (g.beta) v += *c;
+              *c = v;
+            }
+            acc[a][b][rr] = 0.f;
+          }
+          if (g.colsum_part) {
+            csum += __shfl_xor(csum, 32, 64);
+            if (h == 0 && cok && (m0 + wm * WM + a * 32) < g.M)
+              g.colsum_part[(size_t)((m0 + wm * WM + a * 32) >> 5) * g.N + col] = csum;
+          }
+        }
+      }
+      ck = 0; ct += per_xcd;
+      if (more) {
+        tile_coords_b(chunk0 + ct, g.tiles_m, g.tiles_n, g.band_h, tmi0, tni0);
+        m0 = tmi0 * BM; n0 = tni0 * BN;
+      }
+    }
+  }
+#undef MFMA_BLOCK
+#undef READ_FRAGS
+#undef LOAD_UNIT
+}
+
+template <int BM, int BN, bool AKM, bool BKM>
+int launch_b(GemmArgsB g, hipStream_t st, int slots) {
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  const int tiles = g.tiles_m * g.tiles_n;
+  const long panel = (long)BM * g.K * 4;
+  long bh = (3l << 19) / (panel > 0 ? panel : 1);
+  g.band_h = (int)(bh < 1 ? 1 : (bh > 16 ? 16 : bh));
+  if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
+  const int grid = tiles < slots ? (tiles + 7) / 8 * 8 : slots;
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AKM, BKM, 0>), dim3(grid), dim3(256), 0, st, g);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+template <bool AKM, bool BKM>
+int dispatch_b(int cfg, const GemmArgsB& g, hipStream_t st) {
+  switch (cfg) {
+    case 1: return launch_b<128, 128, AKM, BKM>(g, st, 512);
+    case 2: return launch_b<64, 128, AKM, BKM>(g, st, 512);
+    case 3: return launch_b<128, 64, AKM, BKM>(g, st, 512);
+    case 4: return launch_b<64, 64, AKM, BKM>(g, st, 1024);
+    default: uniter_set_error("gemm_bf16: bad cfg %d", cfg); return UNITER_E_ARG;
+  }
+}
+
+}  // namespace
+
+int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda,
+                 const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
+                 const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part, void* stream);
+
+// Same contract as gemm_f32_run, contraction on the bf16 matrix pipe.  Shapes the bf16 kernel does
+// not cover (K % 64 != 0, offsets beyond 31 bits) run on the exact fp32 kernel instead.
+int gemm_bf16_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda,
+                  const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
+                  const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part, void* stream) {
+  UCHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "gemm_bf16: bad argument");
+  const bool ok = K % BKB == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+                  (a_kmajor ? M % 4 == 0 : true) && (b_kmajor ? N % 4 == 0 : true) &&
+                  (size_t)(a_kmajor ? K : M) * lda * 4 < (1ull << 31) &&
+                  (size_t)(b_kmajor ? K : N) * ldb * 4 < (1ull << 31) &&
+                  ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
+  if (!ok)
+    return gemm_f32_run(0, 0, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, epilogue, bias, aux_in, aux_out,
+                        ld_aux, beta, colsum_part, stream);
+  UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_ADD, "gemm_bf16: bad epilogue %d", epilogue);
+  GemmArgsB g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux; g.beta = beta;
+  g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
+  if (cfg == 0) {
+    // operand delivery bound: the biggest tile that still fills the chip
+    // measured on MI355X (tests/tools/gemm_bf16_exp.py): 128x128 only pays once it fills the chip
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    cfg = t128 >= 448 ? 1 : 4;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (!a_kmajor && !b_kmajor) return dispatch_b<false, false>(cfg, g, st);
+  if (!a_kmajor && b_kmajor) return dispatch_b<false, true>(cfg, g, st);
+  if (a_kmajor && b_kmajor) return dispatch_b<true, true>(cfg, g, st);
+  return dispatch_b<true, false>(cfg, g, st);
+}
+
+extern "C" int uniter_gemm_bf16_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,
+                                    int lda, const float* B, int ldb, float* C, int ldc, int epilogue,
+                                    const float* bias, const float* aux_in, float* aux_out, int ld_aux, int beta,
+                                    void* stream) {
+  UCHECK_ARG(!(epilogue == UNITER_EPI_BIAS || epilogue == UNITER_EPI_BIAS_GELU) || bias, "gemm_bf16: epilogue needs bias");
+  UCHECK_ARG(!(epilogue == UNITER_EPI_DGELU || epilogue == UNITER_EPI_ADD) || aux_in, "gemm_bf16: epilogue needs aux_in");
+  return gemm_bf16_run(cfg, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, epilogue, bias, aux_in, aux_out,
+                       ld_aux, beta, nullptr, stream);
+}

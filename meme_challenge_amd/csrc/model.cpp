@@ -20,6 +20,9 @@ int launch_add_f32(float* out, const float* a, const float* b, size_t n, hipStre
 int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda,
                  const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
                  const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part, void* stream);
+int gemm_bf16_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda,
+                  const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
+                  const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part, void* stream);
 int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta, hipStream_t st);
 int launch_masked_rowsum(const float* x, const int64_t* masks, float* out, int rows, int D, hipStream_t st);
 
@@ -76,6 +79,7 @@ struct uniter_model {
   std::vector<float*> p, g;
   std::vector<std::string> names;
   std::vector<hipEvent_t> ev_main, ev_side;
+  int precision = 0;        // 0 = fp32 MFMA GEMMs, 1 = bf16 MFMA GEMMs (fp32 storage)
   // profiling
   int prof_kind = 0;
   std::vector<hipEvent_t> prof_ev;
@@ -192,6 +196,9 @@ int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int
          int lda, const float* B, int ldb, float* C, int ldc, int epi, const float* bias, const float* aux_in,
          float* aux_out, int ld_aux, int beta, float* colsum_part = nullptr) {
   ProfScope ps(m, kind, st);
+  if (m->precision == 1)
+    return gemm_bf16_run(0, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux_in, aux_out, ld_aux, beta,
+                         colsum_part, st);
   return gemm_f32_run(0, kind == UNITER_K_GEMM_FFN_UP_FWD, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias,
                       aux_in, aux_out, ld_aux, beta, colsum_part, st);
 }
@@ -457,7 +464,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   // FFN down dgrad (+ GELU'), FFN up dgrad (+ residual grad)
   // the GEMM's epilogue also emits per-32-row column sums of du (= partial bias gradients of
   // intermediate.dense): saves a 32 MB re-read of du
-  const bool fuse_db1 = H % 32 == 0;
+  const bool fuse_db1 = H % 64 == 0;
   UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, g2, H, m->LP(l, L_W2), I, lb.du, I, UNITER_EPI_DGELU,
                  nullptr, lb.u, nullptr, I, 0, fuse_db1 ? lb.du_csum : nullptr));
   UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, I, lb.du, I, m->LP(l, L_W1), H, lb.dy1, H, UNITER_EPI_ADD,
@@ -550,6 +557,12 @@ extern "C" int uniter_model_backward(uniter_model_t* m, const uniter_batch_t* b,
   UCHECK_RC(uniter_model_backward_begin(m, b, d_hidden, all_layers, seed, offset, ws, ws_bytes, stream, side_stream));
   for (int l = m->cfg.num_hidden_layers - 1; l >= 0; --l) UCHECK_RC(uniter_model_backward_layer(m, l));
   return uniter_model_backward_embed(m);
+}
+
+extern "C" int uniter_model_set_precision(uniter_model_t* m, int precision) {
+  UCHECK_ARG(m && (precision == 0 || precision == 1), "set_precision: 0 (fp32) or 1 (bf16 MFMA GEMMs)");
+  m->precision = precision;
+  return 0;
 }
 
 extern "C" int uniter_prof_enable(uniter_model_t* m, int kind) {

@@ -617,6 +617,7 @@ class UniterModel(UniterPreTrainedModel):
         self.apply(self.init_weights)
         self._handle = None
         self._prefix_names = None
+        self._applied_precision = None
         object.__setattr__(self, '_store_root', None)
         self._ws_cache = {}
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
@@ -624,6 +625,7 @@ class UniterModel(UniterPreTrainedModel):
         self._grad_hook = None       # callable(kind, index) used by the DP gradient exchange
         self._side_stream = None
         self.use_side_stream = True
+        self.precision = 'fp32'      # or 'bf16': bf16 MFMA for the dense GEMMs, fp32 everywhere else
 
     # -- plumbing ------------------------------------------------------------
     def set_dropout_seed(self, seed, offset=0):
@@ -663,6 +665,13 @@ class UniterModel(UniterPreTrainedModel):
             self._destroy_handle()
             self._handle = h
             self._prefix_names = None
+            self._applied_precision = None
+        if self._applied_precision != self.precision:
+            if self.precision not in ('fp32', 'bf16'):
+                raise ValueError("precision must be 'fp32' or 'bf16'")
+            check(_lib.lib().uniter_model_set_precision(self._handle, 1 if self.precision == 'bf16' else 0),
+                  'uniter_model_set_precision')
+            self._applied_precision = self.precision
         return st
 
     def _destroy_handle(self):

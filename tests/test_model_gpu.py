@@ -142,3 +142,37 @@ def test_train_mode_dropout_replay_matches_oracle(tiny):
     # a second forward draws different masks (offset advanced)
     l2 = m(**model_kwargs(to_dev(b)))
     assert maxdiff(l2, logits) > 1e-6
+
+
+def test_bf16_mfma_mode_tracks_fp32_reference(shapes_base):
+    """precision='bf16': dense GEMM operands rounded to bf16 (fp32 accumulate / storage).  Not the
+    1e-3 fp32 parity bar: bf16 has 8 significant bits, so the bar is closeness + gradient direction."""
+    from meme_challenge_amd.trainer import bce_with_logits_loss
+    from meme_challenge_amd.utils import make_synthetic_batch
+    z = shapes_base
+    sd = O.synth_state_dict(BASE, seed=0, ln_jitter=0.02)
+    m = build(BASE, 2048, sd).eval()
+    m.uniter_model.precision = 'bf16'
+    B, T, R, seed = z['cfg1_full/shape'].tolist()
+    b = make_synthetic_batch(B, T, R, seed=seed, device='cuda')
+    logits = m(**model_kwargs(b))
+    ref = torch.from_numpy(z['cfg1_full/logits'])
+    assert maxdiff(logits, ref) < 3e-2
+    assert maxdiff(logits, ref) > 1e-6            # really ran the bf16 path
+    loss = bce_with_logits_loss(logits, b['labels'], 1.8)
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(m.named_parameters())
+    names = list(z['param_names'])
+    norms = z['cfg1_full/grad_norms']
+    rel = [abs(params[n].grad.double().norm().item() - r) / max(r, 1e-12) for n, r in zip(names, norms) if r > 1e-8]
+    assert np.median(rel) < 2e-2 and max(rel) < 0.25
+    for key in [k for k in z.files if k.startswith('cfg1_full/gslice/')]:
+        n = key.split('/gslice/')[1]
+        r = torch.from_numpy(z[key]).double()
+        g = params[n].grad.reshape(-1)[:4096].cpu().double()
+        cos = (g @ r) / (g.norm() * r.norm() + 1e-30)
+        assert cos > 0.99, (n, cos.item())
+    m.uniter_model.precision = 'fp32'
+    l2 = m(**model_kwargs(b))
+    assert maxdiff(l2, ref) < 5e-5               # switching back restores exact fp32 parity
