@@ -79,6 +79,16 @@ int uniter_gemm_bf16_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int 
                     const float* aux_in, float* aux_out, int ld_aux,
                     int beta, void* stream);
 
+/* fp32-ACCURATE product on the bf16 matrix pipe: each fp32 operand is split exactly into three
+ * bf16 pieces and the six significant piece products are accumulated in fp32 (error of the same
+ * order as the native fp32 MFMA chain; see csrc/gemm_split.hip).  Same contract as
+ * uniter_gemm_f32_cfg; shapes with K % 32 != 0 run on the native fp32 kernel. */
+int uniter_gemm_f32x3_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K,
+                    const float* A, int lda, const float* B, int ldb,
+                    float* C, int ldc, int epilogue, const float* bias,
+                    const float* aux_in, float* aux_out, int ld_aux,
+                    int beta, void* stream);
+
 /* out[n] (+)= sum_m X[m*ld + n]   (bias gradients of every nn.Linear) */
 int uniter_colsum_f32(const float* X, int M, int N, int ld, float* out, int beta,
                       void* ws, size_t ws_bytes, void* stream);
