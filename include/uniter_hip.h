@@ -138,11 +138,15 @@ size_t uniter_ln_bwd_ws_bytes(int M, int H);
 int uniter_attn_fwd(const float* qkv, const float* attn_mask, float* ctx, float* lse,
                     int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
                     uint32_t site, void* stream);
-/*   dqkv : [B*L, 3*H] gradients w.r.t. qkv;  delta : [B, nh, L] scratch */
+/*   dqkv : [B*L, 3*H] gradients w.r.t. qkv;  delta : [B, nh, L] scratch;
+ *   ws : device scratch of uniter_attn_bwd_ws_bytes(B, L, nh) bytes (the dropped probabilities and
+ *        score gradients [B*nh, Lr, Lr] x 2 that the dQ kernel hands to the dK/dV kernel when
+ *        L <= 192; 0 bytes / may be NULL for longer sequences) */
+size_t uniter_attn_bwd_ws_bytes(int B, int L, int nh);
 int uniter_attn_bwd(const float* qkv, const float* attn_mask, const float* ctx,
                     const float* lse, const float* dctx, float* dqkv, float* delta,
                     int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
-                    uint32_t site, void* stream);
+                    uint32_t site, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Embeddings (replace UniterTextEmbeddings.forward model/model.py:232-245,

@@ -54,7 +54,8 @@ _SIGS = {
     'uniter_ln_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_ln_bwd_ws_bytes': (_SZ, [_I, _I]),
     'uniter_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P]),
-    'uniter_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P]),
+    'uniter_attn_bwd_ws_bytes': (_SZ, [_I, _I, _I]),
+    'uniter_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_txt_embed_fwd': (_I, [_P] * 9 + [_I] * 8 + [_F, _U64, _U32, _P]),
     'uniter_img_embed_fwd': (_I, [_P] * 14 + [_I] * 6 + [_F, _U64, _U32, _P]),
     'uniter_gather_rows': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -522,6 +522,260 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnArgs a,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Split variants (L <= 192): still one workgroup per (batch, head) with K/V (or Q/dO) resident in
+// LDS, but TWO waves per 32-row block, each covering half of the loop range -- 12 waves at L = 164,
+// three per SIMD, instead of six waves spread 2/2/1/1.  Partial results meet in LDS (the staged
+// operands are dead by then): forward merges the two (max, sum, O) triples, dQ / dK / dV add.
+// The dQ kernel also writes the dropped probabilities Pd and the score gradients dS to a scratch
+// tensor in HBM ([B*nh][key][query], 2 x 28 MB at B = 16): the dK/dV kernel then is two plain
+// products (dV = Pd^T dO, dK = dS^T Q) -- half the MFMAs of recomputing S and dP, no exp, no Philox.
+// ---------------------------------------------------------------------------
+constexpr int SPLIT_MAX_LR = 192;
+constexpr int XROW = 34;             // floats exchanged per lane: 32 accumulators + (m, l)
+
+__global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, int Lr) {
+  float* Ks = dyn_smem;
+  float* Vs = Ks + Lr * LDT;
+  float* mb = Vs + Lr * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int i = lane & 31, h = lane >> 5;
+  const int nblk = Lr >> 5;
+  const int qb = wave % nblk, half = wave / nblk;
+  const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const int ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
+  stage_rows(Ks, base + a.H, ld, a.L, Lr, tid, nthr);
+  stage_rows(Vs, base + 2 * a.H, ld, a.L, Lr, tid, nthr);
+  for (int k = tid; k < Lr; k += nthr)
+    mb[k] = k < a.L ? (1.0f - a.mask[(size_t)b * a.L + k]) * -10000.0f : NEG_INF;
+  const int q = qb * 32 + i;
+  const bool vq = q < a.L;
+  f32x4 qf[8];
+  load_row_frags(qf, base + (size_t)q * ld, vq, h);
+  __syncthreads();
+
+  const int kmid = ((nblk + 1) >> 1) * 32;
+  const int kbeg = half ? kmid : 0, kend = half ? Lr : kmid;
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = NEG_INF, l_run = 0.f;
+  for (int k0 = kbeg; k0 < kend && k0 < a.L; k0 += 32) {
+    f32x16 s = tile_times_frag(Ks + k0 * LDT, qf, i, h);
+    float mx = NEG_INF;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + k0 + 8 * g + 4 * h);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s[4 * g + t] = s[4 * g + t] * a.scale + bias[t];
+        mx = fmaxf(mx, s[4 * g + t]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_new); ls += s[r]; }
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    if (a.drop.active && vq) {
+      const uint64_t grow = ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float m4[4];
+        drop_mult4(a.drop, grow + 2 * g + h, m4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[4 * g + t] *= m4[t];
+      }
+    }
+    tileT_times_acc(Vs + k0 * LDT, s, o0, o1, i, h);
+  }
+  // second-half waves hand (O, m, l) to their partner through LDS
+  __syncthreads();
+  float* xb = dyn_smem + (size_t)qb * XROW * 64;
+  if (half) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { xb[r * 64 + lane] = o0[r]; xb[(16 + r) * 64 + lane] = o1[r]; }
+    xb[32 * 64 + lane] = m_run;
+    xb[33 * 64 + lane] = l_run;
+  }
+  __syncthreads();
+  if (half) return;
+  {
+    const float m_b = xb[32 * 64 + lane], l_b = xb[33 * 64 + lane];
+    const float m_new = fmaxf(m_run, m_b);
+    // a half without any key (L <= 32) carries m = -inf, l = 0: its weight is exp(-inf) = 0
+    const float wa = __expf(m_run - m_new), wb = m_b == NEG_INF ? 0.f : __expf(m_b - m_new);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] = o0[r] * wa + xb[r * 64 + lane] * wb;
+      o1[r] = o1[r] * wa + xb[(16 + r) * 64 + lane] * wb;
+    }
+    l_run = l_run * wa + l_b * wb;
+    m_run = m_new;
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (vq) {
+    store_rowT(a.ctx + ((size_t)b * a.L + q) * a.H + head * D, o0, o1, 1.0f / l_tot, h);
+    if (h == 0 && a.lse) a.lse[(size_t)bh * a.L + q] = m_run + __logf(l_tot);
+  }
+}
+
+__global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a, int Lr, float* __restrict__ pd_ws,
+                                                                float* __restrict__ ds_ws) {
+  float* Ks = dyn_smem;
+  float* Vs = Ks + Lr * LDT;
+  float* mb = Vs + Lr * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int i = lane & 31, h = lane >> 5;
+  const int nblk = Lr >> 5;
+  const int qb = wave % nblk, half = wave / nblk;
+  const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const int ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
+  stage_rows(Ks, base + a.H, ld, a.L, Lr, tid, nthr);
+  stage_rows(Vs, base + 2 * a.H, ld, a.L, Lr, tid, nthr);
+  for (int k = tid; k < Lr; k += nthr)
+    mb[k] = k < a.L ? (1.0f - a.mask[(size_t)b * a.L + k]) * -10000.0f : NEG_INF;
+  const int q = qb * 32 + i;
+  const bool vq = q < a.L;
+  f32x4 qf[8], dof[8];
+  load_row_frags(qf, base + (size_t)q * ld, vq, h);
+  load_row_frags(dof, a.dctx + ((size_t)b * a.L + q) * a.H + head * D, vq, h);
+  float delta = 0.f;
+  {
+    f32x4 of[8];
+    load_row_frags(of, a.ctx + ((size_t)b * a.L + q) * a.H + head * D, vq, h);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) delta += of[kb][t] * dof[kb][t];
+    delta += __shfl_xor(delta, 32, 64);
+    if (vq && h == 0 && half == 0) a.delta[(size_t)bh * a.L + q] = delta;
+  }
+  // an out-of-range query has lse = +inf: every probability (and so Pd, dS) of its column is 0
+  const float lse = vq ? a.lse[(size_t)bh * a.L + q] : -NEG_INF;
+  __syncthreads();
+
+  const int kmid = ((nblk + 1) >> 1) * 32;
+  const int kbeg = half ? kmid : 0, kend = half ? Lr : kmid;
+  float* pdw = pd_ws + (size_t)bh * Lr * Lr + qb * 32 + i;
+  float* dsw = ds_ws + (size_t)bh * Lr * Lr + qb * 32 + i;
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    f32x16 s = tile_times_frag(Ks + k0 * LDT, qf, i, h);
+    f32x16 dp = tile_times_frag(Vs + k0 * LDT, dof, i, h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + k0 + 8 * g + 4 * h);
+      float m4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.drop.active && vq)
+        drop_mult4(a.drop, ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2) + 2 * g + h, m4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float p = __expf(s[4 * g + t] * a.scale + bias[t] - lse);
+        const float pdv = p * m4[t];
+        const float dsv = p * (dp[4 * g + t] * m4[t] - delta) * a.scale;
+        s[4 * g + t] = dsv;
+        const size_t off = (size_t)(k0 + 8 * g + 4 * h + t) * Lr;     // row = key, 32 lanes = 128 contiguous bytes
+        pdw[off] = pdv;
+        dsw[off] = dsv;
+      }
+    }
+    tileT_times_acc(Ks + k0 * LDT, s, dq0, dq1, i, h);
+  }
+  __syncthreads();
+  float* xb = dyn_smem + (size_t)qb * XROW * 64;
+  if (half) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { xb[r * 64 + lane] = dq0[r]; xb[(16 + r) * 64 + lane] = dq1[r]; }
+  }
+  __syncthreads();
+  if (half) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq0[r] += xb[r * 64 + lane]; dq1[r] += xb[(16 + r) * 64 + lane]; }
+  if (vq) store_rowT(a.dqkv + ((size_t)b * a.L + q) * ld + head * D, dq0, dq1, 1.0f, h);
+}
+
+// dV^T[d][key] = sum_q dO[q][d] Pd[q][key],  dK^T[d][key] = sum_q Q[q][d] dS[q][key]
+__global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs a, int Lr,
+                                                                 const float* __restrict__ pd_ws,
+                                                                 const float* __restrict__ ds_ws) {
+  float* Qs = dyn_smem;
+  float* dOs = Qs + Lr * LDT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int i = lane & 31, h = lane >> 5;
+  const int nblk = Lr >> 5;
+  const int kb = wave % nblk, half = wave / nblk;
+  const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const int ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
+  stage_rows(Qs, base, ld, a.L, Lr, tid, nthr);
+  stage_rows(dOs, a.dctx + (size_t)b * a.L * a.H + head * D, a.H, a.L, Lr, tid, nthr);
+  const int key = kb * 32 + i;
+  const bool vk = key < a.L;
+  const int qmid = ((nblk + 1) >> 1) * 32;
+  const int qbeg = half ? qmid : 0, qend = half ? Lr : qmid;
+  // lane (key i, half h) needs, for q-tile q0, the 4 consecutive queries q0 + 8g + 4h .. +3 of its key row
+  const float* pdr = pd_ws + ((size_t)bh * Lr + key) * Lr + 4 * h;
+  const float* dsr = ds_ws + ((size_t)bh * Lr + key) * Lr + 4 * h;
+  f32x4 wp[4], wd[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    wp[g] = *reinterpret_cast<const f32x4*>(pdr + qbeg + 8 * g);
+    wd[g] = *reinterpret_cast<const f32x4*>(dsr + qbeg + 8 * g);
+  }
+  __syncthreads();
+
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+  for (int q0 = qbeg; q0 < qend; q0 += 32) {
+    f32x16 pd, ds;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { pd[4 * g + t] = wp[g][t]; ds[4 * g + t] = wd[g][t]; }
+    if (q0 + 32 < qend) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        wp[g] = *reinterpret_cast<const f32x4*>(pdr + q0 + 32 + 8 * g);
+        wd[g] = *reinterpret_cast<const f32x4*>(dsr + q0 + 32 + 8 * g);
+      }
+    }
+    tileT_times_acc(dOs + q0 * LDT, pd, dv0, dv1, i, h);
+    tileT_times_acc(Qs + q0 * LDT, ds, dk0, dk1, i, h);
+  }
+  __syncthreads();
+  float* xb = dyn_smem + (size_t)kb * 64 * 64;
+  if (half) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xb[r * 64 + lane] = dk0[r]; xb[(16 + r) * 64 + lane] = dk1[r];
+      xb[(32 + r) * 64 + lane] = dv0[r]; xb[(48 + r) * 64 + lane] = dv1[r];
+    }
+  }
+  __syncthreads();
+  if (half) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    dk0[r] += xb[r * 64 + lane]; dk1[r] += xb[(16 + r) * 64 + lane];
+    dv0[r] += xb[(32 + r) * 64 + lane]; dv1[r] += xb[(48 + r) * 64 + lane];
+  }
+  if (vk) {
+    float* row = a.dqkv + ((size_t)b * a.L + key) * ld + head * D;
+    store_rowT(row + a.H, dk0, dk1, 1.0f, h);
+    store_rowT(row + 2 * a.H, dv0, dv1, 1.0f, h);
+  }
+}
+
 constexpr int RES_MAX_LR = 256;      // 8 waves (2 per SIMD: 256 VGPRs each); 2*256*68*4 B = 139 KB LDS
 
 inline size_t res_lds_bytes(int Lr) { return (size_t)(2 * Lr * LDT + 2 * Lr) * sizeof(float); }
@@ -531,6 +785,12 @@ int set_dyn_lds(K kernel, size_t bytes) {
   UCHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return 0;
+}
+
+// UNITER_ATTN_SPLIT=0 keeps the one-wave-per-block resident kernels (A/B measurements)
+bool split_enabled() {
+  static const bool on = [] { const char* e = getenv("UNITER_ATTN_SPLIT"); return !(e && e[0] == '0'); }();
+  return on;
 }
 
 int make_args(AttnArgs& a, int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
@@ -553,7 +813,11 @@ extern "C" int uniter_attn_fwd(const float* qkv, const float* attn_mask, float* 
   UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.ctx = ctx; a.lse = lse;
   const int Lr = (L + 31) / 32 * 32;
-  if (Lr <= RES_MAX_LR) {
+  if (Lr <= SPLIT_MAX_LR && split_enabled()) {
+    const size_t lds = res_lds_bytes(Lr);
+    UCHECK_RC(set_dyn_lds(attn_fwd_split_kernel, lds));
+    hipLaunchKernelGGL(attn_fwd_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr);
+  } else if (Lr <= RES_MAX_LR) {
     const size_t lds = res_lds_bytes(Lr);
     UCHECK_RC(set_dyn_lds(attn_fwd_res_kernel, lds));
     hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(B * nh), dim3(Lr * 2), lds, (hipStream_t)stream, a, Lr);
@@ -565,16 +829,38 @@ extern "C" int uniter_attn_fwd(const float* qkv, const float* attn_mask, float* 
   return 0;
 }
 
+extern "C" size_t uniter_attn_bwd_ws_bytes(int B, int L, int nh) {
+  const int Lr = (L + 31) / 32 * 32;
+  if (B <= 0 || nh <= 0 || Lr > SPLIT_MAX_LR || !split_enabled()) return 0;
+  return (size_t)2 * B * nh * Lr * Lr * sizeof(float);
+}
+
 extern "C" int uniter_attn_bwd(const float* qkv, const float* attn_mask, const float* ctx,
                                const float* lse, const float* dctx, float* dqkv, float* delta, int B,
                                int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
-                               uint32_t site, void* stream) {
+                               uint32_t site, void* ws, size_t ws_bytes, void* stream) {
   UCHECK_ARG(qkv && attn_mask && ctx && lse && dctx && dqkv && delta, "attn_bwd: null pointer");
+  UCHECK_ARG(ws_bytes >= uniter_attn_bwd_ws_bytes(B, L, nh) && (ws || ws_bytes == 0 || uniter_attn_bwd_ws_bytes(B, L, nh) == 0),
+             "attn_bwd: workspace too small (uniter_attn_bwd_ws_bytes)");
   AttnArgs a = {};
   UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
   a.dctx = dctx; a.dqkv = dqkv; a.delta = delta;
   const int Lr = (L + 31) / 32 * 32;
+  if (Lr <= SPLIT_MAX_LR && split_enabled()) {
+    const size_t lds = res_lds_bytes(Lr);
+    float* pd_ws = (float*)ws;
+    float* ds_ws = pd_ws + (size_t)B * nh * Lr * Lr;
+    UCHECK_RC(set_dyn_lds(attn_bwd_dq_split_kernel, lds));
+    UCHECK_RC(set_dyn_lds(attn_bwd_dkv_split_kernel, lds));
+    hipLaunchKernelGGL(attn_bwd_dq_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr,
+                       pd_ws, ds_ws);
+    UCHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr,
+                       pd_ws, ds_ws);
+    UCHECK_LAUNCH();
+    return 0;
+  }
   if (Lr <= RES_MAX_LR) {
     const size_t lds = res_lds_bytes(Lr);
     UCHECK_RC(set_dyn_lds(attn_bwd_dq_res_kernel, lds));

@@ -492,7 +492,12 @@ int launch_v2(GemmArgs g, hipStream_t st) {
 // times the waves sharing the SIMD) to land instead of half of one.  A lone wave per SIMD lost ~19 % to vmcnt stalls with
 // the one-deep version.  Needs the branch-free buffer-load path (K % 32 == 0).
 // ---------------------------------------------------------------------------
-template <int BM, int BN, bool AKM, bool BKM, int TAG>
+//
+// SK = true is the stream-K form for C += A.B (weight gradients: few output tiles, long K): an XCD's
+// unit sequence (its tiles x their k-tiles) is cut into equal contiguous pieces, one per workgroup,
+// so every slot of the chip gets the same number of k-iterations whatever the tile count; a piece
+// that covers part of a tile's K range adds its partial sum with a float atomic.
+template <int BM, int BN, bool AKM, bool BKM, int TAG, bool SK>
 __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int SA = TileSize<BM, AKM>::value, SB = TileSize<BN, BKM>::value;
@@ -508,9 +513,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
   const int q = ntiles >> 3, r = ntiles & 7;
   const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int chunk_n = q + (xcd < r ? 1 : 0);
-  if (idx >= chunk_n) return;
-  const int my_tiles = (chunk_n - idx + per_xcd - 1) / per_xcd;
-  const int total_units = my_tiles * nk;
+  int total_units, t_first, k_first;
+  if (SK) {
+    const long U = (long)chunk_n * nk;
+    const int u0 = (int)(U * idx / per_xcd), u1 = (int)(U * (idx + 1) / per_xcd);
+    total_units = u1 - u0;
+    t_first = u0 / nk; k_first = u0 - t_first * nk;
+  } else {
+    const int my_tiles = idx < chunk_n ? (chunk_n - idx + per_xcd - 1) / per_xcd : 0;
+    total_units = my_tiles * nk;
+    t_first = idx; k_first = 0;
+  }
+  if (total_units == 0) return;
+  const int t_step = SK ? 1 : per_xcd;
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(g.A), 0, (AKM ? g.K : g.M) * g.lda * 4, 0x00020000);
@@ -519,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
   const int kstepA = (AKM ? BK * g.lda : BK) * 4, kstepB = (BKM ? BK * g.ldb : BK) * 4;
 
   // load cursor: (tile, k) of the next unit to fetch
-  int lt = idx, lk = 0, lm0, ln0;
+  int lt = t_first, lk = k_first, lm0, ln0;
   int voA[BM / 32], voB[BN / 32];
   {
     int tmi, tni;
@@ -533,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
   do {                                                                                   \
     ++loaded;                                                                            \
     if (++lk == nk) {                                                                    \
-      lk = 0; lt += per_xcd;                                                             \
+      lk = 0; lt += t_step;                                                              \
       if (loaded < total_units) {                                                        \
         int tmi_, tni_;                                                                  \
         tile_coords(chunk0 + lt, g.tiles_m, g.tiles_n, g.band_h, tmi_, tni_);            \
@@ -566,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
   for (int b = 0; b < TN; ++b) fb0[b] = frag_read<BN, BKM>(smem + SA, wn * WN + b * 32, 0, i, h);
 
   // compute cursor
-  int ct = idx, ck = 0;
+  int ct = t_first, ck = k_first;
   int tmi0, tni0;
   tile_coords(chunk0 + ct, g.tiles_m, g.tiles_n, g.band_h, tmi0, tni0);
   int m0 = tmi0 * BM, n0 = tni0 * BN;
@@ -618,9 +633,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
     if (more) { READ_FRAGS(fa0, fb0, dA, (dA + SA), 0) }                                                \
     MFMA_BLOCK(fa1, fb1)                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (++ck == nk) {                                                                                   \
+    if (++ck == nk || (SK && !more)) {                                                                  \
       EPILOGUE();                                                                                       \
-      ck = 0; ct += per_xcd;                                                                            \
+      ck = 0; ct += t_step;                                                                             \
       if (more) {                                                                                       \
         tile_coords(chunk0 + ct, g.tiles_m, g.tiles_n, g.band_h, tmi0, tni0);                          \
         m0 = tmi0 * BM; n0 = tni0 * BN;                                                                 \
@@ -649,12 +664,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
           }                                                                                             \
           csum += v;                                                                                    \
           float* c = g.C + (size_t)row * g.ldc + col;                                                   \
-          if (g.beta) v += *c;                                                                          \
-          *c = v;                                                                                       \
+          if (SK) { unsafeAtomicAdd(c, v); }                                                            \
+          else { if (g.beta) v += *c; *c = v; }                                                         \
         }                                                                                               \
         acc[a][b][rr] = 0.f;                                                                            \
       }                                                                                                 \
-      if (g.colsum_part) {                                                                              \
+      if (!SK && g.colsum_part) {                                                                       \
         csum += __shfl_xor(csum, 32, 64);                                                               \
         if (h == 0 && cok && (m0 + wm * WM + a * 32) < g.M)                                             \
           g.colsum_part[(size_t)((m0 + wm * WM + a * 32) >> 5) * g.N + col] = csum;                     \
@@ -687,7 +702,19 @@ int launch_v3(GemmArgs g, hipStream_t st, int slots) {
   static const int slots_override = env_int("UNITER_GEMM_SLOTS", 0);
   if (slots_override > 0) slots = slots_override;
   int grid = tiles < slots ? (tiles + 7) / 8 * 8 : slots;
-  hipLaunchKernelGGL((gemm_f32_v3_kernel<BM, BN, AKM, BKM, TAG>), dim3(grid), dim3(256), 0, st, g);
+  // stream-K when the tiles fill the slots unevenly (only legal for a plain accumulating GEMM)
+  static const int sk_mode = env_int("UNITER_GEMM_SK", 1);     // 0 never, 1 heuristic, 2 whenever legal
+  if constexpr (TAG == 0) if (sk_mode && g.beta == 1 && g.epi == UNITER_EPI_NONE && !g.colsum_part && tiles >= 8) {
+    const int rounds = (tiles + slots - 1) / slots;
+    const bool uneven = (long)tiles * 100 < (long)rounds * slots * 88;
+    const long units = (long)tiles * (g.K / BK);
+    if ((uneven || sk_mode == 2) && units >= 8l * slots) {    // >= 8 k-iterations per piece
+      hipLaunchKernelGGL((gemm_f32_v3_kernel<BM, BN, AKM, BKM, 0, true>), dim3(slots), dim3(256), 0, st, g);
+      UCHECK_LAUNCH();
+      return 0;
+    }
+  }
+  hipLaunchKernelGGL((gemm_f32_v3_kernel<BM, BN, AKM, BKM, TAG, false>), dim3(grid), dim3(256), 0, st, g);
   UCHECK_LAUNCH();
   return 0;
 }

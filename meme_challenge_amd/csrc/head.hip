@@ -8,26 +8,34 @@
 
 namespace {
 
-// pooled[b][n] = tanh(sum_k h0[b][k] W[n][k] + bias[n]); one wave per n, loops over b
+// pooled[b][n] = tanh(sum_k h0[b][k] W[n][k] + bias[n]); one wave per (n, group of 4 batch rows):
+// the weight row is read once per wave and the four dot products reduce together
 __global__ __launch_bounds__(256) void pooler_fwd_kernel(const float* __restrict__ hidden,
                                                          const float* __restrict__ W,
                                                          const float* __restrict__ bias,
                                                          float* __restrict__ pooled, int B, int L, int H) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b0 = blockIdx.y * 4;
   if (n >= H) return;
   const float* w = W + (size_t)n * H;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = lane; k < H; k += 64) {
+    const float wk = w[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (b0 + j < B) s[j] += hidden[(size_t)(b0 + j) * L * H + k] * wk;
+  }
   const float bn = bias[n];
-  for (int b = 0; b < B; ++b) {
-    const float* h0 = hidden + (size_t)b * L * H;
-    float s = 0.f;
-    for (int k = lane; k < H; k += 64) s += h0[k] * w[k];
-    s = wave_sum(s);
-    if (lane == 0) pooled[(size_t)b * H + n] = tanhf(s + bn);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float t = wave_sum(s[j]);
+    if (lane == 0 && b0 + j < B) pooled[(size_t)(b0 + j) * H + n] = tanhf(t + bn);
   }
 }
 
 // one wave per n: dbias[n] += sum_b dpre[b][n]; dW[n][:] += sum_b dpre[b][n] * h0[b][:]
+// dpre[b][n] lives in lane b (chunks of 64 batch rows) and is broadcast by shuffles
 __global__ __launch_bounds__(256) void pooler_bwd_w_kernel(const float* __restrict__ dpooled,
                                                            const float* __restrict__ pooled,
                                                            const float* __restrict__ hidden,
@@ -37,35 +45,57 @@ __global__ __launch_bounds__(256) void pooler_bwd_w_kernel(const float* __restri
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= H) return;
   float sb = 0.f;
-  for (int k = lane; k < H; k += 64) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float p = pooled[(size_t)b * H + n];
-      const float dpre = dpooled[(size_t)b * H + n] * (1.0f - p * p);
-      s += dpre * hidden[(size_t)b * L * H + k];
-      if (k == lane) sb += dpre;
+  for (int bc = 0; bc < B; bc += 64) {
+    const int nb = min(64, B - bc);
+    float dpre = 0.f;
+    if (lane < nb) {
+      const float p = pooled[(size_t)(bc + lane) * H + n];
+      dpre = dpooled[(size_t)(bc + lane) * H + n] * (1.0f - p * p);
     }
-    dW[(size_t)n * H + k] += s;
+    sb += wave_sum(dpre);
+    for (int k = lane; k < H; k += 64) {
+      float s = 0.f;
+      for (int b = 0; b < nb; ++b) s += __shfl(dpre, b, 64) * hidden[(size_t)(bc + b) * L * H + k];
+      dW[(size_t)n * H + k] += s;
+    }
   }
   if (lane == 0) dbias[n] += sb;
 }
 
-// one thread per (b,k): dh0[b][k] (+)= sum_n dpre[b][n] W[n][k]
+// dh0[b][k] (+)= sum_n dpre[b][n] W[n][k]: workgroup = (64 columns k, one b); its 4 waves split n
 __global__ __launch_bounds__(256) void pooler_bwd_x_kernel(const float* __restrict__ dpooled,
                                                            const float* __restrict__ pooled,
                                                            const float* __restrict__ W,
                                                            float* __restrict__ dhidden, int B, int L, int H,
                                                            int beta) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
   const int b = blockIdx.y;
-  if (k >= H) return;
-  float s = 0.f;
-  for (int n = 0; n < H; ++n) {
-    const float p = pooled[(size_t)b * H + n];
-    s += dpooled[(size_t)b * H + n] * (1.0f - p * p) * W[(size_t)n * H + k];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (k < H) {
+    const float* dp = dpooled + (size_t)b * H;
+    const float* pp = pooled + (size_t)b * H;
+    int n = wv;
+    for (; n + 12 < H; n += 16) {
+      const float p0 = pp[n], p1 = pp[n + 4], p2 = pp[n + 8], p3 = pp[n + 12];
+      s0 += dp[n] * (1.0f - p0 * p0) * W[(size_t)n * H + k];
+      s1 += dp[n + 4] * (1.0f - p1 * p1) * W[(size_t)(n + 4) * H + k];
+      s2 += dp[n + 8] * (1.0f - p2 * p2) * W[(size_t)(n + 8) * H + k];
+      s3 += dp[n + 12] * (1.0f - p3 * p3) * W[(size_t)(n + 12) * H + k];
+    }
+    for (; n < H; n += 4) {
+      const float p0 = pp[n];
+      s0 += dp[n] * (1.0f - p0 * p0) * W[(size_t)n * H + k];
+    }
   }
-  float* d = dhidden + (size_t)b * L * H + k;
-  *d = beta ? *d + s : s;
+  red[wv][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wv == 0 && k < H) {
+    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float* d = dhidden + (size_t)b * L * H + k;
+    *d = beta ? *d + s : s;
+  }
 }
 
 // y[b][c] = x[b] . W[c] + bias[c]; one wave per (b,c)
@@ -137,7 +167,7 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
 extern "C" int uniter_pooler_fwd(const float* hidden, const float* Wp, const float* bp, float* pooled, int B,
                                  int L, int H, void* stream) {
   UCHECK_ARG(hidden && Wp && bp && pooled && B > 0 && L > 0 && H > 0, "pooler_fwd: bad argument");
-  hipLaunchKernelGGL(pooler_fwd_kernel, dim3((H + 3) / 4), dim3(256), 0, (hipStream_t)stream, hidden, Wp, bp,
+  hipLaunchKernelGGL(pooler_fwd_kernel, dim3((H + 3) / 4, (B + 3) / 4), dim3(256), 0, (hipStream_t)stream, hidden, Wp, bp,
                      pooled, B, L, H);
   UCHECK_LAUNCH();
   return 0;
@@ -153,7 +183,7 @@ extern "C" int uniter_pooler_bwd(const float* dpooled, const float* pooled, cons
                      dbp, B, L, H);
   UCHECK_LAUNCH();
   if (dhidden) {
-    hipLaunchKernelGGL(pooler_bwd_x_kernel, dim3((H + 255) / 256, B), dim3(256), 0, st, dpooled, pooled, Wp,
+    hipLaunchKernelGGL(pooler_bwd_x_kernel, dim3((H + 63) / 64, B), dim3(256), 0, st, dpooled, pooled, Wp,
                        dhidden, B, L, H, beta_dhidden);
     UCHECK_LAUNCH();
   }

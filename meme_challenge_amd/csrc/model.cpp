@@ -66,8 +66,8 @@ struct Plan {
   float *feat_eff, *imgfc, *img_stats, *cat, *emb;
   std::vector<LayerBufs> layers;
   float *dcat, *d_imgfc, *d_posfc, *d_feat, *dsum;
-  void *ln_ws, *col_ws, *emb_ws;
-  size_t ln_ws_bytes, col_ws_bytes, emb_ws_bytes;
+  void *ln_ws, *col_ws, *emb_ws, *attn_ws;
+  size_t ln_ws_bytes, col_ws_bytes, emb_ws_bytes, attn_ws_bytes;
   size_t total;
 };
 
@@ -175,6 +175,8 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
     const int rows = B * (T > R ? T : R);
     pl.emb_ws_bytes = uniter_embed_bwd_ws_bytes(rows, H);
     pl.emb_ws = cv.raw(pl.emb_ws_bytes);
+    pl.attn_ws_bytes = uniter_attn_bwd_ws_bytes(B, L, c.num_attention_heads);
+    pl.attn_ws = cv.raw(pl.attn_ws_bytes);
   }
   pl.total = cv.off;
 }
@@ -480,7 +482,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   {
     ProfScope ps(m, UNITER_K_ATTN_BWD, st);
     UCHECK_RC(uniter_attn_bwd(lb.qkv, m->batch.attention_mask, lb.ctx, lb.lse, lb.dctx, lb.dqkv, lb.delta, B, L,
-                              nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), st));
+                              nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
   }
   UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, 3 * H, lb.dqkv, 3 * H, m->LP(l, L_QW), H, lb.dx, H,
                  UNITER_EPI_ADD, nullptr, lb.dz1, nullptr, H, 0));

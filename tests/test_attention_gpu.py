@@ -28,7 +28,7 @@ def _ref(qkv, mask, B, L, nh, p, seed, offset, site):
 
 
 @pytest.mark.parametrize('B,L,nh,p', [(2, 164, 2, 0.0), (2, 164, 2, 0.1), (3, 16, 2, 0.1), (1, 33, 1, 0.25),
-                                       (2, 100, 12, 0.1), (1, 178, 16, 0.0), (1, 288, 1, 0.1), (1, 300, 2, 0.1)])
+                                       (2, 100, 12, 0.1), (1, 178, 16, 0.0), (1, 200, 2, 0.1), (1, 288, 1, 0.1), (1, 300, 2, 0.1)])
 def test_attention_fwd_bwd(B, L, nh, p):
     from meme_challenge_amd import _lib as Lb
     lib = Lb.lib()
@@ -54,8 +54,11 @@ def test_attention_fwd_bwd(B, L, nh, p):
     assert (lse.cpu().double() - lse_ref.detach()).abs().max() < 2e-5
     dqkv = torch.zeros(B * L, 3 * H, device='cuda')
     delta = torch.empty(B, nh, L, device='cuda')
+    ws_bytes = lib.uniter_attn_bwd_ws_bytes(B, L, nh)
+    ws = torch.full((max(ws_bytes, 4) // 4,), float('nan'), device='cuda')     # every scratch element read must have been written
     Lb.check(lib.uniter_attn_bwd(Lb.ptr(dq), Lb.ptr(dm), Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), Lb.ptr(dqkv),
-                                 Lb.ptr(delta), B, L, nh, p, seed, offset, site, Lb.cur_stream()))
+                                 Lb.ptr(delta), B, L, nh, p, seed, offset, site, Lb.ptr(ws), ws_bytes,
+                                 Lb.cur_stream()))
     torch.cuda.synchronize()
     err = (dqkv.cpu().double() - qr.grad).abs()
     for name, sl in (('dq', slice(0, H)), ('dk', slice(H, 2 * H)), ('dv', slice(2 * H, 3 * H))):

@@ -8,8 +8,9 @@ for p in (0.0, 0.1):
     qkv = torch.randn(B * Lq, 3 * H, device='cuda'); mask = torch.ones(B, Lq, device='cuda')
     ctx = torch.empty(B * Lq, H, device='cuda'); lse = torch.empty(B, nh, Lq, device='cuda')
     dctx = torch.randn(B * Lq, H, device='cuda'); dqkv = torch.empty(B * Lq, 3 * H, device='cuda'); delta = torch.empty(B, nh, Lq, device='cuda')
+    wsb = lib.uniter_attn_bwd_ws_bytes(B, Lq, nh); ws = torch.empty(max(wsb, 4) // 4, device='cuda')
     def fwd(): L.check(lib.uniter_attn_fwd(L.ptr(qkv), L.ptr(mask), L.ptr(ctx), L.ptr(lse), B, Lq, nh, p, 1, 2, 3, L.cur_stream()))
-    def bwd(): L.check(lib.uniter_attn_bwd(L.ptr(qkv), L.ptr(mask), L.ptr(ctx), L.ptr(lse), L.ptr(dctx), L.ptr(dqkv), L.ptr(delta), B, Lq, nh, p, 1, 2, 3, L.cur_stream()))
+    def bwd(): L.check(lib.uniter_attn_bwd(L.ptr(qkv), L.ptr(mask), L.ptr(ctx), L.ptr(lse), L.ptr(dctx), L.ptr(dqkv), L.ptr(delta), B, Lq, nh, p, 1, 2, 3, L.ptr(ws), wsb, L.cur_stream()))
     for name, f in (('fwd', fwd), ('bwd(dq+dkv)', bwd)):
         for _ in range(3): f()
         torch.cuda.synchronize()
