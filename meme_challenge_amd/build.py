@@ -15,7 +15,7 @@ OBJ = os.path.join(PKG, 'build')
 LIB = os.path.join(PKG, 'libuniter_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall',
-         '-Wno-unused-function', '-ffp-contract=off']
+         '-Wno-unused-function', '-ffp-contract=off'] + os.environ.get('UNITER_EXTRA_HIPCC_FLAGS', '').split()
 
 
 def _sources():

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
     for (int b = 0; b < TN; ++b) {
       const int col = n0 + wn * WN + b * 32 + i;
       if (col >= g.N) continue;
-      const float bv = (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU) ? g.bias[col] : 0.f;
+      const float bv = (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D) ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -234,6 +234,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
           v *= dgelu_erf(g.aux_in[(size_t)row * g.ld_aux + col]);
         } else if (g.epi == UNITER_EPI_ADD) {
           v += g.aux_in[(size_t)row * g.ld_aux + col];
+        } else if (g.epi == UNITER_EPI_MUL) {
+          v *= g.aux_in[(size_t)row * g.ld_aux + col];
+        } else if (g.epi == UNITER_EPI_BIAS_GELU_D) {
+          float dg;
+          gelu_pair_fast(v, v, dg);
+          if (g.aux_out) g.aux_out[(size_t)row * g.ld_aux + col] = dg;
         }
         float* c = g.C + (size_t)row * g.ldc + col;
         if (g.beta) v += *c;
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v2_kernel(const GemmArgs g) {
       for (int b = 0; b < TN; ++b) {
         const int col = n0 + wn * WN + b * 32 + i;
         if (col >= g.N) continue;
-        const float bv = (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU) ? g.bias[col] : 0.f;
+        const float bv = (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D) ? g.bias[col] : 0.f;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
           const int row = m0 + wm * WM + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
@@ -437,6 +443,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v2_kernel(const GemmArgs g) {
             v *= dgelu_erf(g.aux_in[(size_t)row * g.ld_aux + col]);
           } else if (g.epi == UNITER_EPI_ADD) {
             v += g.aux_in[(size_t)row * g.ld_aux + col];
+          } else if (g.epi == UNITER_EPI_MUL) {
+            v *= g.aux_in[(size_t)row * g.ld_aux + col];
+          } else if (g.epi == UNITER_EPI_BIAS_GELU_D) {
+            float dg;
+            gelu_pair_fast(v, v, dg);
+            if (g.aux_out) g.aux_out[(size_t)row * g.ld_aux + col] = dg;
           }
           float* c = g.C + (size_t)row * g.ldc + col;
           if (g.beta) v += *c;
@@ -594,6 +606,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) acc[a][b][rr] = 0.f;
 
+  // ADD / MUL epilogues read a second [M, N] operand: fetch this wave's 16 values per tile two
+  // k-iterations before the tile ends, so the epilogue does not start with an exposed HBM round trip
+  const bool has_aux = g.epi == UNITER_EPI_ADD || g.epi == UNITER_EPI_MUL;
+  bool aux_ready = false;
+  float auxr[TM][TN][16];
+#define PREFETCH_AUX()                                                                                  \
+  {                                                                                                     \
+    _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                      \
+    _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                    \
+      const int col = n0 + wn * WN + b * 32 + i;                                                        \
+      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                               \
+        const int row = m0 + wm * WM + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;                       \
+        auxr[a][b][rr] = (col < g.N && row < g.M) ? g.aux_in[(size_t)row * g.ld_aux + col] : 0.f;      \
+      }                                                                                                 \
+    }                                                                                                   \
+    aux_ready = true;                                                                                   \
+  }
 #define MFMA_BLOCK(FA, FB)                                                                              \
   _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
   _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                        \
@@ -611,6 +640,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
     const float* sB = sA + SA;                                                                          \
     float* dA = smem + (((U) + 1) & 1) * (SA + SB);                                                     \
     const bool more = (U) + 1 < total_units;                                                            \
+    if (!SK && has_aux && ck + 2 == nk) { PREFETCH_AUX(); }                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     READ_FRAGS(fa1, fb1, sA, sB, 1)                                                                     \
     MFMA_BLOCK(fa0, fb0)                                                                                \
@@ -635,6 +665,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     if (++ck == nk || (SK && !more)) {                                                                  \
       EPILOGUE();                                                                                       \
+      aux_ready = false;                                                                                \
       ck = 0; ct += t_step;                                                                             \
       if (more) {                                                                                       \
         tile_coords(chunk0 + ct, g.tiles_m, g.tiles_n, g.band_h, tmi0, tni0);                          \
@@ -643,29 +674,44 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
     }                                                                                                   \
   }
 
+// experiment knob: 1 = non-temporal (streaming) stores for the outputs
+#ifndef UNITER_GEMM_NT_STORE
+#define UNITER_GEMM_NT_STORE 0
+#endif
+#if UNITER_GEMM_NT_STORE
+#define STORE_OUT(P, V) __builtin_nontemporal_store((V), (P))
+#else
+#define STORE_OUT(P, V) (*(P) = (V))
+#endif
 #define EPILOGUE()                                                                                      \
   _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                      \
     _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                    \
       const int col = n0 + wn * WN + b * 32 + i;                                                        \
       const bool cok = col < g.N;                                                                       \
-      const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU)) ? g.bias[col] : 0.f; \
+      const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D)) ? g.bias[col] : 0.f; \
       float csum = 0.f;                                                                                 \
       _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                               \
         const int row = m0 + wm * WM + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;                       \
         if (cok && row < g.M) {                                                                         \
           float v = acc[a][b][rr] + bv;                                                                 \
           if (g.epi == UNITER_EPI_BIAS_GELU) {                                                          \
-            if (g.aux_out) g.aux_out[(size_t)row * g.ld_aux + col] = v;                                 \
+            if (g.aux_out) STORE_OUT(g.aux_out + (size_t)row * g.ld_aux + col, v);                      \
             v = gelu_erf(v);                                                                            \
           } else if (g.epi == UNITER_EPI_DGELU) {                                                       \
             v *= dgelu_erf(g.aux_in[(size_t)row * g.ld_aux + col]);                                     \
           } else if (g.epi == UNITER_EPI_ADD) {                                                         \
-            v += g.aux_in[(size_t)row * g.ld_aux + col];                                                \
+            v += aux_ready ? auxr[a][b][rr] : g.aux_in[(size_t)row * g.ld_aux + col];                   \
+          } else if (g.epi == UNITER_EPI_MUL) {                                                         \
+            v *= aux_ready ? auxr[a][b][rr] : g.aux_in[(size_t)row * g.ld_aux + col];                   \
+          } else if (g.epi == UNITER_EPI_BIAS_GELU_D) {                                                 \
+            float dg_;                                                                                  \
+            gelu_pair_fast(v, v, dg_);                                                                  \
+            if (g.aux_out) STORE_OUT(g.aux_out + (size_t)row * g.ld_aux + col, dg_);                    \
           }                                                                                             \
           csum += v;                                                                                    \
           float* c = g.C + (size_t)row * g.ldc + col;                                                   \
           if (SK) { unsafeAtomicAdd(c, v); }                                                            \
-          else { if (g.beta) v += *c; *c = v; }                                                         \
+          else { if (g.beta) v += *c; STORE_OUT(c, v); }                                                \
         }                                                                                               \
         acc[a][b][rr] = 0.f;                                                                            \
       }                                                                                                 \
@@ -682,6 +728,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
   for (int u = 0; u < total_units; ++u) K_ITERATION(u, ra1, rb1, ra1, rb1)
 #undef K_ITERATION
 #undef EPILOGUE
+#undef PREFETCH_AUX
 #undef MFMA_BLOCK
 #undef READ_FRAGS
 #undef LOAD_UNIT
@@ -762,10 +809,10 @@ int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int
                  void* stream) {
   UCHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad dims %d %d %d", M, N, K);
   UCHECK_ARG(A && B && C, "gemm: null operand");
-  UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_ADD, "gemm: bad epilogue %d", epilogue);
-  UCHECK_ARG(!(epilogue == UNITER_EPI_BIAS || epilogue == UNITER_EPI_BIAS_GELU) || bias,
+  UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_MUL, "gemm: bad epilogue %d", epilogue);
+  UCHECK_ARG(!(epilogue == UNITER_EPI_BIAS || epilogue == UNITER_EPI_BIAS_GELU || epilogue == UNITER_EPI_BIAS_GELU_D) || bias,
              "gemm: epilogue needs bias");
-  UCHECK_ARG(!(epilogue == UNITER_EPI_DGELU || epilogue == UNITER_EPI_ADD) || aux_in,
+  UCHECK_ARG(!(epilogue == UNITER_EPI_DGELU || epilogue == UNITER_EPI_ADD || epilogue == UNITER_EPI_MUL) || aux_in,
              "gemm: epilogue needs aux_in");
   // 16-byte vector loads along the contiguous dimension
   if (!a_kmajor) UCHECK_SHAPE(K % 4 == 0 && lda % 4 == 0, "gemm: K/lda must be multiples of 4 (A k-contiguous)");

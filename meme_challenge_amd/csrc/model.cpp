@@ -63,6 +63,7 @@ struct LayerBufs {   // saved activations + backward scratch of one layer
 struct Plan {
   int B, T, R, L, S, T0, M, mode;
   bool has_txt, has_img;
+  bool gelu_d;      // forward stored gelu'(u) in LayerBufs::u (fp32 kernels) rather than u
   float *feat_eff, *imgfc, *img_stats, *cat, *emb;
   std::vector<LayerBufs> layers;
   float *dcat, *d_imgfc, *d_posfc, *d_feat, *dsum;
@@ -349,6 +350,9 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   const float pa = train == 1 ? c.attention_probs_dropout_prob : 0.f;
   const int B = b->B, T = b->T, R = b->R, L = b->L, S = pl.S, M = pl.M;
   const bool save = train != 0;
+  static const bool gelu_d_env = [] { const char* e = getenv("UNITER_GELU_D"); return !(e && e[0] == '0'); }();
+  const bool gelu_d = m->precision == 0 && gelu_d_env;      // UNITER_GELU_D=0: A/B switch
+  pl.gelu_d = gelu_d;
   m->batch = *b; m->hidden_out = hidden_out; m->all_layers = all_layers; m->seed = seed; m->offset = offset;
   m->bwd_open = false;
 
@@ -395,7 +399,7 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
                               SITE_ATTN_OUT(l), st));
     }
     UCHECK_RC(gemm(m, UNITER_K_GEMM_FFN_UP_FWD, st, 0, 0, M, I, H, lb.y1, H, m->LP(l, L_W1), H, lb.hact, I,
-                   UNITER_EPI_BIAS_GELU, m->LP(l, L_B1), nullptr, lb.u, I, 0));
+                   gelu_d ? UNITER_EPI_BIAS_GELU_D : UNITER_EPI_BIAS_GELU, m->LP(l, L_B1), nullptr, lb.u, I, 0));
     UCHECK_RC(gemm(m, UNITER_K_GEMM_FFN_DOWN_FWD, st, 0, 0, M, H, I, lb.hact, I, m->LP(l, L_W2), I, lb.t2, H,
                    UNITER_EPI_BIAS, m->LP(l, L_B2), nullptr, nullptr, 0, 0));
     {
@@ -467,7 +471,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   // the GEMM's epilogue also emits per-32-row column sums of du (= partial bias gradients of
   // intermediate.dense): saves a 32 MB re-read of du
   const bool fuse_db1 = H % 64 == 0;
-  UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, g2, H, m->LP(l, L_W2), I, lb.du, I, UNITER_EPI_DGELU,
+  UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, g2, H, m->LP(l, L_W2), I, lb.du, I, pl.gelu_d ? UNITER_EPI_MUL : UNITER_EPI_DGELU,
                  nullptr, lb.u, nullptr, I, 0, fuse_db1 ? lb.du_csum : nullptr));
   UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, I, lb.du, I, m->LP(l, L_W1), H, lb.dy1, H, UNITER_EPI_ADD,
                  nullptr, lb.dz2, nullptr, H, 0));

@@ -18,7 +18,7 @@ def _run(lib, L, cfg, akm, bkm, M, N, K, epi, beta, seed=0):
     Bm = B if bkm else B.t()
     ref = Am.double() @ Bm.double()
     aux_out_ref = None
-    if epi in (1, 2):
+    if epi in (1, 2, 5):
         ref = ref + bias.double()
     if epi == 2:
         aux_out_ref = ref.clone()
@@ -28,6 +28,12 @@ def _run(lib, L, cfg, akm, bkm, M, N, K, epi, beta, seed=0):
         ref = ref * (0.5 * (1 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi))
     if epi == 4:
         ref = ref + aux.double()
+    if epi == 5:      # forward hands gelu'(u) to the backward pass
+        x = ref
+        aux_out_ref = 0.5 * (1 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+        ref = x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    if epi == 6:
+        ref = ref * aux.double()
     if beta:
         ref = ref + C0.double()
     dA, dB, dbias, daux, dC = (t.cuda().contiguous() for t in (A, B, bias, aux, C0))
@@ -40,7 +46,7 @@ def _run(lib, L, cfg, akm, bkm, M, N, K, epi, beta, seed=0):
     scale = math.sqrt(K)
     err = (dC.cpu().double() - ref).abs().max().item()
     assert err < 2e-5 * scale * 4, (cfg, akm, bkm, M, N, K, epi, beta, err)
-    if epi == 2:
+    if epi in (2, 5):
         assert (daux_out.cpu().double() - aux_out_ref).abs().max().item() < 2e-5 * scale * 4
 
 
@@ -55,11 +61,14 @@ def test_gemm_layouts_and_edges(cfg, layout):
     _run(lib, L, cfg, akm, bkm, M=48, N=128, K=48 if (akm or bkm) else 64, epi=0, beta=1)
 
 
-@pytest.mark.parametrize('epi', [1, 2, 3, 4])
+@pytest.mark.parametrize('epi', [1, 2, 3, 4, 5, 6])
 def test_gemm_epilogues(epi):
     from meme_challenge_amd import _lib as L
     lib = L.lib()
-    _run(lib, L, 0, 0, 0 if epi in (1, 2) else 1, M=300, N=256, K=128, epi=epi, beta=0)
+    _run(lib, L, 0, 0, 0 if epi in (1, 2, 5) else 1, M=300, N=256, K=128, epi=epi, beta=0)
+    _run(lib, L, 0, 0, 0 if epi in (1, 2, 5) else 1, M=300, N=256, K=32, epi=epi, beta=0)     # one k-tile: no aux prefetch
+    _run(lib, L, 21, 0, 0 if epi in (1, 2, 5) else 1, M=300, N=256, K=96, epi=epi, beta=0)
+    _run(lib, L, 4, 0, 0 if epi in (1, 2, 5) else 1, M=100, N=64, K=40, epi=epi, beta=0)      # v1 fallback
 
 
 @pytest.mark.parametrize('cfg', [0, 11, 14, 21, 24])
