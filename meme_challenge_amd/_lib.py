@@ -10,6 +10,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libuniter_hip.so')
+if os.environ.get('UNITER_LIB_VARIANT'):      # experimental build for A/B kernel measurements (build.py)
+    LIB_PATH = os.path.join(_HERE, 'libuniter_hip_%s.so' % os.environ['UNITER_LIB_VARIANT'])
 
 c_f32p = C.c_void_p
 c_i64p = C.c_void_p

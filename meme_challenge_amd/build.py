@@ -10,7 +10,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(PKG, 'csrc')
+CSRC = os.environ.get('UNITER_CSRC_DIR') or os.path.join(PKG, 'csrc')     # override: variant builds of another source tree
 OBJ = os.path.join(PKG, 'build')
 LIB = os.path.join(PKG, 'libuniter_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -37,9 +37,10 @@ def _digest(paths):
     return h.hexdigest()
 
 
-def _compile(src, hdr_digest, force):
-    os.makedirs(OBJ, exist_ok=True)
-    obj = os.path.join(OBJ, os.path.basename(src) + '.o')
+def _compile(src, hdr_digest, force, objdir=None):
+    objdir = objdir or OBJ
+    os.makedirs(objdir, exist_ok=True)
+    obj = os.path.join(objdir, os.path.basename(src) + '.o')
     stamp = obj + '.sha'
     dig = _digest([src]) + hdr_digest
     if (not force and os.path.exists(obj) and os.path.exists(stamp)
@@ -54,11 +55,16 @@ def _compile(src, hdr_digest, force):
     return obj, True
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, variant=None):
+    """variant: name of an experimental build (A/B kernel measurements): objects go to
+    build/<variant>/, the library to libuniter_hip_<variant>.so, loaded when UNITER_LIB_VARIANT
+    names it (see _lib.py).  Compile flags come from UNITER_EXTRA_HIPCC_FLAGS as usual."""
     srcs = _sources()
     hd = _digest(_headers())
+    objdir = os.path.join(OBJ, variant) if variant else OBJ
+    LIB = os.path.join(PKG, 'libuniter_hip_%s.so' % variant) if variant else globals()['LIB']
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        res = list(ex.map(lambda s: _compile(s, hd, force), srcs))
+        res = list(ex.map(lambda s: _compile(s, hd, force, objdir), srcs))
     objs = [o for o, _ in res]
     if any(c for _, c in res) or not os.path.exists(LIB):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs

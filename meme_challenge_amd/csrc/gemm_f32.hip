@@ -43,6 +43,13 @@ struct GemmArgs {
   float* colsum_part;   // optional [ceil(M/32)][N]: per-32-row-block column sums of the stored C (v3 only)
 };
 
+__device__ __forceinline__ float buf_ld_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int aux) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st_f32(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int aux) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -611,15 +618,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
   const bool has_aux = g.epi == UNITER_EPI_ADD || g.epi == UNITER_EPI_MUL;
   bool aux_ready = false;
   float auxr[TM][TN][16];
+#define AUXR(a, b, rr) auxr[a][b][rr]
 #define PREFETCH_AUX()                                                                                  \
   {                                                                                                     \
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(                                \
+        const_cast<float*>(g.aux_in), 0, g.M * g.ld_aux * 4, 0x00020000);                               \
     _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                      \
     _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                    \
       const int col = n0 + wn * WN + b * 32 + i;                                                        \
-      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                               \
-        const int row = m0 + wm * WM + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;                       \
-        auxr[a][b][rr] = (col < g.N && row < g.M) ? g.aux_in[(size_t)row * g.ld_aux + col] : 0.f;      \
-      }                                                                                                 \
+      const int r0 = m0 + wm * WM + a * 32 + 4 * h;                                                     \
+      const int voX = col < g.N ? (r0 * g.ld_aux + col) * 4 : 0x7ffffff0;                               \
+      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr)                                                 \
+        AUXR(a, b, rr) = buf_ld_f32(rsI, voX, ((rr & 3) + 8 * (rr >> 2)) * g.ld_aux * 4, 0); \
     }                                                                                                   \
     aux_ready = true;                                                                                   \
   }
@@ -674,51 +684,60 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
     }                                                                                                   \
   }
 
-// experiment knob: 1 = non-temporal (streaming) stores for the outputs
-#ifndef UNITER_GEMM_NT_STORE
-#define UNITER_GEMM_NT_STORE 0
-#endif
-#if UNITER_GEMM_NT_STORE
-#define STORE_OUT(P, V) __builtin_nontemporal_store((V), (P))
-#else
-#define STORE_OUT(P, V) (*(P) = (V))
-#endif
+// Output addressing costs VALU time that the fp32 MFMAs cannot hide (on gfx950 the fp32 matrix
+// instructions and the vector ALU do not overlap within a SIMD: parking a finished tile and writing
+// it out element by element during the next tile's k-loop made the kernel 13 % SLOWER).  So the
+// epilogue uses buffer instructions: one voffset per lane and column tile, the 16 row steps as
+// scalar offsets, rows >= M and columns >= N dropped by the hardware range check -- no 64-bit
+// address arithmetic, compares or exec-mask branches per element.
 #define EPILOGUE()                                                                                      \
-  _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                      \
-    _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                    \
-      const int col = n0 + wn * WN + b * 32 + i;                                                        \
-      const bool cok = col < g.N;                                                                       \
-      const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D)) ? g.bias[col] : 0.f; \
-      float csum = 0.f;                                                                                 \
-      _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                               \
-        const int row = m0 + wm * WM + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;                       \
-        if (cok && row < g.M) {                                                                         \
+  {                                                                                                     \
+    constexpr int OOB = 0x7ffffff0;                                                                     \
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.M * g.ldc * 4, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(                                \
+        g.aux_out, 0, g.aux_out ? g.M * g.ld_aux * 4 : 0, 0x00020000);                                  \
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(                                \
+        const_cast<float*>(g.aux_in), 0, g.aux_in ? g.M * g.ld_aux * 4 : 0, 0x00020000);                \
+    _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                    \
+      _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                  \
+        const int col = n0 + wn * WN + b * 32 + i;                                                      \
+        const bool cok = col < g.N;                                                                     \
+        const int r0 = m0 + wm * WM + a * 32 + 4 * h;                                                   \
+        const int voC = cok ? (r0 * g.ldc + col) * 4 : OOB;                                             \
+        const int voX = cok ? (r0 * g.ld_aux + col) * 4 : OOB;                                          \
+        const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D)) ? g.bias[col] : 0.f; \
+        float csum = 0.f;                                                                               \
+        _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                             \
+          const int kr = (rr & 3) + 8 * (rr >> 2);                                                      \
           float v = acc[a][b][rr] + bv;                                                                 \
           if (g.epi == UNITER_EPI_BIAS_GELU) {                                                          \
-            if (g.aux_out) STORE_OUT(g.aux_out + (size_t)row * g.ld_aux + col, v);                      \
+            buf_st_f32(v, rsX, voX, kr * g.ld_aux * 4, 0);                   \
             v = gelu_erf(v);                                                                            \
           } else if (g.epi == UNITER_EPI_DGELU) {                                                       \
-            v *= dgelu_erf(g.aux_in[(size_t)row * g.ld_aux + col]);                                     \
+            v *= dgelu_erf(buf_ld_f32(rsI, voX, kr * g.ld_aux * 4, 0));       \
           } else if (g.epi == UNITER_EPI_ADD) {                                                         \
-            v += aux_ready ? auxr[a][b][rr] : g.aux_in[(size_t)row * g.ld_aux + col];                   \
+            v += aux_ready ? AUXR(a, b, rr) : buf_ld_f32(rsI, voX, kr * g.ld_aux * 4, 0); \
           } else if (g.epi == UNITER_EPI_MUL) {                                                         \
-            v *= aux_ready ? auxr[a][b][rr] : g.aux_in[(size_t)row * g.ld_aux + col];                   \
+            v *= aux_ready ? AUXR(a, b, rr) : buf_ld_f32(rsI, voX, kr * g.ld_aux * 4, 0); \
           } else if (g.epi == UNITER_EPI_BIAS_GELU_D) {                                                 \
             float dg_;                                                                                  \
             gelu_pair_fast(v, v, dg_);                                                                  \
-            if (g.aux_out) STORE_OUT(g.aux_out + (size_t)row * g.ld_aux + col, dg_);                    \
+            buf_st_f32(dg_, rsX, voX, kr * g.ld_aux * 4, 0);                 \
           }                                                                                             \
-          csum += v;                                                                                    \
-          float* c = g.C + (size_t)row * g.ldc + col;                                                   \
-          if (SK) { unsafeAtomicAdd(c, v); }                                                            \
-          else { if (g.beta) v += *c; STORE_OUT(c, v); }                                                \
+          if (!SK && g.colsum_part) csum += (r0 + kr < g.M) ? v : 0.f;                                  \
+          if (SK) {                                                                                     \
+            if (cok && r0 + kr < g.M) unsafeAtomicAdd(g.C + (size_t)(r0 + kr) * g.ldc + col, v);        \
+          } else {                                                                                      \
+            if (g.beta) v += buf_ld_f32(rsC, voC, kr * g.ldc * 4, 0);         \
+            buf_st_f32(v, rsC, voC, kr * g.ldc * 4, 0);                      \
+          }                                                                                             \
+          acc[a][b][rr] = 0.f;                                                                          \
         }                                                                                               \
-        acc[a][b][rr] = 0.f;                                                                            \
-      }                                                                                                 \
-      if (!SK && g.colsum_part) {                                                                       \
-        csum += __shfl_xor(csum, 32, 64);                                                               \
-        if (h == 0 && cok && (m0 + wm * WM + a * 32) < g.M)                                             \
-          g.colsum_part[(size_t)((m0 + wm * WM + a * 32) >> 5) * g.N + col] = csum;                     \
+        if (!SK && g.colsum_part) {                                                                     \
+          csum += __shfl_xor(csum, 32, 64);                                                             \
+          if (h == 0 && cok && (m0 + wm * WM + a * 32) < g.M)                                           \
+            g.colsum_part[(size_t)((m0 + wm * WM + a * 32) >> 5) * g.N + col] = csum;                   \
+        }                                                                                               \
       }                                                                                                 \
     }                                                                                                   \
   }
@@ -729,6 +748,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
 #undef K_ITERATION
 #undef EPILOGUE
 #undef PREFETCH_AUX
+#undef AUXR
 #undef MFMA_BLOCK
 #undef READ_FRAGS
 #undef LOAD_UNIT
@@ -779,7 +799,9 @@ int dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
     case 14: return launch_v2<64, 64, AKM, BKM, TAG>(g, st);
     case 21: case 22: case 23: case 24: {
       const bool fast = g.K % BK == 0 && (size_t)(AKM ? g.K : g.M) * g.lda * 4 < (1ull << 31) &&
-                        (size_t)(BKM ? g.K : g.N) * g.ldb * 4 < (1ull << 31);
+                        (size_t)(BKM ? g.K : g.N) * g.ldb * 4 < (1ull << 31) &&
+                        ((size_t)g.M + 128) * g.ldc * 4 < (1ull << 31) &&
+                        ((size_t)g.M + 128) * (g.ld_aux > 0 ? g.ld_aux : 1) * 4 < (1ull << 31);
       if (!fast) return dispatch_cfg<AKM, BKM, TAG>(cfg - 10, g, st);
       if (cfg == 21) return launch_v3<128, 128, AKM, BKM, TAG>(g, st, 512);
       if (cfg == 22) return launch_v3<64, 128, AKM, BKM, TAG>(g, st, 512);

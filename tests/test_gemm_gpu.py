@@ -94,6 +94,19 @@ def test_gemm_streamk_accumulate(cfg, layout):
     _run(lib, L, cfg, akm, bkm, M=200, N=136, K=8192, epi=0, beta=1)
 
 
+@pytest.mark.parametrize('epi', [0, 1, 2, 4, 5, 6])
+@pytest.mark.parametrize('K', [32, 64, 416, 768])
+def test_gemm_many_tiles_all_epilogues(epi, K):
+    """More 64x64 tiles than workgroup slots (two tiles per workgroup), every epilogue, ragged edges
+    handled by the buffer range check."""
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    bkm = 0 if epi in (1, 2, 5) else 1
+    _run(lib, L, 24, 0, bkm, M=2624, N=3072, K=K, epi=epi, beta=0)
+    if K == 64:
+        _run(lib, L, 24, 0, bkm, M=2500, N=3000, K=K, epi=epi, beta=1)      # ragged edges, accumulate
+
+
 def test_gemm_rejects_bad_args():
     from meme_challenge_amd import _lib as L
     lib = L.lib()
