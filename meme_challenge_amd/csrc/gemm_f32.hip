@@ -268,7 +268,7 @@ int launch(GemmArgs g, hipStream_t st) {
 
 
 // ---------------------------------------------------------------------------
-// v2: persistent, software-pipelined across the barrier.
+// Persistent, software-pipelined across the barrier (schedule of the v3 kernel below).
 //   * each workgroup walks a static sequence of output tiles; the first k-tile
 //     of the NEXT output tile is fetched during the last k-iteration of the
 //     current one, so the epilogue stores overlap the next tile's prologue
@@ -294,217 +294,8 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
   tm = band * band_h + (rem - tn * bh);
 }
 
-template <int BM, int BN, bool AKM, bool BKM, int TAG, bool BUF>
-__global__ __launch_bounds__(256, 2) void gemm_f32_v2_kernel(const GemmArgs g) {
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int SA = TileSize<BM, AKM>::value, SB = TileSize<BN, BKM>::value;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int nk = (g.K + BK - 1) / BK;
-
-  // XCD-aware static schedule: the blocks of one XCD (b = x, x+8, ...) share a contiguous
-  // chunk of tiles and stride through it.
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-  const int q = ntiles >> 3, r = ntiles & 7;
-  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int chunk_n = q + (xcd < r ? 1 : 0);
-  if (idx >= chunk_n) return;
-  if (g.prio_mode == 1) {          // experiment: distinct priorities for (probably) co-resident workgroups
-    const int pr = (blockIdx.x >> 8) & 3;
-    if (pr == 1) __builtin_amdgcn_s_setprio(1);
-    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-  }
-
-  f32x4 ra[BM / 32], rb[BN / 32];
-  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-  int t_local = idx;
-  int tile = chunk0 + t_local;
-  int tmi, tni;
-  tile_coords(tile, g.tiles_m, g.tiles_n, g.band_h, tmi, tni);
-  int m0 = tmi * BM, n0 = tni * BN;
-  int it = 0;   // running k-iteration counter: LDS buffer parity
-
-  // buffer descriptors (wave-uniform: kernel arguments only) and per-thread offsets
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g.A), 0, (AKM ? g.K : g.M) * g.lda * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g.B), 0, (BKM ? g.K : g.N) * g.ldb * 4, 0x00020000);
-  const int kstepA = (AKM ? BK * g.lda : BK) * 4, kstepB = (BKM ? BK * g.ldb : BK) * 4;
-  int voA[BM / 32], voB[BN / 32], nvoA[BM / 32], nvoB[BN / 32];
-  if constexpr (BUF) {
-    tile_offsets<BM, AKM>(voA, g.lda, m0, tid);
-    tile_offsets<BN, BKM>(voB, g.ldb, n0, tid);
-    tile_load_buf<BM>(ra, rsA, voA, 0);
-    tile_load_buf<BN>(rb, rsB, voB, 0);
-  } else {
-    tile_load<BM, AKM>(ra, g.A, g.lda, m0, g.M, 0, g.K, tid);
-    tile_load<BN, BKM>(rb, g.B, g.ldb, n0, g.N, 0, g.K, tid);
-  }
-  tile_store<BM, AKM>(ra, smem, tid);
-  tile_store<BN, BKM>(rb, smem + SA, tid);
-  __syncthreads();
-#pragma unroll
-  for (int a = 0; a < TM; ++a) fa0[a] = frag_read<BM, AKM>(smem, wm * WM + a * 32, 0, i, h);
-#pragma unroll
-  for (int b = 0; b < TN; ++b) fb0[b] = frag_read<BN, BKM>(smem + SA, wn * WN + b * 32, 0, i, h);
-
-  while (true) {
-    const int t_next = t_local + per_xcd;
-    const bool has_next_tile = t_next < chunk_n;
-    const int ntile = chunk0 + t_next;
-    tile_coords(has_next_tile ? ntile : tile, g.tiles_m, g.tiles_n, g.band_h, tmi, tni);
-    const int nm0 = tmi * BM, nn0 = tni * BN;
-    if constexpr (BUF) {
-      if (has_next_tile) {
-        tile_offsets<BM, AKM>(nvoA, g.lda, nm0, tid);
-        tile_offsets<BN, BKM>(nvoB, g.ldb, nn0, tid);
-      }
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) acc[a][b][rr] = 0.f;
-
-    for (int kt = 0; kt < nk; ++kt, ++it) {
-      const float* sA = smem + (it & 1) * (SA + SB);
-      const float* sB = sA + SA;
-      float* dA = smem + ((it + 1) & 1) * (SA + SB);
-      const bool last = kt + 1 == nk;
-      const bool more = !last || has_next_tile;
-      if constexpr (BUF) {
-        if (!last) {
-          tile_load_buf<BM>(ra, rsA, voA, (kt + 1) * kstepA);
-          tile_load_buf<BN>(rb, rsB, voB, (kt + 1) * kstepB);
-        } else if (has_next_tile) {
-          tile_load_buf<BM>(ra, rsA, nvoA, 0);
-          tile_load_buf<BN>(rb, rsB, nvoB, 0);
-        }
-      } else {
-        if (!last) {
-          tile_load<BM, AKM>(ra, g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, tid);
-          tile_load<BN, BKM>(rb, g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, tid);
-        } else if (has_next_tile) {
-          tile_load<BM, AKM>(ra, g.A, g.lda, nm0, g.M, 0, g.K, tid);
-          tile_load<BN, BKM>(rb, g.B, g.ldb, nn0, g.N, 0, g.K, tid);
-        }
-      }
-#define MFMA_BLOCK(FA, FB)                                                                              \
-  _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
-  _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                        \
-  _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                        \
-      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[a][t], FB[b][t], acc[a][b], 0, 0, 0);
-#define READ_FRAGS(FA, FB, SAp, SBp, KB)                                                                \
-  _Pragma("unroll") for (int a = 0; a < TM; ++a) FA[a] = frag_read<BM, AKM>(SAp, wm * WM + a * 32, KB, i, h); \
-  _Pragma("unroll") for (int b = 0; b < TN; ++b) FB[b] = frag_read<BN, BKM>(SBp, wn * WN + b * 32, KB, i, h);
-
-      __builtin_amdgcn_sched_barrier(0);
-      READ_FRAGS(fa1, fb1, sA, sB, 1)
-      MFMA_BLOCK(fa0, fb0)
-      __builtin_amdgcn_sched_barrier(0);
-      READ_FRAGS(fa0, fb0, sA, sB, 2)
-      MFMA_BLOCK(fa1, fb1)
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) {
-        tile_store<BM, AKM>(ra, dA, tid);
-        tile_store<BN, BKM>(rb, dA + SA, tid);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      READ_FRAGS(fa1, fb1, sA, sB, 3)
-      MFMA_BLOCK(fa0, fb0)
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) { READ_FRAGS(fa0, fb0, dA, (dA + SA), 0) }
-      MFMA_BLOCK(fa1, fb1)
-      __builtin_amdgcn_sched_barrier(0);
-#undef MFMA_BLOCK
-#undef READ_FRAGS
-    }
-
-    // epilogue of the finished tile (next tile's first k-tile is already in LDS / registers)
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int col = n0 + wn * WN + b * 32 + i;
-        if (col >= g.N) continue;
-        const float bv = (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D) ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const int row = m0 + wm * WM + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-          if (row >= g.M) continue;
-          float v = acc[a][b][rr] + bv;
-          if (g.epi == UNITER_EPI_BIAS_GELU) {
-            if (g.aux_out) g.aux_out[(size_t)row * g.ld_aux + col] = v;
-            v = gelu_erf(v);
-          } else if (g.epi == UNITER_EPI_DGELU) {
-            v *= dgelu_erf(g.aux_in[(size_t)row * g.ld_aux + col]);
-          } else if (g.epi == UNITER_EPI_ADD) {
-            v += g.aux_in[(size_t)row * g.ld_aux + col];
-          } else if (g.epi == UNITER_EPI_MUL) {
-            v *= g.aux_in[(size_t)row * g.ld_aux + col];
-          } else if (g.epi == UNITER_EPI_BIAS_GELU_D) {
-            float dg;
-            gelu_pair_fast(v, v, dg);
-            if (g.aux_out) g.aux_out[(size_t)row * g.ld_aux + col] = dg;
-          }
-          float* c = g.C + (size_t)row * g.ldc + col;
-          if (g.beta) v += *c;
-          *c = v;
-        }
-      }
-    }
-    if (!has_next_tile) break;
-    t_local = t_next; tile = ntile; m0 = nm0; n0 = nn0;
-    if constexpr (BUF) {
-#pragma unroll
-      for (int p = 0; p < BM / 32; ++p) voA[p] = nvoA[p];
-#pragma unroll
-      for (int p = 0; p < BN / 32; ++p) voB[p] = nvoB[p];
-    }
-  }
-}
-
-template <int BM, int BN, bool AKM, bool BKM, int TAG>
-int launch_v2(GemmArgs g, hipStream_t st) {
-  g.tiles_m = (g.M + BM - 1) / BM;
-  g.tiles_n = (g.N + BN - 1) / BN;
-  const int tiles = g.tiles_m * g.tiles_n;
-  {  // band height: keep the band's A panel (band_h x BM x K floats) around 1.5 MB of the 4 MiB L2
-    const long panel = (long)BM * g.K * 4;
-    long bh = (3l << 19) / (panel > 0 ? panel : 1);
-    g.band_h = (int)(bh < 1 ? 1 : (bh > 16 ? 16 : bh));
-    if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
-  }
-  // persistent grid: up to `slots` resident workgroups (multiple of 8 for the XCD schedule)
-  constexpr int SLOTS = (BM * BN >= 128 * 128) ? 512 : (BM * BN >= 64 * 128 ? 512 : 1024);
-  static const int slots_override = env_int("UNITER_GEMM_SLOTS", 0);     // tuning experiments only
-  static const int prio_mode = env_int("UNITER_GEMM_PRIO", 0);
-  const int slots = slots_override > 0 ? slots_override : SLOTS;
-  g.prio_mode = prio_mode;
-  int grid = tiles < slots ? (tiles + 7) / 8 * 8 : slots;
-  // branch-free buffer-load path: no in-row k tail, and byte offsets must fit the 32-bit voffset
-  const bool fast = g.K % BK == 0 && (size_t)(AKM ? g.K : g.M) * g.lda * 4 < (1ull << 31) &&
-                    (size_t)(BKM ? g.K : g.N) * g.ldb * 4 < (1ull << 31);
-  if (fast)
-    hipLaunchKernelGGL((gemm_f32_v2_kernel<BM, BN, AKM, BKM, TAG, true>), dim3(grid), dim3(256), 0, st, g);
-  else
-    hipLaunchKernelGGL((gemm_f32_v2_kernel<BM, BN, AKM, BKM, TAG, false>), dim3(grid), dim3(256), 0, st, g);
-  UCHECK_LAUNCH();
-  return 0;
-}
-
 // ---------------------------------------------------------------------------
-// v3: v2's schedule with a full-iteration prefetch distance.  The k-tiles a workgroup will consume
+// v3: the schedule above with a full-iteration prefetch distance.  The k-tiles a workgroup will consume
 // (across all of its output tiles) form one flat sequence of "units"; in the middle of iteration u
 // the staging registers (unit u+1, fetched during iteration u-1) are written to LDS and at once
 // refilled with unit u+2, so every global load has a full k-iteration (>= 64 MFMAs of this wave,
@@ -644,11 +435,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
 
 // one k-iteration: unit u is in LDS stage (u&1); RS* = registers holding unit u+1 (stored now);
 // RL* = registers that receive unit u+2
-#define K_ITERATION(U, RSA, RSB, RLA, RLB)                                                              \
+#define K_ITERATION(U, STAGE, RSA, RSB, RLA, RLB)                                                       \
   {                                                                                                     \
-    const float* sA = smem + ((U) & 1) * (SA + SB);                                                     \
+    const float* sA = smem + (STAGE) * (SA + SB);                                                       \
     const float* sB = sA + SA;                                                                          \
-    float* dA = smem + (((U) + 1) & 1) * (SA + SB);                                                     \
+    float* dA = smem + (1 - (STAGE)) * (SA + SB);                                                       \
     const bool more = (U) + 1 < total_units;                                                            \
     if (!SK && has_aux && ck + 2 == nk) { PREFETCH_AUX(); }                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
@@ -726,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
           }                                                                                             \
           if (!SK && g.colsum_part) csum += (r0 + kr < g.M) ? v : 0.f;                                  \
           if (SK) {                                                                                     \
-            if (cok && r0 + kr < g.M) unsafeAtomicAdd(g.C + (size_t)(r0 + kr) * g.ldc + col, v);        \
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsC, voC, kr * g.ldc * 4, 0);            \
           } else {                                                                                      \
             if (g.beta) v += buf_ld_f32(rsC, voC, kr * g.ldc * 4, 0);         \
             buf_st_f32(v, rsC, voC, kr * g.ldc * 4, 0);                      \
@@ -744,7 +535,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
 
   // One register set suffices: the set is written to LDS in the middle of iteration u and refilled
   // immediately, and is not needed again until the middle of iteration u+1.
-  for (int u = 0; u < total_units; ++u) K_ITERATION(u, ra1, rb1, ra1, rb1)
+  // unrolled by two so that the LDS stage of every read / write is a compile-time constant (the
+  // stage-dependent address adds were ~10 VALU instructions per k-iteration, and VALU time is not
+  // hidden behind fp32 MFMAs)
+  int u = 0;
+  for (; u + 1 < total_units; u += 2) {
+    K_ITERATION(u, 0, ra1, rb1, ra1, rb1)
+    K_ITERATION(u + 1, 1, ra1, rb1, ra1, rb1)
+  }
+  if (u < total_units) K_ITERATION(u, 0, ra1, rb1, ra1, rb1)
 #undef K_ITERATION
 #undef EPILOGUE
 #undef PREFETCH_AUX
@@ -793,19 +592,13 @@ int dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
     case 2: return launch<64, 128, AKM, BKM, TAG>(g, st);
     case 3: return launch<128, 64, AKM, BKM, TAG>(g, st);
     case 4: return launch<64, 64, AKM, BKM, TAG>(g, st);
-    case 11: return launch_v2<128, 128, AKM, BKM, TAG>(g, st);
-    case 12: return launch_v2<64, 128, AKM, BKM, TAG>(g, st);
-    case 13: return launch_v2<128, 64, AKM, BKM, TAG>(g, st);
-    case 14: return launch_v2<64, 64, AKM, BKM, TAG>(g, st);
-    case 21: case 22: case 23: case 24: {
+    case 21: case 24: {
       const bool fast = g.K % BK == 0 && (size_t)(AKM ? g.K : g.M) * g.lda * 4 < (1ull << 31) &&
                         (size_t)(BKM ? g.K : g.N) * g.ldb * 4 < (1ull << 31) &&
                         ((size_t)g.M + 128) * g.ldc * 4 < (1ull << 31) &&
                         ((size_t)g.M + 128) * (g.ld_aux > 0 ? g.ld_aux : 1) * 4 < (1ull << 31);
-      if (!fast) return dispatch_cfg<AKM, BKM, TAG>(cfg - 10, g, st);
+      if (!fast) return dispatch_cfg<AKM, BKM, TAG>(cfg - 20, g, st);      // one-tile-per-workgroup kernel
       if (cfg == 21) return launch_v3<128, 128, AKM, BKM, TAG>(g, st, 512);
-      if (cfg == 22) return launch_v3<64, 128, AKM, BKM, TAG>(g, st, 512);
-      if (cfg == 23) return launch_v3<128, 64, AKM, BKM, TAG>(g, st, 512);
       return launch_v3<64, 64, AKM, BKM, TAG>(g, st, 1024);
     }
     default: uniter_set_error("gemm: bad cfg %d", cfg); return UNITER_E_ARG;
@@ -818,7 +611,7 @@ int dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
 // there are >= ~3000 64x64 tiles (e.g. 4096^3: 137 vs 128 TFLOP/s).
 int choose_cfg(int M, int N) {
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
-  return t64 >= 3072 ? 21 : 24;      // v3 kernels; they fall back to v2 / v1 when K % 32 != 0
+  return t64 >= 3072 ? 21 : 24;      // v3 kernels; they fall back to the v1 kernel when K % 32 != 0
 }
 
 }  // namespace
@@ -850,7 +643,7 @@ int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int
   if (colsum_part) {
     const bool fast = K % BK == 0 && (size_t)(a_kmajor ? K : M) * lda * 4 < (1ull << 31) &&
                       (size_t)(b_kmajor ? K : N) * ldb * 4 < (1ull << 31);
-    UCHECK_SHAPE(fast && cfg >= 21 && cfg <= 24 && beta == 0, "gemm: fused column sums need the v3 kernel (K %% 32 == 0)");
+    UCHECK_SHAPE(fast && (cfg == 21 || cfg == 24) && beta == 0, "gemm: fused column sums need the v3 kernel (K %% 32 == 0)");
   }
   hipStream_t st = (hipStream_t)stream;
   if (!a_kmajor && !b_kmajor)

@@ -24,12 +24,12 @@ shapes = [('qkv_fwd', 0, 0, 2624, 2304, 768, 1), ('attnout_fwd', 0, 0, 2624, 768
           ('sq4096', 0, 0, 4096, 4096, 4096, 0)]
 for name, akm, bkm, M, N, K, epi in shapes:
     row = []
-    for cfg in (1, 4, 11, 12, 13, 14):
+    for cfg in (1, 4, 21, 24):
         ms, tf = bench(cfg, akm, bkm, M, N, K, epi)
         row.append('cfg%d %.3fms %.1fTF' % (cfg, ms, tf))
     print('%-14s M%d N%d K%d | ' % (name, M, N, K) + ' | '.join(row), flush=True)
 print('--- K sweep (M=2624, N=3072, NT, bias epilogue) ---')
-for cfg in (1, 11, 14):
+for cfg in (1, 21, 24):
     for K in (256, 768, 1536, 3072, 6144):
         ms, tf = bench(cfg, 0, 0, 2624, 3072, K, 1)
         print('cfg%d K=%5d %.4f ms %.1f TF' % (cfg, K, ms, tf), flush=True)

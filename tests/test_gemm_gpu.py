@@ -50,7 +50,7 @@ def _run(lib, L, cfg, akm, bkm, M, N, K, epi, beta, seed=0):
         assert (daux_out.cpu().double() - aux_out_ref).abs().max().item() < 2e-5 * scale * 4
 
 
-@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 11, 12, 13, 14, 21, 22, 23, 24])
+@pytest.mark.parametrize('cfg', [0, 1, 2, 3, 4, 21, 24])
 @pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_layouts_and_edges(cfg, layout):
     from meme_challenge_amd import _lib as L
@@ -71,7 +71,7 @@ def test_gemm_epilogues(epi):
     _run(lib, L, 4, 0, 0 if epi in (1, 2, 5) else 1, M=100, N=64, K=40, epi=epi, beta=0)      # v1 fallback
 
 
-@pytest.mark.parametrize('cfg', [0, 11, 14, 21, 24])
+@pytest.mark.parametrize('cfg', [0, 1, 4, 21, 24])
 def test_gemm_model_shapes(cfg):
     from meme_challenge_amd import _lib as L
     lib = L.lib()

@@ -15,4 +15,4 @@ def bench(cfg, akm, bkm, M, N, K, epi=0, iters=20):
     ms = e0.elapsed_time(e1) / iters
     return ms, 2.0 * M * N * K / ms / 1e9
 for name, akm, bkm, M, N, K, epi in [('qkv', 0, 0, 2624, 2304, 768, 1), ('attno', 0, 0, 2624, 768, 768, 1), ('ffnup', 0, 0, 2624, 3072, 768, 2), ('dgrad1', 0, 1, 2624, 3072, 768, 3), ('dgrad2', 0, 1, 2624, 768, 3072, 4), ('ffndn', 0, 0, 2624, 768, 3072, 1), ('wgrad', 1, 1, 3072, 768, 2624, 0), ('sq4096', 0, 0, 4096, 4096, 4096, 0)]:
-    print(name, ' | '.join('cfg%d %.4fms %.1fTF' % ((c,) + bench(c, akm, bkm, M, N, K, epi)) for c in (11, 14, 21, 22, 23, 24)), flush=True)
+    print(name, ' | '.join('cfg%d %.4fms %.1fTF' % ((c,) + bench(c, akm, bkm, M, N, K, epi)) for c in (1, 4, 21, 24)), flush=True)
