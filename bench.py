@@ -74,6 +74,24 @@ def cpu_baseline(seconds_budget=25.0):
                       'oracle/uniter_oracle.py (torch CPU fp32, dropout on), %.3f s/step' % (n, dt)}
 
 
+def pmc_traffic(args, M, cfgd):
+    """Memory-side bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
+    (separate FETCH_SIZE / WRITE_SIZE runs of this same command, tests/tools/run_profile.sh ->
+    tests/tools/pmc_to_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    Counters cannot be read from inside a timed run, so the figure is a profile artefact: it is
+    reported only when the profiled shape is the one being benchmarked, else null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    try:
+        rec = json.load(open(path))['ffn_up_fwd']
+    except (OSError, KeyError, ValueError):
+        return None
+    shape = rec.get('shape', {})
+    if args.precision != 'fp32' or (shape.get('M'), shape.get('N'), shape.get('K')) != (
+            M, cfgd['intermediate_size'], cfgd['hidden_size']):
+        return None
+    return int(rec['traffic_bytes'])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -186,7 +204,7 @@ def main():
             ach = ffn_up / (avg_ms * 1e-3) / 1e12 if args.prof_kind == 1 else None
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2) if ach else None, 'peak': peak,
                                'unit': 'TFLOP/s', 'frac': round(ach / peak, 4) if ach else None,
-                               'traffic': None,
+                               'traffic': pmc_traffic(args, B * (T + R), cfgd),
                                'kernel': ('gemm_f32_v3_kernel<64,64,false,false,TAG=1>' if args.precision == 'fp32'
                                           else 'gemm_bf16_kernel<...,false,false>') +
                                          ' (FFN-up fwd: M=%d N=%d K=%d, bias+GELU epilogue)'

@@ -106,24 +106,26 @@ __global__ __launch_bounds__(256) void finalize_partials_kernel(const float* __r
 // several outputs of H columns each out of one partial buffer whose rows are [nout][H]:
 // outs[j][c] += sum_p part[p*stride + j*H + c]   (one launch instead of one per output)
 struct MultiOut { float* out[8]; };
-// block = 32 columns x 32 partial-slices (1024 threads): ~10 dependent loads per thread for 328 partial rows
-__global__ __launch_bounds__(1024) void finalize_multi_kernel(const float* __restrict__ part, int nparts,
-                                                              size_t stride, MultiOut outs, int nout, int H) {
-  __shared__ float red[32][33];
-  const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int n = blockIdx.x * 32 + cx, N = nout * H;
+// block = 16 columns x 16 partial-slices.  256-thread blocks: a 1024-thread block needs a CU with 16
+// free wave slots, which the persistent GEMMs of the other stream rarely leave (24 us in situ for a
+// few microseconds of work, on the critical dgrad chain).
+__global__ __launch_bounds__(256) void finalize_multi_kernel(const float* __restrict__ part, int nparts,
+                                                             size_t stride, MultiOut outs, int nout, int H) {
+  __shared__ float red[16][17];
+  const int cx = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + cx, N = nout * H;
   float s = 0.f;
   if (n < N) {
     // four independent loads in flight per thread (a dependent chain of ~10 cost 28 us)
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int p = sl;
-    for (; p + 96 < nparts; p += 128) {
+    for (; p + 48 < nparts; p += 64) {
       a0 += part[(size_t)p * stride + n];
-      a1 += part[(size_t)(p + 32) * stride + n];
-      a2 += part[(size_t)(p + 64) * stride + n];
-      a3 += part[(size_t)(p + 96) * stride + n];
+      a1 += part[(size_t)(p + 16) * stride + n];
+      a2 += part[(size_t)(p + 32) * stride + n];
+      a3 += part[(size_t)(p + 48) * stride + n];
     }
-    for (; p < nparts; p += 32) a0 += part[(size_t)p * stride + n];
+    for (; p < nparts; p += 16) a0 += part[(size_t)p * stride + n];
     s = (a0 + a1) + (a2 + a3);
   }
   red[sl][cx] = s;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(1024) void finalize_multi_kernel(const float* __res
   if (sl == 0 && n < N) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) t += red[k][cx];
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
     float* o = outs.out[n / H];
     if (o) o[n % H] += t;
   }
@@ -188,7 +190,7 @@ int finalize_partials_multi(const float* part, int nparts, size_t stride, float*
                             hipStream_t st) {
   MultiOut mo = {};
   for (int j = 0; j < nout && j < 8; ++j) mo.out[j] = outs[j];
-  hipLaunchKernelGGL(finalize_multi_kernel, dim3((nout * H + 31) / 32), dim3(1024), 0, st, part, nparts, stride,
+  hipLaunchKernelGGL(finalize_multi_kernel, dim3((nout * H + 15) / 16), dim3(256), 0, st, part, nparts, stride,
                      mo, nout, H);
   UCHECK_LAUNCH();
   return 0;

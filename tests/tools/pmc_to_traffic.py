@@ -1,0 +1,42 @@
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tests/tools/run_profile.sh) into the
+per-launch memory-side traffic of the roofline kernel, corrected as MI355X_MICROARCH.md (HBM section)
+prescribes for gfx950: FETCH_SIZE counts 128-B read requests as 64 B -> x2; WRITE_SIZE is exact;
+both are reported in KiB.  The Adam kernel (a pure 16-B/lane stream of known size) is the
+calibration row: its corrected figures must equal 4 x 4 B x n_params each way.
+
+usage: python tests/tools/pmc_to_traffic.py <dir with pmc_fetch.csv pmc_write.csv> <out.json>
+"""
+import csv, json, os, sys
+
+
+def rows(path):
+    return list(csv.DictReader(open(path)))
+
+
+def pick(rs, needle, counter):
+    for r in rs:
+        if needle in r['Kernel_Name'] and r['Counter_Name'] == counter:
+            return float(r['MeanPerLaunch']), int(r['Launches'])
+    raise SystemExit('no %s row for %s' % (counter, needle))
+
+
+def main(src, out):
+    f, w = rows(os.path.join(src, 'pmc_fetch.csv')), rows(os.path.join(src, 'pmc_write.csv'))
+    res = {}
+    for name, needle in (('ffn_up_fwd', 'false, false, 1, false'), ('adam', 'adam_kernel')):
+        fk, n = pick(f, needle, 'FETCH_SIZE')
+        wk, _ = pick(w, needle, 'WRITE_SIZE')
+        res[name] = {'launches': n, 'fetch_size_kib': fk, 'write_size_kib': wk,
+                     'read_bytes': fk * 1024 * 2, 'write_bytes': wk * 1024,
+                     'traffic_bytes': fk * 1024 * 2 + wk * 1024}
+    M, N, K = 2624, 3072, 768
+    res['ffn_up_fwd']['algorithmic_bytes'] = 4 * (M * K + N * K + N + 2 * M * N)
+    res['ffn_up_fwd']['shape'] = {'M': M, 'N': N, 'K': K}
+    res['note'] = ('memory-side (L2 miss) bytes per launch; Infinity-Cache hits are included, so reads exceed the '
+                   'algorithmic bytes by the per-XCD re-fetch of the weight panel (8 L2s)')
+    json.dump(res, open(out, 'w'), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])
