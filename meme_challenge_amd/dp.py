@@ -103,13 +103,13 @@ class GradSync(object):
 
 
 def attach(model, group=None, bucket_bytes=64 << 20):
-    """Wire a GradSync to a MemeUniter (or UniterModel) and return it."""
+    """Wire a GradSync to a MemeUniter, UniterForPretraining or UniterModel and return it."""
     store = model.param_store() if hasattr(model, 'param_store') else None
     if store is None:
         from .model import ensure_store
         store = ensure_store(model)
     gs = GradSync(store.flat_grads, store.bucket_ranges, group=group, bucket_bytes=bucket_bytes)
-    um = getattr(model, 'uniter_model', model)
+    um = getattr(model, 'uniter_model', None) or getattr(model, 'uniter', None) or model   # MemeUniter / UniterForPretraining / UniterModel
     um._grad_hook = gs.hook
     return gs
 

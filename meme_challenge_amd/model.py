@@ -687,8 +687,11 @@ class UniterModel(UniterPreTrainedModel):
 
     def _get_ws(self, nbytes, mode):
         if mode != 0:
-            # activations must survive until backward: fresh buffer per training forward
-            return torch.empty(nbytes, dtype=torch.uint8, device=self.embeddings.LayerNorm.weight.device)
+            # activations must survive until backward: fresh buffer per training forward.  Always the
+            # largest size seen so far, so the caching allocator hands the same block back instead of
+            # freeing / mallocing gigabytes whenever the batch layout (task, lengths) changes
+            self._ws_high = max(getattr(self, '_ws_high', 0), nbytes)
+            return torch.empty(self._ws_high, dtype=torch.uint8, device=self.embeddings.LayerNorm.weight.device)
         ws = self._ws_cache.get(0)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.embeddings.LayerNorm.weight.device)

@@ -98,17 +98,23 @@ class FusedAdam(torch.optim.Optimizer):
         self._ws_bytes = n_ws
         self._flags_key = None
         self._flags = None
+        self._flags_cache = {}      # touched-set -> device flags (multitask training alternates between a few sets)
 
     def _chunk_flags(self):
         st = self.store
         key = frozenset(st.touched)
         if key != self._flags_key:
-            flags = torch.zeros(st.numel // CHUNK, dtype=torch.uint8)
-            for n in st.touched:
-                o = st.offsets[n] // CHUNK
-                k = (st.params[n].numel() + CHUNK - 1) // CHUNK
-                flags[o:o + k] = 1 if no_decay(n) else 2
-            self._flags = flags.to(st.device)
+            flags = self._flags_cache.get(key)
+            if flags is None:
+                host = torch.zeros(st.numel // CHUNK, dtype=torch.uint8)
+                for n in st.touched:
+                    o = st.offsets[n] // CHUNK
+                    k = (st.params[n].numel() + CHUNK - 1) // CHUNK
+                    host[o:o + k] = 1 if no_decay(n) else 2
+                flags = host.to(st.device)
+                if len(self._flags_cache) < 16:
+                    self._flags_cache[key] = flags
+            self._flags = flags
             self._flags_key = key
         return self._flags
 

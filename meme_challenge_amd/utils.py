@@ -85,3 +85,66 @@ def make_synthetic_batch(B, T, R, seed=1234, vocab=28996, img_dim=2048, txt_lens
     if device is not None:
         batch = {k: v.to(device) for k, v in batch.items()}
     return batch
+
+
+def make_synthetic_pretrain_batch(task, B, T, R, seed=1234, vocab=28996, img_dim=2048, txt_lens=None,
+                                  num_bbs=None, mask_prob=0.15, device=None):
+    """Synthetic batch for one pretraining task (BASELINE configs[4]) with the key
+    names the reference's collates produce (`attn_masks` sic):
+
+    * ``mlm``  -- BERT masking of pretrain_mlm.py:35-69: each real token is selected with probability
+      0.15 (at least one per sample), 80 % -> [MASK]=103, 10 % -> random id, 10 % kept;
+      ``txt_labels`` = original id at selected positions, -1 elsewhere;
+    * ``mrfr`` -- region masking of pretrain_mrfr.py:29-51: ``img_masks`` ~ Bernoulli(0.15) over the
+      real regions (at least one), ``img_mask_tgt`` = the same mask placed behind the text part of
+      the gathered sequence, ``feat_targets`` = the masked regions' original features;
+    * ``itm``  -- ``targets`` ~ Bernoulli(0.5) (pretrain_itm.py:27-47 swaps in another image for 0).
+    """
+    if task not in ('mlm', 'mrfr', 'itm'):
+        raise ValueError('invalid task')
+    base = make_synthetic_batch(B, T, R, seed=seed, vocab=vocab, img_dim=img_dim, txt_lens=txt_lens,
+                                num_bbs=num_bbs)
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    txt_lens = [T] * B if txt_lens is None else list(txt_lens)
+    num_bbs = [R] * B if num_bbs is None else list(num_bbs)
+    batch = {'input_ids': base['input_ids'], 'position_ids': base['position_ids'][:1].contiguous(),
+             'img_feat': base['img_feat'], 'img_pos_feat': base['img_pos_feat'],
+             'attn_masks': base['attn_mask'], 'gather_index': base['gather_index']}
+    L = base['attn_mask'].shape[1]
+    if task == 'mlm':
+        ids = batch['input_ids'].numpy().copy()
+        labels = np.full((B, T), -1, dtype=np.int64)
+        for b in range(B):
+            n = txt_lens[b]
+            sel = rng.random(n) < mask_prob
+            sel[0] = False                                     # [CLS] is never masked
+            if n > 1 and not sel.any():
+                sel[1 + rng.integers(0, n - 1)] = True
+            how = rng.random(n)
+            for t in np.nonzero(sel)[0]:
+                labels[b, t] = ids[b, t]
+                if how[t] < 0.8:
+                    ids[b, t] = 103 if vocab > 103 else vocab - 1
+                elif how[t] < 0.9:
+                    ids[b, t] = rng.integers(1, vocab)
+        batch['input_ids'] = torch.from_numpy(ids)
+        batch['txt_labels'] = torch.from_numpy(labels)
+    elif task == 'mrfr':
+        img_masks = np.zeros((B, R), dtype=bool)
+        tgt = np.zeros((B, L), dtype=bool)
+        for b in range(B):
+            n = num_bbs[b]
+            m = rng.random(n) < mask_prob
+            if not m.any():
+                m[rng.integers(0, n)] = True
+            img_masks[b, :n] = m
+            tgt[b, txt_lens[b]:txt_lens[b] + n] = m
+        feat = batch['img_feat']
+        batch['img_masks'] = torch.from_numpy(img_masks)
+        batch['img_mask_tgt'] = torch.from_numpy(tgt)
+        batch['feat_targets'] = feat[torch.from_numpy(img_masks)].contiguous()
+    else:
+        batch['targets'] = torch.from_numpy((rng.random(B) < 0.5).astype(np.int64))
+    if device is not None:
+        batch = {k: v.to(device) for k, v in batch.items()}
+    return batch

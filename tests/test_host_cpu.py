@@ -179,3 +179,34 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
                 assert '/root/reference' not in src
+
+
+@pytest.mark.parametrize('task', ['mlm', 'mrfr', 'itm'])
+def test_synthetic_pretrain_batch_layout(task):
+    """Key names / shapes of the reference's pretraining collates (pretrain_mlm.py:72-130,
+    pretrain_mrfr.py:54-130, pretrain_itm.py:50-117): `attn_masks` (sic), [1,T] position ids,
+    -1 labels off the masked positions, feat_targets = masked regions' features."""
+    from meme_challenge_amd.utils import make_synthetic_pretrain_batch, make_synthetic_batch
+    B, T, R = 3, 12, 5
+    tl, nb = [12, 7, 4], [5, 3, 2]
+    b = make_synthetic_pretrain_batch(task, B, T, R, seed=5, vocab=200, img_dim=8, txt_lens=tl, num_bbs=nb)
+    base = make_synthetic_batch(B, T, R, seed=5, vocab=200, img_dim=8, txt_lens=tl, num_bbs=nb)
+    assert b['position_ids'].shape == (1, T) and 'attn_masks' in b and 'attn_mask' not in b
+    assert torch.equal(b['attn_masks'], base['attn_mask']) and torch.equal(b['gather_index'], base['gather_index'])
+    if task == 'mlm':
+        lab = b['txt_labels']
+        assert lab.shape == (B, T) and (lab[:, 0] == -1).all()
+        for i in range(B):
+            assert (lab[i, tl[i]:] == -1).all() and (lab[i] != -1).sum() >= 1
+        sel = lab != -1
+        assert torch.equal(lab[sel], base['input_ids'][sel])               # label = original token
+        assert torch.equal(b['input_ids'][~sel], base['input_ids'][~sel])   # untouched elsewhere
+    elif task == 'mrfr':
+        m, tgt = b['img_masks'], b['img_mask_tgt']
+        assert m.dtype == torch.bool and m.shape == (B, R) and tgt.shape == b['attn_masks'].shape
+        for i in range(B):
+            assert m[i].sum() >= 1 and not m[i, nb[i]:].any()
+            assert torch.equal(tgt[i, tl[i]:tl[i] + nb[i]], m[i, :nb[i]]) and tgt[i].sum() == m[i].sum()
+        assert torch.equal(b['feat_targets'], base['img_feat'][m])
+    else:
+        assert b['targets'].shape == (B,) and set(b['targets'].tolist()) <= {0, 1}
