@@ -108,6 +108,8 @@ def main():
                          'heads, one task drawn per step (configs[4]; use --batch 32)')
     ap.add_argument('--ragged', action='store_true',
                     help='per-sample lengths tl ~ U{8..T}, nbb ~ U{10..R} (SURVEY 8(d) D1: correctness/reporting variant, not the headline)')
+    ap.add_argument('--packed', action='store_true',
+                    help='token packing: compute the valid positions only (pays off with --ragged; identical results)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_side_stream', action='store_true')
     ap.add_argument('--prof_kind', type=int, default=1, help='UNITER_K_* kind timed with HIP events (1 = FFN-up fwd GEMM)')
@@ -163,6 +165,7 @@ def main():
         task_rng = random.Random(99)                       # same task sequence on every rank
     encoder.use_side_stream = not args.no_side_stream
     encoder.precision = args.precision
+    encoder.pack_padded = args.packed
     encoder.set_dropout_seed(1234 + rank, 0)
     opt = FusedAdam(model, lr=config['lr'], weight_decay=config['weight_decay'])
     sched = get_scheduler(opt, config, steps_per_epoch=1000)
@@ -235,7 +238,7 @@ def main():
                                     'UNITER-%s + ITM/MLM/MRFR heads, one task per step (fwd + loss + bwd + clip + Adam, '
                                     'dropout 0.1; BASELINE configs[4]; FLOP fractions count the encoder only), ') % args.model +
                                    'batch %d per GPU, %d regions x 2048, %d text tokens%s, %s'
-                                   % (B, R, T, ' (ragged: joint length %d)' % L_eff if args.ragged else '',
+                                   % (B, R, T, (' (ragged: joint length %d%s)' % (L_eff, ', packed' if args.packed else '')) if args.ragged else '',
                                       'fp32 (BASELINE configs[1])' if args.precision == 'fp32'
                                       else 'bf16 MFMA GEMMs / fp32 storage (BASELINE configs[2])'),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,

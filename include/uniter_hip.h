@@ -151,6 +151,19 @@ int uniter_attn_bwd(const float* qkv, const float* attn_mask, const float* ctx,
                     const float* lse, const float* dctx, float* dqkv, float* delta,
                     int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
                     uint32_t site, void* ws, size_t ws_bytes, void* stream);
+/* Packed (varlen) batches -- SURVEY 8(f) N3.  Sample b owns rows cu_seqlens[b] .. cu_seqlens[b+1]-1
+ * of qkv / ctx / dqkv ([Mp, 3H] / [Mp, H], Mp = cu_seqlens[B]); every position of a sample is valid,
+ * so there is no mask: the result equals uniter_attn_fwd/bwd on the right-padded layout at the valid
+ * rows (padded keys carry weight exp(-10000) = 0 in fp32 there).  lse / delta stay [B, nh, Lmax];
+ * ws as uniter_attn_bwd_ws_bytes(B, Lmax, nh).  Lmax <= uniter_attn_varlen_max_len() (192). */
+int uniter_attn_varlen_max_len(void);
+int uniter_attn_fwd_varlen(const float* qkv, const int32_t* cu_seqlens, float* ctx, float* lse,
+                           int B, int Lmax, int nh, float p_drop, uint64_t seed, uint32_t offset,
+                           uint32_t site, void* stream);
+int uniter_attn_bwd_varlen(const float* qkv, const int32_t* cu_seqlens, const float* ctx,
+                           const float* lse, const float* dctx, float* dqkv, float* delta,
+                           int B, int Lmax, int nh, float p_drop, uint64_t seed, uint32_t offset,
+                           uint32_t site, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Embeddings (replace UniterTextEmbeddings.forward model/model.py:232-245,
@@ -305,6 +318,16 @@ typedef struct {
   const int64_t* gather_index;   /* [B,L] or NULL */
   int32_t B, T, R, L;            /* L = output sequence length */
   int32_t pos_bcast;
+  /* Packed mode (all NULL / 0 otherwise; needs attention_mask rows of the form 1..1 0..0 and
+   * L <= uniter_attn_varlen_max_len()): only the Mp = cu_seqlens[B] valid positions are computed --
+   * every GEMM / LayerNorm runs on Mp rows instead of B*L.  hidden_out keeps its padded [B,L,H]
+   * layout; padded positions are written as zeros (the reference computes values there that nothing
+   * downstream reads). */
+  const int32_t* cu_seqlens;     /* [B+1] device: prefix sums of the per-sample valid lengths */
+  const int64_t* pack_src;       /* [Mp] device: row of the [B*S] text|image embedding block feeding packed row r
+                                    (b*S + gather_index[b,l], or b*S + l without gather_index) */
+  const int64_t* pack_dst;       /* [Mp] device: row b*L + l of the padded output that packed row r fills */
+  int32_t Mp;
 } uniter_batch_t;
 
 /* 0 (default): exact fp32 MFMA GEMMs.  1: bf16 MFMA for the dense GEMMs of the schedule (operands

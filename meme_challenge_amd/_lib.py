@@ -34,7 +34,9 @@ class UniterBatchC(C.Structure):
                 ('img_masks', C.c_void_p), ('attention_mask', C.c_void_p),
                 ('gather_index', C.c_void_p),
                 ('B', C.c_int32), ('T', C.c_int32), ('R', C.c_int32), ('L', C.c_int32),
-                ('pos_bcast', C.c_int32)]
+                ('pos_bcast', C.c_int32),
+                ('cu_seqlens', C.c_void_p), ('pack_src', C.c_void_p), ('pack_dst', C.c_void_p),
+                ('Mp', C.c_int32)]
 
 
 _I, _F, _P, _SZ, _U64, _U32 = C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32
@@ -57,6 +59,9 @@ _SIGS = {
     'uniter_ln_bwd_ws_bytes': (_SZ, [_I, _I]),
     'uniter_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P]),
     'uniter_attn_bwd_ws_bytes': (_SZ, [_I, _I, _I]),
+    'uniter_attn_varlen_max_len': (_I, []),
+    'uniter_attn_fwd_varlen': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P]),
+    'uniter_attn_bwd_varlen': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_txt_embed_fwd': (_I, [_P] * 9 + [_I] * 8 + [_F, _U64, _U32, _P]),
     'uniter_img_embed_fwd': (_I, [_P] * 14 + [_I] * 6 + [_F, _U64, _U32, _P]),

@@ -41,6 +41,7 @@ struct AttnArgs {
   const float* dctx;
   float* dqkv;
   float* delta;         // [B, nh, L]
+  const int* cu;        // [B+1] prefix sums of per-sample lengths (packed rows), or NULL: sample b owns rows b*L .. b*L+L-1
   int B, L, nh, H, Lp4; // Lp4 = roundup(L,4)/4
   float scale;
   DropCfg drop;
@@ -534,6 +535,22 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnArgs a,
 constexpr int SPLIT_MAX_LR = 192;
 constexpr int XROW = 34;             // floats exchanged per lane: 32 accumulators + (m, l)
 
+// Packed (varlen) batches: with a.cu set, sample b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx / dqkv,
+// every key of a sample is valid (no mask) and waves whose 32-row block lies beyond the sample's
+// length only keep the barriers company.  lse / delta / the scratch stay indexed by the maximum length.
+struct SampleSpan { int row0, Lb, nb; };
+__device__ __forceinline__ SampleSpan sample_span(const AttnArgs& a, int b) {
+  SampleSpan s;
+  s.row0 = a.cu ? a.cu[b] : b * a.L;
+  s.Lb = a.cu ? a.cu[b + 1] - s.row0 : a.L;
+  s.nb = (s.Lb + 31) >> 5;
+  return s;
+}
+__device__ __forceinline__ void stage_mask(float* mb, const AttnArgs& a, int b, int Lb, int Lr, int tid, int nthr) {
+  for (int k = tid; k < Lr; k += nthr)
+    mb[k] = k < Lb ? (a.mask ? (1.0f - a.mask[(size_t)b * a.L + k]) * -10000.0f : 0.f) : NEG_INF;
+}
+
 __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, int Lr) {
   float* Ks = dyn_smem;
   float* Vs = Ks + Lr * LDT;
@@ -543,25 +560,26 @@ __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, i
   const int nblk = Lr >> 5;
   const int qb = wave % nblk, half = wave / nblk;
   const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const SampleSpan sp = sample_span(a, b);
+  const int Lb = sp.Lb;
   const int ld = 3 * a.H;
-  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
-  stage_rows(Ks, base + a.H, ld, a.L, Lr, tid, nthr);
-  stage_rows(Vs, base + 2 * a.H, ld, a.L, Lr, tid, nthr);
-  for (int k = tid; k < Lr; k += nthr)
-    mb[k] = k < a.L ? (1.0f - a.mask[(size_t)b * a.L + k]) * -10000.0f : NEG_INF;
+  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
+  stage_rows(Ks, base + a.H, ld, Lb, Lr, tid, nthr);
+  stage_rows(Vs, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
   const int q = qb * 32 + i;
-  const bool vq = q < a.L;
+  const bool vq = q < Lb;
   f32x4 qf[8];
   load_row_frags(qf, base + (size_t)q * ld, vq, h);
   __syncthreads();
 
-  const int kmid = ((nblk + 1) >> 1) * 32;
-  const int kbeg = half ? kmid : 0, kend = half ? Lr : kmid;
+  const int kmid = ((sp.nb + 1) >> 1) * 32;
+  const int kbeg = half ? kmid : 0, kend = qb < sp.nb ? (half ? sp.nb * 32 : kmid) : 0;
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = NEG_INF, l_run = 0.f;
-  for (int k0 = kbeg; k0 < kend && k0 < a.L; k0 += 32) {
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
     f32x16 s = tile_times_frag(Ks + k0 * LDT, qf, i, h);
     float mx = NEG_INF;
 #pragma unroll
@@ -609,7 +627,7 @@ __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, i
   {
     const float m_b = xb[32 * 64 + lane], l_b = xb[33 * 64 + lane];
     const float m_new = fmaxf(m_run, m_b);
-    // a half without any key (L <= 32) carries m = -inf, l = 0: its weight is exp(-inf) = 0
+    // a half without any key (one key block) carries m = -inf, l = 0: its weight is exp(-inf) = 0
     const float wa = __expf(m_run - m_new), wb = m_b == NEG_INF ? 0.f : __expf(m_b - m_new);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -621,7 +639,7 @@ __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, i
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (vq) {
-    store_rowT(a.ctx + ((size_t)b * a.L + q) * a.H + head * D, o0, o1, 1.0f / l_tot, h);
+    store_rowT(a.ctx + ((size_t)sp.row0 + q) * a.H + head * D, o0, o1, 1.0f / l_tot, h);
     if (h == 0 && a.lse) a.lse[(size_t)bh * a.L + q] = m_run + __logf(l_tot);
   }
 }
@@ -636,21 +654,22 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
   const int nblk = Lr >> 5;
   const int qb = wave % nblk, half = wave / nblk;
   const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const SampleSpan sp = sample_span(a, b);
+  const int Lb = sp.Lb;
   const int ld = 3 * a.H;
-  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
-  stage_rows(Ks, base + a.H, ld, a.L, Lr, tid, nthr);
-  stage_rows(Vs, base + 2 * a.H, ld, a.L, Lr, tid, nthr);
-  for (int k = tid; k < Lr; k += nthr)
-    mb[k] = k < a.L ? (1.0f - a.mask[(size_t)b * a.L + k]) * -10000.0f : NEG_INF;
+  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
+  stage_rows(Ks, base + a.H, ld, Lb, Lr, tid, nthr);
+  stage_rows(Vs, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
   const int q = qb * 32 + i;
-  const bool vq = q < a.L;
+  const bool vq = q < Lb;
   f32x4 qf[8], dof[8];
   load_row_frags(qf, base + (size_t)q * ld, vq, h);
-  load_row_frags(dof, a.dctx + ((size_t)b * a.L + q) * a.H + head * D, vq, h);
+  load_row_frags(dof, a.dctx + ((size_t)sp.row0 + q) * a.H + head * D, vq, h);
   float delta = 0.f;
   {
     f32x4 of[8];
-    load_row_frags(of, a.ctx + ((size_t)b * a.L + q) * a.H + head * D, vq, h);
+    load_row_frags(of, a.ctx + ((size_t)sp.row0 + q) * a.H + head * D, vq, h);
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
@@ -662,8 +681,10 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
   const float lse = vq ? a.lse[(size_t)bh * a.L + q] : -NEG_INF;
   __syncthreads();
 
-  const int kmid = ((nblk + 1) >> 1) * 32;
-  const int kbeg = half ? kmid : 0, kend = half ? Lr : kmid;
+  // blocks [0, nb) x [0, nb) of the scratch are written in full (zeros where query or key >= Lb):
+  // that is exactly what the dK/dV kernel reads
+  const int kmid = ((sp.nb + 1) >> 1) * 32;
+  const int kbeg = half ? kmid : 0, kend = qb < sp.nb ? (half ? sp.nb * 32 : kmid) : 0;
   float* pdw = pd_ws + (size_t)bh * Lr * Lr + qb * 32 + i;
   float* dsw = ds_ws + (size_t)bh * Lr * Lr + qb * 32 + i;
   f32x16 dq0, dq1;
@@ -701,7 +722,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
   if (half) return;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dq0[r] += xb[r * 64 + lane]; dq1[r] += xb[(16 + r) * 64 + lane]; }
-  if (vq) store_rowT(a.dqkv + ((size_t)b * a.L + q) * ld + head * D, dq0, dq1, 1.0f, h);
+  if (vq) store_rowT(a.dqkv + ((size_t)sp.row0 + q) * ld + head * D, dq0, dq1, 1.0f, h);
 }
 
 // dV^T[d][key] = sum_q dO[q][d] Pd[q][key],  dK^T[d][key] = sum_q Q[q][d] dS[q][key]
@@ -715,22 +736,28 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs 
   const int nblk = Lr >> 5;
   const int kb = wave % nblk, half = wave / nblk;
   const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const SampleSpan sp = sample_span(a, b);
+  const int Lb = sp.Lb;
   const int ld = 3 * a.H;
-  const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
-  stage_rows(Qs, base, ld, a.L, Lr, tid, nthr);
-  stage_rows(dOs, a.dctx + (size_t)b * a.L * a.H + head * D, a.H, a.L, Lr, tid, nthr);
+  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
+  stage_rows(Qs, base, ld, Lb, Lr, tid, nthr);
+  stage_rows(dOs, a.dctx + (size_t)sp.row0 * a.H + head * D, a.H, Lb, Lr, tid, nthr);
   const int key = kb * 32 + i;
-  const bool vk = key < a.L;
-  const int qmid = ((nblk + 1) >> 1) * 32;
-  const int qbeg = half ? qmid : 0, qend = half ? Lr : qmid;
+  const bool vk = key < Lb;
+  const int qmid = ((sp.nb + 1) >> 1) * 32;
+  const int qbeg = half ? qmid : 0, qend = kb < sp.nb ? (half ? sp.nb * 32 : qmid) : 0;
   // lane (key i, half h) needs, for q-tile q0, the 4 consecutive queries q0 + 8g + 4h .. +3 of its key row
   const float* pdr = pd_ws + ((size_t)bh * Lr + key) * Lr + 4 * h;
   const float* dsr = ds_ws + ((size_t)bh * Lr + key) * Lr + 4 * h;
   f32x4 wp[4], wd[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    wp[g] = *reinterpret_cast<const f32x4*>(pdr + qbeg + 8 * g);
-    wd[g] = *reinterpret_cast<const f32x4*>(dsr + qbeg + 8 * g);
+  for (int g = 0; g < 4; ++g) { wp[g] = f32x4{0.f, 0.f, 0.f, 0.f}; wd[g] = wp[g]; }
+  if (qbeg < qend) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      wp[g] = *reinterpret_cast<const f32x4*>(pdr + qbeg + 8 * g);
+      wd[g] = *reinterpret_cast<const f32x4*>(dsr + qbeg + 8 * g);
+    }
   }
   __syncthreads();
 
@@ -770,7 +797,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs 
     dv0[r] += xb[(32 + r) * 64 + lane]; dv1[r] += xb[(48 + r) * 64 + lane];
   }
   if (vk) {
-    float* row = a.dqkv + ((size_t)b * a.L + key) * ld + head * D;
+    float* row = a.dqkv + ((size_t)sp.row0 + key) * ld + head * D;
     store_rowT(row + a.H, dk0, dk1, 1.0f, h);
     store_rowT(row + 2 * a.H, dv0, dv1, 1.0f, h);
   }
@@ -825,6 +852,49 @@ extern "C" int uniter_attn_fwd(const float* qkv, const float* attn_mask, float* 
     dim3 grid((L + 32 * NW - 1) / (32 * NW), B * nh);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(NW * 64), 0, (hipStream_t)stream, a);
   }
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+// Packed batches (uniter_hip.h): the split kernels only -- Lmax <= 192.
+extern "C" int uniter_attn_varlen_max_len(void) { return split_enabled() ? SPLIT_MAX_LR : 0; }
+
+extern "C" int uniter_attn_fwd_varlen(const float* qkv, const int32_t* cu_seqlens, float* ctx, float* lse, int B,
+                                      int Lmax, int nh, float p_drop, uint64_t seed, uint32_t offset,
+                                      uint32_t site, void* stream) {
+  UCHECK_ARG(qkv && cu_seqlens && ctx, "attn_fwd_varlen: null pointer");
+  AttnArgs a = {};
+  UCHECK_RC(make_args(a, B, Lmax, nh, p_drop, seed, offset, site));
+  a.qkv = qkv; a.mask = nullptr; a.cu = cu_seqlens; a.ctx = ctx; a.lse = lse;
+  const int Lr = (Lmax + 31) / 32 * 32;
+  UCHECK_SHAPE(Lr <= uniter_attn_varlen_max_len(), "attn_fwd_varlen: Lmax %d > %d", Lmax, uniter_attn_varlen_max_len());
+  const size_t lds = res_lds_bytes(Lr);
+  UCHECK_RC(set_dyn_lds(attn_fwd_split_kernel, lds));
+  hipLaunchKernelGGL(attn_fwd_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_attn_bwd_varlen(const float* qkv, const int32_t* cu_seqlens, const float* ctx,
+                                      const float* lse, const float* dctx, float* dqkv, float* delta, int B,
+                                      int Lmax, int nh, float p_drop, uint64_t seed, uint32_t offset,
+                                      uint32_t site, void* ws, size_t ws_bytes, void* stream) {
+  UCHECK_ARG(qkv && cu_seqlens && ctx && lse && dctx && dqkv && delta && ws, "attn_bwd_varlen: null pointer");
+  const int Lr = (Lmax + 31) / 32 * 32;
+  UCHECK_SHAPE(Lr <= uniter_attn_varlen_max_len(), "attn_bwd_varlen: Lmax %d > %d", Lmax, uniter_attn_varlen_max_len());
+  UCHECK_ARG(ws_bytes >= (size_t)2 * B * nh * Lr * Lr * sizeof(float), "attn_bwd_varlen: workspace too small");
+  AttnArgs a = {};
+  UCHECK_RC(make_args(a, B, Lmax, nh, p_drop, seed, offset, site));
+  a.qkv = qkv; a.mask = nullptr; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
+  a.dctx = dctx; a.dqkv = dqkv; a.delta = delta;
+  const size_t lds = res_lds_bytes(Lr);
+  float* pd_ws = (float*)ws;
+  float* ds_ws = pd_ws + (size_t)B * nh * Lr * Lr;
+  UCHECK_RC(set_dyn_lds(attn_bwd_dq_split_kernel, lds));
+  UCHECK_RC(set_dyn_lds(attn_bwd_dkv_split_kernel, lds));
+  hipLaunchKernelGGL(attn_bwd_dq_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr, pd_ws, ds_ws);
+  UCHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr, pd_ws, ds_ws);
   UCHECK_LAUNCH();
   return 0;
 }

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntiles = g.tiles_m * g.tiles_n;
-  const int nk = g.K / BK;
+  const int nk = (g.K + BK - 1) / BK;      // a ragged last k-tile is legal for k-major operands only: rows >= K read as 0
 
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
   const int q = ntiles >> 3, r = ntiles & 7;
@@ -573,7 +573,7 @@ int launch_v3(GemmArgs g, hipStream_t st, int slots) {
   if constexpr (TAG == 0) if (sk_mode && g.beta == 1 && g.epi == UNITER_EPI_NONE && !g.colsum_part && tiles >= 8) {
     const int rounds = (tiles + slots - 1) / slots;
     const bool uneven = (long)tiles * 100 < (long)rounds * slots * 88;
-    const long units = (long)tiles * (g.K / BK);
+    const long units = (long)tiles * ((g.K + BK - 1) / BK);
     if ((uneven || sk_mode == 2) && units >= 8l * slots) {    // >= 8 k-iterations per piece
       hipLaunchKernelGGL((gemm_f32_v3_kernel<BM, BN, AKM, BKM, 0, true>), dim3(slots), dim3(256), 0, st, g);
       UCHECK_LAUNCH();
@@ -593,7 +593,7 @@ int dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
     case 3: return launch<128, 64, AKM, BKM, TAG>(g, st);
     case 4: return launch<64, 64, AKM, BKM, TAG>(g, st);
     case 21: case 24: {
-      const bool fast = g.K % BK == 0 && (size_t)(AKM ? g.K : g.M) * g.lda * 4 < (1ull << 31) &&
+      const bool fast = (g.K % BK == 0 || (AKM && BKM)) && (size_t)(AKM ? g.K : g.M) * g.lda * 4 < (1ull << 31) &&
                         (size_t)(BKM ? g.K : g.N) * g.ldb * 4 < (1ull << 31) &&
                         ((size_t)g.M + 128) * g.ldc * 4 < (1ull << 31) &&
                         ((size_t)g.M + 128) * (g.ld_aux > 0 ? g.ld_aux : 1) * 4 < (1ull << 31);
@@ -641,7 +641,7 @@ int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int
   g.beta = beta; g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.prio_mode = 0; g.colsum_part = colsum_part;
   if (cfg == 0) cfg = choose_cfg(M, N);
   if (colsum_part) {
-    const bool fast = K % BK == 0 && (size_t)(a_kmajor ? K : M) * lda * 4 < (1ull << 31) &&
+    const bool fast = (K % BK == 0 || (a_kmajor && b_kmajor)) && (size_t)(a_kmajor ? K : M) * lda * 4 < (1ull << 31) &&
                       (size_t)(b_kmajor ? K : N) * ldb * 4 < (1ull << 31);
     UCHECK_SHAPE(fast && (cfg == 21 || cfg == 24) && beta == 0, "gemm: fused column sums need the v3 kernel (K %% 32 == 0)");
   }

@@ -66,7 +66,8 @@ struct Plan {
   bool gelu_d;      // forward stored gelu'(u) in LayerBufs::u (fp32 kernels) rather than u
   float *feat_eff, *imgfc, *img_stats, *cat, *emb;
   std::vector<LayerBufs> layers;
-  float *dcat, *d_imgfc, *d_posfc, *d_feat, *dsum;
+  float *dcat, *d_imgfc, *d_posfc, *d_feat, *dsum, *dpk;
+  bool packed;      // rows = valid positions only (uniter_batch_t::cu_seqlens)
   void *ln_ws, *col_ws, *emb_ws, *attn_ws;
   size_t ln_ws_bytes, col_ws_bytes, emb_ws_bytes, attn_ws_bytes;
   size_t total;
@@ -119,13 +120,14 @@ int check_cfg(const uniter_config_t* c) {
 }
 
 void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, int L, bool has_txt,
-               bool has_img, bool has_masks, int mode) {
+               bool has_img, bool has_masks, int mode, int Mrows = -1) {
   const uniter_config_t& c = m->cfg;
   const int H = c.hidden_size, I = c.intermediate_size, nl = c.num_hidden_layers, nh = c.num_attention_heads;
   pl.B = B; pl.T = T; pl.R = R; pl.L = L; pl.mode = mode; pl.has_txt = has_txt; pl.has_img = has_img;
   pl.T0 = has_txt ? T : 0;
   pl.S = pl.T0 + (has_img ? R : 0);
-  pl.M = B * L;
+  pl.packed = Mrows >= 0;
+  pl.M = pl.packed ? Mrows : B * L;
   const size_t M = (size_t)pl.M;
   Carver cv(ws);
   const size_t BR = (size_t)B * (has_img ? R : 0);
@@ -168,6 +170,7 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
     pl.d_posfc = cv.f(BR * H);
     pl.d_feat = has_masks ? cv.f(BR * c.img_dim) : nullptr;
     pl.dsum = cv.f(M * H);
+    pl.dpk = cv.f(M * H);          // packed mode: d_hidden gathered to the valid rows
     pl.ln_ws_bytes = uniter_ln_bwd_ws_bytes(pl.M, H);
     pl.ln_ws = cv.raw(pl.ln_ws_bytes);
     const int maxN = 3 * H > I ? 3 * H : I;
@@ -340,7 +343,15 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   const int H = c.hidden_size, I = c.intermediate_size, nl = c.num_hidden_layers, nh = c.num_attention_heads;
   const bool has_txt = b->input_ids != nullptr, has_img = b->img_feat != nullptr;
   Plan& pl = m->plan;
-  make_plan(m, pl, ws, b->B, b->T, b->R, b->L, has_txt, has_img, b->img_masks != nullptr, train);
+  const bool packed = b->cu_seqlens != nullptr;
+  if (packed) {
+    UCHECK_ARG(b->pack_src && b->pack_dst, "model_forward: packed mode needs pack_src and pack_dst");
+    UCHECK_SHAPE(b->Mp > 0 && (int64_t)b->Mp <= (int64_t)b->B * b->L, "model_forward: bad Mp %d", b->Mp);
+    UCHECK_SHAPE(b->L <= uniter_attn_varlen_max_len(), "model_forward: packed mode supports L <= %d (got %d)",
+                 uniter_attn_varlen_max_len(), b->L);
+  }
+  make_plan(m, pl, ws, b->B, b->T, b->R, b->L, has_txt, has_img, b->img_masks != nullptr, train,
+            packed ? b->Mp : -1);
   if (pl.total > ws_bytes) {
     uniter_set_error("model_forward: workspace too small (%zu < %zu)", ws_bytes, pl.total);
     return UNITER_E_WS;
@@ -376,19 +387,25 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
                                    pl.T0, S, H, c.type_vocab_size, ph, seed, offset, st));
   }
   const bool joint = has_txt && has_img;
-  UCHECK_RC(uniter_gather_rows(pl.cat, joint ? b->gather_index : nullptr, pl.emb, B, S, L, H, st));
+  if (packed) UCHECK_RC(uniter_row_gather(pl.cat, b->pack_src, pl.emb, M, H, B * S, st));
+  else UCHECK_RC(uniter_gather_rows(pl.cat, joint ? b->gather_index : nullptr, pl.emb, B, S, L, H, st));
+  const size_t PH = (size_t)B * L * H;          // one layer of the padded output
 
   // ---- encoder (model/model.py:282-292; model/layer.py:166-170) ----
   const float* x = pl.emb;
   for (int l = 0; l < nl; ++l) {
     LayerBufs& lb = pl.layers[l];
-    float* y2 = all_layers ? hidden_out + (size_t)l * M * H : (l == nl - 1 ? hidden_out : lb.y2);
+    float* y2 = packed ? lb.y2 : (all_layers ? hidden_out + l * PH : (l == nl - 1 ? hidden_out : lb.y2));
     UCHECK_RC(gemm(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, x, H, m->LP(l, L_QW), H, lb.qkv, 3 * H,
                    UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
     {
       ProfScope ps(m, UNITER_K_ATTN_FWD, st);
-      UCHECK_RC(uniter_attn_fwd(lb.qkv, b->attention_mask, lb.ctx, lb.lse, B, L, nh, pa, seed, offset,
-                                SITE_ATTN_PROBS(l), st));
+      if (packed)
+        UCHECK_RC(uniter_attn_fwd_varlen(lb.qkv, b->cu_seqlens, lb.ctx, lb.lse, B, L, nh, pa, seed, offset,
+                                         SITE_ATTN_PROBS(l), st));
+      else
+        UCHECK_RC(uniter_attn_fwd(lb.qkv, b->attention_mask, lb.ctx, lb.lse, B, L, nh, pa, seed, offset,
+                                  SITE_ATTN_PROBS(l), st));
     }
     UCHECK_RC(gemm(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, 0, M, H, H, lb.ctx, H, m->LP(l, L_OW), H, lb.t1, H,
                    UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, nullptr, 0, 0));
@@ -410,6 +427,12 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     }
     lb.y2 = y2;
     x = y2;
+    if (packed && (all_layers || l == nl - 1)) {
+      // padded [B, L, H] view for the caller: valid rows scattered, padded positions zero
+      float* dst = all_layers ? hidden_out + l * PH : hidden_out;
+      UCHECK_HIP(hipMemsetAsync(dst, 0, PH * sizeof(float), st));
+      UCHECK_RC(uniter_row_scatter_add(y2, b->pack_dst, dst, M, H, B * L, st));
+    }
   }
   return 0;
 }
@@ -449,12 +472,21 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   const float* x = l == 0 ? pl.emb : pl.layers[l - 1].y2;
   const size_t MH = (size_t)M * H;
 
-  // upstream gradient w.r.t. this layer's output
+  // upstream gradient w.r.t. this layer's output (packed mode: the caller's padded gradient gathered
+  // to the valid rows; gradients at padded positions are dropped, as nothing was computed there)
   const float* dy;
+  const float* dh = nullptr;
+  if (l == nl - 1 || m->all_layers) {
+    dh = m->d_hidden + (m->all_layers ? (size_t)l * ((size_t)B * L * H) : 0);
+    if (pl.packed) {
+      UCHECK_RC(uniter_row_gather(dh, m->batch.pack_dst, pl.dpk, M, H, B * L, st));
+      dh = pl.dpk;
+    }
+  }
   if (l == nl - 1) {
-    dy = m->all_layers ? m->d_hidden + (size_t)l * MH : m->d_hidden;
+    dy = dh;
   } else if (m->all_layers) {
-    UCHECK_RC(launch_add_f32(pl.dsum, pl.layers[l + 1].dx, m->d_hidden + (size_t)l * MH, MH, st));
+    UCHECK_RC(launch_add_f32(pl.dsum, pl.layers[l + 1].dx, dh, MH, st));
     dy = pl.dsum;
   } else {
     dy = pl.layers[l + 1].dx;
@@ -485,8 +517,13 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                  nullptr, nullptr, nullptr, 0, 0));
   {
     ProfScope ps(m, UNITER_K_ATTN_BWD, st);
-    UCHECK_RC(uniter_attn_bwd(lb.qkv, m->batch.attention_mask, lb.ctx, lb.lse, lb.dctx, lb.dqkv, lb.delta, B, L,
-                              nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
+    if (pl.packed)
+      UCHECK_RC(uniter_attn_bwd_varlen(lb.qkv, m->batch.cu_seqlens, lb.ctx, lb.lse, lb.dctx, lb.dqkv, lb.delta, B,
+                                       L, nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), pl.attn_ws,
+                                       pl.attn_ws_bytes, st));
+    else
+      UCHECK_RC(uniter_attn_bwd(lb.qkv, m->batch.attention_mask, lb.ctx, lb.lse, lb.dctx, lb.dqkv, lb.delta, B, L,
+                                nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
   }
   UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, 3 * H, lb.dqkv, 3 * H, m->LP(l, L_QW), H, lb.dx, H,
                  UNITER_EPI_ADD, nullptr, lb.dz1, nullptr, H, 0));
@@ -523,7 +560,12 @@ extern "C" int uniter_model_backward_embed(uniter_model_t* m) {
   hipStream_t st = m->st, sd = m->side;
   const float* demb = pl.layers[0].dx;
   const bool joint = pl.has_txt && pl.has_img;
-  UCHECK_RC(uniter_gather_rows_bwd(demb, joint ? b.gather_index : nullptr, pl.dcat, B, S, L, H, st));
+  if (pl.packed) {
+    UCHECK_HIP(hipMemsetAsync(pl.dcat, 0, (size_t)B * S * H * sizeof(float), st));
+    UCHECK_RC(uniter_row_scatter_add(demb, b.pack_src, pl.dcat, pl.M, H, B * S, st));
+  } else {
+    UCHECK_RC(uniter_gather_rows_bwd(demb, joint ? b.gather_index : nullptr, pl.dcat, B, S, L, H, st));
+  }
   if (pl.has_txt)
     UCHECK_RC(uniter_txt_embed_bwd(pl.dcat, b.input_ids, b.position_ids, b.txt_type_ids, m->P(P_WORD),
                                    m->P(P_POS), m->P(P_TYPE), m->P(P_ELN_G), m->G(P_WORD), m->G(P_POS),

@@ -104,6 +104,9 @@ class MemeDataset(data.Dataset):
                 attn = torch.cat((texts['attention_mask'].float(), get_attention_mask([0] * B, img_len)), dim=1)
             gi = get_gather_index(text_len, img_len, B, T, attn.shape[1])
             batch.update(img_feat=img_feat, img_pos_feat=img_pos, attn_mask=attn, gather_index=gi)
+            if self.compact_batch:
+                # host-side lengths (extension): lets UniterModel.pack_padded skip a device->host copy
+                batch['seq_lens'] = [int(t) + int(n) for t, n in zip(text_len, img_len)]
             return batch
         return collate_fn
 

@@ -26,6 +26,8 @@ import ctypes as C
 import json
 import logging
 
+import numpy as np
+
 import torch
 from torch import nn
 
@@ -626,6 +628,7 @@ class UniterModel(UniterPreTrainedModel):
         self._side_stream = None
         self.use_side_stream = True
         self.precision = 'fp32'      # or 'bf16': bf16 MFMA for the dense GEMMs, fp32 everywhere else
+        self.pack_padded = False     # True: compute the valid positions only (see _pack); padded outputs are 0
 
     # -- plumbing ------------------------------------------------------------
     def set_dropout_seed(self, seed, offset=0):
@@ -751,12 +754,44 @@ class UniterModel(UniterPreTrainedModel):
         if hook is not None:
             hook('embed', None, main)
 
+    def _pack(self, b, keep, attention_mask, gather_index, seq_lens):
+        """Token packing: hand the library the valid positions only.  The
+        attention mask must be right-padded (1..1 0..0 per row, what get_attention_mask builds):
+        padded keys then carry weight exp(-10000) = 0 in fp32 and padded queries feed nothing
+        downstream, so dropping those rows changes no valid output and no gradient."""
+        B, L = b.B, b.L
+        if seq_lens is None:
+            lens = attention_mask.sum(dim=1).to(torch.int64).cpu().numpy()       # device -> host sync
+        else:
+            lens = np.asarray(torch.as_tensor(seq_lens).cpu().numpy(), dtype=np.int64).reshape(-1)
+        if lens.shape[0] != B or (lens < 1).any() or (lens > L).any():
+            raise ValueError('seq_lens must hold B values in [1, L]')
+        cu = np.zeros(B + 1, dtype=np.int32)
+        cu[1:] = np.cumsum(lens)
+        dst = np.concatenate([np.arange(int(n), dtype=np.int64) + i * L for i, n in enumerate(lens)])
+        dev = attention_mask.device
+        cu_t = torch.from_numpy(cu).to(dev)
+        dst_t = torch.from_numpy(dst).to(dev)
+        S = (b.T if b.input_ids else 0) + (b.R if b.img_feat else 0)
+        if gather_index is not None and b.input_ids and b.img_feat:
+            flat = (gather_index + torch.arange(B, device=dev, dtype=torch.int64).unsqueeze(1) * S).reshape(-1)
+            src_t = flat.index_select(0, dst_t)
+        else:
+            if S != L:
+                raise ValueError('without gather_index the output length must equal T+R')
+            src_t = dst_t
+        keep.extend([cu_t, dst_t, src_t])
+        b.cu_seqlens, b.pack_src, b.pack_dst, b.Mp = cu_t.data_ptr(), src_t.data_ptr(), dst_t.data_ptr(), int(cu[-1])
+
     # -- the reference's public surface ---------------------------------------
     def forward(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
                 gather_index=None, img_masks=None, output_all_encoded_layers=True,
-                txt_type_ids=None, img_type_ids=None):
+                txt_type_ids=None, img_type_ids=None, seq_lens=None):
         """Same signature / return as model/model.py:336-367: list of per-layer
-        hidden states, or the last layer's [B, L, H] tensor."""
+        hidden states, or the last layer's [B, L, H] tensor.
+
+        ``seq_lens`` (extension, host list of tl+nbb per sample) is only read when
+        ``self.pack_padded`` is set: it saves the device->host copy of ``attention_mask.sum(1)``."""
         self._ensure_handle()
         dev = self.embeddings.LayerNorm.weight.device
         keep = []
@@ -816,6 +851,9 @@ class UniterModel(UniterPreTrainedModel):
                        ('img_masks', img_masks), ('attention_mask', attention_mask),
                        ('gather_index', gather_index)):
             setattr(b, fld, t.data_ptr() if t is not None else None)
+
+        if self.pack_padded and b.L <= _lib.lib().uniter_attn_varlen_max_len():
+            self._pack(b, keep, attention_mask, gather_index, seq_lens)
 
         grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         mode = 0 if not grad else (1 if self.training else 2)

@@ -234,7 +234,7 @@ class TrainStep(object):
         return dict(img_feat=batch['img_feat'], img_pos_feat=batch['img_pos_feat'],
                     input_ids=batch['input_ids'], position_ids=batch['position_ids'],
                     attention_mask=batch['attn_mask'], gather_index=batch['gather_index'],
-                    output_all_encoded_layers=False)
+                    output_all_encoded_layers=False, seq_lens=batch.get('seq_lens'))
 
     def train_iter(self, batch, iters=None):
         if iters is not None:

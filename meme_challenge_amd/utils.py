@@ -84,6 +84,7 @@ def make_synthetic_batch(B, T, R, seed=1234, vocab=28996, img_dim=2048, txt_lens
              'labels': torch.from_numpy(labels)}
     if device is not None:
         batch = {k: v.to(device) for k, v in batch.items()}
+    batch['seq_lens'] = [int(t) + int(n) for t, n in zip(txt_lens, num_bbs)]     # host list (see data.py collate)
     return batch
 
 
@@ -147,4 +148,5 @@ def make_synthetic_pretrain_batch(task, B, T, R, seed=1234, vocab=28996, img_dim
         batch['targets'] = torch.from_numpy((rng.random(B) < 0.5).astype(np.int64))
     if device is not None:
         batch = {k: v.to(device) for k, v in batch.items()}
+    batch['seq_lens'] = base['seq_lens']
     return batch

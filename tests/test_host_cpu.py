@@ -137,6 +137,7 @@ def test_input_helpers_match_reference(host_helpers):
         assert np.array_equal(gi.numpy(), z['gi/%s/gather_index' % k])
     a = make_synthetic_batch(3, 12, 5, seed=9, txt_lens=[12, 3, 7], num_bbs=[5, 5, 2])
     b = O.synth_batch(3, 12, 5, seed=9, txt_lens=[12, 3, 7], num_bbs=[5, 5, 2])
+    assert a.pop('seq_lens') == [17, 8, 9]          # host-side lengths (extension key for token packing)
     for k in a:
         assert torch.equal(a[k], b[k]), k
 

@@ -54,7 +54,7 @@ class TrainerUniter(TrainerTemplate):
         return self.model(img_feat=batch['img_feat'], img_pos_feat=batch['img_pos_feat'],
                           input_ids=batch['input_ids'], position_ids=batch['position_ids'],
                           attention_mask=batch['attn_mask'], gather_index=batch['gather_index'],
-                          output_all_encoded_layers=False)
+                          output_all_encoded_layers=False, seq_lens=batch.get('seq_lens'))
 
     def eval_iter_step(self, iters, batch, test):
         self.calculate_loss(self._forward(batch), batch['labels'], grad_step=False)
