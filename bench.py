@@ -112,6 +112,8 @@ def main():
                     help='token packing: compute the valid positions only (pays off with --ragged; identical results)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_side_stream', action='store_true')
+    ap.add_argument('--no_adam_overlap', action='store_true',
+                    help='run the optimizer step as one launch on the main stream instead of block by block beside the next forward')
     ap.add_argument('--prof_kind', type=int, default=1, help='UNITER_K_* kind timed with HIP events (1 = FFN-up fwd GEMM)')
     args = ap.parse_args()
 
@@ -168,6 +170,8 @@ def main():
     encoder.pack_padded = args.packed
     encoder.set_dropout_seed(1234 + rank, 0)
     opt = FusedAdam(model, lr=config['lr'], weight_decay=config['weight_decay'])
+    if not args.no_adam_overlap:
+        opt.overlap_encoder = encoder
     sched = get_scheduler(opt, config, steps_per_epoch=1000)
     sync = None
     if use_dist:
@@ -242,7 +246,8 @@ def main():
                                       'fp32 (BASELINE configs[1])' if args.precision == 'fp32'
                                       else 'bf16 MFMA GEMMs / fp32 storage (BASELINE configs[2])'),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                       'side_stream_wgrad': not args.no_side_stream},
+                       'side_stream_wgrad': not args.no_side_stream,
+                       'optimizer_overlaps_next_forward': not args.no_adam_overlap},
             'step_mfma_frac': round(total / (ms * 1e-3) / world * world / (peak * 1e12), 4),
             'ffn_roofline_frac': round(ffn / (ms * 1e-3) / (peak * 1e12), 4),
             'final_loss': round(loss, 5),

@@ -333,6 +333,11 @@ typedef struct {
 /* 0 (default): exact fp32 MFMA GEMMs.  1: bf16 MFMA for the dense GEMMs of the schedule (operands
  * rounded to bf16 in flight; storage, LayerNorm, softmax, attention, loss and optimizer stay fp32) */
 int  uniter_model_set_precision(uniter_model_t* m, int precision);
+/* Overlap of the optimizer step with the next forward: `events` = hipEvent_t[num_hidden_layers + 1]
+ * (embedding block, layer 0, layer 1, ..), each fired once that block's parameters (and zeroed
+ * gradients) are final.  The next uniter_model_forward makes its stream wait for events[0] before
+ * the embeddings and events[1 + l] before layer l, then forgets them.  n = 0 clears. */
+int  uniter_model_set_ready_events(uniter_model_t* m, void* const* events, int n);
 size_t uniter_model_ws_bytes(const uniter_model_t* m, int B, int T, int R, int L, int train);
 /* hidden_out: [B,L,H] last layer (all_layers = 0) or [nl,B,L,H] (all_layers = 1).
  * train != 0 applies dropout and keeps activations in `ws` for uniter_model_backward. */

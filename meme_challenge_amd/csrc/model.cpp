@@ -82,6 +82,7 @@ struct uniter_model {
   std::vector<std::string> names;
   std::vector<hipEvent_t> ev_main, ev_side;
   int precision = 0;        // 0 = fp32 MFMA GEMMs, 1 = bf16 MFMA GEMMs (fp32 storage)
+  std::vector<hipEvent_t> ready;   // [embeddings, layer 0 .. nl-1]: parameters usable once the event has fired (consumed by the next forward)
   // profiling
   int prof_kind = 0;
   std::vector<hipEvent_t> prof_ev;
@@ -367,6 +368,10 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   m->batch = *b; m->hidden_out = hidden_out; m->all_layers = all_layers; m->seed = seed; m->offset = offset;
   m->bwd_open = false;
 
+  // parameters still being written by an optimizer step on another stream (uniter_model_set_ready_events)
+  const bool gated = (int)m->ready.size() == nl + 1;
+  if (gated) UCHECK_HIP(hipStreamWaitEvent(st, m->ready[0], 0));
+
   // ---- embeddings (model/model.py:321-334) ----
   if (has_txt)
     UCHECK_RC(uniter_txt_embed_fwd(b->input_ids, b->position_ids, b->txt_type_ids, m->P(P_WORD), m->P(P_POS),
@@ -395,6 +400,7 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   const float* x = pl.emb;
   for (int l = 0; l < nl; ++l) {
     LayerBufs& lb = pl.layers[l];
+    if (gated) UCHECK_HIP(hipStreamWaitEvent(st, m->ready[1 + l], 0));
     float* y2 = packed ? lb.y2 : (all_layers ? hidden_out + l * PH : (l == nl - 1 ? hidden_out : lb.y2));
     UCHECK_RC(gemm(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, x, H, m->LP(l, L_QW), H, lb.qkv, 3 * H,
                    UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
@@ -434,6 +440,7 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
       UCHECK_RC(uniter_row_scatter_add(y2, b->pack_dst, dst, M, H, B * L, st));
     }
   }
+  m->ready.clear();
   return 0;
 }
 
@@ -605,6 +612,17 @@ extern "C" int uniter_model_backward(uniter_model_t* m, const uniter_batch_t* b,
   UCHECK_RC(uniter_model_backward_begin(m, b, d_hidden, all_layers, seed, offset, ws, ws_bytes, stream, side_stream));
   for (int l = m->cfg.num_hidden_layers - 1; l >= 0; --l) UCHECK_RC(uniter_model_backward_layer(m, l));
   return uniter_model_backward_embed(m);
+}
+
+extern "C" int uniter_model_set_ready_events(uniter_model_t* m, void* const* events, int n) {
+  UCHECK_ARG(m && (n == 0 || (events && n == m->cfg.num_hidden_layers + 1)),
+             "set_ready_events: need num_hidden_layers + 1 events (embeddings, layer 0 ..) or n = 0");
+  m->ready.clear();
+  for (int i = 0; i < n; ++i) {
+    UCHECK_ARG(events[i], "set_ready_events: event %d is NULL", i);
+    m->ready.push_back((hipEvent_t)events[i]);
+  }
+  return 0;
 }
 
 extern "C" int uniter_model_set_precision(uniter_model_t* m, int precision) {

@@ -754,6 +754,15 @@ class UniterModel(UniterPreTrainedModel):
         if hook is not None:
             hook('embed', None, main)
 
+    def _set_ready_events(self, events):
+        """Per-block 'parameters final' events of an optimizer step overlapped with this forward
+        (trainer.FusedAdam); consumed by the next uniter_model_forward."""
+        self._ensure_handle()
+        self._ready_events = list(events)            # keep the torch events alive until they are consumed
+        arr = (C.c_void_p * len(events))(*[C.c_void_p(e.cuda_event) for e in events])
+        check(_lib.lib().uniter_model_set_ready_events(self._handle, arr, len(events)),
+              'uniter_model_set_ready_events')
+
     def _pack(self, b, keep, attention_mask, gather_index, seq_lens):
         """Token packing: hand the library the valid positions only.  The
         attention mask must be right-padded (1..1 0..0 per row, what get_attention_mask builds):

@@ -58,6 +58,8 @@ class ModelSaver(object):
         self.output_path = output_path
 
     def save(self, model, optimizer=None):
+        if optimizer is not None and hasattr(optimizer, 'join'):
+            optimizer.join()
         state_dict = {k: v.detach().cpu().clone() if isinstance(v, torch.Tensor) else v
                       for k, v in model.state_dict().items()}
         torch.save({'model_state_dict': state_dict}, self.output_path)
@@ -103,6 +105,11 @@ class TrainerTemplate(object):
 
     def init_optimizer(self):
         self.optimizer = get_optimizer(self.model, self.config)
+        enc = getattr(self.model, 'uniter_model', None)
+        if enc is not None and self.config.get('overlap_optimizer', True):
+            # the update of step i runs beside the forward of step i+1 (trainer.FusedAdam.step);
+            # every other reader of the parameters joins first (ModelSaver.save below)
+            self.optimizer.overlap_encoder = enc
 
     # --------------------------------------------------------------------- step
     def calculate_loss(self, preds, batch_label, grad_step):
@@ -199,7 +206,7 @@ class TrainerTemplate(object):
             self.best_val_metrics = self.val_metrics
             self.best_val_loss = self.val_loss
             if not self.config["no_model_checkpoints"] and self._is_main():
-                self.model_saver.save(self.model)
+                self.model_saver.save(self.model, self.optimizer)
         diff = best - this if key == 'loss' else this - best
         if diff < self.config['early_stop_thresh']:
             self.not_improved += 1

@@ -99,6 +99,32 @@ class FusedAdam(torch.optim.Optimizer):
         self._flags_key = None
         self._flags = None
         self._flags_cache = {}      # touched-set -> device flags (multitask training alternates between a few sets)
+        # set to the UniterModel to overlap the update with the next forward (see step()); anything
+        # else that reads parameters on the current stream must call join() first
+        self.overlap_encoder = None
+        self._pending = None
+        self._plan_cache = None
+
+    def _overlap_plan(self, enc):
+        """(head ranges, [embeddings, layer 0, ..] ranges) in flat-buffer elements, or None when the
+        store's buckets are not [head | layer nl-1 .. 0 | embeddings]."""
+        if self._plan_cache is None:
+            st, nl = self.store, enc.config.num_hidden_layers
+            r = list(st.bucket_ranges)
+            ok = len(r) in (nl + 1, nl + 2)
+            head = r[:len(r) - nl - 1] if ok else []
+            blocks = [r[-1]] + r[-2:-2 - nl:-1] if ok else []
+            covered = sorted(head + blocks)
+            ok = ok and covered[0][0] == 0 and covered[-1][1] == st.numel and \
+                all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+            self._plan_cache = (head, blocks) if ok else False
+        return self._plan_cache or None
+
+    def join(self):
+        """Make the current stream wait for an overlapped update still running on the side stream."""
+        if self._pending is not None:
+            torch.cuda.current_stream().wait_event(self._pending)
+            self._pending = None
 
     def _chunk_flags(self):
         st = self.store
@@ -145,12 +171,42 @@ class FusedAdam(torch.optim.Optimizer):
                   'uniter_grad_sumsq')
         self.step_count += 1
         b1, b2 = g0['betas']
-        check(lib.uniter_adam_step(ptr(st.flat_params), ptr(st.flat_grads), ptr(self.exp_avg),
-                                   ptr(self.exp_avg_sq), ptr(flags), st.numel, ptr(self._sumsq),
-                                   float(grad_scale), float(max_grad_norm or 0.0), lr, float(b1), float(b2),
-                                   float(g0['eps']), float(g0['weight_decay']), self.step_count,
-                                   int(self.adamw), int(bool(zero_grads)), _lib.cur_stream()),
-              'uniter_adam_step')
+
+        def launch(lo, hi, stream_ptr):
+            off = lo * 4
+            check(lib.uniter_adam_step(st.flat_params.data_ptr() + off, st.flat_grads.data_ptr() + off,
+                                       self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
+                                       flags.data_ptr() + lo // CHUNK, hi - lo, ptr(self._sumsq),
+                                       float(grad_scale), float(max_grad_norm or 0.0), lr, float(b1), float(b2),
+                                       float(g0['eps']), float(g0['weight_decay']), self.step_count,
+                                       int(self.adamw), int(bool(zero_grads)), stream_ptr),
+                  'uniter_adam_step')
+
+        enc = self.overlap_encoder
+        plan = self._overlap_plan(enc) if enc is not None else None
+        if plan is None:
+            launch(0, st.numel, _lib.cur_stream())
+        else:
+            # The update is HBM-bound, the next forward MFMA-bound: run the encoder's blocks on the
+            # side stream in the order the forward needs them (embeddings, layer 0, 1, ..), one event
+            # per block; the next uniter_model_forward waits block by block instead of for all of it.
+            head, blocks = plan
+            main = torch.cuda.current_stream()
+            for lo, hi in head:                                  # pooler / heads: tiny, stay on this stream
+                launch(lo, hi, _lib.cur_stream())
+            side = enc._side_stream
+            if side is None:
+                side = enc._side_stream = torch.cuda.Stream(device=st.device)
+            side.wait_stream(main)
+            events = []
+            import ctypes as C
+            for lo, hi in blocks:
+                launch(lo, hi, C.c_void_p(side.cuda_stream))
+                ev = torch.cuda.Event()
+                ev.record(side)
+                events.append(ev)
+            enc._set_ready_events(events)
+            self._pending = events[-1]
         if zero_grads:
             st.touched.clear()      # flags stay cached: the same set is touched again next step
 
