@@ -56,7 +56,7 @@ enum {
   UNITER_EPI_BIAS_GELU = 2,   /* u = acc + bias[n]; aux_out = u; C = gelu_erf(u)       */
   UNITER_EPI_DGELU     = 3,   /* C = acc * gelu_erf'(aux_in[m,n])                      */
   UNITER_EPI_ADD       = 4,   /* C = acc + aux_in[m,n]                                 */
-  /* fp32 kernel only: the forward pass hands the backward pass gelu'(u) instead of u, so the
+  /* the forward pass hands the backward pass gelu'(u) instead of u, so the
    * backward epilogue is one multiply (the erf / exp are evaluated once per element, not twice) */
   UNITER_EPI_BIAS_GELU_D = 5, /* u = acc + bias[n]; aux_out = gelu_erf'(u); C = gelu_erf(u) */
   UNITER_EPI_MUL       = 6    /* C = acc * aux_in[m,n]                                 */

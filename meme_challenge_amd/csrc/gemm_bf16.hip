@@ -39,6 +39,13 @@ struct GemmArgsB {
   float* colsum_part;
 };
 
+__device__ __forceinline__ float buf_ld_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st_f32(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 constexpr int BKB = 64;            // k-tile depth
 constexpr int LDB16 = 72;          // LDS row stride in bf16 elements (144 B)
 
@@ -111,7 +118,9 @@ __device__ __forceinline__ bf16x8 frag_read_b(const unsigned short* s, int r0, i
   return *reinterpret_cast<const bf16x8*>(s + (r0 + i) * LDB16 + ks * 16 + 8 * h);
 }
 
-template <int BM, int BN, bool AKM, bool BKM, int TAG>
+// SK = stream-K for C += A.B (weight gradients), as in gemm_f32.hip: equal contiguous pieces of an
+// XCD's unit sequence per workgroup, partial tiles added with buffer_atomic_add_f32.
+template <int BM, int BN, bool AKM, bool BKM, int TAG, bool SK>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int SA = BM * LDB16, SB = BN * LDB16;              // bf16 elements
@@ -121,15 +130,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntiles = g.tiles_m * g.tiles_n;
-  const int nk = g.K / BKB;
+  const int nk = (g.K + BKB - 1) / BKB;     // ragged last k-tile: k-major operands only (rows >= K read as 0)
 
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
   const int q = ntiles >> 3, r = ntiles & 7;
   const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int chunk_n = q + (xcd < r ? 1 : 0);
-  if (idx >= chunk_n) return;
-  const int my_tiles = (chunk_n - idx + per_xcd - 1) / per_xcd;
-  const int total_units = my_tiles * nk;
+  int total_units, t_first, k_first;
+  if (SK) {
+    const long U = (long)chunk_n * nk;
+    const int u0 = (int)(U * idx / per_xcd), u1 = (int)(U * (idx + 1) / per_xcd);
+    total_units = u1 - u0;
+    t_first = u0 / nk; k_first = u0 - t_first * nk;
+  } else {
+    const int my_tiles = idx < chunk_n ? (chunk_n - idx + per_xcd - 1) / per_xcd : 0;
+    total_units = my_tiles * nk;
+    t_first = idx; k_first = 0;
+  }
+  if (total_units == 0) return;
+  const int t_step = SK ? 1 : per_xcd;
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(g.A), 0, (AKM ? g.K : g.M) * g.lda * 4, 0x00020000);
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
       const_cast<float*>(g.B), 0, (BKM ? g.K : g.N) * g.ldb * 4, 0x00020000);
   const int kstepA = (AKM ? BKB * g.lda : BKB) * 4, kstepB = (BKM ? BKB * g.ldb : BKB) * 4;
 
-  int lt = idx, lk = 0;
+  int lt = t_first, lk = k_first;
   int voA[BM / 16], voB[BN / 16];
   {
     int tmi, tni;
@@ -153,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
       tile_load_b<BN>(RB, rsB, voB, lk * kstepB);                                        \
       ++loaded;                                                                          \
       if (++lk == nk) {                                                                  \
-        lk = 0; lt += per_xcd;                                                           \
+        lk = 0; lt += t_step;                                                            \
         if (loaded < total_units) {                                                      \
           int tmi_, tni_;                                                                \
           tile_coords_b(chunk0 + lt, g.tiles_m, g.tiles_n, g.band_h, tmi_, tni_);        \
@@ -177,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
 #pragma unroll
   for (int b = 0; b < TN; ++b) fb0[b] = frag_read_b(smem + SA, wn * WN + b * 32, 0, i, h);
 
-  int ct = idx, ck = 0;
+  int ct = t_first, ck = k_first;
   int tmi0, tni0;
   tile_coords_b(chunk0 + ct, g.tiles_m, g.tiles_n, g.band_h, tmi0, tni0);
   int m0 = tmi0 * BM, n0 = tni0 * BN;
@@ -198,76 +217,105 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
   _Pragma("unroll") for (int a = 0; a < TM; ++a) FA[a] = frag_read_b(SAp, wm * WM + a * 32, KS, i, h);  \
   _Pragma("unroll") for (int b = 0; b < TN; ++b) FB[b] = frag_read_b(SBp, wn * WN + b * 32, KS, i, h);
 
-  for (int u = 0; u < total_units; ++u) {
-    const unsigned short* sA = smem + (u & 1) * (SA + SB);
-    const unsigned short* sB = sA + SA;
-    unsigned short* dA = smem + ((u + 1) & 1) * (SA + SB);
-    const bool more = u + 1 < total_units;
-    __builtin_amdgcn_sched_barrier(0);
-    READ_FRAGS(fa1, fb1, sA, sB, 1)
-    MFMA_BLOCK(fa0, fb0)
-    __builtin_amdgcn_sched_barrier(0);
-    READ_FRAGS(fa0, fb0, sA, sB, 2)
-    MFMA_BLOCK(fa1, fb1)
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) {
-      tile_store_b<BM, AKM>(ra, dA, tid);
-      tile_store_b<BN, BKM>(rb, dA + SA, tid);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    LOAD_UNIT(ra, rb);
-    __builtin_amdgcn_sched_barrier(0);
-    READ_FRAGS(fa1, fb1, sA, sB, 3)
-    MFMA_BLOCK(fa0, fb0)
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) { READ_FRAGS(fa0, fb0, dA, (dA + SA), 0) }
-    MFMA_BLOCK(fa1, fb1)
-    __builtin_amdgcn_sched_barrier(0);
-    if (++ck == nk) {
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          const int col = n0 + wn * WN + b * 32 + i;
-          const bool cok = col < g.N;
-          const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU)) ? g.bias[col] : 0.f;
-          float csum = 0.f;
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr) {
-            const int row = m0 + wm * WM + a * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
-            if (cok && row < g.M) {
-              float v = acc[a][b][rr] + bv;
-              if (g.epi == UNITER_EPI_BIAS_GELU) {
-                if (g.aux_out) g.aux_out[(size_t)row * g.ld_aux + col] = v;
-                v = gelu_erf(v);
-              } else if (g.epi == UNITER_EPI_DGELU) {
-                v *= dgelu_erf(g.aux_in[(size_t)row * g.ld_aux + col]);
-              } else if (g.epi == UNITER_EPI_ADD) {
-                v += g.aux_in[(size_t)row * g.ld_aux + col];
-              }
-              csum += v;
-              float* c = g.C + (size_t)row * g.ldc + col;
-              if (g.beta) v += *c;
-              *c = v;
-            }
-            acc[a][b][rr] = 0.f;
-          }
-          if (g.colsum_part) {
-            csum += __shfl_xor(csum, 32, 64);
-            if (h == 0 && cok && (m0 + wm * WM + a * 32) < g.M)
-              g.colsum_part[(size_t)((m0 + wm * WM + a * 32) >> 5) * g.N + col] = csum;
-          }
-        }
-      }
-      ck = 0; ct += per_xcd;
-      if (more) {
-        tile_coords_b(chunk0 + ct, g.tiles_m, g.tiles_n, g.band_h, tmi0, tni0);
-        m0 = tmi0 * BM; n0 = tni0 * BN;
-      }
-    }
+#define EPILOGUE_B()                                                                                    \
+  {                                                                                                     \
+    constexpr int OOB = 0x7ffffff0;                                                                     \
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.M * g.ldc * 4, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(                                \
+        g.aux_out, 0, g.aux_out ? g.M * g.ld_aux * 4 : 0, 0x00020000);                                  \
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(                                \
+        const_cast<float*>(g.aux_in), 0, g.aux_in ? g.M * g.ld_aux * 4 : 0, 0x00020000);                \
+    _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                    \
+      _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                  \
+        const int col = n0 + wn * WN + b * 32 + i;                                                      \
+        const bool cok = col < g.N;                                                                     \
+        const int r0 = m0 + wm * WM + a * 32 + 4 * h;                                                   \
+        const int voC = cok ? (r0 * g.ldc + col) * 4 : OOB;                                             \
+        const int voX = cok ? (r0 * g.ld_aux + col) * 4 : OOB;                                          \
+        const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D)) ? g.bias[col] : 0.f; \
+        float csum = 0.f;                                                                               \
+        _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                             \
+          const int kr = (rr & 3) + 8 * (rr >> 2);                                                      \
+          float v = acc[a][b][rr] + bv;                                                                 \
+          if (g.epi == UNITER_EPI_BIAS_GELU) {                                                          \
+            buf_st_f32(v, rsX, voX, kr * g.ld_aux * 4);                                                 \
+            v = gelu_erf(v);                                                                            \
+          } else if (g.epi == UNITER_EPI_DGELU) {                                                       \
+            v *= dgelu_erf(buf_ld_f32(rsI, voX, kr * g.ld_aux * 4));                                    \
+          } else if (g.epi == UNITER_EPI_ADD) {                                                         \
+            v += buf_ld_f32(rsI, voX, kr * g.ld_aux * 4);                                               \
+          } else if (g.epi == UNITER_EPI_MUL) {                                                         \
+            v *= buf_ld_f32(rsI, voX, kr * g.ld_aux * 4);                                               \
+          } else if (g.epi == UNITER_EPI_BIAS_GELU_D) {                                                 \
+            float dg_;                                                                                  \
+            gelu_pair_fast(v, v, dg_);                                                                  \
+            buf_st_f32(dg_, rsX, voX, kr * g.ld_aux * 4);                                               \
+          }                                                                                             \
+          if (!SK && g.colsum_part) csum += (r0 + kr < g.M) ? v : 0.f;                                  \
+          if (SK) {                                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsC, voC, kr * g.ldc * 4, 0);            \
+          } else {                                                                                      \
+            if (g.beta) v += buf_ld_f32(rsC, voC, kr * g.ldc * 4);                                      \
+            buf_st_f32(v, rsC, voC, kr * g.ldc * 4);                                                    \
+          }                                                                                             \
+          acc[a][b][rr] = 0.f;                                                                          \
+        }                                                                                               \
+        if (!SK && g.colsum_part) {                                                                     \
+          csum += __shfl_xor(csum, 32, 64);                                                             \
+          if (h == 0 && cok && (m0 + wm * WM + a * 32) < g.M)                                           \
+            g.colsum_part[(size_t)((m0 + wm * WM + a * 32) >> 5) * g.N + col] = csum;                   \
+        }                                                                                               \
+      }                                                                                                 \
+    }                                                                                                   \
   }
+
+// one k-iteration with a compile-time LDS stage (the loop is unrolled by two: no address VALU)
+#define K_ITERATION_B(U, STAGE)                                                                         \
+  {                                                                                                     \
+    const unsigned short* sA = smem + (STAGE) * (SA + SB);                                              \
+    const unsigned short* sB = sA + SA;                                                                 \
+    unsigned short* dA = smem + (1 - (STAGE)) * (SA + SB);                                              \
+    const bool more = (U) + 1 < total_units;                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    READ_FRAGS(fa1, fb1, sA, sB, 1)                                                                     \
+    MFMA_BLOCK(fa0, fb0)                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    READ_FRAGS(fa0, fb0, sA, sB, 2)                                                                     \
+    MFMA_BLOCK(fa1, fb1)                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (more) {                                                                                         \
+      tile_store_b<BM, AKM>(ra, dA, tid);                                                               \
+      tile_store_b<BN, BKM>(rb, dA + SA, tid);                                                          \
+    }                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    LOAD_UNIT(ra, rb);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    READ_FRAGS(fa1, fb1, sA, sB, 3)                                                                     \
+    MFMA_BLOCK(fa0, fb0)                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    __syncthreads();                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (more) { READ_FRAGS(fa0, fb0, dA, (dA + SA), 0) }                                                \
+    MFMA_BLOCK(fa1, fb1)                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (++ck == nk || (SK && !more)) {                                                                  \
+      EPILOGUE_B();                                                                                     \
+      ck = 0; ct += t_step;                                                                             \
+      if (more) {                                                                                       \
+        tile_coords_b(chunk0 + ct, g.tiles_m, g.tiles_n, g.band_h, tmi0, tni0);                         \
+        m0 = tmi0 * BM; n0 = tni0 * BN;                                                                 \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+
+  int u = 0;
+  for (; u + 1 < total_units; u += 2) {
+    K_ITERATION_B(u, 0)
+    K_ITERATION_B(u + 1, 1)
+  }
+  if (u < total_units) K_ITERATION_B(u, 0)
+#undef K_ITERATION_B
+#undef EPILOGUE_B
 #undef MFMA_BLOCK
 #undef READ_FRAGS
 #undef LOAD_UNIT
@@ -283,7 +331,17 @@ int launch_b(GemmArgsB g, hipStream_t st, int slots) {
   g.band_h = (int)(bh < 1 ? 1 : (bh > 16 ? 16 : bh));
   if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
   const int grid = tiles < slots ? (tiles + 7) / 8 * 8 : slots;
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AKM, BKM, 0>), dim3(grid), dim3(256), 0, st, g);
+  if (g.beta == 1 && g.epi == UNITER_EPI_NONE && !g.colsum_part && tiles >= 8) {
+    const int rounds = (tiles + slots - 1) / slots;
+    const bool uneven = (long)tiles * 100 < (long)rounds * slots * 88;
+    const long units = (long)tiles * ((g.K + BKB - 1) / BKB);
+    if (uneven && units >= 8l * slots) {
+      hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AKM, BKM, 0, true>), dim3(slots), dim3(256), 0, st, g);
+      UCHECK_LAUNCH();
+      return 0;
+    }
+  }
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AKM, BKM, 0, false>), dim3(grid), dim3(256), 0, st, g);
   UCHECK_LAUNCH();
   return 0;
 }
@@ -311,7 +369,8 @@ int gemm_bf16_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, cons
                   const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
                   const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part, void* stream) {
   UCHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "gemm_bf16: bad argument");
-  const bool ok = K % BKB == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+  const bool ok = (K % BKB == 0 || (a_kmajor && b_kmajor && K % 2 == 0)) && lda % 4 == 0 && ldb % 4 == 0 &&
+                  ((size_t)M + 128) * ldc * 4 < (1ull << 31) && ((size_t)M + 128) * (ld_aux > 0 ? ld_aux : 1) * 4 < (1ull << 31) &&
                   (a_kmajor ? M % 4 == 0 : true) && (b_kmajor ? N % 4 == 0 : true) &&
                   (size_t)(a_kmajor ? K : M) * lda * 4 < (1ull << 31) &&
                   (size_t)(b_kmajor ? K : N) * ldb * 4 < (1ull << 31) &&
@@ -319,7 +378,7 @@ int gemm_bf16_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, cons
   if (!ok)
     return gemm_f32_run(0, 0, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, epilogue, bias, aux_in, aux_out,
                         ld_aux, beta, colsum_part, stream);
-  UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_ADD, "gemm_bf16: bad epilogue %d", epilogue);
+  UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_MUL, "gemm_bf16: bad epilogue %d", epilogue);
   GemmArgsB g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux; g.beta = beta;
@@ -341,8 +400,10 @@ extern "C" int uniter_gemm_bf16_cfg(int cfg, int a_kmajor, int b_kmajor, int M, 
                                     int lda, const float* B, int ldb, float* C, int ldc, int epilogue,
                                     const float* bias, const float* aux_in, float* aux_out, int ld_aux, int beta,
                                     void* stream) {
-  UCHECK_ARG(!(epilogue == UNITER_EPI_BIAS || epilogue == UNITER_EPI_BIAS_GELU) || bias, "gemm_bf16: epilogue needs bias");
-  UCHECK_ARG(!(epilogue == UNITER_EPI_DGELU || epilogue == UNITER_EPI_ADD) || aux_in, "gemm_bf16: epilogue needs aux_in");
+  UCHECK_ARG(!(epilogue == UNITER_EPI_BIAS || epilogue == UNITER_EPI_BIAS_GELU || epilogue == UNITER_EPI_BIAS_GELU_D) || bias,
+             "gemm_bf16: epilogue needs bias");
+  UCHECK_ARG(!(epilogue == UNITER_EPI_DGELU || epilogue == UNITER_EPI_ADD || epilogue == UNITER_EPI_MUL) || aux_in,
+             "gemm_bf16: epilogue needs aux_in");
   return gemm_bf16_run(cfg, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, epilogue, bias, aux_in, aux_out,
                        ld_aux, beta, nullptr, stream);
 }

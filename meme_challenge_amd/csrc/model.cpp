@@ -63,7 +63,7 @@ struct LayerBufs {   // saved activations + backward scratch of one layer
 struct Plan {
   int B, T, R, L, S, T0, M, mode;
   bool has_txt, has_img;
-  bool gelu_d;      // forward stored gelu'(u) in LayerBufs::u (fp32 kernels) rather than u
+  bool gelu_d;      // forward stored gelu'(u) in LayerBufs::u rather than u
   float *feat_eff, *imgfc, *img_stats, *cat, *emb;
   std::vector<LayerBufs> layers;
   float *dcat, *d_imgfc, *d_posfc, *d_feat, *dsum, *dpk;
@@ -363,7 +363,7 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   const int B = b->B, T = b->T, R = b->R, L = b->L, S = pl.S, M = pl.M;
   const bool save = train != 0;
   static const bool gelu_d_env = [] { const char* e = getenv("UNITER_GELU_D"); return !(e && e[0] == '0'); }();
-  const bool gelu_d = m->precision == 0 && gelu_d_env;      // UNITER_GELU_D=0: A/B switch
+  const bool gelu_d = gelu_d_env;      // UNITER_GELU_D=0: A/B switch (store the pre-activation, libm erf twice)
   pl.gelu_d = gelu_d;
   m->batch = *b; m->hidden_out = hidden_out; m->all_layers = all_layers; m->seed = seed; m->offset = offset;
   m->bwd_open = false;

@@ -18,9 +18,15 @@ def _run(cfg, akm, bkm, M, N, K, epi, beta, seed=0):
     bias, aux, C0 = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
     Ar, Br = A.bfloat16().double(), B.bfloat16().double()
     ref = (Ar.t() if akm else Ar) @ (Br if bkm else Br.t())
-    if epi in (1, 2):
+    if epi in (1, 2, 5):
         ref = ref + bias.double()
     pre = ref.clone()
+    if epi == 5:      # gelu(u) out, gelu'(u) to aux_out
+        x = ref
+        pre = 0.5 * (1 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+        ref = x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    if epi == 6:
+        ref = ref * aux.double()
     if epi == 2:
         ref = ref * 0.5 * (1.0 + torch.erf(ref / math.sqrt(2.0)))
     if epi == 3:
@@ -38,7 +44,7 @@ def _run(cfg, akm, bkm, M, N, K, epi, beta, seed=0):
     torch.cuda.synchronize()
     err = (dC.cpu().double() - ref).abs().max().item()
     assert err < 1e-4 * math.sqrt(K), (cfg, akm, bkm, M, N, K, epi, beta, err)
-    if epi == 2:
+    if epi in (2, 5):
         assert (dauxo.cpu().double() - pre).abs().max().item() < 1e-4 * math.sqrt(K)
 
 
@@ -56,7 +62,11 @@ def test_gemm_bf16_model_shapes(cfg):
     _run(cfg, 0, 0, M=2624, N=3072, K=768, epi=2, beta=0)
     _run(cfg, 0, 1, M=2624, N=768, K=3072, epi=4, beta=0)
     _run(cfg, 0, 1, M=2624, N=3072, K=768, epi=3, beta=0)
-    _run(cfg, 1, 1, M=768, N=3072, K=2624, epi=0, beta=1)
+    _run(cfg, 1, 1, M=768, N=3072, K=2624, epi=0, beta=1)          # stream-K (atomics)
+    _run(cfg, 1, 1, M=768, N=768, K=2624, epi=0, beta=1)
+    _run(cfg, 0, 0, M=2624, N=3072, K=768, epi=5, beta=0)
+    _run(cfg, 0, 1, M=2624, N=3072, K=768, epi=6, beta=0)
+    _run(cfg, 1, 1, M=768, N=256, K=1458, epi=0, beta=1)           # ragged K (packed batches): k-major operands only
 
 
 def test_gemm_bf16_falls_back_to_fp32_when_k_not_multiple_of_64():
