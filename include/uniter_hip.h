@@ -82,6 +82,16 @@ int uniter_gemm_bf16_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int 
                     float* C, int ldc, int epilogue, const float* bias,
                     const float* aux_in, float* aux_out, int ld_aux,
                     int beta, void* stream);
+/* All-bf16 operands (resident bf16 activations / the bf16 mirror of the weights), fp32 accumulate;
+ * writes C (fp32, may be NULL) and / or C_bf16 (bf16 copy for the next GEMM, may be NULL).  lda / ldb /
+ * ldcb count bf16 elements.  Layouts: (0,0) x @ W^T, (0,1) dgrad, (1,1) wgrad.  cfg 0 / 1 / 4.
+ * K % 64 == 0 (any even K for (1,1)), leading dimensions % 8, 16-byte aligned operands. */
+int uniter_gemm_bf16res_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K,
+                            const void* A, int lda, const void* B, int ldb,
+                            float* C, int ldc, void* C_bf16, int ldcb, int epilogue, const float* bias,
+                            const float* aux_in, float* aux_out, int ld_aux, int beta, void* stream);
+/* dst[i] = bf16(src[i]) (round to nearest even); n % 4 == 0 */
+int uniter_cast_bf16(const float* src, void* dst, size_t n, void* stream);
 
 /* fp32-ACCURATE product on the bf16 matrix pipe: each fp32 operand is split exactly into three
  * bf16 pieces and the six significant piece products are accumulated in fp32 (error of the same

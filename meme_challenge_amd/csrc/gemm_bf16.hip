@@ -26,9 +26,10 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 struct GemmArgsB {
   int M, N, K;
-  const float* A; int lda;
-  const float* B; int ldb;
+  const void* A; int lda;      // fp32 (converted while staged) or, in the RES kernels, bf16 as stored
+  const void* B; int ldb;
   float* C; int ldc;
+  unsigned short* Cb; int ldcb;   // optional bf16 copy of C (the next GEMM's operand)
   int epi;
   const float* bias;
   const float* aux_in;
@@ -120,7 +121,97 @@ __device__ __forceinline__ bf16x8 frag_read_b(const unsigned short* s, int r0, i
 
 // SK = stream-K for C += A.B (weight gradients), as in gemm_f32.hip: equal contiguous pieces of an
 // XCD's unit sequence per workgroup, partial tiles added with buffer_atomic_add_f32.
-template <int BM, int BN, bool AKM, bool BKM, int TAG, bool SK>
+// ---- operand staging: global -> registers -> LDS image [R][LDB16] bf16 -------------------------
+// RES = false: fp32 in memory, rounded to bf16 on the way (the functions above).
+// RES = true : bf16 in memory (resident activations / weight mirror): half the bytes, no conversion.
+//   k-contiguous rows: 8 lanes x 16 B per 64-k row, written as whole 16-B slots;
+//   k-major: a lane takes 8 consecutive columns of a k-pair of rows and writes 8 (k, k+1) words.
+//   The 16-B slots of a row are XOR-swizzled by (row >> 3) & 3 so that the four lanes that differ
+//   only in their column group do not share a bank on those word writes.
+template <int R, bool KM, bool RES> struct Stager;
+
+template <int R, bool KM> struct Stager<R, KM, false> {
+  int voff[R / 16];
+  f32x4 reg[R / 16];
+  static __device__ __forceinline__ int kstep(int ld) { return (KM ? BKB * ld : BKB) * 4; }
+  static __device__ __forceinline__ size_t bytes(int rows, int ld) { return (size_t)rows * ld * 4; }
+  __device__ __forceinline__ void offsets(int ld, int row0, int tid) { tile_offsets_b<R, KM>(voff, ld, row0, tid); }
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int soff) { tile_load_b<R>(reg, rs, voff, soff); }
+  __device__ __forceinline__ void store(unsigned short* s, int tid) const { tile_store_b<R, KM>(reg, s, tid); }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned short* s, int r0, int ks, int i, int h) {
+    return frag_read_b(s, r0, ks, i, h);
+  }
+};
+
+template <int R> struct Stager<R, false, true> {
+  static constexpr int NP = R / 32;
+  int voff[NP];
+  u32x4_t reg[NP];
+  static __device__ __forceinline__ int kstep(int) { return BKB * 2; }
+  static __device__ __forceinline__ size_t bytes(int rows, int ld) { return (size_t)rows * ld * 2; }
+  __device__ __forceinline__ void offsets(int ld, int row0, int tid) {
+    const int c8 = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) voff[p] = ((row0 + rr + 32 * p) * ld + c8 * 8) * 2;
+  }
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int soff) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) reg[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], soff, 0);
+  }
+  __device__ __forceinline__ void store(unsigned short* s, int tid) const {
+    const int c8 = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int row = rr + 32 * p;
+      *reinterpret_cast<u32x4_t*>(s + row * LDB16 + ((c8 ^ ((row >> 3) & 3)) << 3)) = reg[p];
+    }
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned short* s, int r0, int ks, int i, int h) {
+    const int row = r0 + i;
+    return *reinterpret_cast<const bf16x8*>(s + row * LDB16 + (((2 * ks + h) ^ ((row >> 3) & 3)) << 3));
+  }
+};
+
+template <int R> struct Stager<R, true, true> {
+  static constexpr int NP = R / 64;
+  int voff[2 * NP];
+  u32x4_t reg[2 * NP];
+  static __device__ __forceinline__ int kstep(int ld) { return BKB * ld * 2; }
+  static __device__ __forceinline__ size_t bytes(int rows, int ld) { return (size_t)rows * ld * 2; }
+  __device__ __forceinline__ void offsets(int ld, int row0, int tid) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int id = tid + 256 * p;
+      const int cg = ((id >> 7) << 2) | (id & 3), kp = (id >> 2) & 31;
+      voff[2 * p] = ((2 * kp) * ld + row0 + cg * 8) * 2;
+      voff[2 * p + 1] = voff[2 * p] + ld * 2;
+    }
+  }
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int soff) {
+#pragma unroll
+    for (int p = 0; p < 2 * NP; ++p) reg[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], soff, 0);
+  }
+  __device__ __forceinline__ void store(unsigned short* s, int tid) const {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int id = tid + 256 * p;
+      const int cg = ((id >> 7) << 2) | (id & 3), kp = (id >> 2) & 31;
+      const int slot = ((kp >> 2) ^ (cg & 3)) << 3;             // rows cg*8 .. cg*8+7 share (row >> 3) & 3 = cg & 3
+      unsigned short* d = s + (cg * 8) * LDB16 + slot + 2 * (kp & 3);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const unsigned lo = reg[2 * p][w], hi = reg[2 * p + 1][w];     // columns 2w, 2w+1 of rows k, k+1
+        *reinterpret_cast<unsigned*>(d + (2 * w) * LDB16) = (lo & 0xffffu) | (hi << 16);
+        *reinterpret_cast<unsigned*>(d + (2 * w + 1) * LDB16) = (lo >> 16) | (hi & 0xffff0000u);
+      }
+    }
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned short* s, int r0, int ks, int i, int h) {
+    return Stager<R, false, true>::frag(s, r0, ks, i, h);
+  }
+};
+
+template <int BM, int BN, bool AKM, bool BKM, int TAG, bool SK, bool RES = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int SA = BM * LDB16, SB = BN * LDB16;              // bf16 elements
@@ -150,51 +241,53 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
   if (total_units == 0) return;
   const int t_step = SK ? 1 : per_xcd;
 
+  using StA = Stager<BM, AKM, RES>;
+  using StB = Stager<BN, BKM, RES>;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g.A), 0, (AKM ? g.K : g.M) * g.lda * 4, 0x00020000);
+      const_cast<void*>(g.A), 0, (int)StA::bytes(AKM ? g.K : g.M, g.lda), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g.B), 0, (BKM ? g.K : g.N) * g.ldb * 4, 0x00020000);
-  const int kstepA = (AKM ? BKB * g.lda : BKB) * 4, kstepB = (BKM ? BKB * g.ldb : BKB) * 4;
+      const_cast<void*>(g.B), 0, (int)StB::bytes(BKM ? g.K : g.N, g.ldb), 0x00020000);
+  const int kstepA = StA::kstep(g.lda), kstepB = StB::kstep(g.ldb);
 
   int lt = t_first, lk = k_first;
-  int voA[BM / 16], voB[BN / 16];
+  StA sa;
+  StB sb;
   {
     int tmi, tni;
     tile_coords_b(chunk0 + lt, g.tiles_m, g.tiles_n, g.band_h, tmi, tni);
-    tile_offsets_b<BM, AKM>(voA, g.lda, tmi * BM, tid);
-    tile_offsets_b<BN, BKM>(voB, g.ldb, tni * BN, tid);
+    sa.offsets(g.lda, tmi * BM, tid);
+    sb.offsets(g.ldb, tni * BN, tid);
   }
   int loaded = 0;
-#define LOAD_UNIT(RA, RB)                                                                \
+#define LOAD_UNIT()                                                                      \
   do {                                                                                   \
     if (loaded < total_units) {                                                          \
-      tile_load_b<BM>(RA, rsA, voA, lk * kstepA);                                        \
-      tile_load_b<BN>(RB, rsB, voB, lk * kstepB);                                        \
+      sa.load(rsA, lk * kstepA);                                                         \
+      sb.load(rsB, lk * kstepB);                                                         \
       ++loaded;                                                                          \
       if (++lk == nk) {                                                                  \
         lk = 0; lt += t_step;                                                            \
         if (loaded < total_units) {                                                      \
           int tmi_, tni_;                                                                \
           tile_coords_b(chunk0 + lt, g.tiles_m, g.tiles_n, g.band_h, tmi_, tni_);        \
-          tile_offsets_b<BM, AKM>(voA, g.lda, tmi_ * BM, tid);                           \
-          tile_offsets_b<BN, BKM>(voB, g.ldb, tni_ * BN, tid);                           \
+          sa.offsets(g.lda, tmi_ * BM, tid);                                             \
+          sb.offsets(g.ldb, tni_ * BN, tid);                                             \
         }                                                                                \
       }                                                                                  \
     }                                                                                    \
   } while (0)
 
-  f32x4 ra[BM / 16], rb[BN / 16];
   bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
 
-  LOAD_UNIT(ra, rb);
-  tile_store_b<BM, AKM>(ra, smem, tid);
-  tile_store_b<BN, BKM>(rb, smem + SA, tid);
-  LOAD_UNIT(ra, rb);
+  LOAD_UNIT();
+  sa.store(smem, tid);
+  sb.store(smem + SA, tid);
+  LOAD_UNIT();
   __syncthreads();
 #pragma unroll
-  for (int a = 0; a < TM; ++a) fa0[a] = frag_read_b(smem, wm * WM + a * 32, 0, i, h);
+  for (int a = 0; a < TM; ++a) fa0[a] = StA::frag(smem, wm * WM + a * 32, 0, i, h);
 #pragma unroll
-  for (int b = 0; b < TN; ++b) fb0[b] = frag_read_b(smem + SA, wn * WN + b * 32, 0, i, h);
+  for (int b = 0; b < TN; ++b) fb0[b] = StB::frag(smem + SA, wn * WN + b * 32, 0, i, h);
 
   int ct = t_first, ck = k_first;
   int tmi0, tni0;
@@ -214,13 +307,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
   _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                        \
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[a], FB[b], acc[a][b], 0, 0, 0);
 #define READ_FRAGS(FA, FB, SAp, SBp, KS)                                                                \
-  _Pragma("unroll") for (int a = 0; a < TM; ++a) FA[a] = frag_read_b(SAp, wm * WM + a * 32, KS, i, h);  \
-  _Pragma("unroll") for (int b = 0; b < TN; ++b) FB[b] = frag_read_b(SBp, wn * WN + b * 32, KS, i, h);
+  _Pragma("unroll") for (int a = 0; a < TM; ++a) FA[a] = StA::frag(SAp, wm * WM + a * 32, KS, i, h);    \
+  _Pragma("unroll") for (int b = 0; b < TN; ++b) FB[b] = StB::frag(SBp, wn * WN + b * 32, KS, i, h);
 
 #define EPILOGUE_B()                                                                                    \
   {                                                                                                     \
     constexpr int OOB = 0x7ffffff0;                                                                     \
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.M * g.ldc * 4, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.C ? g.M * g.ldc * 4 : 0, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t rsCb = __builtin_amdgcn_make_buffer_rsrc(g.Cb, 0, g.Cb ? g.M * g.ldcb * 2 : 0, 0x00020000); \
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(                                \
         g.aux_out, 0, g.aux_out ? g.M * g.ld_aux * 4 : 0, 0x00020000);                                  \
     const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(                                \
@@ -232,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
         const int r0 = m0 + wm * WM + a * 32 + 4 * h;                                                   \
         const int voC = cok ? (r0 * g.ldc + col) * 4 : OOB;                                             \
         const int voX = cok ? (r0 * g.ld_aux + col) * 4 : OOB;                                          \
+        const int voCb = cok ? (r0 * g.ldcb + col) * 2 : OOB;                                           \
         const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D)) ? g.bias[col] : 0.f; \
         float csum = 0.f;                                                                               \
         _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                             \
@@ -256,7 +351,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
             __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsC, voC, kr * g.ldc * 4, 0);            \
           } else {                                                                                      \
             if (g.beta) v += buf_ld_f32(rsC, voC, kr * g.ldc * 4);                                      \
-            buf_st_f32(v, rsC, voC, kr * g.ldc * 4);                                                    \
+            if (g.C) buf_st_f32(v, rsC, voC, kr * g.ldc * 4);                                           \
+            if (g.Cb) __builtin_amdgcn_raw_buffer_store_b16(                                            \
+                __builtin_bit_cast(unsigned short, (__bf16)v), rsCb, voCb, kr * g.ldcb * 2, 0);         \
           }                                                                                             \
           acc[a][b][rr] = 0.f;                                                                          \
         }                                                                                               \
@@ -284,11 +381,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
     MFMA_BLOCK(fa1, fb1)                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     if (more) {                                                                                         \
-      tile_store_b<BM, AKM>(ra, dA, tid);                                                               \
-      tile_store_b<BN, BKM>(rb, dA + SA, tid);                                                          \
+      sa.store(dA, tid);                                                                                \
+      sb.store(dA + SA, tid);                                                                           \
     }                                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
-    LOAD_UNIT(ra, rb);                                                                                  \
+    LOAD_UNIT();                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     READ_FRAGS(fa1, fb1, sA, sB, 3)                                                                     \
     MFMA_BLOCK(fa0, fb0)                                                                                \
@@ -321,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
 #undef LOAD_UNIT
 }
 
-template <int BM, int BN, bool AKM, bool BKM>
+template <int BM, int BN, bool AKM, bool BKM, bool RES = false>
 int launch_b(GemmArgsB g, hipStream_t st, int slots) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
@@ -336,12 +433,12 @@ int launch_b(GemmArgsB g, hipStream_t st, int slots) {
     const bool uneven = (long)tiles * 100 < (long)rounds * slots * 88;
     const long units = (long)tiles * ((g.K + BKB - 1) / BKB);
     if (uneven && units >= 8l * slots) {
-      hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AKM, BKM, 0, true>), dim3(slots), dim3(256), 0, st, g);
+      hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AKM, BKM, 0, true, RES>), dim3(slots), dim3(256), 0, st, g);
       UCHECK_LAUNCH();
       return 0;
     }
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AKM, BKM, 0, false>), dim3(grid), dim3(256), 0, st, g);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AKM, BKM, 0, false, RES>), dim3(grid), dim3(256), 0, st, g);
   UCHECK_LAUNCH();
   return 0;
 }
@@ -357,7 +454,78 @@ int dispatch_b(int cfg, const GemmArgsB& g, hipStream_t st) {
   }
 }
 
+template <bool AKM, bool BKM>
+int dispatch_r(int cfg, const GemmArgsB& g, hipStream_t st) {
+  switch (cfg) {
+    case 1: return launch_b<128, 128, AKM, BKM, true>(g, st, 512);
+    case 4: return launch_b<64, 64, AKM, BKM, true>(g, st, 1024);
+    default: uniter_set_error("gemm_bf16res: bad cfg %d (1 or 4)", cfg); return UNITER_E_ARG;
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                        size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    u32x2_t o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+    reinterpret_cast<u32x2_t*>(dst)[i] = o;
+  }
+}
+
 }  // namespace
+
+// All-bf16 operands (resident activations / weight mirror), fp32 accumulate, fp32 and / or bf16 output.
+int gemm_bf16res_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,
+                     int ldb, float* C, int ldc, void* Cb, int ldcb, int epilogue, const float* bias,
+                     const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part, void* stream) {
+  UCHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && (C || Cb), "gemm_bf16res: bad argument");
+  UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_MUL, "gemm_bf16res: bad epilogue %d", epilogue);
+  UCHECK_ARG(!(a_kmajor && !b_kmajor), "gemm_bf16res: layout (A k-major, B k-contiguous) is not built");
+  UCHECK_ARG(!beta || C, "gemm_bf16res: beta needs the fp32 output");
+  UCHECK_SHAPE((K % BKB == 0 || (a_kmajor && b_kmajor && K % 2 == 0)) && lda % 8 == 0 && ldb % 8 == 0 &&
+               (a_kmajor ? M % 8 == 0 : true) && (b_kmajor ? N % 8 == 0 : true) &&
+               ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
+               "gemm_bf16res: K %% 64, leading dimensions %% 8 and 16-byte aligned operands required (M=%d N=%d K=%d)", M, N, K);
+  UCHECK_SHAPE((size_t)(a_kmajor ? K : M) * lda * 2 < (1ull << 31) && (size_t)(b_kmajor ? K : N) * ldb * 2 < (1ull << 31) &&
+               ((size_t)M + 128) * (ldc > 0 ? ldc : 1) * 4 < (1ull << 31) &&
+               ((size_t)M + 128) * (ld_aux > 0 ? ld_aux : 1) * 4 < (1ull << 31), "gemm_bf16res: operand beyond 31-bit offsets");
+  GemmArgsB g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.Cb = (unsigned short*)Cb; g.ldcb = ldcb;
+  g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux; g.beta = beta;
+  g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
+  if (cfg == 0) {
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    cfg = t128 >= 448 ? 1 : 4;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (!a_kmajor && !b_kmajor) return dispatch_r<false, false>(cfg, g, st);
+  if (!a_kmajor && b_kmajor) return dispatch_r<false, true>(cfg, g, st);
+  return dispatch_r<true, true>(cfg, g, st);
+}
+
+extern "C" int uniter_gemm_bf16res_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A,
+                                       int lda, const void* B, int ldb, float* C, int ldc, void* C_bf16, int ldcb,
+                                       int epilogue, const float* bias, const float* aux_in, float* aux_out,
+                                       int ld_aux, int beta, void* stream) {
+  UCHECK_ARG(!(epilogue == UNITER_EPI_BIAS || epilogue == UNITER_EPI_BIAS_GELU || epilogue == UNITER_EPI_BIAS_GELU_D) || bias,
+             "gemm_bf16res: epilogue needs bias");
+  UCHECK_ARG(!(epilogue == UNITER_EPI_DGELU || epilogue == UNITER_EPI_ADD || epilogue == UNITER_EPI_MUL) || aux_in,
+             "gemm_bf16res: epilogue needs aux_in");
+  return gemm_bf16res_run(cfg, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, C_bf16, ldcb, epilogue, bias,
+                          aux_in, aux_out, ld_aux, beta, nullptr, stream);
+}
+
+extern "C" int uniter_cast_bf16(const float* src, void* dst, size_t n, void* stream) {
+  UCHECK_ARG(src && dst && n % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0,
+             "cast_bf16: n must be a multiple of 4 and the buffers aligned");
+  if (n == 0) return 0;
+  const size_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n4);
+  UCHECK_LAUNCH();
+  return 0;
+}
 
 int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda,
                  const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
@@ -381,6 +549,7 @@ int gemm_bf16_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, cons
   UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_MUL, "gemm_bf16: bad epilogue %d", epilogue);
   GemmArgsB g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.Cb = nullptr; g.ldcb = 0;
   g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux; g.beta = beta;
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
   if (cfg == 0) {
