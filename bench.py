@@ -101,7 +101,7 @@ def main():
     ap.add_argument('--txt_len', type=int, default=128)
     ap.add_argument('--num_bb', type=int, default=36)
     ap.add_argument('--model', choices=['base', 'large'], default='base')
-    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
+    ap.add_argument('--precision', choices=['fp32', 'bf16', 'bf16_hybrid'], default='fp32',
                     help="fp32 (BASELINE configs[1], default) or bf16: bf16 MFMA for the dense GEMMs, fp32 elsewhere (configs[2])")
     ap.add_argument('--workload', choices=['finetune', 'multitask'], default='finetune',
                     help='finetune = MemeUniter step (BASELINE configs[1-3], default); multitask = UNITER + ITM/MLM/MRFR '

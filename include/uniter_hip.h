@@ -85,7 +85,7 @@ int uniter_gemm_bf16_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int 
 /* All-bf16 operands (resident bf16 activations / the bf16 mirror of the weights), fp32 accumulate;
  * writes C (fp32, may be NULL) and / or C_bf16 (bf16 copy for the next GEMM, may be NULL).  lda / ldb /
  * ldcb count bf16 elements.  Layouts: (0,0) x @ W^T, (0,1) dgrad, (1,1) wgrad.  cfg 0 / 1 / 4.
- * K % 64 == 0 (any even K for (1,1)), leading dimensions % 8, 16-byte aligned operands. */
+ * K % 64 == 0 (any K for (1,1): rows beyond K read as zero), leading dimensions % 8, 16-byte aligned operands. */
 int uniter_gemm_bf16res_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K,
                             const void* A, int lda, const void* B, int ldb,
                             float* C, int ldc, void* C_bf16, int ldcb, int epilogue, const float* bias,
@@ -341,7 +341,12 @@ typedef struct {
 } uniter_batch_t;
 
 /* 0 (default): exact fp32 MFMA GEMMs.  1: bf16 MFMA for the dense GEMMs of the schedule (operands
- * rounded to bf16 in flight; storage, LayerNorm, softmax, attention, loss and optimizer stay fp32) */
+ * rounded to bf16 in flight; storage, LayerNorm, softmax, attention, loss and optimizer stay fp32).
+ * 2: as 1 with bf16-RESIDENT GEMM operands: the encoder weights are read from a bf16 mirror of the
+ * flat parameter buffer (uniter_model_set_weight_mirror; the caller refreshes it after every update
+ * with uniter_cast_bf16) and activations are handed from kernel to kernel as bf16 copies; the FFN
+ * activation and its gradient exist only in bf16. */
+int  uniter_model_set_weight_mirror(uniter_model_t* m, const float* flat_base, const void* mirror_bf16, size_t numel);
 int  uniter_model_set_precision(uniter_model_t* m, int precision);
 /* Overlap of the optimizer step with the next forward: `events` = hipEvent_t[num_hidden_layers + 1]
  * (embedding block, layer 0, layer 1, ..), each fired once that block's parameters (and zeroed

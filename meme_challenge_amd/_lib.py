@@ -94,6 +94,7 @@ _SIGS = {
     'uniter_model_create': (_I, [C.POINTER(UniterConfigC), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p)]),
     'uniter_model_destroy': (None, [_P]),
     'uniter_model_set_ready_events': (_I, [_P, _P, _I]),
+    'uniter_model_set_weight_mirror': (_I, [_P, _P, _P, _SZ]),
     'uniter_model_set_precision': (_I, [_P, _I]),
     'uniter_model_ws_bytes': (_SZ, [_P, _I, _I, _I, _I, _I]),
     'uniter_model_forward': (_I, [_P, C.POINTER(UniterBatchC), _P, _I, _I, _U64, _U32, _P, _SZ, _P]),

@@ -482,7 +482,7 @@ int gemm_bf16res_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, c
   UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_MUL, "gemm_bf16res: bad epilogue %d", epilogue);
   UCHECK_ARG(!(a_kmajor && !b_kmajor), "gemm_bf16res: layout (A k-major, B k-contiguous) is not built");
   UCHECK_ARG(!beta || C, "gemm_bf16res: beta needs the fp32 output");
-  UCHECK_SHAPE((K % BKB == 0 || (a_kmajor && b_kmajor && K % 2 == 0)) && lda % 8 == 0 && ldb % 8 == 0 &&
+  UCHECK_SHAPE((K % BKB == 0 || (a_kmajor && b_kmajor)) && lda % 8 == 0 && ldb % 8 == 0 &&
                (a_kmajor ? M % 8 == 0 : true) && (b_kmajor ? N % 8 == 0 : true) &&
                ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
                "gemm_bf16res: K %% 64, leading dimensions %% 8 and 16-byte aligned operands required (M=%d N=%d K=%d)", M, N, K);
@@ -537,7 +537,7 @@ int gemm_bf16_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, cons
                   const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
                   const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part, void* stream) {
   UCHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C, "gemm_bf16: bad argument");
-  const bool ok = (K % BKB == 0 || (a_kmajor && b_kmajor && K % 2 == 0)) && lda % 4 == 0 && ldb % 4 == 0 &&
+  const bool ok = (K % BKB == 0 || (a_kmajor && b_kmajor)) && lda % 4 == 0 && ldb % 4 == 0 &&
                   ((size_t)M + 128) * ldc * 4 < (1ull << 31) && ((size_t)M + 128) * (ld_aux > 0 ? ld_aux : 1) * 4 < (1ull << 31) &&
                   (a_kmajor ? M % 4 == 0 : true) && (b_kmajor ? N % 4 == 0 : true) &&
                   (size_t)(a_kmajor ? K : M) * lda * 4 < (1ull << 31) &&

@@ -23,6 +23,9 @@ int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int
 int gemm_bf16_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda,
                   const float* B, int ldb, float* C, int ldc, int epilogue, const float* bias,
                   const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part, void* stream);
+int gemm_bf16res_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,
+                     int ldb, float* C, int ldc, void* Cb, int ldcb, int epilogue, const float* bias,
+                     const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part, void* stream);
 int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta, hipStream_t st);
 int launch_masked_rowsum(const float* x, const int64_t* masks, float* out, int rows, int D, hipStream_t st);
 
@@ -52,12 +55,15 @@ struct Carver {
   char* base; size_t off;
   explicit Carver(void* b) : base((char*)b), off(0) {}
   float* f(size_t n) { float* p = (float*)(base + off); off += align_up(n * sizeof(float), 256); return p; }
+  unsigned short* h(size_t n) { unsigned short* p = (unsigned short*)(base + off); off += align_up(n * 2, 256); return p; }
   void* raw(size_t n) { void* p = base + off; off += align_up(n, 256); return p; }
 };
 
 struct LayerBufs {   // saved activations + backward scratch of one layer
   float *qkv, *lse, *ctx, *t1, *z1, *mean1, *rstd1, *y1, *u, *hact, *t2, *z2, *mean2, *rstd2, *y2;
   float *dz2, *g2, *du, *dy1, *dz1, *g1, *dctx, *dqkv, *delta, *dx, *du_csum;
+  // precision 2: bf16 copies that feed the bf16-resident GEMMs (hact and du exist only in bf16 there)
+  unsigned short *ctxb, *y1b, *hactb, *y2b, *g2b, *dub, *g1b, *dqkvb;
 };
 
 struct Plan {
@@ -67,6 +73,8 @@ struct Plan {
   float *feat_eff, *imgfc, *img_stats, *cat, *emb;
   std::vector<LayerBufs> layers;
   float *dcat, *d_imgfc, *d_posfc, *d_feat, *dsum, *dpk;
+  unsigned short* embb;   // precision 2: bf16 copy of the embedding output
+  bool res;               // this plan was carved for precision 2
   bool packed;      // rows = valid positions only (uniter_batch_t::cu_seqlens)
   void *ln_ws, *col_ws, *emb_ws, *attn_ws;
   size_t ln_ws_bytes, col_ws_bytes, emb_ws_bytes, attn_ws_bytes;
@@ -82,6 +90,10 @@ struct uniter_model {
   std::vector<std::string> names;
   std::vector<hipEvent_t> ev_main, ev_side;
   int precision = 0;        // 0 = fp32 MFMA GEMMs, 1 = bf16 MFMA GEMMs (fp32 storage)
+  const unsigned short* mirror = nullptr;   // bf16 copy of the flat parameter buffer (precision 2)
+  const float* mirror_base = nullptr;
+  size_t mirror_numel = 0;
+  const unsigned short* WB(int l, int k) const { return mirror + (LP(l, k) - mirror_base); }
   std::vector<hipEvent_t> ready;   // [embeddings, layer 0 .. nl-1]: parameters usable once the event has fired (consumed by the next forward)
   // profiling
   int prof_kind = 0;
@@ -137,6 +149,8 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
   pl.img_stats = cv.f(BR * 6);
   pl.cat = cv.f((size_t)B * pl.S * H);
   pl.emb = cv.f(M * H);
+  pl.res = m->precision == 2;
+  pl.embb = pl.res ? cv.h(M * H) : nullptr;
   pl.layers.resize(nl);
   const bool save = mode != 0;
   auto alloc_fwd = [&](LayerBufs& b) {
@@ -144,6 +158,7 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
     b.z1 = save ? cv.f(M * H) : nullptr; b.mean1 = cv.f(M); b.rstd1 = cv.f(M); b.y1 = cv.f(M * H);
     b.u = save ? cv.f(M * I) : nullptr; b.hact = cv.f(M * I); b.t2 = cv.f(M * H);
     b.z2 = save ? cv.f(M * H) : nullptr; b.mean2 = cv.f(M); b.rstd2 = cv.f(M); b.y2 = cv.f(M * H);
+    if (pl.res) { b.ctxb = cv.h(M * H); b.y1b = cv.h(M * H); b.hactb = cv.h(M * I); b.y2b = cv.h(M * H); }
   };
   if (save) {
     for (int l = 0; l < nl; ++l) {
@@ -154,6 +169,7 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
       b.g1 = cv.f(M * H); b.dctx = cv.f(M * H); b.dqkv = cv.f(M * 3 * H); b.delta = cv.f((size_t)B * nh * L);
       b.dx = cv.f(M * H);
       b.du_csum = cv.f((size_t)((M + 31) / 32) * I);
+      if (pl.res) { b.g2b = cv.h(M * H); b.dub = cv.h(M * I); b.g1b = cv.h(M * H); b.dqkvb = cv.h(M * 3 * H); }
     }
   } else {
     // inference: every layer reuses one set of buffers; the layer output ping-pongs
@@ -203,12 +219,22 @@ int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int
          int lda, const float* B, int ldb, float* C, int ldc, int epi, const float* bias, const float* aux_in,
          float* aux_out, int ld_aux, int beta, float* colsum_part = nullptr) {
   ProfScope ps(m, kind, st);
-  if (m->precision == 1)
+  if (m->precision >= 1)      // embeddings' projections (fp32 inputs) also run on the bf16 pipe in mode 2
     return gemm_bf16_run(0, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux_in, aux_out, ld_aux, beta,
                          colsum_part, st);
   return gemm_f32_run(0, kind == UNITER_K_GEMM_FFN_UP_FWD, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias,
                       aux_in, aux_out, ld_aux, beta, colsum_part, st);
 }
+
+// precision 2: both operands already bf16 in memory
+int gemm_r(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int N, int K, const void* A, int lda,
+           const void* B, int ldb, float* C, int ldc, unsigned short* Cb, int ldcb, int epi, const float* bias,
+           const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part = nullptr) {
+  ProfScope ps(m, kind, st);
+  return gemm_bf16res_run(0, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, Cb, ldcb, epi, bias, aux_in, aux_out, ld_aux,
+                          beta, colsum_part, st);
+}
+int cast_b(const float* src, unsigned short* dst, size_t n, hipStream_t st) { return uniter_cast_bf16(src, dst, n, st); }
 
 int validate_batch(const uniter_model* m, const uniter_batch_t* b) {
   UCHECK_ARG(b, "batch is NULL");
@@ -395,6 +421,12 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   if (packed) UCHECK_RC(uniter_row_gather(pl.cat, b->pack_src, pl.emb, M, H, B * S, st));
   else UCHECK_RC(uniter_gather_rows(pl.cat, joint ? b->gather_index : nullptr, pl.emb, B, S, L, H, st));
   const size_t PH = (size_t)B * L * H;          // one layer of the padded output
+  const bool res = pl.res;
+  if (res) {
+    UCHECK_ARG(m->mirror != nullptr, "model_forward: precision 2 needs uniter_model_set_weight_mirror");
+    UCHECK_RC(cast_b(pl.emb, pl.embb, (size_t)M * H, st));
+  }
+  const unsigned short* xb = pl.embb;
 
   // ---- encoder (model/model.py:282-292; model/layer.py:166-170) ----
   const float* x = pl.emb;
@@ -402,8 +434,12 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     LayerBufs& lb = pl.layers[l];
     if (gated) UCHECK_HIP(hipStreamWaitEvent(st, m->ready[1 + l], 0));
     float* y2 = packed ? lb.y2 : (all_layers ? hidden_out + l * PH : (l == nl - 1 ? hidden_out : lb.y2));
-    UCHECK_RC(gemm(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, x, H, m->LP(l, L_QW), H, lb.qkv, 3 * H,
-                   UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
+    if (res)
+      UCHECK_RC(gemm_r(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, xb, H, m->WB(l, L_QW), H, lb.qkv, 3 * H,
+                       nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
+    else
+      UCHECK_RC(gemm(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, x, H, m->LP(l, L_QW), H, lb.qkv, 3 * H,
+                     UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
     {
       ProfScope ps(m, UNITER_K_ATTN_FWD, st);
       if (packed)
@@ -413,18 +449,34 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
         UCHECK_RC(uniter_attn_fwd(lb.qkv, b->attention_mask, lb.ctx, lb.lse, B, L, nh, pa, seed, offset,
                                   SITE_ATTN_PROBS(l), st));
     }
-    UCHECK_RC(gemm(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, 0, M, H, H, lb.ctx, H, m->LP(l, L_OW), H, lb.t1, H,
-                   UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, nullptr, 0, 0));
+    if (res) {
+      UCHECK_RC(cast_b(lb.ctx, lb.ctxb, (size_t)M * H, st));
+      UCHECK_RC(gemm_r(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, 0, M, H, H, lb.ctxb, H, m->WB(l, L_OW), H, lb.t1, H,
+                       nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, nullptr, 0, 0));
+    } else {
+      UCHECK_RC(gemm(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, 0, M, H, H, lb.ctx, H, m->LP(l, L_OW), H, lb.t1, H,
+                     UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, nullptr, 0, 0));
+    }
     {
       ProfScope ps(m, UNITER_K_LN, st);
       UCHECK_RC(uniter_ln_fwd(lb.t1, x, m->LP(l, L_LN1_G), m->LP(l, L_LN1_B), lb.z1, lb.y1,
                               save ? lb.mean1 : nullptr, save ? lb.rstd1 : nullptr, M, H, ph, seed, offset,
                               SITE_ATTN_OUT(l), st));
     }
-    UCHECK_RC(gemm(m, UNITER_K_GEMM_FFN_UP_FWD, st, 0, 0, M, I, H, lb.y1, H, m->LP(l, L_W1), H, lb.hact, I,
-                   gelu_d ? UNITER_EPI_BIAS_GELU_D : UNITER_EPI_BIAS_GELU, m->LP(l, L_B1), nullptr, lb.u, I, 0));
-    UCHECK_RC(gemm(m, UNITER_K_GEMM_FFN_DOWN_FWD, st, 0, 0, M, H, I, lb.hact, I, m->LP(l, L_W2), I, lb.t2, H,
-                   UNITER_EPI_BIAS, m->LP(l, L_B2), nullptr, nullptr, 0, 0));
+    if (res) {
+      // the activation only exists in bf16 (operand of FFN-down and of its weight gradient)
+      UCHECK_RC(cast_b(lb.y1, lb.y1b, (size_t)M * H, st));
+      UCHECK_RC(gemm_r(m, UNITER_K_GEMM_FFN_UP_FWD, st, 0, 0, M, I, H, lb.y1b, H, m->WB(l, L_W1), H, nullptr, I,
+                       lb.hactb, I, gelu_d ? UNITER_EPI_BIAS_GELU_D : UNITER_EPI_BIAS_GELU, m->LP(l, L_B1), nullptr,
+                       lb.u, I, 0));
+      UCHECK_RC(gemm_r(m, UNITER_K_GEMM_FFN_DOWN_FWD, st, 0, 0, M, H, I, lb.hactb, I, m->WB(l, L_W2), I, lb.t2, H,
+                       nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_B2), nullptr, nullptr, 0, 0));
+    } else {
+      UCHECK_RC(gemm(m, UNITER_K_GEMM_FFN_UP_FWD, st, 0, 0, M, I, H, lb.y1, H, m->LP(l, L_W1), H, lb.hact, I,
+                     gelu_d ? UNITER_EPI_BIAS_GELU_D : UNITER_EPI_BIAS_GELU, m->LP(l, L_B1), nullptr, lb.u, I, 0));
+      UCHECK_RC(gemm(m, UNITER_K_GEMM_FFN_DOWN_FWD, st, 0, 0, M, H, I, lb.hact, I, m->LP(l, L_W2), I, lb.t2, H,
+                     UNITER_EPI_BIAS, m->LP(l, L_B2), nullptr, nullptr, 0, 0));
+    }
     {
       ProfScope ps(m, UNITER_K_LN, st);
       UCHECK_RC(uniter_ln_fwd(lb.t2, lb.y1, m->LP(l, L_LN2_G), m->LP(l, L_LN2_B), lb.z2, y2,
@@ -433,6 +485,10 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     }
     lb.y2 = y2;
     x = y2;
+    if (res) {
+      UCHECK_RC(cast_b(y2, lb.y2b, (size_t)M * H, st));
+      xb = lb.y2b;
+    }
     if (packed && (all_layers || l == nl - 1)) {
       // padded [B, L, H] view for the caller: valid rows scattered, padded positions zero
       float* dst = all_layers ? hidden_out + l * PH : hidden_out;
@@ -510,18 +566,34 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   // the GEMM's epilogue also emits per-32-row column sums of du (= partial bias gradients of
   // intermediate.dense): saves a 32 MB re-read of du
   const bool fuse_db1 = H % 64 == 0;
-  UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, g2, H, m->LP(l, L_W2), I, lb.du, I, pl.gelu_d ? UNITER_EPI_MUL : UNITER_EPI_DGELU,
-                 nullptr, lb.u, nullptr, I, 0, fuse_db1 ? lb.du_csum : nullptr));
-  UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, I, lb.du, I, m->LP(l, L_W1), H, lb.dy1, H, UNITER_EPI_ADD,
-                 nullptr, lb.dz2, nullptr, H, 0));
+  const bool res = pl.res;
+  const int epi_du = pl.gelu_d ? UNITER_EPI_MUL : UNITER_EPI_DGELU;
+  if (res) {
+    UCHECK_RC(cast_b(g2, lb.g2b, MH, st));
+    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, lb.g2b, H, m->WB(l, L_W2), I, nullptr, I, lb.dub, I,
+                     epi_du, nullptr, lb.u, nullptr, I, 0, lb.du_csum));
+    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, I, lb.dub, I, m->WB(l, L_W1), H, lb.dy1, H, nullptr, 0,
+                     UNITER_EPI_ADD, nullptr, lb.dz2, nullptr, H, 0));
+  } else {
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, g2, H, m->LP(l, L_W2), I, lb.du, I, epi_du,
+                   nullptr, lb.u, nullptr, I, 0, fuse_db1 ? lb.du_csum : nullptr));
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, I, lb.du, I, m->LP(l, L_W1), H, lb.dy1, H, UNITER_EPI_ADD,
+                   nullptr, lb.dz2, nullptr, H, 0));
+  }
   {
     ProfScope ps(m, UNITER_K_LN, st);
     UCHECK_RC(uniter_ln_bwd(lb.dy1, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1, g1, m->LG(l, L_LN1_G),
                             m->LG(l, L_LN1_B), m->LG(l, L_OB), M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l), pl.ln_ws,
                             pl.ln_ws_bytes, st));
   }
-  UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, H, g1, H, m->LP(l, L_OW), H, lb.dctx, H, UNITER_EPI_NONE,
-                 nullptr, nullptr, nullptr, 0, 0));
+  if (res) {
+    UCHECK_RC(cast_b(g1, lb.g1b, MH, st));
+    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, H, lb.g1b, H, m->WB(l, L_OW), H, lb.dctx, H, nullptr, 0,
+                     UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 0));
+  } else {
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, H, g1, H, m->LP(l, L_OW), H, lb.dctx, H, UNITER_EPI_NONE,
+                   nullptr, nullptr, nullptr, 0, 0));
+  }
   {
     ProfScope ps(m, UNITER_K_ATTN_BWD, st);
     if (pl.packed)
@@ -532,24 +604,43 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
       UCHECK_RC(uniter_attn_bwd(lb.qkv, m->batch.attention_mask, lb.ctx, lb.lse, lb.dctx, lb.dqkv, lb.delta, B, L,
                                 nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
   }
-  UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, 3 * H, lb.dqkv, 3 * H, m->LP(l, L_QW), H, lb.dx, H,
-                 UNITER_EPI_ADD, nullptr, lb.dz1, nullptr, H, 0));
+  if (res) {
+    UCHECK_RC(cast_b(lb.dqkv, lb.dqkvb, (size_t)M * 3 * H, st));
+    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, 3 * H, lb.dqkvb, 3 * H, m->WB(l, L_QW), H, lb.dx, H,
+                     nullptr, 0, UNITER_EPI_ADD, nullptr, lb.dz1, nullptr, H, 0));
+  } else {
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, 3 * H, lb.dqkv, 3 * H, m->LP(l, L_QW), H, lb.dx, H,
+                   UNITER_EPI_ADD, nullptr, lb.dz1, nullptr, H, 0));
+  }
 
   // weight / bias gradients on the side stream (accumulate into the bound grad buffers)
   if (sd != st) {
     UCHECK_HIP(hipEventRecord(m->ev_main[l], st));
     UCHECK_HIP(hipStreamWaitEvent(sd, m->ev_main[l], 0));
   }
-  UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, g2, H, lb.hact, I, m->LG(l, L_W2), I, UNITER_EPI_NONE,
-                 nullptr, nullptr, nullptr, 0, 1));
-  UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, I, H, M, lb.du, I, lb.y1, H, m->LG(l, L_W1), H, UNITER_EPI_NONE,
-                 nullptr, nullptr, nullptr, 0, 1));
-  if (fuse_db1) UCHECK_RC(finalize_partials(lb.du_csum, (M + 31) / 32, (size_t)I, m->LG(l, L_B1), I, 1, sd));
-  else UCHECK_RC(uniter_colsum_f32(lb.du, M, I, I, m->LG(l, L_B1), 1, pl.col_ws, pl.col_ws_bytes, sd));
-  UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, H, M, g1, H, lb.ctx, H, m->LG(l, L_OW), H, UNITER_EPI_NONE,
-                 nullptr, nullptr, nullptr, 0, 1));
-  UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkv, 3 * H, x, H, m->LG(l, L_QW), H,
-                 UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+  if (res) {
+    const unsigned short* xb = l == 0 ? pl.embb : pl.layers[l - 1].y2b;
+    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, lb.g2b, H, lb.hactb, I, m->LG(l, L_W2), I, nullptr, 0,
+                     UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, I, H, M, lb.dub, I, lb.y1b, H, m->LG(l, L_W1), H, nullptr, 0,
+                     UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+    UCHECK_RC(finalize_partials(lb.du_csum, (M + 31) / 32, (size_t)I, m->LG(l, L_B1), I, 1, sd));
+    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, H, M, lb.g1b, H, lb.ctxb, H, m->LG(l, L_OW), H, nullptr, 0,
+                     UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkvb, 3 * H, xb, H, m->LG(l, L_QW), H, nullptr, 0,
+                     UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+  } else {
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, g2, H, lb.hact, I, m->LG(l, L_W2), I, UNITER_EPI_NONE,
+                   nullptr, nullptr, nullptr, 0, 1));
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, I, H, M, lb.du, I, lb.y1, H, m->LG(l, L_W1), H, UNITER_EPI_NONE,
+                   nullptr, nullptr, nullptr, 0, 1));
+    if (fuse_db1) UCHECK_RC(finalize_partials(lb.du_csum, (M + 31) / 32, (size_t)I, m->LG(l, L_B1), I, 1, sd));
+    else UCHECK_RC(uniter_colsum_f32(lb.du, M, I, I, m->LG(l, L_B1), 1, pl.col_ws, pl.col_ws_bytes, sd));
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, H, M, g1, H, lb.ctx, H, m->LG(l, L_OW), H, UNITER_EPI_NONE,
+                   nullptr, nullptr, nullptr, 0, 1));
+    UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkv, 3 * H, x, H, m->LG(l, L_QW), H,
+                   UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+  }
   UCHECK_RC(uniter_colsum_f32(lb.dqkv, M, 3 * H, 3 * H, m->LG(l, L_QB), 1, pl.col_ws, pl.col_ws_bytes, sd));
   if (sd != st) UCHECK_HIP(hipEventRecord(m->ev_side[l], sd));
   return 0;
@@ -625,8 +716,26 @@ extern "C" int uniter_model_set_ready_events(uniter_model_t* m, void* const* eve
   return 0;
 }
 
+extern "C" int uniter_model_set_weight_mirror(uniter_model_t* m, const float* flat_base, const void* mirror_bf16,
+                                              size_t numel) {
+  UCHECK_ARG(m, "set_weight_mirror: null model");
+  if (!mirror_bf16) { m->mirror = nullptr; m->mirror_base = nullptr; m->mirror_numel = 0; return 0; }
+  UCHECK_ARG(flat_base && numel > 0, "set_weight_mirror: bad argument");
+  const uniter_config_t& c = m->cfg;
+  static const int ws[4] = {L_QW, L_OW, L_W1, L_W2};
+  for (int l = 0; l < c.num_hidden_layers; ++l)
+    for (int k = 0; k < 4; ++k) {
+      const float* p = m->LP(l, ws[k]);
+      UCHECK_ARG(p >= flat_base && p < flat_base + numel && (((uintptr_t)(p - flat_base) * 2) & 15) == 0,
+                 "set_weight_mirror: layer %d weight %d is not inside the flat buffer on a 16-byte bf16 boundary", l, k);
+    }
+  m->mirror = (const unsigned short*)mirror_bf16; m->mirror_base = flat_base; m->mirror_numel = numel;
+  return 0;
+}
+
 extern "C" int uniter_model_set_precision(uniter_model_t* m, int precision) {
-  UCHECK_ARG(m && (precision == 0 || precision == 1), "set_precision: 0 (fp32) or 1 (bf16 MFMA GEMMs)");
+  UCHECK_ARG(m && precision >= 0 && precision <= 2, "set_precision: 0 (fp32), 1 (bf16 MFMA, fp32 operands) or 2 (bf16-resident operands)");
+  UCHECK_ARG(precision != 2 || m->mirror, "set_precision: precision 2 needs uniter_model_set_weight_mirror first");
   m->precision = precision;
   return 0;
 }

@@ -246,6 +246,29 @@ class ParamStore(object):
     def touch(self, names):
         self.touched.update(names)
 
+    # -- bf16 mirror of the parameters (precision 'bf16': GEMM weight operands are read from it) ----
+    def ensure_mirror(self):
+        """Allocate / refresh the bf16 copy of the flat parameter buffer.  Stale when a torch op wrote
+        a parameter in place (load_state_dict, p.add_(..): every Parameter's version counter is summed,
+        ~20 us for 212 tensors) or a raw-pointer kernel did and said so (mirror_dirty; trainer.FusedAdam
+        refreshes the mirror itself, block by block)."""
+        if getattr(self, 'mirror', None) is None or self.mirror.device != self.flat_params.device:
+            self.mirror = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat_params.device)
+            self.mirror_dirty = True
+            self._mirror_version = -1
+        version = self.flat_params._version
+        for p in self.params.values():
+            version += p._version
+        if self.mirror_dirty or self._mirror_version != version:
+            self.refresh_mirror(0, self.numel, _lib.cur_stream())
+            self.mirror_dirty = False
+            self._mirror_version = version
+        return self.mirror
+
+    def refresh_mirror(self, lo, hi, stream_ptr):
+        check(_lib.lib().uniter_cast_bf16(self.flat_params.data_ptr() + 4 * lo, self.mirror.data_ptr() + 2 * lo,
+                                          hi - lo, stream_ptr), 'uniter_cast_bf16')
+
     def zero_grads(self):
         self.flat_grads.zero_()
         self.touched.clear()
@@ -627,7 +650,9 @@ class UniterModel(UniterPreTrainedModel):
         self._grad_hook = None       # callable(kind, index) used by the DP gradient exchange
         self._side_stream = None
         self.use_side_stream = True
-        self.precision = 'fp32'      # or 'bf16': bf16 MFMA for the dense GEMMs, fp32 everywhere else
+        # 'fp32'; 'bf16': bf16 MFMA GEMMs on bf16-resident operands (weight mirror + bf16 activation copies),
+        # fp32 master weights / LayerNorm / softmax / optimizer; 'bf16_hybrid': bf16 MFMA, operands converted in flight
+        self.precision = 'fp32'
         self.pack_padded = False     # True: compute the valid positions only (see _pack); padded outputs are 0
 
     # -- plumbing ------------------------------------------------------------
@@ -669,10 +694,17 @@ class UniterModel(UniterPreTrainedModel):
             self._handle = h
             self._prefix_names = None
             self._applied_precision = None
-        if self._applied_precision != self.precision:
-            if self.precision not in ('fp32', 'bf16'):
-                raise ValueError("precision must be 'fp32' or 'bf16'")
-            check(_lib.lib().uniter_model_set_precision(self._handle, 1 if self.precision == 'bf16' else 0),
+        if self.precision not in ('fp32', 'bf16', 'bf16_hybrid'):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16_hybrid'")
+        if self.precision == 'bf16':
+            mirror = st.ensure_mirror()            # refreshed here whenever the parameters changed behind its back
+            if self._applied_precision != (self.precision, mirror.data_ptr()):
+                check(_lib.lib().uniter_model_set_weight_mirror(self._handle, ptr(st.flat_params), ptr(mirror),
+                                                                st.numel), 'uniter_model_set_weight_mirror')
+                check(_lib.lib().uniter_model_set_precision(self._handle, 2), 'uniter_model_set_precision')
+                self._applied_precision = (self.precision, mirror.data_ptr())
+        elif self._applied_precision != self.precision:
+            check(_lib.lib().uniter_model_set_precision(self._handle, 1 if self.precision == 'bf16_hybrid' else 0),
                   'uniter_model_set_precision')
             self._applied_precision = self.precision
         return st

@@ -182,6 +182,13 @@ class FusedAdam(torch.optim.Optimizer):
                                        int(self.adamw), int(bool(zero_grads)), stream_ptr),
                   'uniter_adam_step')
 
+        mirror = getattr(st, 'mirror', None)
+
+        def launch(lo, hi, stream_ptr, _adam=launch):
+            _adam(lo, hi, stream_ptr)
+            if mirror is not None:                 # keep the bf16 weight mirror in step, on the same stream
+                st.refresh_mirror(lo, hi, stream_ptr)
+
         enc = self.overlap_encoder
         plan = self._overlap_plan(enc) if enc is not None else None
         if plan is None:

@@ -144,15 +144,18 @@ def test_train_mode_dropout_replay_matches_oracle(tiny):
     assert maxdiff(l2, logits) > 1e-6
 
 
-def test_bf16_mfma_mode_tracks_fp32_reference(shapes_base):
-    """precision='bf16': dense GEMM operands rounded to bf16 (fp32 accumulate / storage).  Not the
-    1e-3 fp32 parity bar: bf16 has 8 significant bits, so the bar is closeness + gradient direction."""
+@pytest.mark.parametrize('mode', ['bf16', 'bf16_hybrid'])
+def test_bf16_mfma_mode_tracks_fp32_reference(shapes_base, mode):
+    """precision='bf16' (bf16-resident operands: weight mirror + bf16 activation copies) and
+    'bf16_hybrid' (fp32 operands rounded in flight): dense GEMM inputs in bf16, fp32 accumulate,
+    fp32 everything else.  Not the 1e-3 fp32 parity bar: bf16 has 8 significant bits, so the bar is
+    closeness + gradient direction."""
     from meme_challenge_amd.trainer import bce_with_logits_loss
     from meme_challenge_amd.utils import make_synthetic_batch
     z = shapes_base
     sd = O.synth_state_dict(BASE, seed=0, ln_jitter=0.02)
     m = build(BASE, 2048, sd).eval()
-    m.uniter_model.precision = 'bf16'
+    m.uniter_model.precision = mode
     B, T, R, seed = z['cfg1_full/shape'].tolist()
     b = make_synthetic_batch(B, T, R, seed=seed, device='cuda')
     logits = m(**model_kwargs(b))
@@ -176,3 +179,34 @@ def test_bf16_mfma_mode_tracks_fp32_reference(shapes_base):
     m.uniter_model.precision = 'fp32'
     l2 = m(**model_kwargs(b))
     assert maxdiff(l2, ref) < 5e-5               # switching back restores exact fp32 parity
+
+
+def test_bf16_resident_equals_hybrid_and_follows_weight_updates(shapes_base):
+    """The resident path multiplies the same bf16 values as the hybrid one (only the summation order
+    of the atomically accumulated weight gradients differs), and its bf16 weight mirror follows both
+    torch-side writes (load_state_dict) and FusedAdam steps."""
+    from meme_challenge_amd.trainer import bce_with_logits_loss, FusedAdam
+    from meme_challenge_amd.utils import make_synthetic_batch
+    z = shapes_base
+    sd = O.synth_state_dict(BASE, seed=0, ln_jitter=0.02)
+    B, T, R, seed = z['cfg1_full/shape'].tolist()
+    b = make_synthetic_batch(B, T, R, seed=seed, device='cuda')
+    out = {}
+    for mode in ('bf16_hybrid', 'bf16'):
+        m = build(BASE, 2048, sd).eval()
+        m.uniter_model.precision = mode
+        opt = FusedAdam(m, lr=1e-3, weight_decay=0.0)
+        logits0 = m(**model_kwargs(b))
+        bce_with_logits_loss(logits0, b['labels'], 1.8).backward()
+        g = m.uniter_model.encoder.layer[3].intermediate.dense.weight.grad.detach().clone()
+        opt.step(grad_scale=1.0, max_grad_norm=5.0)
+        with torch.no_grad():
+            logits1 = m(**model_kwargs(b))                  # must see the updated weights
+            m.load_state_dict(sd)
+            logits2 = m(**model_kwargs(b))                  # and the restored ones
+        out[mode] = (logits0.detach(), g, logits1, logits2)
+    h, r = out['bf16_hybrid'], out['bf16']
+    assert maxdiff(r[0], h[0]) < 1e-5
+    assert maxdiff(r[1], h[1]) < 1e-6 + 1e-3 * h[1].abs().max().item()
+    assert maxdiff(r[2], h[2]) < 2e-3 and maxdiff(r[2], r[0]) > 1e-3      # the step moved the logits, equally in both
+    assert maxdiff(r[3], r[0]) < 1e-6
