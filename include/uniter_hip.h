@@ -138,6 +138,15 @@ int uniter_ln_bwd(const float* dy, const float* z, const float* mean, const floa
                   const float* gamma, float* dz, float* dx, float* dgamma, float* dbeta,
                   float* dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
                   uint32_t site, void* ws, size_t ws_bytes, void* stream);
+/* As uniter_ln_fwd / uniter_ln_bwd with an additional bf16 (round-to-nearest-even) copy of y / dx for the
+ * bf16-resident GEMMs (NULL = none): saves a separate uniter_cast_bf16 pass over the activation. */
+int uniter_ln_fwd_b16(const float* x, const float* res, const float* gamma, const float* beta,
+                      float* z_out, float* y, void* y_bf16, float* mean, float* rstd, int M, int H,
+                      float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream);
+int uniter_ln_bwd_b16(const float* dy, const float* z, const float* mean, const float* rstd,
+                      const float* gamma, float* dz, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
+                      float* dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
+                      uint32_t site, void* ws, size_t ws_bytes, void* stream);
 size_t uniter_ln_bwd_ws_bytes(int M, int H);
 
 /* ------------------------------------------------------------------------- *
@@ -174,6 +183,15 @@ int uniter_attn_bwd_varlen(const float* qkv, const int32_t* cu_seqlens, const fl
                            const float* lse, const float* dctx, float* dqkv, float* delta,
                            int B, int Lmax, int nh, float p_drop, uint64_t seed, uint32_t offset,
                            uint32_t site, void* ws, size_t ws_bytes, void* stream);
+/* General forms of the L <= uniter_attn_varlen_max_len() kernels: exactly one of attn_mask / cu_seqlens,
+ * plus optional bf16 copies of ctx / dqkv (operands of the bf16-resident GEMMs; NULL = none). */
+int uniter_attn_fwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+                       void* ctx_bf16, float* lse, int B, int L, int nh, float p_drop, uint64_t seed,
+                       uint32_t offset, uint32_t site, void* stream);
+int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
+                       const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16,
+                       float* delta, int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
+                       uint32_t site, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Embeddings (replace UniterTextEmbeddings.forward model/model.py:232-245,

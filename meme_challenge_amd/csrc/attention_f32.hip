@@ -41,6 +41,8 @@ struct AttnArgs {
   const float* dctx;
   float* dqkv;
   float* delta;         // [B, nh, L]
+  unsigned short* ctx_b16;   // optional bf16 copies of ctx / dqkv (operands of bf16-resident GEMMs)
+  unsigned short* dqkv_b16;
   const int* cu;        // [B+1] prefix sums of per-sample lengths (packed rows), or NULL: sample b owns rows b*L .. b*L+L-1
   int B, L, nh, H, Lp4; // Lp4 = roundup(L,4)/4
   float scale;
@@ -105,6 +107,18 @@ __device__ __forceinline__ void store_rowT(float* __restrict__ row, const f32x16
     f32x4 v1 = {a1[4 * g] * mul, a1[4 * g + 1] * mul, a1[4 * g + 2] * mul, a1[4 * g + 3] * mul};
     *reinterpret_cast<f32x4*>(row + 8 * g + 4 * h) = v0;
     *reinterpret_cast<f32x4*>(row + 32 + 8 * g + 4 * h) = v1;
+  }
+}
+
+__device__ __forceinline__ void store_rowT_bf16(unsigned short* __restrict__ row, const f32x16& a0, const f32x16& a1,
+                                                float mul, int h) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bf16x4_t v0 = {(__bf16)(a0[4 * g] * mul), (__bf16)(a0[4 * g + 1] * mul), (__bf16)(a0[4 * g + 2] * mul), (__bf16)(a0[4 * g + 3] * mul)};
+    bf16x4_t v1 = {(__bf16)(a1[4 * g] * mul), (__bf16)(a1[4 * g + 1] * mul), (__bf16)(a1[4 * g + 2] * mul), (__bf16)(a1[4 * g + 3] * mul)};
+    *reinterpret_cast<bf16x4_t*>(row + 8 * g + 4 * h) = v0;
+    *reinterpret_cast<bf16x4_t*>(row + 32 + 8 * g + 4 * h) = v1;
   }
 }
 
@@ -640,6 +654,7 @@ __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, i
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (vq) {
     store_rowT(a.ctx + ((size_t)sp.row0 + q) * a.H + head * D, o0, o1, 1.0f / l_tot, h);
+    if (a.ctx_b16) store_rowT_bf16(a.ctx_b16 + ((size_t)sp.row0 + q) * a.H + head * D, o0, o1, 1.0f / l_tot, h);
     if (h == 0 && a.lse) a.lse[(size_t)bh * a.L + q] = m_run + __logf(l_tot);
   }
 }
@@ -722,7 +737,10 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
   if (half) return;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dq0[r] += xb[r * 64 + lane]; dq1[r] += xb[(16 + r) * 64 + lane]; }
-  if (vq) store_rowT(a.dqkv + ((size_t)sp.row0 + q) * ld + head * D, dq0, dq1, 1.0f, h);
+  if (vq) {
+    store_rowT(a.dqkv + ((size_t)sp.row0 + q) * ld + head * D, dq0, dq1, 1.0f, h);
+    if (a.dqkv_b16) store_rowT_bf16(a.dqkv_b16 + ((size_t)sp.row0 + q) * ld + head * D, dq0, dq1, 1.0f, h);
+  }
 }
 
 // dV^T[d][key] = sum_q dO[q][d] Pd[q][key],  dK^T[d][key] = sum_q Q[q][d] dS[q][key]
@@ -800,6 +818,11 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs 
     float* row = a.dqkv + ((size_t)sp.row0 + key) * ld + head * D;
     store_rowT(row + a.H, dk0, dk1, 1.0f, h);
     store_rowT(row + 2 * a.H, dv0, dv1, 1.0f, h);
+    if (a.dqkv_b16) {
+      unsigned short* rb = a.dqkv_b16 + ((size_t)sp.row0 + key) * ld + head * D;
+      store_rowT_bf16(rb + a.H, dk0, dk1, 1.0f, h);
+      store_rowT_bf16(rb + 2 * a.H, dv0, dv1, 1.0f, h);
+    }
   }
 }
 
@@ -887,6 +910,48 @@ extern "C" int uniter_attn_bwd_varlen(const float* qkv, const int32_t* cu_seqlen
   UCHECK_RC(make_args(a, B, Lmax, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = nullptr; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
   a.dctx = dctx; a.dqkv = dqkv; a.delta = delta;
+  const size_t lds = res_lds_bytes(Lr);
+  float* pd_ws = (float*)ws;
+  float* ds_ws = pd_ws + (size_t)B * nh * Lr * Lr;
+  UCHECK_RC(set_dyn_lds(attn_bwd_dq_split_kernel, lds));
+  UCHECK_RC(set_dyn_lds(attn_bwd_dkv_split_kernel, lds));
+  hipLaunchKernelGGL(attn_bwd_dq_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr, pd_ws, ds_ws);
+  UCHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr, pd_ws, ds_ws);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+// General forms: mask XOR cu_seqlens, optional bf16 copies of the outputs (split kernels only: L <= 192).
+extern "C" int uniter_attn_fwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+                                  void* ctx_bf16, float* lse, int B, int L, int nh, float p_drop, uint64_t seed,
+                                  uint32_t offset, uint32_t site, void* stream) {
+  UCHECK_ARG(qkv && ctx && ((attn_mask != nullptr) != (cu_seqlens != nullptr)), "attn_fwd_ex: need attn_mask or cu_seqlens (not both)");
+  AttnArgs a = {};
+  UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
+  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_b16 = (unsigned short*)ctx_bf16; a.lse = lse;
+  const int Lr = (L + 31) / 32 * 32;
+  UCHECK_SHAPE(Lr <= uniter_attn_varlen_max_len(), "attn_fwd_ex: L %d > %d", L, uniter_attn_varlen_max_len());
+  const size_t lds = res_lds_bytes(Lr);
+  UCHECK_RC(set_dyn_lds(attn_fwd_split_kernel, lds));
+  hipLaunchKernelGGL(attn_fwd_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
+                                  const float* ctx, const float* lse, const float* dctx, float* dqkv,
+                                  void* dqkv_bf16, float* delta, int B, int L, int nh, float p_drop, uint64_t seed,
+                                  uint32_t offset, uint32_t site, void* ws, size_t ws_bytes, void* stream) {
+  UCHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta && ws && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
+             "attn_bwd_ex: null pointer, or not exactly one of attn_mask / cu_seqlens");
+  const int Lr = (L + 31) / 32 * 32;
+  UCHECK_SHAPE(Lr <= uniter_attn_varlen_max_len(), "attn_bwd_ex: L %d > %d", L, uniter_attn_varlen_max_len());
+  UCHECK_ARG(ws_bytes >= (size_t)2 * B * nh * Lr * Lr * sizeof(float), "attn_bwd_ex: workspace too small");
+  AttnArgs a = {};
+  UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
+  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
+  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (unsigned short*)dqkv_bf16; a.delta = delta;
   const size_t lds = res_lds_bytes(Lr);
   float* pd_ws = (float*)ws;
   float* ds_ws = pd_ws + (size_t)B * nh * Lr * Lr;

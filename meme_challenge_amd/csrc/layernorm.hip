@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ z_out, float* __restrict__ y,
                                                      float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int M, int H,
-                                                     DropCfg drop) {
+                                                     DropCfg drop, unsigned short* __restrict__ y_b16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if (mean_out && lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
   row_affine<NV>(v, gamma, beta, mean, rstd, H4, lane);
   row_store<NV>(v, y + (size_t)row * H, H4, lane);
+  if (y_b16) row_store_bf16<NV>(v, y_b16 + (size_t)row * H, H4, lane);     // operand copy for a bf16-resident GEMM
 }
 
 // grid: nblk workgroups of 4 waves; wave w of block b walks rows b*4+w, +4*nblk, ...
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma,
                                                      float* __restrict__ dz, float* __restrict__ dx,
                                                      float* __restrict__ part, int M, int H,
-                                                     DropCfg drop, int want_dbias) {
+                                                     DropCfg drop, int want_dbias,
+                                                     unsigned short* __restrict__ dx_b16) {
   __shared__ __attribute__((aligned(16))) float red[4 * NV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H4 = H >> 2;
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     if (dz) row_store<NV>(d, dz + (size_t)row * H, H4, lane);
     if (drop.active) row_dropout<NV>(d, drop, (uint64_t)row * H4, H4, lane);
     if (dx && (dx != dz || drop.active)) row_store<NV>(d, dx + (size_t)row * H, H4, lane);
+    if (dx_b16) row_store_bf16<NV>(d, dx_b16 + (size_t)row * H, H4, lane);
     if (want_dbias) {
 #pragma unroll
       for (int k = 0; k < NV; ++k) if (lane + 64 * k < H4) dbx[k] += d[k];
@@ -235,6 +238,12 @@ extern "C" int uniter_ln_fwd(const float* x, const float* res, const float* gamm
                              float* z_out, float* y, float* mean, float* rstd, int M, int H,
                              float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
                              void* stream) {
+  return uniter_ln_fwd_b16(x, res, gamma, beta, z_out, y, nullptr, mean, rstd, M, H, p_drop, seed, offset, site, stream);
+}
+
+extern "C" int uniter_ln_fwd_b16(const float* x, const float* res, const float* gamma, const float* beta,
+                                 float* z_out, float* y, void* y_bf16, float* mean, float* rstd, int M, int H,
+                                 float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
   UCHECK_ARG(x && gamma && beta && y, "ln_fwd: null pointer");
   UCHECK_ARG((mean == nullptr) == (rstd == nullptr), "ln_fwd: mean/rstd must both be given or NULL");
   UCHECK_SHAPE(H % 4 == 0 && H >= 4, "ln_fwd: H must be a multiple of 4");
@@ -243,7 +252,8 @@ extern "C" int uniter_ln_fwd(const float* x, const float* res, const float* gamm
   hipStream_t st = (hipStream_t)stream;
   const DropCfg drop = make_drop(p_drop, seed, offset, site);
   const int nv = (H / 4 + 63) / 64;
-  LN_DISPATCH(nv, ln_fwd_kernel, dim3((M + 3) / 4), x, res, gamma, beta, z_out, y, mean, rstd, M, H, drop);
+  LN_DISPATCH(nv, ln_fwd_kernel, dim3((M + 3) / 4), x, res, gamma, beta, z_out, y, mean, rstd, M, H, drop,
+              (unsigned short*)y_bf16);
   UCHECK_LAUNCH();
   return 0;
 }
@@ -256,6 +266,14 @@ extern "C" int uniter_ln_bwd(const float* dy, const float* z, const float* mean,
                              const float* gamma, float* dz, float* dx, float* dgamma, float* dbeta,
                              float* dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
                              uint32_t site, void* ws, size_t ws_bytes, void* stream) {
+  return uniter_ln_bwd_b16(dy, z, mean, rstd, gamma, dz, dx, nullptr, dgamma, dbeta, dbias, M, H, p_drop, seed, offset,
+                           site, ws, ws_bytes, stream);
+}
+
+extern "C" int uniter_ln_bwd_b16(const float* dy, const float* z, const float* mean, const float* rstd,
+                                 const float* gamma, float* dz, float* dx, void* dx_bf16, float* dgamma,
+                                 float* dbeta, float* dbias, int M, int H, float p_drop, uint64_t seed,
+                                 uint32_t offset, uint32_t site, void* ws, size_t ws_bytes, void* stream) {
   UCHECK_ARG(dy && z && mean && rstd && gamma && dgamma && dbeta && ws, "ln_bwd: null pointer");
   UCHECK_ARG(dz || dx, "ln_bwd: need dz or dx");
   UCHECK_SHAPE(H % 4 == 0 && H >= 4, "ln_bwd: H must be a multiple of 4");
@@ -266,7 +284,8 @@ extern "C" int uniter_ln_bwd(const float* dy, const float* z, const float* mean,
   const int nv = (H / 4 + 63) / 64;
   const int nblk = ln_bwd_blocks(M);
   float* part = (float*)ws;
-  LN_DISPATCH(nv, ln_bwd_kernel, dim3(nblk), dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop, dbias != nullptr);
+  LN_DISPATCH(nv, ln_bwd_kernel, dim3(nblk), dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop, dbias != nullptr,
+              (unsigned short*)dx_bf16);
   UCHECK_LAUNCH();
   float* outs[3] = {dgamma, dbeta, dbias};
   return finalize_partials_multi(part, nblk, (size_t)3 * H, outs, dbias ? 3 : 2, H, st);

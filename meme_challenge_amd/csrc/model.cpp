@@ -427,6 +427,8 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     UCHECK_RC(cast_b(pl.emb, pl.embb, (size_t)M * H, st));
   }
   const unsigned short* xb = pl.embb;
+  // the L <= 192 attention kernels write the bf16 copies of their outputs themselves
+  const bool attn_b16 = res && L <= uniter_attn_varlen_max_len();
 
   // ---- encoder (model/model.py:282-292; model/layer.py:166-170) ----
   const float* x = pl.emb;
@@ -442,15 +444,16 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
                      UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
     {
       ProfScope ps(m, UNITER_K_ATTN_FWD, st);
-      if (packed)
-        UCHECK_RC(uniter_attn_fwd_varlen(lb.qkv, b->cu_seqlens, lb.ctx, lb.lse, B, L, nh, pa, seed, offset,
-                                         SITE_ATTN_PROBS(l), st));
+      if (packed || attn_b16)
+        UCHECK_RC(uniter_attn_fwd_ex(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
+                                     lb.ctx, attn_b16 ? lb.ctxb : nullptr, lb.lse, B, L, nh, pa, seed, offset,
+                                     SITE_ATTN_PROBS(l), st));
       else
         UCHECK_RC(uniter_attn_fwd(lb.qkv, b->attention_mask, lb.ctx, lb.lse, B, L, nh, pa, seed, offset,
                                   SITE_ATTN_PROBS(l), st));
     }
     if (res) {
-      UCHECK_RC(cast_b(lb.ctx, lb.ctxb, (size_t)M * H, st));
+      if (!attn_b16) UCHECK_RC(cast_b(lb.ctx, lb.ctxb, (size_t)M * H, st));
       UCHECK_RC(gemm_r(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, 0, M, H, H, lb.ctxb, H, m->WB(l, L_OW), H, lb.t1, H,
                        nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, nullptr, 0, 0));
     } else {
@@ -459,13 +462,12 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     }
     {
       ProfScope ps(m, UNITER_K_LN, st);
-      UCHECK_RC(uniter_ln_fwd(lb.t1, x, m->LP(l, L_LN1_G), m->LP(l, L_LN1_B), lb.z1, lb.y1,
-                              save ? lb.mean1 : nullptr, save ? lb.rstd1 : nullptr, M, H, ph, seed, offset,
-                              SITE_ATTN_OUT(l), st));
+      UCHECK_RC(uniter_ln_fwd_b16(lb.t1, x, m->LP(l, L_LN1_G), m->LP(l, L_LN1_B), lb.z1, lb.y1, res ? lb.y1b : nullptr,
+                                  save ? lb.mean1 : nullptr, save ? lb.rstd1 : nullptr, M, H, ph, seed, offset,
+                                  SITE_ATTN_OUT(l), st));
     }
     if (res) {
       // the activation only exists in bf16 (operand of FFN-down and of its weight gradient)
-      UCHECK_RC(cast_b(lb.y1, lb.y1b, (size_t)M * H, st));
       UCHECK_RC(gemm_r(m, UNITER_K_GEMM_FFN_UP_FWD, st, 0, 0, M, I, H, lb.y1b, H, m->WB(l, L_W1), H, nullptr, I,
                        lb.hactb, I, gelu_d ? UNITER_EPI_BIAS_GELU_D : UNITER_EPI_BIAS_GELU, m->LP(l, L_B1), nullptr,
                        lb.u, I, 0));
@@ -479,16 +481,13 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     }
     {
       ProfScope ps(m, UNITER_K_LN, st);
-      UCHECK_RC(uniter_ln_fwd(lb.t2, lb.y1, m->LP(l, L_LN2_G), m->LP(l, L_LN2_B), lb.z2, y2,
-                              save ? lb.mean2 : nullptr, save ? lb.rstd2 : nullptr, M, H, ph, seed, offset,
-                              SITE_FFN_OUT(l), st));
+      UCHECK_RC(uniter_ln_fwd_b16(lb.t2, lb.y1, m->LP(l, L_LN2_G), m->LP(l, L_LN2_B), lb.z2, y2, res ? lb.y2b : nullptr,
+                                  save ? lb.mean2 : nullptr, save ? lb.rstd2 : nullptr, M, H, ph, seed, offset,
+                                  SITE_FFN_OUT(l), st));
     }
     lb.y2 = y2;
     x = y2;
-    if (res) {
-      UCHECK_RC(cast_b(y2, lb.y2b, (size_t)M * H, st));
-      xb = lb.y2b;
-    }
+    if (res) xb = lb.y2b;
     if (packed && (all_layers || l == nl - 1)) {
       // padded [B, L, H] view for the caller: valid rows scattered, padded positions zero
       float* dst = all_layers ? hidden_out + l * PH : hidden_out;
@@ -558,18 +557,18 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   float* g1 = ph > 0.f ? lb.g1 : lb.dz1;
   {
     ProfScope ps(m, UNITER_K_LN, st);
-    UCHECK_RC(uniter_ln_bwd(dy, lb.z2, lb.mean2, lb.rstd2, m->LP(l, L_LN2_G), lb.dz2, g2, m->LG(l, L_LN2_G),
-                            m->LG(l, L_LN2_B), m->LG(l, L_B2), M, H, ph, m->seed, m->offset, SITE_FFN_OUT(l), pl.ln_ws,
-                            pl.ln_ws_bytes, st));
+    UCHECK_RC(uniter_ln_bwd_b16(dy, lb.z2, lb.mean2, lb.rstd2, m->LP(l, L_LN2_G), lb.dz2, g2, pl.res ? lb.g2b : nullptr,
+                                m->LG(l, L_LN2_G), m->LG(l, L_LN2_B), m->LG(l, L_B2), M, H, ph, m->seed, m->offset,
+                                SITE_FFN_OUT(l), pl.ln_ws, pl.ln_ws_bytes, st));
   }
   // FFN down dgrad (+ GELU'), FFN up dgrad (+ residual grad)
   // the GEMM's epilogue also emits per-32-row column sums of du (= partial bias gradients of
   // intermediate.dense): saves a 32 MB re-read of du
   const bool fuse_db1 = H % 64 == 0;
   const bool res = pl.res;
+  const bool attn_b16 = res && L <= uniter_attn_varlen_max_len();
   const int epi_du = pl.gelu_d ? UNITER_EPI_MUL : UNITER_EPI_DGELU;
   if (res) {
-    UCHECK_RC(cast_b(g2, lb.g2b, MH, st));
     UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, lb.g2b, H, m->WB(l, L_W2), I, nullptr, I, lb.dub, I,
                      epi_du, nullptr, lb.u, nullptr, I, 0, lb.du_csum));
     UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, I, lb.dub, I, m->WB(l, L_W1), H, lb.dy1, H, nullptr, 0,
@@ -582,12 +581,11 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   {
     ProfScope ps(m, UNITER_K_LN, st);
-    UCHECK_RC(uniter_ln_bwd(lb.dy1, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1, g1, m->LG(l, L_LN1_G),
-                            m->LG(l, L_LN1_B), m->LG(l, L_OB), M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l), pl.ln_ws,
-                            pl.ln_ws_bytes, st));
+    UCHECK_RC(uniter_ln_bwd_b16(lb.dy1, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1, g1, res ? lb.g1b : nullptr,
+                                m->LG(l, L_LN1_G), m->LG(l, L_LN1_B), m->LG(l, L_OB), M, H, ph, m->seed, m->offset,
+                                SITE_ATTN_OUT(l), pl.ln_ws, pl.ln_ws_bytes, st));
   }
   if (res) {
-    UCHECK_RC(cast_b(g1, lb.g1b, MH, st));
     UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, H, lb.g1b, H, m->WB(l, L_OW), H, lb.dctx, H, nullptr, 0,
                      UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 0));
   } else {
@@ -596,16 +594,17 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   {
     ProfScope ps(m, UNITER_K_ATTN_BWD, st);
-    if (pl.packed)
-      UCHECK_RC(uniter_attn_bwd_varlen(lb.qkv, m->batch.cu_seqlens, lb.ctx, lb.lse, lb.dctx, lb.dqkv, lb.delta, B,
-                                       L, nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), pl.attn_ws,
-                                       pl.attn_ws_bytes, st));
+    if (pl.packed || attn_b16)
+      UCHECK_RC(uniter_attn_bwd_ex(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
+                                   pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, lb.dqkv,
+                                   attn_b16 ? lb.dqkvb : nullptr, lb.delta, B, L, nh, pa, m->seed, m->offset,
+                                   SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
     else
       UCHECK_RC(uniter_attn_bwd(lb.qkv, m->batch.attention_mask, lb.ctx, lb.lse, lb.dctx, lb.dqkv, lb.delta, B, L,
                                 nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
   }
   if (res) {
-    UCHECK_RC(cast_b(lb.dqkv, lb.dqkvb, (size_t)M * 3 * H, st));
+    if (!attn_b16) UCHECK_RC(cast_b(lb.dqkv, lb.dqkvb, (size_t)M * 3 * H, st));
     UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, 3 * H, lb.dqkvb, 3 * H, m->WB(l, L_QW), H, lb.dx, H,
                      nullptr, 0, UNITER_EPI_ADD, nullptr, lb.dz1, nullptr, H, 0));
   } else {

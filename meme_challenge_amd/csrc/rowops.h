@@ -23,6 +23,19 @@ __device__ __forceinline__ void row_store(const f32x4 (&v)[NV], float* __restric
     if (c < H4) reinterpret_cast<f32x4*>(p)[c] = v[k];
   }
 }
+// bf16 (round-to-nearest-even) copy of a row: 4 elements = 8 bytes per lane and vector
+template <int NV>
+__device__ __forceinline__ void row_store_bf16(const f32x4 (&v)[NV], unsigned short* __restrict__ p, int H4, int lane) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = lane + 64 * k;
+    if (c < H4) {
+      bf16x4_t o = {(__bf16)v[k][0], (__bf16)v[k][1], (__bf16)v[k][2], (__bf16)v[k][3]};
+      reinterpret_cast<bf16x4_t*>(p)[c] = o;
+    }
+  }
+}
 // multiply by the dropout keep-mask * 1/(1-p); group0 = index of the row's first 4-element group
 template <int NV>
 __device__ __forceinline__ void row_dropout(f32x4 (&v)[NV], const DropCfg& d, uint64_t group0, int H4, int lane) {
