@@ -31,13 +31,17 @@ LARGE = dict(BASE, hidden_size=1024, intermediate_size=4096, num_attention_heads
 PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}       # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32)
 
 
-def flops_per_step(cfg, B, T, R, L=None):
+def flops_per_step(cfg, B, T, R, L=None, lens=None):
     """Algorithmic FLOPs: 2MNK per GEMM, bwd = 2x fwd, attention
     QK^T and PV included, elementwise excluded.  Returns (total, ffn_only, ffn_up_fwd)."""
     H, I, nl = cfg['hidden_size'], cfg['intermediate_size'], cfg['num_hidden_layers']
     L = T + R if L is None else L         # compacted joint length (max over the batch of tl + nbb)
     M = B * L
-    per_layer = 2 * M * H * 3 * H + 2 * M * H * H + 2 * 2 * M * H * I + 2 * 2 * B * L * L * H
+    sq = B * L * L
+    if lens is not None:                  # token packing: only the valid positions are computed
+        M = sum(lens)
+        sq = sum(n * n for n in lens)
+    per_layer = 2 * M * H * 3 * H + 2 * M * H * H + 2 * 2 * M * H * I + 2 * 2 * sq * H
     fwd = nl * per_layer + 2 * B * R * 2048 * H + 2 * B * H * H + 2 * B * H
     ffn_up_fwd = 2 * M * H * I
     return 3 * fwd, 3 * nl * 2 * ffn_up_fwd, ffn_up_fwd
@@ -229,7 +233,9 @@ def main():
         value = B * world * args.steps / dt
         L_eff = int((batch if args.workload == 'finetune' else batches['itm'])
                     ['attn_mask' if args.workload == 'finetune' else 'attn_masks'].shape[1])
-        total, ffn, ffn_up = flops_per_step(cfgd, B, T, R, L_eff)
+        cur = batch if args.workload == 'finetune' else batches['itm']
+        total, ffn, ffn_up = flops_per_step(cfgd, B, T, R, L_eff, cur['seq_lens'] if args.packed else None)
+        M_eff = sum(cur['seq_lens']) if args.packed else B * L_eff
         dt_name = 'f32' if args.precision == 'fp32' else 'bf16'
         peak = PEAK_TFLOPS[dt_name]
         out = {
@@ -257,11 +263,11 @@ def main():
             ach = ffn_up / (avg_ms * 1e-3) / 1e12 if args.prof_kind == 1 else None
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2) if ach else None, 'peak': peak,
                                'unit': 'TFLOP/s', 'frac': round(ach / peak, 4) if ach else None,
-                               'traffic': pmc_traffic(args, B * L_eff, cfgd),
+                               'traffic': pmc_traffic(args, M_eff, cfgd),
                                'kernel': ('gemm_f32_v3_kernel<64,64,false,false,TAG=1>' if args.precision == 'fp32'
                                           else 'gemm_bf16_kernel<...,false,false>') +
                                          ' (FFN-up fwd: M=%d N=%d K=%d, bias+GELU epilogue)'
-                                         % (B * L_eff, cfgd['intermediate_size'], cfgd['hidden_size']),
+                                         % (M_eff, cfgd['intermediate_size'], cfgd['hidden_size']),
                                'launches': n_launch.value, 'avg_ms': round(avg_ms, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
