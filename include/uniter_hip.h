@@ -147,6 +147,15 @@ int uniter_ln_bwd_b16(const float* dy, const float* z, const float* mean, const 
                       const float* gamma, float* dz, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
                       float* dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
                       uint32_t site, void* ws, size_t ws_bytes, void* stream);
+/* uniter_ln_bwd_b16 in two calls: _rows writes dz / dx (what the backward chain needs) and the per-block
+ * column partials into ws; _finalize reduces them into dgamma / dbeta / dbias (+=) and may run later on
+ * another stream (ws must stay untouched in between). */
+int uniter_ln_bwd_rows(const float* dy, const float* z, const float* mean, const float* rstd,
+                       const float* gamma, float* dz, float* dx, void* dx_bf16, int want_dbias, int M, int H,
+                       float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws, size_t ws_bytes,
+                       void* stream);
+int uniter_ln_bwd_finalize(const void* ws, size_t ws_bytes, int M, int H, float* dgamma, float* dbeta,
+                           float* dbias, void* stream);
 size_t uniter_ln_bwd_ws_bytes(int M, int H);
 
 /* ------------------------------------------------------------------------- *

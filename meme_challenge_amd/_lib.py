@@ -57,6 +57,8 @@ _SIGS = {
     'uniter_ln_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P]),
     'uniter_ln_fwd_b16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P]),
     'uniter_ln_bwd_b16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
+    'uniter_ln_bwd_rows': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
+    'uniter_ln_bwd_finalize': (_I, [_P, _SZ, _I, _I, _P, _P, _P, _P]),
     'uniter_ln_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_ln_bwd_ws_bytes': (_SZ, [_I, _I]),
     'uniter_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P]),

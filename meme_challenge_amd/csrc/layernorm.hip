@@ -274,7 +274,20 @@ extern "C" int uniter_ln_bwd_b16(const float* dy, const float* z, const float* m
                                  const float* gamma, float* dz, float* dx, void* dx_bf16, float* dgamma,
                                  float* dbeta, float* dbias, int M, int H, float p_drop, uint64_t seed,
                                  uint32_t offset, uint32_t site, void* ws, size_t ws_bytes, void* stream) {
-  UCHECK_ARG(dy && z && mean && rstd && gamma && dgamma && dbeta && ws, "ln_bwd: null pointer");
+  UCHECK_ARG(dgamma && dbeta, "ln_bwd: null pointer");
+  UCHECK_RC(uniter_ln_bwd_rows(dy, z, mean, rstd, gamma, dz, dx, dx_bf16, dbias != nullptr, M, H, p_drop, seed, offset,
+                               site, ws, ws_bytes, stream));
+  return uniter_ln_bwd_finalize(ws, ws_bytes, M, H, dgamma, dbeta, dbias, stream);
+}
+
+// The two halves of uniter_ln_bwd_b16 as separate calls: the row pass produces everything the
+// backward CHAIN needs (dz, dx); the column reduction only feeds parameter gradients and can run
+// later on another stream, out of the critical path (the caller keeps `ws` untouched in between).
+extern "C" int uniter_ln_bwd_rows(const float* dy, const float* z, const float* mean, const float* rstd,
+                                  const float* gamma, float* dz, float* dx, void* dx_bf16, int want_dbias, int M,
+                                  int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  UCHECK_ARG(dy && z && mean && rstd && gamma && ws, "ln_bwd: null pointer");
   UCHECK_ARG(dz || dx, "ln_bwd: need dz or dx");
   UCHECK_SHAPE(H % 4 == 0 && H >= 4, "ln_bwd: H must be a multiple of 4");
   UCHECK_ARG(ws_bytes >= uniter_ln_bwd_ws_bytes(M, H), "ln_bwd: workspace too small");
@@ -284,9 +297,17 @@ extern "C" int uniter_ln_bwd_b16(const float* dy, const float* z, const float* m
   const int nv = (H / 4 + 63) / 64;
   const int nblk = ln_bwd_blocks(M);
   float* part = (float*)ws;
-  LN_DISPATCH(nv, ln_bwd_kernel, dim3(nblk), dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop, dbias != nullptr,
+  LN_DISPATCH(nv, ln_bwd_kernel, dim3(nblk), dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop, want_dbias != 0,
               (unsigned short*)dx_bf16);
   UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_ln_bwd_finalize(const void* ws, size_t ws_bytes, int M, int H, float* dgamma, float* dbeta,
+                                      float* dbias, void* stream) {
+  UCHECK_ARG(ws && dgamma && dbeta && ws_bytes >= uniter_ln_bwd_ws_bytes(M, H), "ln_bwd_finalize: bad argument");
+  if (M <= 0) return 0;
   float* outs[3] = {dgamma, dbeta, dbias};
-  return finalize_partials_multi(part, nblk, (size_t)3 * H, outs, dbias ? 3 : 2, H, st);
+  return finalize_partials_multi((const float*)ws, ln_bwd_blocks(M), (size_t)3 * H, outs, dbias ? 3 : 2, H,
+                                 (hipStream_t)stream);
 }

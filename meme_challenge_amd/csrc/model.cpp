@@ -62,6 +62,7 @@ struct Carver {
 struct LayerBufs {   // saved activations + backward scratch of one layer
   float *qkv, *lse, *ctx, *t1, *z1, *mean1, *rstd1, *y1, *u, *hact, *t2, *z2, *mean2, *rstd2, *y2;
   float *dz2, *g2, *du, *dy1, *dz1, *g1, *dctx, *dqkv, *delta, *dx, *du_csum;
+  void *ln_ws1, *ln_ws2;      // column partials of the two LayerNorm backward passes (finalized on the side stream)
   // precision 2: bf16 copies that feed the bf16-resident GEMMs (hact and du exist only in bf16 there)
   unsigned short *ctxb, *y1b, *hactb, *y2b, *g2b, *dub, *g1b, *dqkvb;
 };
@@ -169,6 +170,8 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
       b.g1 = cv.f(M * H); b.dctx = cv.f(M * H); b.dqkv = cv.f(M * 3 * H); b.delta = cv.f((size_t)B * nh * L);
       b.dx = cv.f(M * H);
       b.du_csum = cv.f((size_t)((M + 31) / 32) * I);
+      b.ln_ws1 = cv.raw(uniter_ln_bwd_ws_bytes(pl.M, H));
+      b.ln_ws2 = cv.raw(uniter_ln_bwd_ws_bytes(pl.M, H));
       if (pl.res) { b.g2b = cv.h(M * H); b.dub = cv.h(M * I); b.g1b = cv.h(M * H); b.dqkvb = cv.h(M * 3 * H); }
     }
   } else {
@@ -557,9 +560,8 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   float* g1 = ph > 0.f ? lb.g1 : lb.dz1;
   {
     ProfScope ps(m, UNITER_K_LN, st);
-    UCHECK_RC(uniter_ln_bwd_b16(dy, lb.z2, lb.mean2, lb.rstd2, m->LP(l, L_LN2_G), lb.dz2, g2, pl.res ? lb.g2b : nullptr,
-                                m->LG(l, L_LN2_G), m->LG(l, L_LN2_B), m->LG(l, L_B2), M, H, ph, m->seed, m->offset,
-                                SITE_FFN_OUT(l), pl.ln_ws, pl.ln_ws_bytes, st));
+    UCHECK_RC(uniter_ln_bwd_rows(dy, lb.z2, lb.mean2, lb.rstd2, m->LP(l, L_LN2_G), lb.dz2, g2, pl.res ? lb.g2b : nullptr, 1,
+                                 M, H, ph, m->seed, m->offset, SITE_FFN_OUT(l), lb.ln_ws2, pl.ln_ws_bytes, st));
   }
   // FFN down dgrad (+ GELU'), FFN up dgrad (+ residual grad)
   // the GEMM's epilogue also emits per-32-row column sums of du (= partial bias gradients of
@@ -581,9 +583,8 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   {
     ProfScope ps(m, UNITER_K_LN, st);
-    UCHECK_RC(uniter_ln_bwd_b16(lb.dy1, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1, g1, res ? lb.g1b : nullptr,
-                                m->LG(l, L_LN1_G), m->LG(l, L_LN1_B), m->LG(l, L_OB), M, H, ph, m->seed, m->offset,
-                                SITE_ATTN_OUT(l), pl.ln_ws, pl.ln_ws_bytes, st));
+    UCHECK_RC(uniter_ln_bwd_rows(lb.dy1, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1, g1, res ? lb.g1b : nullptr, 1,
+                                 M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l), lb.ln_ws1, pl.ln_ws_bytes, st));
   }
   if (res) {
     UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, H, lb.g1b, H, m->WB(l, L_OW), H, lb.dctx, H, nullptr, 0,
@@ -617,6 +618,9 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     UCHECK_HIP(hipEventRecord(m->ev_main[l], st));
     UCHECK_HIP(hipStreamWaitEvent(sd, m->ev_main[l], 0));
   }
+  // LayerNorm / dense-bias gradients: the column reductions of the two row passes above
+  UCHECK_RC(uniter_ln_bwd_finalize(lb.ln_ws2, pl.ln_ws_bytes, M, H, m->LG(l, L_LN2_G), m->LG(l, L_LN2_B), m->LG(l, L_B2), sd));
+  UCHECK_RC(uniter_ln_bwd_finalize(lb.ln_ws1, pl.ln_ws_bytes, M, H, m->LG(l, L_LN1_G), m->LG(l, L_LN1_B), m->LG(l, L_OB), sd));
   if (res) {
     const unsigned short* xb = l == 0 ? pl.embb : pl.layers[l - 1].y2b;
     UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, lb.g2b, H, lb.hactb, I, m->LG(l, L_W2), I, nullptr, 0,
