@@ -1,0 +1,51 @@
+"""GPU: bench.py keeps its output contract (one JSON line with the driver's keys, the roofline and
+cpu_baseline objects) and __graft_entry__.smoke() runs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', *flags],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_default_contract():
+    d = _bench()
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'samples/s' and d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 16 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0.3 < r['frac'] < 1.0
+    assert r['launches'] == 3 * 12                       # one FFN-up GEMM per layer and step, timed inside the run
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['unit'] == 'samples/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']
+
+
+@pytest.mark.parametrize('flags', [('--precision', 'bf16', '--no_cpu_baseline'),
+                                   ('--ragged', '--packed', '--no_cpu_baseline'),
+                                   ('--workload', 'multitask', '--batch', '8', '--no_cpu_baseline')])
+def test_bench_variants_run(flags):
+    d = _bench(*flags)
+    assert d['value'] > 0 and 'cpu_baseline' not in d
+
+
+def test_graft_entry_smoke():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.smoke()
