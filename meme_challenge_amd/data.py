@@ -40,9 +40,107 @@ def load_img_feature(feature_dir, img_id, normalize=True):
     return feat.float(), pos, info['objects'], conf
 
 
+# ---- packed feature shard -------------------------------------------------------
+# At >1000 samples/s per GPU the per-sample `<id>.npy` + pickled `<id>_info.npy` pair (two opens, one
+# unpickle, 295 KB) is the input bottleneck.  A shard is the same data laid out for streaming: one
+# fp32 matrix of all region features, one of the 7-d box features already computed as
+# load_img_feature does, one of the detector confidences, and an index; all memory-mapped, so a
+# sample is two slices of page cache and DataLoader workers share the pages.
+SHARD_MAGIC = 'uniter-feature-shard-v1'
+
+
+def build_feature_shard(feature_dir, img_ids, out_prefix, normalize=True):
+    """Pack the reference-format feature files of `img_ids` into `<out_prefix>.{feat,pos,conf}.npy` +
+    `<out_prefix>.index.json`.  Returns the index dict."""
+    ids = [int(i) for i in img_ids]
+    loaded = [load_img_feature(feature_dir, i, normalize=normalize) for i in ids]
+    counts = [int(f.shape[0]) for f, _, _, _ in loaded]
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    dim = int(loaded[0][0].shape[1]) if loaded else 0
+    feat = np.lib.format.open_memmap(out_prefix + '.feat.npy', mode='w+', dtype=np.float32, shape=(int(offs[-1]), dim))
+    pos = np.lib.format.open_memmap(out_prefix + '.pos.npy', mode='w+', dtype=np.float32, shape=(int(offs[-1]), 7))
+    conf = np.lib.format.open_memmap(out_prefix + '.conf.npy', mode='w+', dtype=np.float32, shape=(int(offs[-1]),))
+    for k, (f, p, _, c) in enumerate(loaded):
+        feat[offs[k]:offs[k + 1]] = f.numpy()
+        pos[offs[k]:offs[k + 1]] = p.numpy()
+        conf[offs[k]:offs[k + 1]] = np.asarray(c, dtype=np.float32).reshape(-1)
+    for a in (feat, pos, conf):
+        a.flush()
+    index = {'magic': SHARD_MAGIC, 'ids': ids, 'offsets': offs.tolist(), 'dim': dim, 'normalize': bool(normalize)}
+    with open(out_prefix + '.index.json', 'w') as f:
+        json.dump(index, f)
+    return index
+
+
+class FeatureShard(object):
+    """Read side of build_feature_shard: `shard[img_id] -> (feat [nbb, D], pos [nbb, 7], conf [nbb])` as torch
+    views of the memory map (zero copy until collate pads them)."""
+
+    def __init__(self, prefix):
+        with open(prefix + '.index.json') as f:
+            idx = json.load(f)
+        if idx.get('magic') != SHARD_MAGIC:
+            raise ValueError('%s.index.json is not a feature shard' % prefix)
+        self.offsets = np.asarray(idx['offsets'], dtype=np.int64)
+        self.row = {int(i): k for k, i in enumerate(idx['ids'])}
+        self.feat = np.load(prefix + '.feat.npy', mmap_mode='r')
+        self.pos = np.load(prefix + '.pos.npy', mmap_mode='r')
+        self.conf = np.load(prefix + '.conf.npy', mmap_mode='r')
+
+    def __contains__(self, img_id):
+        return int(img_id) in self.row
+
+    def __getitem__(self, img_id):
+        k = self.row[int(img_id)]
+        a, b = int(self.offsets[k]), int(self.offsets[k + 1])
+        # np.array(copy) of a contiguous slice: one memcpy out of the page cache, then an owned tensor
+        return (torch.from_numpy(np.array(self.feat[a:b])), torch.from_numpy(np.array(self.pos[a:b])),
+                np.array(self.conf[a:b]))
+
+
+class DevicePrefetcher(object):
+    """Iterates a DataLoader one batch ahead: batch i+1 is copied to the GPU on a side stream (from the
+    loader's pinned buffers, non-blocking) while step i computes, so the hot path never waits for PCIe.
+    Non-tensor entries (seq_lens lists, None) pass through."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    @property
+    def dataset(self):
+        return self.loader.dataset
+
+    def _to_device(self, batch):
+        with torch.cuda.stream(self.stream):
+            return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._to_device(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur = nxt
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)       # cur's copies are done
+            for v in cur.values():
+                if torch.is_tensor(v):
+                    v.record_stream(torch.cuda.current_stream(self.device))       # allocator: in use on the compute stream
+            try:
+                nxt = self._to_device(next(it))                                  # overlaps with the caller's step on `cur`
+            except StopIteration:
+                nxt = None
+            yield cur
+
+
 class MemeDataset(data.Dataset):
     def __init__(self, filepath, feature_dir=None, text_padding=None, return_ids=False, compact_batch=True,
-                 confidence_threshold=0.0, preload_images=False, text_only=False, debug=False, **unused):
+                 confidence_threshold=0.0, preload_images=False, text_only=False, debug=False,
+                 feature_shard=None, **unused):
         assert os.path.isfile(filepath), "Dataset file cannot be found: \"%s\"." % filepath
         assert filepath.endswith(".jsonl"), "The filepath requires a JSON list file (\".jsonl\")."
         self.filepath, self.feature_dir = filepath, feature_dir
@@ -56,8 +154,12 @@ class MemeDataset(data.Dataset):
             labels=torch.LongTensor([j.get("label", -1) for j in js]),
             text=[j["text"] for j in js],
             imgs=[os.path.join(os.path.dirname(filepath), j.get("img", "")) for j in js])
+        self.shard = FeatureShard(feature_shard) if (feature_shard and not text_only) else None
         if not text_only:
             for i in self.data.ids.tolist():
+                if self.shard is not None:
+                    assert i in self.shard, "Image %d is not in the feature shard %s." % (i, feature_shard)
+                    continue
                 for suffix in ('.npy', '_info.npy'):
                     p = os.path.join(feature_dir, expand_id(i) + suffix)
                     assert os.path.isfile(p), "Feature file %s does not exist." % p
@@ -72,8 +174,12 @@ class MemeDataset(data.Dataset):
         data_id, label = self.data.ids[idx], self.data.labels[idx]
         feat = pos = None
         if not self.text_only:
-            feat, pos, _, conf = self._cache[idx] if self._cache is not None else \
-                load_img_feature(self.feature_dir, data_id.item())
+            if self._cache is not None:
+                feat, pos, _, conf = self._cache[idx]
+            elif self.shard is not None:
+                feat, pos, conf = self.shard[data_id.item()]
+            else:
+                feat, pos, _, conf = load_img_feature(self.feature_dir, data_id.item())
             if self.confidence_threshold > 0.0:
                 keep = torch.from_numpy(np.asarray(conf) > self.confidence_threshold)
                 feat, pos = feat[keep], pos[keep]

@@ -49,3 +49,52 @@ def test_cli_trains_exports_and_checkpoint_reloads(tmp_path):
                             gather_index=b['gather_index'], output_all_encoded_layers=False)).reshape(-1).cpu()
     exported = torch.tensor([float(l.split(',')[1]) for l in csv[1:9]])
     assert (p - exported).abs().max() < 1e-4
+
+
+def test_device_prefetcher_yields_the_loader_batches_on_the_gpu():
+    """DevicePrefetcher: same batches, same order as the wrapped DataLoader, tensors on the GPU, non-tensor
+    entries (seq_lens) passed through; safe to consume while the next copy is in flight."""
+    import torch
+    from torch.utils import data
+    from meme_challenge_amd.data import DevicePrefetcher
+
+    class DS(data.Dataset):
+        name = 'toy'
+
+        def __len__(self):
+            return 23
+
+        def __getitem__(self, i):
+            return {'x': torch.full((5, 7), float(i)), 'i': torch.tensor(i)}
+
+    def collate(samples):
+        return {'x': torch.stack([s['x'] for s in samples]), 'i': torch.stack([s['i'] for s in samples]),
+                'seq_lens': [int(s['i']) for s in samples], 'none': None}
+
+    loader = data.DataLoader(DS(), batch_size=4, collate_fn=collate, pin_memory=True)
+    pf = DevicePrefetcher(loader, 'cuda')
+    assert len(pf) == len(loader) and pf.dataset.name == 'toy'
+    seen = []
+    for ref, got in zip(loader, pf):
+        assert got['x'].is_cuda and got['i'].is_cuda and got['none'] is None and got['seq_lens'] == ref['seq_lens']
+        y = (got['x'] * 2).sum()                      # consume on the compute stream
+        assert torch.equal(got['x'].cpu(), ref['x']) and torch.equal(got['i'].cpu(), ref['i'])
+        assert y.item() == ref['x'].sum().item() * 2
+        seen.extend(got['i'].tolist())
+    assert seen == list(range(23))
+    assert sum(1 for _ in pf) == len(loader)          # re-iterable
+
+
+def test_cli_with_shards_prefetch_and_packing(tmp_path):
+    """The same run through the packed feature shard, the device prefetcher (default) and token packing."""
+    import train_uniter
+    cfg = tmp_path / 'tiny.json'
+    cfg.write_text(json.dumps(dict(TINY, vocab_size=28996, max_position_embeddings=64)))
+    data_dir, model_dir = str(tmp_path / 'data'), str(tmp_path / 'ckpt')
+    best, _ = train_uniter.main([
+        '--config', str(cfg), '--data_path', data_dir, '--model_path', model_dir, '--vis_path', str(tmp_path / 'vis'),
+        '--synthetic', '48', '--batch_size', '8', '--max_epoch', '3', '--lr', '1e-3', '--warmup_steps', '2',
+        '--pos_wt', '1.8', '--max_txt_len', '16', '--seed', '1', '--log_every', '3',
+        '--feature_shards', '--pack_padded'])
+    assert os.path.isfile(os.path.join(data_dir, 'train_shard.feat.npy'))
+    assert 0.5 < best['aucroc'] <= 1.0

@@ -12,13 +12,15 @@ Additive flags (not in the reference): --synthetic N (write a synthetic dataset 
 on-disk format under --data_path and train on it), --hash_tokenizer (offline tokenizer).
 """
 import argparse
+import json
 import os
 from functools import partial
 
 import torch
 from torch.utils import data
 
-from meme_challenge_amd.data import MemeDataset, ConfounderSampler, HashTokenizer, write_synthetic_dataset
+from meme_challenge_amd.data import (MemeDataset, ConfounderSampler, HashTokenizer, write_synthetic_dataset,
+                                     build_feature_shard, DevicePrefetcher)
 from meme_challenge_amd.meme_uniter import MemeUniter
 from meme_challenge_amd.model import UniterModel, UniterConfig, resolve_config
 from meme_challenge_amd.train_template import TrainerTemplate, LOGGER
@@ -39,6 +41,7 @@ class TrainerUniter(TrainerTemplate):
                                     n_classes=self.config['n_classes'])
         else:
             self.load_model()
+        self.model.uniter_model.pack_padded = bool(self.config.get('pack_padded', False))
 
     def load_model(self):
         uniter_config = resolve_config(self.config['config'])
@@ -82,6 +85,11 @@ def build_parser():
     # additive
     parser.add_argument('--synthetic', type=int, default=0, help='write + use a synthetic dataset of N samples per split')
     parser.add_argument('--hash_tokenizer', action='store_true', help='offline tokenizer instead of bert-base-cased')
+    parser.add_argument('--feature_shards', action='store_true',
+                        help='pack the per-sample region-feature files of every split into one memory-mapped shard '
+                             '(built next to the jsonl on first use) and read from it')
+    parser.add_argument('--no_prefetch', action='store_true', help='copy each batch to the GPU synchronously (default: one batch ahead on a side stream)')
+    parser.add_argument('--pack_padded', action='store_true', help='token packing: compute the valid positions only')
     return parser
 
 
@@ -108,12 +116,20 @@ def main(argv=None):
                              return_tensors='pt', return_length=True)
 
     def make(fname, train=False, ids=False):
-        ds = MemeDataset(filepath=os.path.join(config['data_path'], fname), feature_dir=config['feature_path'],
+        path = os.path.join(config['data_path'], fname)
+        shard = None
+        if config['feature_shards']:
+            shard = os.path.splitext(path)[0] + '_shard'
+            if not os.path.isfile(shard + '.index.json'):
+                with open(path) as f:
+                    build_feature_shard(config['feature_path'], [json.loads(l)['id'] for l in f if l.strip()], shard)
+        ds = MemeDataset(filepath=path, feature_dir=config['feature_path'], feature_shard=shard,
                          text_padding=tokenizer_func, return_ids=ids, confidence_threshold=config['object_conf_thresh'])
-        kw = dict(batch_size=config['batch_size'], num_workers=config['num_workers'], collate_fn=ds.get_collate_fn())
-        if train:
-            return data.DataLoader(ds, pin_memory=True, sampler=ConfounderSampler(ds, config['confounder_repeat']), **kw)
-        return data.DataLoader(ds, **kw)
+        kw = dict(batch_size=config['batch_size'], num_workers=config['num_workers'], collate_fn=ds.get_collate_fn(),
+                  pin_memory=True)
+        loader = data.DataLoader(ds, sampler=ConfounderSampler(ds, config['confounder_repeat']), **kw) if train \
+            else data.DataLoader(ds, **kw)
+        return loader if config['no_prefetch'] else DevicePrefetcher(loader, config['device'])
 
     config['train_loader'] = make('train.jsonl', train=True)
     config['val_loader'] = make('dev_seen.jsonl')
