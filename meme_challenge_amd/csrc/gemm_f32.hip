@@ -39,7 +39,6 @@ struct GemmArgs {
   int beta;
   int tiles_m, tiles_n;
   int band_h;
-  int prio_mode;
   float* colsum_part;   // optional [ceil(M/32)][N]: per-32-row-block column sums of the stored C (v3 only)
 };
 
@@ -565,8 +564,6 @@ int launch_v3(GemmArgs g, hipStream_t st, int slots) {
     g.band_h = (int)(bh < 1 ? 1 : (bh > 16 ? 16 : bh));
     if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
   }
-  static const int slots_override = env_int("UNITER_GEMM_SLOTS", 0);
-  if (slots_override > 0) slots = slots_override;
   int grid = tiles < slots ? (tiles + 7) / 8 * 8 : slots;
   // stream-K when the tiles fill the slots unevenly (only legal for a plain accumulating GEMM)
   static const int sk_mode = env_int("UNITER_GEMM_SK", 1);     // 0 never, 1 heuristic, 2 whenever legal
@@ -638,7 +635,7 @@ int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int
   GemmArgs g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux;
-  g.beta = beta; g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.prio_mode = 0; g.colsum_part = colsum_part;
+  g.beta = beta; g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
   if (cfg == 0) cfg = choose_cfg(M, N);
   if (colsum_part) {
     const bool fast = (K % BK == 0 || (a_kmajor && b_kmajor)) && (size_t)(a_kmajor ? K : M) * lda * 4 < (1ull << 31) &&
