@@ -201,6 +201,18 @@ int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, const int32_t* 
                        const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16,
                        float* delta, int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
                        uint32_t site, void* ws, size_t ws_bytes, void* stream);
+/* The same two operations on the bf16 matrix pipe (precision mode 2): Q, K, V rounded to bf16 while
+ * staged, fp32 scores / softmax / dropout / LSE, probabilities and score gradients rounded to bf16 as
+ * MFMA operands.  Same arguments and Philox element indices as the _ex forms; L <= 192;
+ * ws: uniter_attn_bf16_bwd_ws_bytes (bf16 Pd / dS scratch, half of the fp32 kernels'). */
+size_t uniter_attn_bf16_bwd_ws_bytes(int B, int L, int nh);
+int uniter_attn_bf16_fwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+                         void* ctx_bf16, float* lse, int B, int L, int nh, float p_drop, uint64_t seed,
+                         uint32_t offset, uint32_t site, void* stream);
+int uniter_attn_bf16_bwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
+                         const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16,
+                         float* delta, int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
+                         uint32_t site, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Embeddings (replace UniterTextEmbeddings.forward model/model.py:232-245,

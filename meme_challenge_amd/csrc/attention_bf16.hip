@@ -1,0 +1,467 @@
+// Fused self-attention on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for the
+// bf16 precision mode: Q, K, V (fp32 in memory, the QKV GEMM's output) are rounded to bf16 while they
+// are staged, scores / softmax / dropout / LSE / deltas stay fp32, the probabilities and score
+// gradients are rounded to bf16 where they become MFMA operands -- the usual mixed-precision
+// attention.  Replaces the same reference code as attention_f32.hip (model/layer.py:80-100) and is
+// drop-in for its L <= 192 "split" kernels: same work decomposition (one workgroup per (batch,
+// head), two waves per 32-row block meeting in LDS), same transposed orientation (the accumulator
+// of S^T = K.Q^T feeds O^T = V^T.P^T from registers), same Philox element indices, same varlen
+// (cu_seqlens) support, same outputs (fp32 + optional bf16 copies).
+//
+// What changes with the 16-deep bf16 MFMA:
+//   * a 32x32 score tile costs 4 MFMAs of 32 cycles instead of 32 of 64: the kernels are VALU-bound
+//     (softmax, Philox), not matrix-bound;
+//   * operand k-slots: lane-half h of k16-step s supplies 8 values.  For operands that come out of
+//     an accumulator (P^T, dS^T: lane = query, registers = keys) the 8 values are registers
+//     8s .. 8s+7, i.e. keys 16s + 8(t>>2) + 4h + (t&3): the partner operand (V^T or K^T) is therefore
+//     staged TRANSPOSED in LDS ([64 d][keys], 400-B rows) and read as two 8-byte pieces per MFMA at
+//     columns 16s+4h and 16s+8+4h -- conflict-free, no transposed-read instruction needed;
+//   * the dK/dV kernel contracts over queries with both operands in natural order: Q^T / dO^T
+//     transposed in LDS (one ds_read_b128 per MFMA) against Pd / dS read from the bf16 scratch the dQ
+//     kernel wrote ([B*nh][key][query], half the bytes of the fp32 kernels' scratch).
+#include "common.h"
+#include "philox.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+constexpr int D = 64;
+constexpr int KLD = 72;          // row-major image [row][64 d] bf16, 144-B rows (conflict-free ds_read_b128)
+constexpr int TLD = 200;         // transposed image [64 d][<= 192 rows] bf16, 400-B rows
+constexpr int MAXL = 192;
+constexpr int XROW = 34;         // floats exchanged per lane between the two halves (32 accumulators + m, l)
+constexpr float NEG_INF = -__builtin_huge_valf();
+
+struct Args {
+  const float* qkv;        // [rows, 3H]
+  const float* mask;       // [B, L] or NULL (varlen)
+  const int* cu;           // [B+1] or NULL
+  float* ctx; u16* ctx_b16;
+  float* lse;              // [B, nh, L]
+  const float* dctx;
+  float* dqkv; u16* dqkv_b16;
+  float* delta;            // [B, nh, L]
+  u16* pd_ws; u16* ds_ws;  // [B*nh][Lr][Lr] bf16, indexed [key][query]
+  int B, L, nh, H, Lp4;
+  float scale;
+  DropCfg drop;
+};
+
+struct Span { int row0, Lb, nb; };
+__device__ __forceinline__ Span span_of(const Args& a, int b) {
+  Span s;
+  s.row0 = a.cu ? a.cu[b] : b * a.L;
+  s.Lb = a.cu ? a.cu[b + 1] - s.row0 : a.L;
+  s.nb = (s.Lb + 31) >> 5;
+  return s;
+}
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// rows [0, Lr) x 64 columns of an fp32 matrix (row stride ld) -> bf16 [row][KLD]; rows >= L are zero
+__device__ __forceinline__ void stage_rm(u16* s, const float* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
+  for (int idx = tid; idx < Lr * 16; idx += nthr) {
+    const int r = idx >> 4, c4 = idx & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < L) v = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c4 * 4);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(s + r * KLD + c4 * 4) = o;
+  }
+}
+// same source -> transposed bf16 [d][TLD] (column = row of the source); columns >= L are zero
+__device__ __forceinline__ void stage_tr(u16* s, const float* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
+  for (int idx = tid; idx < Lr * 16; idx += nthr) {
+    const int r = idx >> 4, c4 = idx & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < L) v = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c4 * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[(c4 * 4 + e) * TLD + r] = __builtin_bit_cast(u16, (__bf16)v[e]);
+  }
+}
+
+// B operand from a global fp32 row (64 values): step s, half h -> d = 16s + 8h .. +7
+__device__ __forceinline__ void row_frags(bf16x8 (&f)[4], const float* __restrict__ row, bool valid, int h) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (valid) {
+      a = *reinterpret_cast<const f32x4*>(row + 16 * s + 8 * h);
+      b = *reinterpret_cast<const f32x4*>(row + 16 * s + 8 * h + 4);
+    }
+    f[s] = bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+  }
+}
+// A operand out of a row-major image: row r, step s, half h
+__device__ __forceinline__ bf16x8 frag_rm(const u16* s, int r, int step, int h) {
+  return *reinterpret_cast<const bf16x8*>(s + r * KLD + step * 16 + 8 * h);
+}
+// A operand out of a transposed image in ACCUMULATOR k-order: columns c0+16s+4h..+3 and c0+16s+8+4h..+3
+__device__ __forceinline__ bf16x8 frag_t_acc(const u16* s, int d, int c0, int step, int h) {
+  const u16* p = s + d * TLD + c0 + 16 * step + 4 * h;
+  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p), hi = *reinterpret_cast<const bf16x4*>(p + 8);
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// A operand out of a transposed image in natural k-order: columns c0+16s+8h .. +7
+__device__ __forceinline__ bf16x8 frag_t_nat(const u16* s, int d, int c0, int step, int h) {
+  return *reinterpret_cast<const bf16x8*>(s + d * TLD + c0 + 16 * step + 8 * h);
+}
+// B operand out of an accumulator: registers 8s .. 8s+7
+__device__ __forceinline__ bf16x8 pack_acc(const f32x16& v, int step) {
+  const int o = 8 * step;
+  return bf16x8{(__bf16)v[o], (__bf16)v[o + 1], (__bf16)v[o + 2], (__bf16)v[o + 3],
+                (__bf16)v[o + 4], (__bf16)v[o + 5], (__bf16)v[o + 6], (__bf16)v[o + 7]};
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// transposed accumulator pair (rows = d) -> one row of the [rows, H] / [rows, 3H] output, fp32 and bf16
+__device__ __forceinline__ void store_rowT(float* __restrict__ row, u16* __restrict__ row_b, const f32x16& a0,
+                                           const f32x16& a1, float mul, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 v0 = {a0[4 * g] * mul, a0[4 * g + 1] * mul, a0[4 * g + 2] * mul, a0[4 * g + 3] * mul};
+    const f32x4 v1 = {a1[4 * g] * mul, a1[4 * g + 1] * mul, a1[4 * g + 2] * mul, a1[4 * g + 3] * mul};
+    *reinterpret_cast<f32x4*>(row + 8 * g + 4 * h) = v0;
+    *reinterpret_cast<f32x4*>(row + 32 + 8 * g + 4 * h) = v1;
+    if (row_b) {
+      *reinterpret_cast<bf16x4*>(row_b + 8 * g + 4 * h) = bf16x4{(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3]};
+      *reinterpret_cast<bf16x4*>(row_b + 32 + 8 * g + 4 * h) = bf16x4{(__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
+    }
+  }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+__device__ __forceinline__ void stage_mask(float* mb, const Args& a, int b, int Lb, int Lr, int tid, int nthr) {
+  for (int k = tid; k < Lr; k += nthr)
+    mb[k] = k < Lb ? (a.mask ? (1.0f - a.mask[(size_t)b * a.L + k]) * -10000.0f : 0.f) : NEG_INF;
+}
+
+// ---------------------------------------------------------------- forward ---
+// LDS: K row-major | V transposed | mask bias; afterwards the (O, m, l) exchange aliases it
+__global__ __launch_bounds__(768) void attn_b16_fwd_kernel(const Args a, int Lr) {
+  u16* Kb = reinterpret_cast<u16*>(smem_raw);
+  u16* Vt = Kb + Lr * KLD;
+  float* mb = reinterpret_cast<float*>(Vt + D * TLD);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int i = lane & 31, h = lane >> 5;
+  const int nblk = Lr >> 5;
+  const int qb = wave % nblk, half = wave / nblk;
+  const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const Span sp = span_of(a, b);
+  const int Lb = sp.Lb, ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
+  stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
+  stage_tr(Vt, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+  const int q = qb * 32 + i;
+  const bool vq = q < Lb;
+  bf16x8 qf[4];
+  row_frags(qf, base + (size_t)q * ld, vq, h);
+  __syncthreads();
+
+  const int kmid = ((sp.nb + 1) >> 1) * 32;
+  const int kbeg = half ? kmid : 0, kend = qb < sp.nb ? (half ? sp.nb * 32 : kmid) : 0;
+  f32x16 o0 = zero16(), o1 = zero16();
+  float m_run = NEG_INF, l_run = 0.f;
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    f32x16 s = zero16();
+#pragma unroll
+    for (int st = 0; st < 4; ++st) s = MFMA(frag_rm(Kb, k0 + i, st, h), qf[st], s);     // S^T[key][query]
+    float mx = NEG_INF;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + k0 + 8 * g + 4 * h);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s[4 * g + t] = s[4 * g + t] * a.scale + bias[t];
+        mx = fmaxf(mx, s[4 * g + t]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_new); ls += s[r]; }
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    if (a.drop.active && vq) {
+      const uint64_t grow = ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float m4[4];
+        drop_mult4(a.drop, grow + 2 * g + h, m4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[4 * g + t] *= m4[t];
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {                                   // O^T[d][query] += V^T . Pd^T
+      const bf16x8 pb = pack_acc(s, st);
+      o0 = MFMA(frag_t_acc(Vt, i, k0, st, h), pb, o0);
+      o1 = MFMA(frag_t_acc(Vt, 32 + i, k0, st, h), pb, o1);
+    }
+  }
+  __syncthreads();
+  float* xb = reinterpret_cast<float*>(smem_raw) + (size_t)qb * XROW * 64;
+  if (half) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { xb[r * 64 + lane] = o0[r]; xb[(16 + r) * 64 + lane] = o1[r]; }
+    xb[32 * 64 + lane] = m_run;
+    xb[33 * 64 + lane] = l_run;
+  }
+  __syncthreads();
+  if (half) return;
+  {
+    const float m_b = xb[32 * 64 + lane], l_b = xb[33 * 64 + lane];
+    const float m_new = fmaxf(m_run, m_b);
+    const float wa = __expf(m_run - m_new), wb = m_b == NEG_INF ? 0.f : __expf(m_b - m_new);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] = o0[r] * wa + xb[r * 64 + lane] * wb;
+      o1[r] = o1[r] * wa + xb[(16 + r) * 64 + lane] * wb;
+    }
+    l_run = l_run * wa + l_b * wb;
+    m_run = m_new;
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (vq) {
+    const size_t off = ((size_t)sp.row0 + q) * a.H + head * D;
+    store_rowT(a.ctx + off, a.ctx_b16 ? a.ctx_b16 + off : nullptr, o0, o1, 1.0f / l_tot, h);
+    if (h == 0 && a.lse) a.lse[(size_t)bh * a.L + q] = m_run + __logf(l_tot);
+  }
+}
+
+// ------------------------------------------------- backward: dQ, delta, Pd / dS scratch ---
+// LDS: K row-major | V row-major | K transposed | mask bias
+__global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr) {
+  u16* Kb = reinterpret_cast<u16*>(smem_raw);
+  u16* Vb = Kb + Lr * KLD;
+  u16* Kt = Vb + Lr * KLD;
+  float* mb = reinterpret_cast<float*>(Kt + D * TLD);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int i = lane & 31, h = lane >> 5;
+  const int nblk = Lr >> 5;
+  const int qb = wave % nblk, half = wave / nblk;
+  const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const Span sp = span_of(a, b);
+  const int Lb = sp.Lb, ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
+  stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
+  stage_rm(Vb, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+  stage_tr(Kt, base + a.H, ld, Lb, Lr, tid, nthr);
+  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+  const int q = qb * 32 + i;
+  const bool vq = q < Lb;
+  bf16x8 qf[4], dof[4];
+  row_frags(qf, base + (size_t)q * ld, vq, h);
+  const float* dorow = a.dctx + ((size_t)sp.row0 + q) * a.H + head * D;
+  row_frags(dof, dorow, vq, h);
+  float delta = 0.f;
+  if (vq) {
+    const float* orow = a.ctx + ((size_t)sp.row0 + q) * a.H + head * D;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(orow + 32 * h + 4 * c);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dorow + 32 * h + 4 * c);
+      delta += o[0] * d[0] + o[1] * d[1] + o[2] * d[2] + o[3] * d[3];
+    }
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  if (vq && h == 0 && half == 0) a.delta[(size_t)bh * a.L + q] = delta;
+  const float lse = vq ? a.lse[(size_t)bh * a.L + q] : -NEG_INF;      // +inf: every probability of a padded query is 0
+  __syncthreads();
+
+  const int kmid = ((sp.nb + 1) >> 1) * 32;
+  const int kbeg = half ? kmid : 0, kend = qb < sp.nb ? (half ? sp.nb * 32 : kmid) : 0;
+  u16* pdw = a.pd_ws + (size_t)bh * Lr * Lr + qb * 32 + i;
+  u16* dsw = a.ds_ws + (size_t)bh * Lr * Lr + qb * 32 + i;
+  f32x16 dq0 = zero16(), dq1 = zero16();
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      s = MFMA(frag_rm(Kb, k0 + i, st, h), qf[st], s);
+      dp = MFMA(frag_rm(Vb, k0 + i, st, h), dof[st], dp);               // dP^T[key][query] = V . dO^T
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + k0 + 8 * g + 4 * h);
+      float m4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.drop.active && vq)
+        drop_mult4(a.drop, ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2) + 2 * g + h, m4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float p = __expf(s[4 * g + t] * a.scale + bias[t] - lse);
+        const float pdv = p * m4[t];
+        const float dsv = p * (dp[4 * g + t] * m4[t] - delta) * a.scale;
+        s[4 * g + t] = dsv;
+        const size_t off = (size_t)(k0 + 8 * g + 4 * h + t) * Lr;         // row = key, 32 lanes = 64 contiguous bytes
+        pdw[off] = __builtin_bit_cast(u16, (__bf16)pdv);
+        dsw[off] = __builtin_bit_cast(u16, (__bf16)dsv);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {                                    // dQ^T[d][query] += K^T . dS^T
+      const bf16x8 db = pack_acc(s, st);
+      dq0 = MFMA(frag_t_acc(Kt, i, k0, st, h), db, dq0);
+      dq1 = MFMA(frag_t_acc(Kt, 32 + i, k0, st, h), db, dq1);
+    }
+  }
+  __syncthreads();
+  float* xb = reinterpret_cast<float*>(smem_raw) + (size_t)qb * XROW * 64;
+  if (half) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { xb[r * 64 + lane] = dq0[r]; xb[(16 + r) * 64 + lane] = dq1[r]; }
+  }
+  __syncthreads();
+  if (half) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq0[r] += xb[r * 64 + lane]; dq1[r] += xb[(16 + r) * 64 + lane]; }
+  if (vq) {
+    const size_t off = ((size_t)sp.row0 + q) * ld + head * D;
+    store_rowT(a.dqkv + off, a.dqkv_b16 ? a.dqkv_b16 + off : nullptr, dq0, dq1, 1.0f, h);
+  }
+}
+
+// ------------------------------------------------------------ backward: dK, dV ---
+// LDS: Q transposed | dO transposed.  dV^T[d][key] = sum_q dO[q][d] Pd[q][key], dK^T = sum_q Q[q][d] dS[q][key]
+__global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr) {
+  u16* Qt = reinterpret_cast<u16*>(smem_raw);
+  u16* dOt = Qt + D * TLD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int i = lane & 31, h = lane >> 5;
+  const int nblk = Lr >> 5;
+  const int kb = wave % nblk, half = wave / nblk;
+  const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const Span sp = span_of(a, b);
+  const int Lb = sp.Lb, ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
+  stage_tr(Qt, base, ld, Lb, Lr, tid, nthr);
+  stage_tr(dOt, a.dctx + (size_t)sp.row0 * a.H + head * D, a.H, Lb, Lr, tid, nthr);
+  const int key = kb * 32 + i;
+  const bool vk = key < Lb;
+  const int qmid = ((sp.nb + 1) >> 1) * 32;
+  const int qbeg = half ? qmid : 0, qend = kb < sp.nb ? (half ? sp.nb * 32 : qmid) : 0;
+  const u16* pdr = a.pd_ws + ((size_t)bh * Lr + key) * Lr + 8 * h;      // lane's key row, natural query order
+  const u16* dsr = a.ds_ws + ((size_t)bh * Lr + key) * Lr + 8 * h;
+  __syncthreads();
+
+  f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+  for (int q0 = qbeg; q0 < qend; q0 += 32) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const bf16x8 pb = *reinterpret_cast<const bf16x8*>(pdr + q0 + 16 * st);
+      const bf16x8 db = *reinterpret_cast<const bf16x8*>(dsr + q0 + 16 * st);
+      dv0 = MFMA(frag_t_nat(dOt, i, q0, st, h), pb, dv0);
+      dv1 = MFMA(frag_t_nat(dOt, 32 + i, q0, st, h), pb, dv1);
+      dk0 = MFMA(frag_t_nat(Qt, i, q0, st, h), db, dk0);
+      dk1 = MFMA(frag_t_nat(Qt, 32 + i, q0, st, h), db, dk1);
+    }
+  }
+  __syncthreads();
+  float* xb = reinterpret_cast<float*>(smem_raw) + (size_t)kb * 64 * 64;
+  if (half) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xb[r * 64 + lane] = dk0[r]; xb[(16 + r) * 64 + lane] = dk1[r];
+      xb[(32 + r) * 64 + lane] = dv0[r]; xb[(48 + r) * 64 + lane] = dv1[r];
+    }
+  }
+  __syncthreads();
+  if (half) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    dk0[r] += xb[r * 64 + lane]; dk1[r] += xb[(16 + r) * 64 + lane];
+    dv0[r] += xb[(32 + r) * 64 + lane]; dv1[r] += xb[(48 + r) * 64 + lane];
+  }
+  if (vk) {
+    const size_t off = ((size_t)sp.row0 + key) * ld + head * D;
+    store_rowT(a.dqkv + off + a.H, a.dqkv_b16 ? a.dqkv_b16 + off + a.H : nullptr, dk0, dk1, 1.0f, h);
+    store_rowT(a.dqkv + off + 2 * a.H, a.dqkv_b16 ? a.dqkv_b16 + off + 2 * a.H : nullptr, dv0, dv1, 1.0f, h);
+  }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  UCHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)bytes));
+  return 0;
+}
+size_t max3(size_t x, size_t y, size_t z) { return x > y ? (x > z ? x : z) : (y > z ? y : z); }
+
+int fill(Args& a, int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset, uint32_t site) {
+  UCHECK_ARG(B > 0 && L > 0 && nh > 0, "attn_bf16: bad dims B=%d L=%d nh=%d", B, L, nh);
+  UCHECK_SHAPE(L <= MAXL, "attn_bf16: L %d > %d", L, MAXL);
+  UCHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "attn_bf16: bad dropout p");
+  a.B = B; a.L = L; a.nh = nh; a.H = nh * D; a.Lp4 = (L + 3) / 4;
+  a.scale = 0.125f;        // 1/sqrt(64), model/layer.py:86
+  a.drop = make_drop(p_drop, seed, offset, site);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t uniter_attn_bf16_bwd_ws_bytes(int B, int L, int nh) {
+  const int Lr = (L + 31) / 32 * 32;
+  if (B <= 0 || nh <= 0 || L > MAXL) return 0;
+  return (size_t)2 * B * nh * Lr * Lr * sizeof(unsigned short);
+}
+
+extern "C" int uniter_attn_bf16_fwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+                                    void* ctx_bf16, float* lse, int B, int L, int nh, float p_drop, uint64_t seed,
+                                    uint32_t offset, uint32_t site, void* stream) {
+  UCHECK_ARG(qkv && ctx && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
+             "attn_bf16_fwd: need attn_mask or cu_seqlens (not both)");
+  Args a = {};
+  UCHECK_RC(fill(a, B, L, nh, p_drop, seed, offset, site));
+  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_b16 = (u16*)ctx_bf16; a.lse = lse;
+  const int Lr = (L + 31) / 32 * 32, nblk = Lr / 32;
+  const size_t lds = max3((size_t)(Lr * KLD + D * TLD) * 2 + Lr * 4, (size_t)nblk * XROW * 64 * 4, 0);
+  UCHECK_RC(set_lds(attn_b16_fwd_kernel, lds));
+  hipLaunchKernelGGL(attn_b16_fwd_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_attn_bf16_bwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
+                                    const float* ctx, const float* lse, const float* dctx, float* dqkv,
+                                    void* dqkv_bf16, float* delta, int B, int L, int nh, float p_drop,
+                                    uint64_t seed, uint32_t offset, uint32_t site, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  UCHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta && ws && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
+             "attn_bf16_bwd: null pointer, or not exactly one of attn_mask / cu_seqlens");
+  UCHECK_ARG(ws_bytes >= uniter_attn_bf16_bwd_ws_bytes(B, L, nh), "attn_bf16_bwd: workspace too small");
+  Args a = {};
+  UCHECK_RC(fill(a, B, L, nh, p_drop, seed, offset, site));
+  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
+  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (u16*)dqkv_bf16; a.delta = delta;
+  const int Lr = (L + 31) / 32 * 32, nblk = Lr / 32;
+  a.pd_ws = (u16*)ws;
+  a.ds_ws = a.pd_ws + (size_t)B * nh * Lr * Lr;
+  const size_t lds_dq = max3((size_t)(2 * Lr * KLD + D * TLD) * 2 + Lr * 4, (size_t)nblk * XROW * 64 * 4, 0);
+  const size_t lds_dkv = max3((size_t)(2 * D * TLD) * 2, (size_t)nblk * 64 * 64 * 4, 0);
+  UCHECK_RC(set_lds(attn_b16_dq_kernel, lds_dq));
+  UCHECK_RC(set_lds(attn_b16_dkv_kernel, lds_dkv));
+  hipLaunchKernelGGL(attn_b16_dq_kernel, dim3(B * nh), dim3(Lr * 4), lds_dq, (hipStream_t)stream, a, Lr);
+  UCHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_b16_dkv_kernel, dim3(B * nh), dim3(Lr * 4), lds_dkv, (hipStream_t)stream, a, Lr);
+  UCHECK_LAUNCH();
+  return 0;
+}

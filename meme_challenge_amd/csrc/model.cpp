@@ -430,7 +430,7 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     UCHECK_RC(cast_b(pl.emb, pl.embb, (size_t)M * H, st));
   }
   const unsigned short* xb = pl.embb;
-  // the L <= 192 attention kernels write the bf16 copies of their outputs themselves
+  // L <= 192: attention on the bf16 pipe (attention_bf16.hip), which also writes the bf16 copies of its outputs
   const bool attn_b16 = res && L <= uniter_attn_varlen_max_len();
 
   // ---- encoder (model/model.py:282-292; model/layer.py:166-170) ----
@@ -447,10 +447,12 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
                      UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
     {
       ProfScope ps(m, UNITER_K_ATTN_FWD, st);
-      if (packed || attn_b16)
-        UCHECK_RC(uniter_attn_fwd_ex(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
-                                     lb.ctx, attn_b16 ? lb.ctxb : nullptr, lb.lse, B, L, nh, pa, seed, offset,
-                                     SITE_ATTN_PROBS(l), st));
+      if (attn_b16)      // precision 2: the attention products run on the bf16 pipe as well
+        UCHECK_RC(uniter_attn_bf16_fwd(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
+                                       lb.ctx, lb.ctxb, lb.lse, B, L, nh, pa, seed, offset, SITE_ATTN_PROBS(l), st));
+      else if (packed)
+        UCHECK_RC(uniter_attn_fwd_ex(lb.qkv, nullptr, b->cu_seqlens, lb.ctx, nullptr, lb.lse, B, L, nh, pa, seed,
+                                     offset, SITE_ATTN_PROBS(l), st));
       else
         UCHECK_RC(uniter_attn_fwd(lb.qkv, b->attention_mask, lb.ctx, lb.lse, B, L, nh, pa, seed, offset,
                                   SITE_ATTN_PROBS(l), st));
@@ -595,11 +597,15 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   {
     ProfScope ps(m, UNITER_K_ATTN_BWD, st);
-    if (pl.packed || attn_b16)
-      UCHECK_RC(uniter_attn_bwd_ex(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
-                                   pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, lb.dqkv,
-                                   attn_b16 ? lb.dqkvb : nullptr, lb.delta, B, L, nh, pa, m->seed, m->offset,
-                                   SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
+    if (attn_b16)
+      UCHECK_RC(uniter_attn_bf16_bwd(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
+                                     pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, lb.dqkv,
+                                     lb.dqkvb, lb.delta, B, L, nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l),
+                                     pl.attn_ws, pl.attn_ws_bytes, st));
+    else if (pl.packed)
+      UCHECK_RC(uniter_attn_bwd_ex(lb.qkv, nullptr, m->batch.cu_seqlens, lb.ctx, lb.lse, lb.dctx, lb.dqkv, nullptr,
+                                   lb.delta, B, L, nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), pl.attn_ws,
+                                   pl.attn_ws_bytes, st));
     else
       UCHECK_RC(uniter_attn_bwd(lb.qkv, m->batch.attention_mask, lb.ctx, lb.lse, lb.dctx, lb.dqkv, lb.delta, B, L,
                                 nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));

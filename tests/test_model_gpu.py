@@ -182,9 +182,9 @@ def test_bf16_mfma_mode_tracks_fp32_reference(shapes_base, mode):
 
 
 def test_bf16_resident_equals_hybrid_and_follows_weight_updates(shapes_base):
-    """The resident path multiplies the same bf16 values as the hybrid one (only the summation order
-    of the atomically accumulated weight gradients differs), and its bf16 weight mirror follows both
-    torch-side writes (load_state_dict) and FusedAdam steps."""
+    """The resident path's GEMMs multiply the same bf16 values as the hybrid one; it additionally runs the
+    attention products on the bf16 pipe, so the two agree to bf16 accuracy.  Its bf16 weight mirror
+    follows both torch-side writes (load_state_dict) and FusedAdam steps."""
     from meme_challenge_amd.trainer import bce_with_logits_loss, FusedAdam
     from meme_challenge_amd.utils import make_synthetic_batch
     z = shapes_base
@@ -206,9 +206,10 @@ def test_bf16_resident_equals_hybrid_and_follows_weight_updates(shapes_base):
             logits2 = m(**model_kwargs(b))                  # and the restored ones
         out[mode] = (logits0.detach(), g, logits1, logits2)
     h, r = out['bf16_hybrid'], out['bf16']
-    assert maxdiff(r[0], h[0]) < 1e-5
-    assert maxdiff(r[1], h[1]) < 1e-6 + 1e-3 * h[1].abs().max().item()
-    assert maxdiff(r[2], h[2]) < 2e-3 and maxdiff(r[2], r[0]) > 1e-3      # the step moved the logits, equally in both
+    assert maxdiff(r[0], h[0]) < 5e-3
+    assert maxdiff(r[1], h[1]) < 1e-6 + 5e-2 * h[1].abs().max().item()
+    # one Adam step at lr 1e-3 moves the logits by ~4; Adam's sign-like update amplifies bf16-level gradient differences
+    assert maxdiff(r[2], h[2]) < 0.1 and maxdiff(r[2], r[0]) > 1.0
     assert maxdiff(r[3], r[0]) < 1e-6
 
 
