@@ -43,6 +43,7 @@ struct Args {
   float* lse;              // [B, nh, L]
   const float* dctx;
   float* dqkv; u16* dqkv_b16;
+  float* bias_part;        // optional [B, 3H] per-sample column sums of dqkv (QKV bias gradient partials)
   float* delta;            // [B, nh, L]
   u16* pd_ws; u16* ds_ws;  // [B*nh][Lr][Lr] bf16, indexed [key][query]
   int B, L, nh, H, Lp4;
@@ -139,6 +140,24 @@ __device__ __forceinline__ void store_rowT(float* __restrict__ row, u16* __restr
     if (row_b) {
       *reinterpret_cast<bf16x4*>(row_b + 8 * g + 4 * h) = bf16x4{(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3]};
       *reinterpret_cast<bf16x4*>(row_b + 32 + 8 * g + 4 * h) = bf16x4{(__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
+    }
+  }
+}
+
+// sum over the 32 lanes of each wave half; column sums of a transposed accumulator pair -> red[0..63] (LDS)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ void acc_colsum(float* red, const f32x16& a0, const f32x16& a1, bool valid, int i, int h) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float s0 = half_sum(valid ? a0[r] : 0.f), s1 = half_sum(valid ? a1[r] : 0.f);
+    if (i == 0) {
+      const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+      atomicAdd(red + d, s0);
+      atomicAdd(red + 32 + d, s1);
     }
   }
 }
@@ -250,7 +269,7 @@ __global__ __launch_bounds__(768) void attn_b16_fwd_kernel(const Args a, int Lr)
 
 // ------------------------------------------------- backward: dQ, delta, Pd / dS scratch ---
 // LDS: K row-major | V row-major | K transposed | mask bias
-__global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr) {
+__global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr, int red_off) {
   u16* Kb = reinterpret_cast<u16*>(smem_raw);
   u16* Vb = Kb + Lr * KLD;
   u16* Kt = Vb + Lr * KLD;
@@ -267,6 +286,8 @@ __global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr) 
   stage_rm(Vb, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
   stage_tr(Kt, base + a.H, ld, Lb, Lr, tid, nthr);
   stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+  float* red = reinterpret_cast<float*>(smem_raw + red_off);
+  for (int t = tid; t < 192; t += nthr) red[t] = 0.f;        // (a 32-row workgroup has only 128 threads)
   const int q = qb * 32 + i;
   const bool vq = q < Lb;
   bf16x8 qf[4], dof[4];
@@ -331,18 +352,24 @@ __global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr) 
     for (int r = 0; r < 16; ++r) { xb[r * 64 + lane] = dq0[r]; xb[(16 + r) * 64 + lane] = dq1[r]; }
   }
   __syncthreads();
-  if (half) return;
+  if (!half) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { dq0[r] += xb[r * 64 + lane]; dq1[r] += xb[(16 + r) * 64 + lane]; }
-  if (vq) {
-    const size_t off = ((size_t)sp.row0 + q) * ld + head * D;
-    store_rowT(a.dqkv + off, a.dqkv_b16 ? a.dqkv_b16 + off : nullptr, dq0, dq1, 1.0f, h);
+    for (int r = 0; r < 16; ++r) { dq0[r] += xb[r * 64 + lane]; dq1[r] += xb[(16 + r) * 64 + lane]; }
+    if (vq) {
+      const size_t off = ((size_t)sp.row0 + q) * ld + head * D;
+      store_rowT(a.dqkv + off, a.dqkv_b16 ? a.dqkv_b16 + off : nullptr, dq0, dq1, 1.0f, h);
+    }
+    if (a.bias_part) acc_colsum(red, dq0, dq1, vq, i, h);
+  }
+  if (a.bias_part) {
+    __syncthreads();
+    if (tid < 64) a.bias_part[(size_t)b * 3 * a.H + head * D + tid] = red[tid];
   }
 }
 
 // ------------------------------------------------------------ backward: dK, dV ---
 // LDS: Q transposed | dO transposed.  dV^T[d][key] = sum_q dO[q][d] Pd[q][key], dK^T = sum_q Q[q][d] dS[q][key]
-__global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr) {
+__global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr, int red_off) {
   u16* Qt = reinterpret_cast<u16*>(smem_raw);
   u16* dOt = Qt + D * TLD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
@@ -355,6 +382,8 @@ __global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr)
   const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
   stage_tr(Qt, base, ld, Lb, Lr, tid, nthr);
   stage_tr(dOt, a.dctx + (size_t)sp.row0 * a.H + head * D, a.H, Lb, Lr, tid, nthr);
+  float* red = reinterpret_cast<float*>(smem_raw + red_off);
+  for (int t = tid; t < 192; t += nthr) red[t] = 0.f;        // (a 32-row workgroup has only 128 threads)
   const int key = kb * 32 + i;
   const bool vk = key < Lb;
   const int qmid = ((sp.nb + 1) >> 1) * 32;
@@ -385,16 +414,23 @@ __global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr)
     }
   }
   __syncthreads();
-  if (half) return;
+  if (!half) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    dk0[r] += xb[r * 64 + lane]; dk1[r] += xb[(16 + r) * 64 + lane];
-    dv0[r] += xb[(32 + r) * 64 + lane]; dv1[r] += xb[(48 + r) * 64 + lane];
+    for (int r = 0; r < 16; ++r) {
+      dk0[r] += xb[r * 64 + lane]; dk1[r] += xb[(16 + r) * 64 + lane];
+      dv0[r] += xb[(32 + r) * 64 + lane]; dv1[r] += xb[(48 + r) * 64 + lane];
+    }
+    if (vk) {
+      const size_t off = ((size_t)sp.row0 + key) * ld + head * D;
+      store_rowT(a.dqkv + off + a.H, a.dqkv_b16 ? a.dqkv_b16 + off + a.H : nullptr, dk0, dk1, 1.0f, h);
+      store_rowT(a.dqkv + off + 2 * a.H, a.dqkv_b16 ? a.dqkv_b16 + off + 2 * a.H : nullptr, dv0, dv1, 1.0f, h);
+    }
+    if (a.bias_part) { acc_colsum(red + 64, dk0, dk1, vk, i, h); acc_colsum(red + 128, dv0, dv1, vk, i, h); }
   }
-  if (vk) {
-    const size_t off = ((size_t)sp.row0 + key) * ld + head * D;
-    store_rowT(a.dqkv + off + a.H, a.dqkv_b16 ? a.dqkv_b16 + off + a.H : nullptr, dk0, dk1, 1.0f, h);
-    store_rowT(a.dqkv + off + 2 * a.H, a.dqkv_b16 ? a.dqkv_b16 + off + 2 * a.H : nullptr, dv0, dv1, 1.0f, h);
+  if (a.bias_part) {
+    __syncthreads();
+    for (int t = tid; t < 128; t += nthr)
+      a.bias_part[(size_t)b * 3 * a.H + (1 + (t >> 6)) * a.H + head * D + (t & 63)] = red[64 + t];
   }
 }
 
@@ -442,26 +478,28 @@ extern "C" int uniter_attn_bf16_fwd(const float* qkv, const float* attn_mask, co
 
 extern "C" int uniter_attn_bf16_bwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
                                     const float* ctx, const float* lse, const float* dctx, float* dqkv,
-                                    void* dqkv_bf16, float* delta, int B, int L, int nh, float p_drop,
-                                    uint64_t seed, uint32_t offset, uint32_t site, void* ws, size_t ws_bytes,
-                                    void* stream) {
+                                    void* dqkv_bf16, float* bias_part, float* delta, int B, int L, int nh,
+                                    float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws,
+                                    size_t ws_bytes, void* stream) {
   UCHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta && ws && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_bf16_bwd: null pointer, or not exactly one of attn_mask / cu_seqlens");
   UCHECK_ARG(ws_bytes >= uniter_attn_bf16_bwd_ws_bytes(B, L, nh), "attn_bf16_bwd: workspace too small");
   Args a = {};
   UCHECK_RC(fill(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
-  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (u16*)dqkv_bf16; a.delta = delta;
+  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (u16*)dqkv_bf16; a.bias_part = bias_part; a.delta = delta;
   const int Lr = (L + 31) / 32 * 32, nblk = Lr / 32;
   a.pd_ws = (u16*)ws;
   a.ds_ws = a.pd_ws + (size_t)B * nh * Lr * Lr;
-  const size_t lds_dq = max3((size_t)(2 * Lr * KLD + D * TLD) * 2 + Lr * 4, (size_t)nblk * XROW * 64 * 4, 0);
-  const size_t lds_dkv = max3((size_t)(2 * D * TLD) * 2, (size_t)nblk * 64 * 64 * 4, 0);
+  // the 192-float column-sum area sits behind both the staged images and the exchange area that later aliases them
+  const size_t red_dq = max3((size_t)(2 * Lr * KLD + D * TLD) * 2 + Lr * 4, (size_t)nblk * XROW * 64 * 4, 0);
+  const size_t red_dkv = max3((size_t)(2 * D * TLD) * 2, (size_t)nblk * 64 * 64 * 4, 0);
+  const size_t lds_dq = red_dq + 192 * 4, lds_dkv = red_dkv + 192 * 4;
   UCHECK_RC(set_lds(attn_b16_dq_kernel, lds_dq));
   UCHECK_RC(set_lds(attn_b16_dkv_kernel, lds_dkv));
-  hipLaunchKernelGGL(attn_b16_dq_kernel, dim3(B * nh), dim3(Lr * 4), lds_dq, (hipStream_t)stream, a, Lr);
+  hipLaunchKernelGGL(attn_b16_dq_kernel, dim3(B * nh), dim3(Lr * 4), lds_dq, (hipStream_t)stream, a, Lr, (int)red_dq);
   UCHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_b16_dkv_kernel, dim3(B * nh), dim3(Lr * 4), lds_dkv, (hipStream_t)stream, a, Lr);
+  hipLaunchKernelGGL(attn_b16_dkv_kernel, dim3(B * nh), dim3(Lr * 4), lds_dkv, (hipStream_t)stream, a, Lr, (int)red_dkv);
   UCHECK_LAUNCH();
   return 0;
 }

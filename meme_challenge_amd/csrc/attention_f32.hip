@@ -43,6 +43,7 @@ struct AttnArgs {
   float* delta;         // [B, nh, L]
   unsigned short* ctx_b16;   // optional bf16 copies of ctx / dqkv (operands of bf16-resident GEMMs)
   unsigned short* dqkv_b16;
+  float* bias_part;          // optional [B, 3H]: per-sample column sums of dqkv (the QKV bias gradient, reduced over B later)
   const int* cu;        // [B+1] prefix sums of per-sample lengths (packed rows), or NULL: sample b owns rows b*L .. b*L+L-1
   int B, L, nh, H, Lp4; // Lp4 = roundup(L,4)/4
   float scale;
@@ -552,6 +553,25 @@ constexpr int XROW = 34;             // floats exchanged per lane: 32 accumulato
 // Packed (varlen) batches: with a.cu set, sample b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx / dqkv,
 // every key of a sample is valid (no mask) and waves whose 32-row block lies beyond the sample's
 // length only keep the barriers company.  lse / delta / the scratch stay indexed by the maximum length.
+// sum over the 32 lanes of each wave half
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// column sums of a transposed accumulator pair over the wave's valid lanes -> red[0..63] (LDS, pre-zeroed)
+__device__ __forceinline__ void acc_colsum(float* red, const f32x16& a0, const f32x16& a1, bool valid, int i, int h) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float s0 = half_sum(valid ? a0[r] : 0.f), s1 = half_sum(valid ? a1[r] : 0.f);
+    if (i == 0) {
+      const int d = (r & 3) + 8 * (r >> 2) + 4 * h;
+      atomicAdd(red + d, s0);
+      atomicAdd(red + 32 + d, s1);
+    }
+  }
+}
+
 struct SampleSpan { int row0, Lb, nb; };
 __device__ __forceinline__ SampleSpan sample_span(const AttnArgs& a, int b) {
   SampleSpan s;
@@ -676,6 +696,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
   stage_rows(Ks, base + a.H, ld, Lb, Lr, tid, nthr);
   stage_rows(Vs, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
   stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+  for (int t = tid; t < 192; t += nthr) dyn_smem[2 * Lr * LDT + 2 * Lr + t] = 0.f;      // (a 32-row workgroup has only 128 threads)
   const int q = qb * 32 + i;
   const bool vq = q < Lb;
   f32x4 qf[8], dof[8];
@@ -734,12 +755,19 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
     for (int r = 0; r < 16; ++r) { xb[r * 64 + lane] = dq0[r]; xb[(16 + r) * 64 + lane] = dq1[r]; }
   }
   __syncthreads();
-  if (half) return;
+  float* red = dyn_smem + 2 * Lr * LDT + 2 * Lr;        // 192 floats behind everything else (res_lds_bytes)
+  if (!half) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { dq0[r] += xb[r * 64 + lane]; dq1[r] += xb[(16 + r) * 64 + lane]; }
-  if (vq) {
-    store_rowT(a.dqkv + ((size_t)sp.row0 + q) * ld + head * D, dq0, dq1, 1.0f, h);
-    if (a.dqkv_b16) store_rowT_bf16(a.dqkv_b16 + ((size_t)sp.row0 + q) * ld + head * D, dq0, dq1, 1.0f, h);
+    for (int r = 0; r < 16; ++r) { dq0[r] += xb[r * 64 + lane]; dq1[r] += xb[(16 + r) * 64 + lane]; }
+    if (vq) {
+      store_rowT(a.dqkv + ((size_t)sp.row0 + q) * ld + head * D, dq0, dq1, 1.0f, h);
+      if (a.dqkv_b16) store_rowT_bf16(a.dqkv_b16 + ((size_t)sp.row0 + q) * ld + head * D, dq0, dq1, 1.0f, h);
+    }
+    if (a.bias_part) acc_colsum(red, dq0, dq1, vq, i, h);
+  }
+  if (a.bias_part) {
+    __syncthreads();
+    if (tid < 64) a.bias_part[(size_t)b * 3 * a.H + head * D + tid] = red[tid];
   }
 }
 
@@ -760,6 +788,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs 
   const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
   stage_rows(Qs, base, ld, Lb, Lr, tid, nthr);
   stage_rows(dOs, a.dctx + (size_t)sp.row0 * a.H + head * D, a.H, Lb, Lr, tid, nthr);
+  for (int t = tid; t < 192; t += nthr) dyn_smem[2 * Lr * LDT + 2 * Lr + t] = 0.f;      // (a 32-row workgroup has only 128 threads)
   const int key = kb * 32 + i;
   const bool vk = key < Lb;
   const int qmid = ((sp.nb + 1) >> 1) * 32;
@@ -808,27 +837,35 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs 
     }
   }
   __syncthreads();
-  if (half) return;
+  float* red = dyn_smem + 2 * Lr * LDT + 2 * Lr;
+  if (!half) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    dk0[r] += xb[r * 64 + lane]; dk1[r] += xb[(16 + r) * 64 + lane];
-    dv0[r] += xb[(32 + r) * 64 + lane]; dv1[r] += xb[(48 + r) * 64 + lane];
-  }
-  if (vk) {
-    float* row = a.dqkv + ((size_t)sp.row0 + key) * ld + head * D;
-    store_rowT(row + a.H, dk0, dk1, 1.0f, h);
-    store_rowT(row + 2 * a.H, dv0, dv1, 1.0f, h);
-    if (a.dqkv_b16) {
-      unsigned short* rb = a.dqkv_b16 + ((size_t)sp.row0 + key) * ld + head * D;
-      store_rowT_bf16(rb + a.H, dk0, dk1, 1.0f, h);
-      store_rowT_bf16(rb + 2 * a.H, dv0, dv1, 1.0f, h);
+    for (int r = 0; r < 16; ++r) {
+      dk0[r] += xb[r * 64 + lane]; dk1[r] += xb[(16 + r) * 64 + lane];
+      dv0[r] += xb[(32 + r) * 64 + lane]; dv1[r] += xb[(48 + r) * 64 + lane];
     }
+    if (vk) {
+      float* row = a.dqkv + ((size_t)sp.row0 + key) * ld + head * D;
+      store_rowT(row + a.H, dk0, dk1, 1.0f, h);
+      store_rowT(row + 2 * a.H, dv0, dv1, 1.0f, h);
+      if (a.dqkv_b16) {
+        unsigned short* rb = a.dqkv_b16 + ((size_t)sp.row0 + key) * ld + head * D;
+        store_rowT_bf16(rb + a.H, dk0, dk1, 1.0f, h);
+        store_rowT_bf16(rb + 2 * a.H, dv0, dv1, 1.0f, h);
+      }
+    }
+    if (a.bias_part) { acc_colsum(red + 64, dk0, dk1, vk, i, h); acc_colsum(red + 128, dv0, dv1, vk, i, h); }
+  }
+  if (a.bias_part) {
+    __syncthreads();
+    for (int t = tid; t < 128; t += nthr)
+      a.bias_part[(size_t)b * 3 * a.H + (1 + (t >> 6)) * a.H + head * D + (t & 63)] = red[64 + t];
   }
 }
 
 constexpr int RES_MAX_LR = 256;      // 8 waves (2 per SIMD: 256 VGPRs each); 2*256*68*4 B = 139 KB LDS
 
-inline size_t res_lds_bytes(int Lr) { return (size_t)(2 * Lr * LDT + 2 * Lr) * sizeof(float); }
+inline size_t res_lds_bytes(int Lr) { return (size_t)(2 * Lr * LDT + 2 * Lr + 192) * sizeof(float); }
 
 template <typename K>
 int set_dyn_lds(K kernel, size_t bytes) {
@@ -941,8 +978,9 @@ extern "C" int uniter_attn_fwd_ex(const float* qkv, const float* attn_mask, cons
 
 extern "C" int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
                                   const float* ctx, const float* lse, const float* dctx, float* dqkv,
-                                  void* dqkv_bf16, float* delta, int B, int L, int nh, float p_drop, uint64_t seed,
-                                  uint32_t offset, uint32_t site, void* ws, size_t ws_bytes, void* stream) {
+                                  void* dqkv_bf16, float* bias_part, float* delta, int B, int L, int nh, float p_drop,
+                                  uint64_t seed, uint32_t offset, uint32_t site, void* ws, size_t ws_bytes,
+                                  void* stream) {
   UCHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta && ws && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_bwd_ex: null pointer, or not exactly one of attn_mask / cu_seqlens");
   const int Lr = (L + 31) / 32 * 32;
@@ -951,7 +989,7 @@ extern "C" int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, cons
   AttnArgs a = {};
   UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
-  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (unsigned short*)dqkv_bf16; a.delta = delta;
+  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (unsigned short*)dqkv_bf16; a.bias_part = bias_part; a.delta = delta;
   const size_t lds = res_lds_bytes(Lr);
   float* pd_ws = (float*)ws;
   float* ds_ws = pd_ws + (size_t)B * nh * Lr * Lr;

@@ -62,6 +62,7 @@ struct Carver {
 struct LayerBufs {   // saved activations + backward scratch of one layer
   float *qkv, *lse, *ctx, *t1, *z1, *mean1, *rstd1, *y1, *u, *hact, *t2, *z2, *mean2, *rstd2, *y2;
   float *dz2, *g2, *du, *dy1, *dz1, *g1, *dctx, *dqkv, *delta, *dx, *du_csum;
+  float* qb_part;             // [B, 3H] per-sample column sums of dqkv from the attention backward kernels
   void *ln_ws1, *ln_ws2;      // column partials of the two LayerNorm backward passes (finalized on the side stream)
   // precision 2: bf16 copies that feed the bf16-resident GEMMs (hact and du exist only in bf16 there)
   unsigned short *ctxb, *y1b, *hactb, *y2b, *g2b, *dub, *g1b, *dqkvb;
@@ -170,6 +171,7 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
       b.g1 = cv.f(M * H); b.dctx = cv.f(M * H); b.dqkv = cv.f(M * 3 * H); b.delta = cv.f((size_t)B * nh * L);
       b.dx = cv.f(M * H);
       b.du_csum = cv.f((size_t)((M + 31) / 32) * I);
+      b.qb_part = cv.f((size_t)B * 3 * H);
       b.ln_ws1 = cv.raw(uniter_ln_bwd_ws_bytes(pl.M, H));
       b.ln_ws2 = cv.raw(uniter_ln_bwd_ws_bytes(pl.M, H));
       if (pl.res) { b.g2b = cv.h(M * H); b.dub = cv.h(M * I); b.g1b = cv.h(M * H); b.dqkvb = cv.h(M * 3 * H); }
@@ -571,6 +573,9 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   const bool fuse_db1 = H % 64 == 0;
   const bool res = pl.res;
   const bool attn_b16 = res && L <= uniter_attn_varlen_max_len();
+  // the L <= 192 attention backward kernels also emit the per-sample column sums of dqkv (the fused
+  // query|key|value bias gradient before its sum over the batch): no 24 MB re-read of dqkv
+  const bool fused_qb = L <= uniter_attn_varlen_max_len();
   const int epi_du = pl.gelu_d ? UNITER_EPI_MUL : UNITER_EPI_DGELU;
   if (res) {
     UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, lb.g2b, H, m->WB(l, L_W2), I, nullptr, I, lb.dub, I,
@@ -600,12 +605,13 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     if (attn_b16)
       UCHECK_RC(uniter_attn_bf16_bwd(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
                                      pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, lb.dqkv,
-                                     lb.dqkvb, lb.delta, B, L, nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l),
-                                     pl.attn_ws, pl.attn_ws_bytes, st));
-    else if (pl.packed)
-      UCHECK_RC(uniter_attn_bwd_ex(lb.qkv, nullptr, m->batch.cu_seqlens, lb.ctx, lb.lse, lb.dctx, lb.dqkv, nullptr,
-                                   lb.delta, B, L, nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), pl.attn_ws,
-                                   pl.attn_ws_bytes, st));
+                                     lb.dqkvb, lb.qb_part, lb.delta, B, L, nh, pa, m->seed, m->offset,
+                                     SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
+    else if (fused_qb)
+      UCHECK_RC(uniter_attn_bwd_ex(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
+                                   pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, lb.dqkv, nullptr,
+                                   lb.qb_part, lb.delta, B, L, nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l),
+                                   pl.attn_ws, pl.attn_ws_bytes, st));
     else
       UCHECK_RC(uniter_attn_bwd(lb.qkv, m->batch.attention_mask, lb.ctx, lb.lse, lb.dctx, lb.dqkv, lb.delta, B, L,
                                 nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
@@ -650,7 +656,8 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkv, 3 * H, x, H, m->LG(l, L_QW), H,
                    UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
   }
-  UCHECK_RC(uniter_colsum_f32(lb.dqkv, M, 3 * H, 3 * H, m->LG(l, L_QB), 1, pl.col_ws, pl.col_ws_bytes, sd));
+  if (fused_qb) UCHECK_RC(finalize_partials(lb.qb_part, B, (size_t)3 * H, m->LG(l, L_QB), 3 * H, 1, sd));
+  else UCHECK_RC(uniter_colsum_f32(lb.dqkv, M, 3 * H, 3 * H, m->LG(l, L_QB), 1, pl.col_ws, pl.col_ws_bytes, sd));
   if (sd != st) UCHECK_HIP(hipEventRecord(m->ev_side[l], sd));
   return 0;
 }

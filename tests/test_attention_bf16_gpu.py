@@ -70,12 +70,13 @@ def test_attention_bf16_fwd_bwd(B, L, nh, p, lens, varlen):
     ctx = torch.zeros(M, H, device='cuda'); ctxb = torch.zeros(M, H, dtype=torch.bfloat16, device='cuda')
     lse = torch.zeros(B, nh, L, device='cuda'); delta = torch.zeros(B, nh, L, device='cuda')
     dqkv = torch.zeros(M, 3 * H, device='cuda'); dqkvb = torch.zeros(M, 3 * H, dtype=torch.bfloat16, device='cuda')
+    bpart = torch.full((B, 3 * H), float('nan'), device='cuda')
     wsb = lib.uniter_attn_bf16_bwd_ws_bytes(B, L, nh)
     ws = torch.full((max(wsb, 4) // 2,), float('nan'), dtype=torch.bfloat16, device='cuda')
     Lb.check(lib.uniter_attn_bf16_fwd(Lb.ptr(qd), mptr, cptr, Lb.ptr(ctx), Lb.ptr(ctxb), Lb.ptr(lse), B, L, nh, p, seed,
                                       offset, site, Lb.cur_stream()))
     Lb.check(lib.uniter_attn_bf16_bwd(Lb.ptr(qd), mptr, cptr, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), Lb.ptr(dqkv),
-                                      Lb.ptr(dqkvb), Lb.ptr(delta), B, L, nh, p, seed, offset, site, Lb.ptr(ws), wsb,
+                                      Lb.ptr(dqkvb), Lb.ptr(bpart), Lb.ptr(delta), B, L, nh, p, seed, offset, site, Lb.ptr(ws), wsb,
                                       Lb.cur_stream()))
     torch.cuda.synchronize()
     sel = slice(None) if varlen else rows
@@ -91,6 +92,13 @@ def test_attention_bf16_fwd_bwd(B, L, nh, p, lens, varlen):
     for name, sl in (('dq', slice(0, H)), ('dk', slice(H, 2 * H)), ('dv', slice(2 * H, 3 * H))):
         err = (got_d[:, sl] - ref_d[:, sl]).abs().max().item()
         assert err < 1.5e-2 * max(1.0, ref_d[:, sl].abs().max().item()), (name, err)
+    # per-sample column sums of dqkv (the fused QKV-bias gradient before the sum over the batch)
+    full = dqkv.cpu().double()
+    start = 0
+    for bb, n in enumerate(lens):
+        blk = full[start:start + n] if varlen else full[bb * L:(bb + 1) * L]
+        start += n
+        assert (bpart.cpu().double()[bb] - blk.sum(0)).abs().max() < 1e-3 * max(1.0, blk.abs().sum(0).max().item()), bb
     # the bf16 copies are the rounded fp32 outputs
     assert torch.equal(ctxb.cpu()[sel], ctx.cpu()[sel].bfloat16())
     assert torch.equal(dqkvb.cpu()[sel], dqkv.cpu()[sel].bfloat16())

@@ -81,3 +81,32 @@ def test_attention_fully_masked_row_matches_reference_semantics():
     Lb.check(lib.uniter_attn_fwd(Lb.ptr(dq), Lb.ptr(dm), Lb.ptr(ctx), None, B, L, nh, 0.0, 0,
                                  0, 0, Lb.cur_stream()))
     assert (ctx.cpu() - ctx_ref).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize('B,L,nh,p', [(3, 164, 2, 0.1), (2, 40, 12, 0.0), (2, 20, 1, 0.2)])
+def test_attention_bwd_ex_emits_qkv_bias_partials(B, L, nh, p):
+    """uniter_attn_bwd_ex: bias_part[b] = column sums of sample b's dqkv rows (fused into the dQ / dK,dV
+    kernels), with bf16 copies of the outputs."""
+    from meme_challenge_amd import _lib as Lb
+    lib = Lb.lib()
+    H = nh * 64
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B * L, 3 * H, generator=g).cuda()
+    dctx = torch.randn(B * L, H, generator=g).cuda()
+    mask = torch.ones(B, L).cuda()
+    mask[1, L - 9:] = 0
+    ctx = torch.empty(B * L, H, device='cuda'); ctxb = torch.empty(B * L, H, dtype=torch.bfloat16, device='cuda')
+    lse = torch.empty(B, nh, L, device='cuda'); delta = torch.empty(B, nh, L, device='cuda')
+    dqkv = torch.zeros(B * L, 3 * H, device='cuda'); dqkvb = torch.zeros(B * L, 3 * H, dtype=torch.bfloat16, device='cuda')
+    part = torch.full((B, 3 * H), float('nan'), device='cuda')
+    wsb = lib.uniter_attn_bwd_ws_bytes(B, L, nh)
+    ws = torch.empty(max(wsb, 4) // 4, device='cuda')
+    Lb.check(lib.uniter_attn_fwd_ex(Lb.ptr(qkv), Lb.ptr(mask), None, Lb.ptr(ctx), Lb.ptr(ctxb), Lb.ptr(lse), B, L, nh, p,
+                                    11, 2, 3, Lb.cur_stream()))
+    Lb.check(lib.uniter_attn_bwd_ex(Lb.ptr(qkv), Lb.ptr(mask), None, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dctx), Lb.ptr(dqkv),
+                                    Lb.ptr(dqkvb), Lb.ptr(part), Lb.ptr(delta), B, L, nh, p, 11, 2, 3, Lb.ptr(ws), wsb,
+                                    Lb.cur_stream()))
+    torch.cuda.synchronize()
+    ref = dqkv.view(B, L, 3 * H).double().sum(1)
+    assert (part.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    assert torch.equal(ctxb, ctx.bfloat16()) and torch.equal(dqkvb, dqkv.bfloat16())
