@@ -131,6 +131,7 @@ __device__ __forceinline__ bf16x8 frag_read_b(const unsigned short* s, int r0, i
 template <int R, bool KM, bool RES> struct Stager;
 
 template <int R, bool KM> struct Stager<R, KM, false> {
+  static constexpr int IMG = R * LDB16;
   int voff[R / 16];
   f32x4 reg[R / 16];
   static __device__ __forceinline__ int kstep(int ld) { return (KM ? BKB * ld : BKB) * 4; }
@@ -145,6 +146,7 @@ template <int R, bool KM> struct Stager<R, KM, false> {
 
 template <int R> struct Stager<R, false, true> {
   static constexpr int NP = R / 32;
+  static constexpr int IMG = R * LDB16;
   int voff[NP];
   u32x4_t reg[NP];
   static __device__ __forceinline__ int kstep(int) { return BKB * 2; }
@@ -172,49 +174,58 @@ template <int R> struct Stager<R, false, true> {
   }
 };
 
+// k-major resident operand ([k][n] in memory, n contiguous: dgrad's weight, both wgrad operands).  The
+// tile goes to LDS AS IT IS -- [64 k][R n] rows of 16-byte pieces, no register transposition, no
+// per-element LDS writes -- and the MFMA operand (8 consecutive k of one n per lane) is gathered by
+// ds_read_b64_tr_b16: per 16-lane group the instruction reads a 4 (k) x 16 (n) block and hands lane i
+// column i.  Lane 4q+p of a group addresses row k0+q, columns n0+4p..+3; two reads (k0, k0+4) make
+// one bf16x8 fragment.  Row stride 192 B (R = 64) / 320 B (R = 128): the four rows a 32-lane half
+// touches fall into disjoint 16-bank windows.
 template <int R> struct Stager<R, true, true> {
-  static constexpr int NP = R / 64;
-  int voff[2 * NP];
-  u32x4_t reg[2 * NP];
+  static constexpr int NP = R / 32;                   // 16-B pieces per thread: 64 rows x R/8 pieces / 256 threads
+  static constexpr int LDK = R == 64 ? 96 : 160;      // LDS row stride in bf16 elements
+  static constexpr int IMG = BKB * LDK;
+  int voff[NP];
+  u32x4_t reg[NP];
   static __device__ __forceinline__ int kstep(int ld) { return BKB * ld * 2; }
   static __device__ __forceinline__ size_t bytes(int rows, int ld) { return (size_t)rows * ld * 2; }
   __device__ __forceinline__ void offsets(int ld, int row0, int tid) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int id = tid + 256 * p;
-      const int cg = ((id >> 7) << 2) | (id & 3), kp = (id >> 2) & 31;
-      voff[2 * p] = ((2 * kp) * ld + row0 + cg * 8) * 2;
-      voff[2 * p + 1] = voff[2 * p] + ld * 2;
+      const int c8 = id % (R / 8), k = id / (R / 8);
+      voff[p] = (k * ld + row0 + c8 * 8) * 2;
     }
   }
   __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int soff) {
 #pragma unroll
-    for (int p = 0; p < 2 * NP; ++p) reg[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], soff, 0);
+    for (int p = 0; p < NP; ++p) reg[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], soff, 0);
   }
   __device__ __forceinline__ void store(unsigned short* s, int tid) const {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int id = tid + 256 * p;
-      const int cg = ((id >> 7) << 2) | (id & 3), kp = (id >> 2) & 31;
-      const int slot = ((kp >> 2) ^ (cg & 3)) << 3;             // rows cg*8 .. cg*8+7 share (row >> 3) & 3 = cg & 3
-      unsigned short* d = s + (cg * 8) * LDB16 + slot + 2 * (kp & 3);
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const unsigned lo = reg[2 * p][w], hi = reg[2 * p + 1][w];     // columns 2w, 2w+1 of rows k, k+1
-        *reinterpret_cast<unsigned*>(d + (2 * w) * LDB16) = (lo & 0xffffu) | (hi << 16);
-        *reinterpret_cast<unsigned*>(d + (2 * w + 1) * LDB16) = (lo >> 16) | (hi & 0xffff0000u);
-      }
+      const int c8 = id % (R / 8), k = id / (R / 8);
+      *reinterpret_cast<u32x4_t*>(s + k * LDK + c8 * 8) = reg[p];
     }
   }
   static __device__ __forceinline__ bf16x8 frag(const unsigned short* s, int r0, int ks, int i, int h) {
-    return Stager<R, false, true>::frag(s, r0, ks, i, h);
+    typedef short short4v __attribute__((ext_vector_type(4)));
+    typedef short4v __attribute__((address_space(3))) * lds_s4;
+    const int lane16 = i & 15, q = lane16 >> 2, p = lane16 & 3;
+    const unsigned short* a0 = s + (ks * 16 + 8 * h + q) * LDK + r0 + (i & 16) + 4 * p;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(a0));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(a0 + 4 * LDK));
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    const short8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
   }
 };
 
 template <int BM, int BN, bool AKM, bool BKM, int TAG, bool SK, bool RES = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int SA = BM * LDB16, SB = BN * LDB16;              // bf16 elements
+  constexpr int SA = Stager<BM, AKM, RES>::IMG, SB = Stager<BN, BKM, RES>::IMG;      // bf16 elements per LDS image
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (SA + SB)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -420,6 +431,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
 
 template <int BM, int BN, bool AKM, bool BKM, bool RES = false>
 int launch_b(GemmArgsB g, hipStream_t st, int slots) {
+  // the k-major LDS images of the resident kernels are larger (43 - 49 KB per 64x64 workgroup): three fit a CU
+  if (RES && (AKM || BKM) && BM == 64 && BN == 64) slots = 768;
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   const int tiles = g.tiles_m * g.tiles_n;
