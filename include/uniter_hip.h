@@ -333,6 +333,13 @@ int uniter_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg
                      float grad_scale, float max_norm, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, int adamw, int zero_grads,
                      void* stream);
+/* as uniter_adam_step; additionally mirror_bf16[i] = bf16(params[i]) for every updated element (the bf16
+ * weight mirror of precision mode 2 stays in step without a separate cast pass); NULL = none */
+int uniter_adam_step_mirror(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                            const uint8_t* chunk_flags, size_t n, const double* sumsq,
+                            float grad_scale, float max_norm, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int step, int adamw, int zero_grads,
+                            void* mirror_bf16, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Whole-model schedule: the library owns the kernel sequence of

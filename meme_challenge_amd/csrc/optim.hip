@@ -54,6 +54,7 @@ struct AdamArgs {
   const double* sumsq;
   float gscale, max_norm, lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2;
   int adamw, zero_grads;
+  unsigned short* mirror;     // optional bf16 copy of the updated parameters (precision 'bf16' weight mirror)
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
@@ -83,6 +84,10 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
       p[e] = pp - a.step_size * (m[e] / denom);
     }
     reinterpret_cast<f32x4*>(a.p)[i] = p;
+    if (a.mirror) {
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      reinterpret_cast<bf16x4_t*>(a.mirror)[i] = bf16x4_t{(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
+    }
     reinterpret_cast<f32x4*>(a.m)[i] = m;
     reinterpret_cast<f32x4*>(a.v)[i] = v;
     if (a.zero_grads) reinterpret_cast<f32x4*>(a.g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -116,6 +121,15 @@ extern "C" int uniter_adam_step(float* params, float* grads, float* exp_avg, flo
                                 const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale,
                                 float max_norm, float lr, float beta1, float beta2, float eps,
                                 float weight_decay, int step, int adamw, int zero_grads, void* stream) {
+  return uniter_adam_step_mirror(params, grads, exp_avg, exp_avg_sq, chunk_flags, n, sumsq, grad_scale, max_norm, lr,
+                                 beta1, beta2, eps, weight_decay, step, adamw, zero_grads, nullptr, stream);
+}
+
+extern "C" int uniter_adam_step_mirror(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                       const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale,
+                                       float max_norm, float lr, float beta1, float beta2, float eps,
+                                       float weight_decay, int step, int adamw, int zero_grads,
+                                       void* mirror_bf16, void* stream) {
   UCHECK_ARG(params && grads && exp_avg && exp_avg_sq && chunk_flags, "adam_step: null pointer");
   UCHECK_SHAPE(n % CHUNK == 0, "adam_step: n must be a multiple of 64");
   UCHECK_ARG(step >= 1, "adam_step: step must be >= 1");
@@ -124,6 +138,7 @@ extern "C" int uniter_adam_step(float* params, float* grads, float* exp_avg, flo
   a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.flags = chunk_flags; a.n4 = n / 4;
   a.sumsq = sumsq; a.gscale = grad_scale; a.max_norm = max_norm; a.lr = lr; a.b1 = beta1; a.b2 = beta2;
   a.eps = eps; a.wd = weight_decay; a.adamw = adamw; a.zero_grads = zero_grads;
+  a.mirror = (unsigned short*)mirror_bf16;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   a.step_size = (float)((double)lr / bc1);

@@ -172,22 +172,19 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count += 1
         b1, b2 = g0['betas']
 
-        def launch(lo, hi, stream_ptr):
-            off = lo * 4
-            check(lib.uniter_adam_step(st.flat_params.data_ptr() + off, st.flat_grads.data_ptr() + off,
-                                       self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
-                                       flags.data_ptr() + lo // CHUNK, hi - lo, ptr(self._sumsq),
-                                       float(grad_scale), float(max_grad_norm or 0.0), lr, float(b1), float(b2),
-                                       float(g0['eps']), float(g0['weight_decay']), self.step_count,
-                                       int(self.adamw), int(bool(zero_grads)), stream_ptr),
-                  'uniter_adam_step')
-
         mirror = getattr(st, 'mirror', None)
 
-        def launch(lo, hi, stream_ptr, _adam=launch):
-            _adam(lo, hi, stream_ptr)
-            if mirror is not None:                 # keep the bf16 weight mirror in step, on the same stream
-                st.refresh_mirror(lo, hi, stream_ptr)
+        def launch(lo, hi, stream_ptr):
+            off = lo * 4
+            # the bf16 weight mirror (precision 'bf16') is written by the same kernel, on the same stream
+            check(lib.uniter_adam_step_mirror(st.flat_params.data_ptr() + off, st.flat_grads.data_ptr() + off,
+                                              self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
+                                              flags.data_ptr() + lo // CHUNK, hi - lo, ptr(self._sumsq),
+                                              float(grad_scale), float(max_grad_norm or 0.0), lr, float(b1), float(b2),
+                                              float(g0['eps']), float(g0['weight_decay']), self.step_count,
+                                              int(self.adamw), int(bool(zero_grads)),
+                                              (mirror.data_ptr() + lo * 2) if mirror is not None else None, stream_ptr),
+                  'uniter_adam_step')
 
         enc = self.overlap_encoder
         plan = self._overlap_plan(enc) if enc is not None else None
