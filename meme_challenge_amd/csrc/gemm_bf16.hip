@@ -509,7 +509,7 @@ int gemm_bf16res_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, c
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
   if (cfg == 0) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    cfg = t128 >= 448 ? 1 : 4;
+    cfg = t128 >= 1024 ? 1 : 4;     // measured (r01_gemm_bf16_resident_vs_hybrid.txt): 64x64 wins on every model shape
   }
   hipStream_t st = (hipStream_t)stream;
   if (!a_kmajor && !b_kmajor) return dispatch_r<false, false>(cfg, g, st);
