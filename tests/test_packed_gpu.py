@@ -171,3 +171,54 @@ def test_packed_training_step_runs_and_tracks_padded_loss():
     assert all(np.isfinite(losses[True]))
     assert abs(losses[True][-1] - losses[False][-1]) < 0.25
     assert losses[True][-1] < losses[True][0]
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['txt', 'img', 'joint', 'joint_masks'])
+def test_single_modality_and_mask_inputs_in_every_layout(tiny, precision, mode):
+    """Text-only / image-only / joint (+ img_masks) inputs through the padded and the packed layout, in fp32 and
+    in the bf16-resident mode: packed == padded at the valid positions (fp32: round-off; bf16: bf16 accuracy)."""
+    sd = sd_from_npz(tiny)
+    b = to_dev(batch_from_npz(tiny))
+    B, T = b['input_ids'].shape
+    R = b['img_feat'].shape[1]
+    tl = (b['input_ids'] != 0).sum(1)
+    nbb = b['attn_mask'].sum(1).long() - tl
+    ar = lambda n: torch.arange(n, device='cuda').unsqueeze(0)
+    if mode == 'txt':
+        kw = dict(input_ids=b['input_ids'], position_ids=b['position_ids'], img_feat=None, img_pos_feat=None,
+                  attention_mask=(ar(T) < tl.unsqueeze(1)).float())
+    elif mode == 'img':
+        kw = dict(input_ids=None, position_ids=None, img_feat=b['img_feat'], img_pos_feat=b['img_pos_feat'],
+                  attention_mask=(ar(R) < nbb.unsqueeze(1)).float())
+    else:
+        kw = model_kwargs(b)
+        kw.pop('output_all_encoded_layers')
+        if mode == 'joint_masks':
+            kw['img_masks'] = b['img_masks']
+    outs = {}
+    for packed in (False, True):
+        m = build(TINY, TINY_IMG_DIM, sd).eval()
+        m.uniter_model.precision = precision
+        m.uniter_model.pack_padded = packed
+        h = m.uniter_model(output_all_encoded_layers=False, **kw)
+        (h * h).sum().backward()
+        torch.cuda.synchronize()
+        outs[packed] = (h.detach().clone(), _grads(m))
+    valid = kw['attention_mask'].bool()
+    tol = 2e-5 if precision == 'fp32' else 3e-2
+    assert maxdiff(outs[True][0][valid], outs[False][0][valid]) < tol * max(1.0, outs[False][0].abs().max().item())
+    assert outs[True][0][~valid].abs().max().item() == 0.0 if (~valid).any() else True
+    # the loss above also sums the padded positions of the padded layout, so only compare where both define it:
+    # gradients flow from valid rows only once the padded rows are excluded
+    for packed in (False, True):
+        m = build(TINY, TINY_IMG_DIM, sd).eval()
+        m.uniter_model.precision = precision
+        m.uniter_model.pack_padded = packed
+        h = m.uniter_model(output_all_encoded_layers=False, **kw)
+        ((h * valid.unsqueeze(-1)) ** 2).sum().backward()
+        torch.cuda.synchronize()
+        outs[packed] = _grads(m)
+    gtol = 3e-4 if precision == 'fp32' else 6e-2
+    for n, gp in outs[False].items():
+        assert maxdiff(outs[True][n], gp) <= 1e-5 + gtol * max(gp.abs().max().item(), 1e-3), (n, maxdiff(outs[True][n], gp))
