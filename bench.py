@@ -239,7 +239,7 @@ def main():
         dt_name = 'f32' if args.precision == 'fp32' else 'bf16'
         peak = PEAK_TFLOPS[dt_name]
         out = {
-            'metric': 'train samples/sec UNITER-%s (36 regions, 128 tok)' % args.model,
+            'metric': 'train samples/sec UNITER-%s (%d regions, %d tok)' % (args.model, R, T),
             'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': dt_name, 'data': 'synthetic',
