@@ -11,6 +11,8 @@ torch.manual_seed(0)
 cfg = UniterConfig.from_dict(BASE)
 model = MemeUniter(UniterModel(cfg, img_dim=2048), cfg.hidden_size, 1).to(dev).train()
 model.uniter_model.set_dropout_seed(1234, 0)
+if len(sys.argv) > 1:
+    model.uniter_model.precision = sys.argv[1]
 batch = make_synthetic_batch(16, 128, 36, seed=1234, device=dev)
 config = dict(optimizer='adam', lr=3e-5, beta1=0.9, beta2=0.999, weight_decay=1e-3, gradient_accumulation=1, max_grad_norm=5,
               pos_wt=1.8, loss_func='bce_logits', scheduler='warmup_cosine', warmup_steps=500, max_epoch=30)
