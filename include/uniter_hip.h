@@ -196,25 +196,29 @@ int uniter_attn_bwd_varlen(const float* qkv, const int32_t* cu_seqlens, const fl
  * plus optional bf16 copies of ctx / dqkv (operands of the bf16-resident GEMMs; NULL = none) and, for the
  * backward pass, bias_part [B, 3H] (NULL = none): per-sample column sums of dqkv, i.e. the gradient of the
  * fused query|key|value bias before the sum over the batch -- saves a 24 MB re-read of dqkv. */
+/* keep_bits (NULL = none): uniter_attn_keep_bits_bytes(B, L, nh) bytes; the forward pass stores the dropout
+ * keep flags it drew (one bit per probability) and the backward pass reads them instead of evaluating
+ * Philox a second time -- same masks, ~0.75 MB per layer at B = 16. */
+size_t uniter_attn_keep_bits_bytes(int B, int L, int nh);
 int uniter_attn_fwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
-                       void* ctx_bf16, float* lse, int B, int L, int nh, float p_drop, uint64_t seed,
-                       uint32_t offset, uint32_t site, void* stream);
+                       void* ctx_bf16, float* lse, void* keep_bits, int B, int L, int nh, float p_drop,
+                       uint64_t seed, uint32_t offset, uint32_t site, void* stream);
 int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
                        const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16,
-                       float* bias_part, float* delta, int B, int L, int nh, float p_drop, uint64_t seed,
-                       uint32_t offset, uint32_t site, void* ws, size_t ws_bytes, void* stream);
+                       float* bias_part, const void* keep_bits, float* delta, int B, int L, int nh, float p_drop,
+                       uint64_t seed, uint32_t offset, uint32_t site, void* ws, size_t ws_bytes, void* stream);
 /* The same two operations on the bf16 matrix pipe (precision mode 2): Q, K, V rounded to bf16 while
  * staged, fp32 scores / softmax / dropout / LSE, probabilities and score gradients rounded to bf16 as
  * MFMA operands.  Same arguments and Philox element indices as the _ex forms; L <= 192;
  * ws: uniter_attn_bf16_bwd_ws_bytes (bf16 Pd / dS scratch, half of the fp32 kernels'). */
 size_t uniter_attn_bf16_bwd_ws_bytes(int B, int L, int nh);
 int uniter_attn_bf16_fwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
-                         void* ctx_bf16, float* lse, int B, int L, int nh, float p_drop, uint64_t seed,
-                         uint32_t offset, uint32_t site, void* stream);
+                         void* ctx_bf16, float* lse, void* keep_bits, int B, int L, int nh, float p_drop,
+                         uint64_t seed, uint32_t offset, uint32_t site, void* stream);
 int uniter_attn_bf16_bwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
                          const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16,
-                         float* bias_part, float* delta, int B, int L, int nh, float p_drop, uint64_t seed,
-                         uint32_t offset, uint32_t site, void* ws, size_t ws_bytes, void* stream);
+                         float* bias_part, const void* keep_bits, float* delta, int B, int L, int nh, float p_drop,
+                         uint64_t seed, uint32_t offset, uint32_t site, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Embeddings (replace UniterTextEmbeddings.forward model/model.py:232-245,

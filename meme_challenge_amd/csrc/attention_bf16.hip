@@ -43,6 +43,7 @@ struct Args {
   float* lse;              // [B, nh, L]
   const float* dctx;
   float* dqkv; u16* dqkv_b16;
+  u16* keep_bits;          // optional [B*nh, L, Lr/32, 2] dropout keep flags written by the forward pass, read by dQ
   float* bias_part;        // optional [B, 3H] per-sample column sums of dqkv (QKV bias gradient partials)
   float* delta;            // [B, nh, L]
   u16* pd_ws; u16* ds_ws;  // [B*nh][Lr][Lr] bf16, indexed [key][query]
@@ -222,13 +223,15 @@ __global__ __launch_bounds__(768) void attn_b16_fwd_kernel(const Args a, int Lr)
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
     if (a.drop.active && vq) {
       const uint64_t grow = ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2);
+      unsigned bits = 0;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float m4[4];
-        drop_mult4(a.drop, grow + 2 * g + h, m4);
+        const unsigned b4 = drop_bits4(a.drop, grow + 2 * g + h);
+        bits |= b4 << (4 * g);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s[4 * g + t] *= m4[t];
+        for (int t = 0; t < 4; ++t) s[4 * g + t] *= ((b4 >> t) & 1u) ? a.drop.scale : 0.f;
       }
+      if (a.keep_bits) a.keep_bits[(((size_t)bh * a.L + q) * nblk + (k0 >> 5)) * 2 + h] = (u16)bits;
     }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {                                   // O^T[d][query] += V^T . Pd^T
@@ -321,12 +324,19 @@ __global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr, 
       s = MFMA(frag_rm(Kb, k0 + i, st, h), qf[st], s);
       dp = MFMA(frag_rm(Vb, k0 + i, st, h), dof[st], dp);               // dP^T[key][query] = V . dO^T
     }
+    unsigned bits = 0xffffu;
+    const bool stored = a.drop.active && vq && a.keep_bits;
+    if (stored) bits = a.keep_bits[(((size_t)bh * a.L + q) * nblk + (k0 >> 5)) * 2 + h];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + k0 + 8 * g + 4 * h);
       float m4[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.drop.active && vq)
+      if (stored) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m4[t] = ((bits >> (4 * g + t)) & 1u) ? a.drop.scale : 0.f;
+      } else if (a.drop.active && vq) {
         drop_mult4(a.drop, ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2) + 2 * g + h, m4);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float p = __expf(s[4 * g + t] * a.scale + bias[t] - lse);
@@ -461,13 +471,14 @@ extern "C" size_t uniter_attn_bf16_bwd_ws_bytes(int B, int L, int nh) {
 }
 
 extern "C" int uniter_attn_bf16_fwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
-                                    void* ctx_bf16, float* lse, int B, int L, int nh, float p_drop, uint64_t seed,
-                                    uint32_t offset, uint32_t site, void* stream) {
+                                    void* ctx_bf16, float* lse, void* keep_bits, int B, int L, int nh, float p_drop,
+                                    uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
   UCHECK_ARG(qkv && ctx && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_bf16_fwd: need attn_mask or cu_seqlens (not both)");
   Args a = {};
   UCHECK_RC(fill(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_b16 = (u16*)ctx_bf16; a.lse = lse;
+  a.keep_bits = (u16*)keep_bits;
   const int Lr = (L + 31) / 32 * 32, nblk = Lr / 32;
   const size_t lds = max3((size_t)(Lr * KLD + D * TLD) * 2 + Lr * 4, (size_t)nblk * XROW * 64 * 4, 0);
   UCHECK_RC(set_lds(attn_b16_fwd_kernel, lds));
@@ -478,8 +489,8 @@ extern "C" int uniter_attn_bf16_fwd(const float* qkv, const float* attn_mask, co
 
 extern "C" int uniter_attn_bf16_bwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
                                     const float* ctx, const float* lse, const float* dctx, float* dqkv,
-                                    void* dqkv_bf16, float* bias_part, float* delta, int B, int L, int nh,
-                                    float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws,
+                                    void* dqkv_bf16, float* bias_part, const void* keep_bits, float* delta, int B, int L,
+                                    int nh, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws,
                                     size_t ws_bytes, void* stream) {
   UCHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta && ws && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_bf16_bwd: null pointer, or not exactly one of attn_mask / cu_seqlens");
@@ -487,7 +498,7 @@ extern "C" int uniter_attn_bf16_bwd(const float* qkv, const float* attn_mask, co
   Args a = {};
   UCHECK_RC(fill(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
-  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (u16*)dqkv_bf16; a.bias_part = bias_part; a.delta = delta;
+  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (u16*)dqkv_bf16; a.bias_part = bias_part; a.keep_bits = (u16*)keep_bits; a.delta = delta;
   const int Lr = (L + 31) / 32 * 32, nblk = Lr / 32;
   a.pd_ws = (u16*)ws;
   a.ds_ws = a.pd_ws + (size_t)B * nh * Lr * Lr;

@@ -43,6 +43,8 @@ struct AttnArgs {
   float* delta;         // [B, nh, L]
   unsigned short* ctx_b16;   // optional bf16 copies of ctx / dqkv (operands of bf16-resident GEMMs)
   unsigned short* dqkv_b16;
+  unsigned short* keep_bits; // optional [B*nh, L, Lr/32, 2]: dropout keep flags of a (query, key block, lane half), written by the
+                             // forward pass and read by dQ instead of a second Philox evaluation
   float* bias_part;          // optional [B, 3H]: per-sample column sums of dqkv (the QKV bias gradient, reduced over B later)
   const int* cu;        // [B+1] prefix sums of per-sample lengths (packed rows), or NULL: sample b owns rows b*L .. b*L+L-1
   int B, L, nh, H, Lp4; // Lp4 = roundup(L,4)/4
@@ -637,13 +639,15 @@ __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, i
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
     if (a.drop.active && vq) {
       const uint64_t grow = ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2);
+      unsigned bits = 0;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float m4[4];
-        drop_mult4(a.drop, grow + 2 * g + h, m4);
+        const unsigned b4 = drop_bits4(a.drop, grow + 2 * g + h);
+        bits |= b4 << (4 * g);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s[4 * g + t] *= m4[t];
+        for (int t = 0; t < 4; ++t) s[4 * g + t] *= ((b4 >> t) & 1u) ? a.drop.scale : 0.f;
       }
+      if (a.keep_bits) a.keep_bits[(((size_t)bh * a.L + q) * nblk + (k0 >> 5)) * 2 + h] = (unsigned short)bits;
     }
     tileT_times_acc(Vs + k0 * LDT, s, o0, o1, i, h);
   }
@@ -729,12 +733,19 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
   for (int k0 = kbeg; k0 < kend; k0 += 32) {
     f32x16 s = tile_times_frag(Ks + k0 * LDT, qf, i, h);
     f32x16 dp = tile_times_frag(Vs + k0 * LDT, dof, i, h);
+    unsigned bits = 0xffffu;
+    const bool stored = a.drop.active && vq && a.keep_bits;
+    if (stored) bits = a.keep_bits[(((size_t)bh * a.L + q) * nblk + (k0 >> 5)) * 2 + h];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + k0 + 8 * g + 4 * h);
       float m4[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.drop.active && vq)
+      if (stored) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m4[t] = ((bits >> (4 * g + t)) & 1u) ? a.drop.scale : 0.f;
+      } else if (a.drop.active && vq) {
         drop_mult4(a.drop, ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2) + 2 * g + h, m4);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float p = __expf(s[4 * g + t] * a.scale + bias[t] - lse);
@@ -960,13 +971,19 @@ extern "C" int uniter_attn_bwd_varlen(const float* qkv, const int32_t* cu_seqlen
 }
 
 // General forms: mask XOR cu_seqlens, optional bf16 copies of the outputs (split kernels only: L <= 192).
+extern "C" size_t uniter_attn_keep_bits_bytes(int B, int L, int nh) {
+  const int Lr = (L + 31) / 32 * 32;
+  return (size_t)B * nh * L * (Lr / 32) * 2 * sizeof(unsigned short);
+}
+
 extern "C" int uniter_attn_fwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
-                                  void* ctx_bf16, float* lse, int B, int L, int nh, float p_drop, uint64_t seed,
-                                  uint32_t offset, uint32_t site, void* stream) {
+                                  void* ctx_bf16, float* lse, void* keep_bits, int B, int L, int nh, float p_drop,
+                                  uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
   UCHECK_ARG(qkv && ctx && ((attn_mask != nullptr) != (cu_seqlens != nullptr)), "attn_fwd_ex: need attn_mask or cu_seqlens (not both)");
   AttnArgs a = {};
   UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_b16 = (unsigned short*)ctx_bf16; a.lse = lse;
+  a.keep_bits = (unsigned short*)keep_bits;
   const int Lr = (L + 31) / 32 * 32;
   UCHECK_SHAPE(Lr <= uniter_attn_varlen_max_len(), "attn_fwd_ex: L %d > %d", L, uniter_attn_varlen_max_len());
   const size_t lds = res_lds_bytes(Lr);
@@ -978,9 +995,9 @@ extern "C" int uniter_attn_fwd_ex(const float* qkv, const float* attn_mask, cons
 
 extern "C" int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
                                   const float* ctx, const float* lse, const float* dctx, float* dqkv,
-                                  void* dqkv_bf16, float* bias_part, float* delta, int B, int L, int nh, float p_drop,
-                                  uint64_t seed, uint32_t offset, uint32_t site, void* ws, size_t ws_bytes,
-                                  void* stream) {
+                                  void* dqkv_bf16, float* bias_part, const void* keep_bits, float* delta, int B, int L,
+                                  int nh, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws,
+                                  size_t ws_bytes, void* stream) {
   UCHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta && ws && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_bwd_ex: null pointer, or not exactly one of attn_mask / cu_seqlens");
   const int Lr = (L + 31) / 32 * 32;
@@ -989,7 +1006,7 @@ extern "C" int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, cons
   AttnArgs a = {};
   UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
-  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (unsigned short*)dqkv_bf16; a.bias_part = bias_part; a.delta = delta;
+  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (unsigned short*)dqkv_bf16; a.bias_part = bias_part; a.keep_bits = (unsigned short*)keep_bits; a.delta = delta;
   const size_t lds = res_lds_bytes(Lr);
   float* pd_ws = (float*)ws;
   float* ds_ws = pd_ws + (size_t)B * nh * Lr * Lr;

@@ -62,6 +62,7 @@ struct Carver {
 struct LayerBufs {   // saved activations + backward scratch of one layer
   float *qkv, *lse, *ctx, *t1, *z1, *mean1, *rstd1, *y1, *u, *hact, *t2, *z2, *mean2, *rstd2, *y2;
   float *dz2, *g2, *du, *dy1, *dz1, *g1, *dctx, *dqkv, *delta, *dx, *du_csum;
+  unsigned short* keepb;      // dropout keep flags of the attention probabilities (forward -> dQ)
   float* qb_part;             // [B, 3H] per-sample column sums of dqkv from the attention backward kernels
   void *ln_ws1, *ln_ws2;      // column partials of the two LayerNorm backward passes (finalized on the side stream)
   // precision 2: bf16 copies that feed the bf16-resident GEMMs (hact and du exist only in bf16 there)
@@ -172,6 +173,7 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
       b.dx = cv.f(M * H);
       b.du_csum = cv.f((size_t)((M + 31) / 32) * I);
       b.qb_part = cv.f((size_t)B * 3 * H);
+      b.keepb = (unsigned short*)cv.raw(uniter_attn_keep_bits_bytes(B, L, nh));
       b.ln_ws1 = cv.raw(uniter_ln_bwd_ws_bytes(pl.M, H));
       b.ln_ws2 = cv.raw(uniter_ln_bwd_ws_bytes(pl.M, H));
       if (pl.res) { b.g2b = cv.h(M * H); b.dub = cv.h(M * I); b.g1b = cv.h(M * H); b.dqkvb = cv.h(M * 3 * H); }
@@ -451,10 +453,12 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
       ProfScope ps(m, UNITER_K_ATTN_FWD, st);
       if (attn_b16)      // precision 2: the attention products run on the bf16 pipe as well
         UCHECK_RC(uniter_attn_bf16_fwd(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
-                                       lb.ctx, lb.ctxb, lb.lse, B, L, nh, pa, seed, offset, SITE_ATTN_PROBS(l), st));
-      else if (packed)
-        UCHECK_RC(uniter_attn_fwd_ex(lb.qkv, nullptr, b->cu_seqlens, lb.ctx, nullptr, lb.lse, B, L, nh, pa, seed,
-                                     offset, SITE_ATTN_PROBS(l), st));
+                                       lb.ctx, lb.ctxb, lb.lse, save ? lb.keepb : nullptr, B, L, nh, pa, seed, offset,
+                                       SITE_ATTN_PROBS(l), st));
+      else if (packed || (save && L <= uniter_attn_varlen_max_len()))
+        UCHECK_RC(uniter_attn_fwd_ex(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
+                                     lb.ctx, nullptr, lb.lse, save ? lb.keepb : nullptr, B, L, nh, pa, seed, offset,
+                                     SITE_ATTN_PROBS(l), st));
       else
         UCHECK_RC(uniter_attn_fwd(lb.qkv, b->attention_mask, lb.ctx, lb.lse, B, L, nh, pa, seed, offset,
                                   SITE_ATTN_PROBS(l), st));
@@ -605,12 +609,12 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     if (attn_b16)
       UCHECK_RC(uniter_attn_bf16_bwd(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
                                      pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, lb.dqkv,
-                                     lb.dqkvb, lb.qb_part, lb.delta, B, L, nh, pa, m->seed, m->offset,
+                                     lb.dqkvb, lb.qb_part, lb.keepb, lb.delta, B, L, nh, pa, m->seed, m->offset,
                                      SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
     else if (fused_qb)
       UCHECK_RC(uniter_attn_bwd_ex(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
                                    pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, lb.dqkv, nullptr,
-                                   lb.qb_part, lb.delta, B, L, nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l),
+                                   lb.qb_part, lb.keepb, lb.delta, B, L, nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l),
                                    pl.attn_ws, pl.attn_ws_bytes, st));
     else
       UCHECK_RC(uniter_attn_bwd(lb.qkv, m->batch.attention_mask, lb.ctx, lb.lse, lb.dctx, lb.dqkv, lb.delta, B, L,

@@ -60,4 +60,9 @@ __device__ __forceinline__ void drop_mult4(const DropCfg& d, uint64_t group, flo
   m[2] = r.z >= d.thresh ? d.scale : 0.0f;
   m[3] = r.w >= d.thresh ? d.scale : 0.0f;
 }
+// keep flags of the group's 4 elements as a 4-bit mask (bit t = element t kept)
+__device__ __forceinline__ unsigned drop_bits4(const DropCfg& d, uint64_t group) {
+  const u32x4 r = drop_words(d, group);
+  return (r.x >= d.thresh ? 1u : 0u) | (r.y >= d.thresh ? 2u : 0u) | (r.z >= d.thresh ? 4u : 0u) | (r.w >= d.thresh ? 8u : 0u);
+}
 #endif

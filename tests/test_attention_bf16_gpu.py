@@ -73,11 +73,20 @@ def test_attention_bf16_fwd_bwd(B, L, nh, p, lens, varlen):
     bpart = torch.full((B, 3 * H), float('nan'), device='cuda')
     wsb = lib.uniter_attn_bf16_bwd_ws_bytes(B, L, nh)
     ws = torch.full((max(wsb, 4) // 2,), float('nan'), dtype=torch.bfloat16, device='cuda')
-    Lb.check(lib.uniter_attn_bf16_fwd(Lb.ptr(qd), mptr, cptr, Lb.ptr(ctx), Lb.ptr(ctxb), Lb.ptr(lse), B, L, nh, p, seed,
-                                      offset, site, Lb.cur_stream()))
-    Lb.check(lib.uniter_attn_bf16_bwd(Lb.ptr(qd), mptr, cptr, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), Lb.ptr(dqkv),
-                                      Lb.ptr(dqkvb), Lb.ptr(bpart), Lb.ptr(delta), B, L, nh, p, seed, offset, site, Lb.ptr(ws), wsb,
-                                      Lb.cur_stream()))
+    keep = torch.zeros(lib.uniter_attn_keep_bits_bytes(B, L, nh) // 2, dtype=torch.int16, device='cuda')
+
+    def run(kp):
+        Lb.check(lib.uniter_attn_bf16_fwd(Lb.ptr(qd), mptr, cptr, Lb.ptr(ctx), Lb.ptr(ctxb), Lb.ptr(lse), kp, B, L, nh, p,
+                                          seed, offset, site, Lb.cur_stream()))
+        Lb.check(lib.uniter_attn_bf16_bwd(Lb.ptr(qd), mptr, cptr, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), Lb.ptr(dqkv),
+                                          Lb.ptr(dqkvb), Lb.ptr(bpart), kp, Lb.ptr(delta), B, L, nh, p, seed, offset, site,
+                                          Lb.ptr(ws), wsb, Lb.cur_stream()))
+        torch.cuda.synchronize()
+
+    run(None)                       # dQ evaluates Philox again
+    plain = (ctx.clone(), dqkv.clone())
+    run(Lb.ptr(keep))               # dQ reads the keep flags the forward pass stored: the same masks, bit for bit
+    assert torch.equal(plain[0], ctx) and torch.equal(plain[1], dqkv)
     torch.cuda.synchronize()
     sel = slice(None) if varlen else rows
     got_ctx, got_d = ctx.cpu().double()[sel], dqkv.cpu().double()[sel]

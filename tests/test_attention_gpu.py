@@ -101,12 +101,22 @@ def test_attention_bwd_ex_emits_qkv_bias_partials(B, L, nh, p):
     part = torch.full((B, 3 * H), float('nan'), device='cuda')
     wsb = lib.uniter_attn_bwd_ws_bytes(B, L, nh)
     ws = torch.empty(max(wsb, 4) // 4, device='cuda')
-    Lb.check(lib.uniter_attn_fwd_ex(Lb.ptr(qkv), Lb.ptr(mask), None, Lb.ptr(ctx), Lb.ptr(ctxb), Lb.ptr(lse), B, L, nh, p,
-                                    11, 2, 3, Lb.cur_stream()))
-    Lb.check(lib.uniter_attn_bwd_ex(Lb.ptr(qkv), Lb.ptr(mask), None, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dctx), Lb.ptr(dqkv),
-                                    Lb.ptr(dqkvb), Lb.ptr(part), Lb.ptr(delta), B, L, nh, p, 11, 2, 3, Lb.ptr(ws), wsb,
-                                    Lb.cur_stream()))
-    torch.cuda.synchronize()
+    keep = torch.zeros(lib.uniter_attn_keep_bits_bytes(B, L, nh) // 2, dtype=torch.int16, device='cuda')
+
+    def run(kp):
+        Lb.check(lib.uniter_attn_fwd_ex(Lb.ptr(qkv), Lb.ptr(mask), None, Lb.ptr(ctx), Lb.ptr(ctxb), Lb.ptr(lse), kp, B, L,
+                                        nh, p, 11, 2, 3, Lb.cur_stream()))
+        Lb.check(lib.uniter_attn_bwd_ex(Lb.ptr(qkv), Lb.ptr(mask), None, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dctx),
+                                        Lb.ptr(dqkv), Lb.ptr(dqkvb), Lb.ptr(part), kp, Lb.ptr(delta), B, L, nh, p, 11, 2, 3,
+                                        Lb.ptr(ws), wsb, Lb.cur_stream()))
+        torch.cuda.synchronize()
+
+    run(None)                       # dQ evaluates Philox again
+    plain = (ctx.clone(), dqkv.clone())
+    run(Lb.ptr(keep))               # dQ reads the keep flags stored by the forward pass: identical masks
+    assert torch.equal(plain[0], ctx) and torch.equal(plain[1], dqkv)
+    if p > 0:
+        assert keep.any()
     ref = dqkv.view(B, L, 3 * H).double().sum(1)
     assert (part.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
     assert torch.equal(ctxb, ctx.bfloat16()) and torch.equal(dqkvb, dqkv.bfloat16())
