@@ -69,7 +69,10 @@ __device__ __forceinline__ void gelu_pair_fast(float x, float& g, float& dg) {
   const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   g = x * cdf;
-  dg = cdf + x * pdf;
+  // one fused op on purpose: with separate mul + add the compiler pairs neighbouring elements into
+  // v_pk_mul_f32 / v_pk_add_f32 (op_sel), and that sequence dropped the cdf term on a few lanes per launch in the
+  // 128x128 bf16 kernels on gfx950 (tests/tools/dbg_epi_res.py: 12 of 12 launches bad, 0 of 12 with the fma)
+  dg = __builtin_fmaf(x, pdf, cdf);
 }
 // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
 __device__ __forceinline__ float dgelu_erf(float x) {

@@ -222,9 +222,18 @@ template <int R> struct Stager<R, true, true> {
   }
 };
 
+// workgroups per CU the register allocator has to leave room for: 64x64 tiles run 3 deep (<= 168 VGPRs, and
+// the k-major resident LDS images are 43 - 49 KB), everything larger 2 deep
+template <int BM, int BN, bool KM, bool RES> constexpr int wgs_per_cu() {
+  return (BM == 64 && BN == 64) ? 3 : 2;
+}
+
 template <int BM, int BN, bool AKM, bool BKM, int TAG, bool SK, bool RES = false>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
+__global__ __launch_bounds__(256, (wgs_per_cu<BM, BN, AKM || BKM, RES>())) void gemm_bf16_kernel(const GemmArgsB g) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  // aux operand of an epilogue prefetched per 32x32 block (16 registers) -- not in the 128x128 convert-in-flight
+  // kernels, whose fp32 staging registers leave no room for it
+  constexpr bool AUXPF = RES || BM * BN < 128 * 128;
   constexpr int SA = Stager<BM, AKM, RES>::IMG, SB = Stager<BN, BKM, RES>::IMG;      // bf16 elements per LDS image
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (SA + SB)];
 
@@ -321,6 +330,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
   _Pragma("unroll") for (int a = 0; a < TM; ++a) FA[a] = StA::frag(SAp, wm * WM + a * 32, KS, i, h);    \
   _Pragma("unroll") for (int b = 0; b < TN; ++b) FB[b] = StB::frag(SBp, wn * WN + b * 32, KS, i, h);
 
+// Epilogue ordering: on gfx9 loads and stores share vmcnt and the compiler has to assume they retire out of
+// order, so ANY load result needed while stores are in flight becomes s_waitcnt vmcnt(0) -- a full drain of
+// the stores (measured: 13 - 28 us per 128x128 tile when bias / aux / beta loads sat between the stores).
+// Hence: every load of the tile (bias, the aux operand) is issued before its first store, and C += is a
+// buffer_atomic_add (no read).
+#define AUXV(rr) (AUXPF ? auxv[rr] : buf_ld_f32(rsI, voX, (((rr) & 3) + 8 * ((rr) >> 2)) * stX))
 #define EPILOGUE_B()                                                                                    \
   {                                                                                                     \
     constexpr int OOB = 0x7ffffff0;                                                                     \
@@ -330,6 +345,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
         g.aux_out, 0, g.aux_out ? g.M * g.ld_aux * 4 : 0, 0x00020000);                                  \
     const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(                                \
         const_cast<float*>(g.aux_in), 0, g.aux_in ? g.M * g.ld_aux * 4 : 0, 0x00020000);                \
+    const bool has_bias = g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D; \
+    const bool has_aux = g.epi == UNITER_EPI_DGELU || g.epi == UNITER_EPI_ADD || g.epi == UNITER_EPI_MUL; \
+    float bvv[TN];                                                                                      \
+    _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                    \
+      const int col = n0 + wn * WN + b * 32 + i;                                                        \
+      bvv[b] = (has_bias && col < g.N) ? g.bias[col] : 0.f;                                             \
+    }                                                                                                   \
+    /* rows of a 32x32 accumulator block: kr(rr) = (rr & 3) + 8 (rr >> 2); the addresses walk down them in a */ \
+    /* VGPR (+1 row, or +5 after every fourth) -- 16 scalar row offsets per stream do not fit the SGPR file  */ \
+    const int stC = g.ldc * 4, stX = g.ld_aux * 4, stCb = g.ldcb * 2;                                   \
     _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                    \
       _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                  \
         const int col = n0 + wn * WN + b * 32 + i;                                                      \
@@ -338,41 +363,77 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
         const int voC = cok ? (r0 * g.ldc + col) * 4 : OOB;                                             \
         const int voX = cok ? (r0 * g.ld_aux + col) * 4 : OOB;                                          \
         const int voCb = cok ? (r0 * g.ldcb + col) * 2 : OOB;                                           \
-        const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D)) ? g.bias[col] : 0.f; \
-        float csum = 0.f;                                                                               \
-        _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                             \
-          const int kr = (rr & 3) + 8 * (rr >> 2);                                                      \
-          float v = acc[a][b][rr] + bv;                                                                 \
-          if (g.epi == UNITER_EPI_BIAS_GELU) {                                                          \
-            buf_st_f32(v, rsX, voX, kr * g.ld_aux * 4);                                                 \
-            v = gelu_erf(v);                                                                            \
-          } else if (g.epi == UNITER_EPI_DGELU) {                                                       \
-            v *= dgelu_erf(buf_ld_f32(rsI, voX, kr * g.ld_aux * 4));                                    \
-          } else if (g.epi == UNITER_EPI_ADD) {                                                         \
-            v += buf_ld_f32(rsI, voX, kr * g.ld_aux * 4);                                               \
-          } else if (g.epi == UNITER_EPI_MUL) {                                                         \
-            v *= buf_ld_f32(rsI, voX, kr * g.ld_aux * 4);                                               \
-          } else if (g.epi == UNITER_EPI_BIAS_GELU_D) {                                                 \
+        /* the aux operand of this 32x32 block (all of a 64x64 tile's per-wave output; a 128x128 tile */  \
+        /* waits for the previous block's stores before each of its other three) */                     \
+        float auxv[16];                                                                                 \
+        if (AUXPF && has_aux) {                                                                         \
+          int p_ = voX;                                                                                 \
+          _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                           \
+            auxv[rr] = buf_ld_f32(rsI, p_, 0);                                                          \
+            p_ += ((rr & 3) == 3 ? 5 : 1) * stX;                                                        \
+          }                                                                                             \
+        }                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        const float bv = bvv[b];                                                                        \
+        /* the epilogue kind and the output set are uniform: branch once per 32x32 block, not per element */ \
+        f32x16& v = acc[a][b];                                                                          \
+        _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) v[rr] += bv;                                  \
+        if (g.epi == UNITER_EPI_BIAS_GELU_D) {                                                          \
+          int p_ = voX;                                                                                 \
+          _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                           \
             float dg_;                                                                                  \
-            gelu_pair_fast(v, v, dg_);                                                                  \
-            buf_st_f32(dg_, rsX, voX, kr * g.ld_aux * 4);                                               \
+            float x_ = v[rr], y_;                                                                       \
+            gelu_pair_fast(x_, y_, dg_);                                                                \
+            v[rr] = y_;                                                                                 \
+            buf_st_f32(dg_, rsX, p_, 0);                                                                \
+            p_ += ((rr & 3) == 3 ? 5 : 1) * stX;                                                        \
+            if ((rr & 3) == 3) __builtin_amdgcn_sched_barrier(0);                                       \
           }                                                                                             \
-          if (!SK && g.colsum_part) csum += (r0 + kr < g.M) ? v : 0.f;                                  \
-          if (SK) {                                                                                     \
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsC, voC, kr * g.ldc * 4, 0);            \
-          } else {                                                                                      \
-            if (g.beta) v += buf_ld_f32(rsC, voC, kr * g.ldc * 4);                                      \
-            if (g.C) buf_st_f32(v, rsC, voC, kr * g.ldc * 4);                                           \
-            if (g.Cb) __builtin_amdgcn_raw_buffer_store_b16(                                            \
-                __builtin_bit_cast(unsigned short, (__bf16)v), rsCb, voCb, kr * g.ldcb * 2, 0);         \
+        } else if (g.epi == UNITER_EPI_MUL) {                                                           \
+          _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) v[rr] *= AUXV(rr);                          \
+        } else if (g.epi == UNITER_EPI_ADD) {                                                           \
+          _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) v[rr] += AUXV(rr);                          \
+        } else if (g.epi == UNITER_EPI_BIAS_GELU) {                                                     \
+          int p_ = voX;                                                                                 \
+          _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                           \
+            buf_st_f32(v[rr], rsX, p_, 0);                                                              \
+            p_ += ((rr & 3) == 3 ? 5 : 1) * stX;                                                        \
+            v[rr] = gelu_erf(v[rr]);                                                                    \
           }                                                                                             \
-          acc[a][b][rr] = 0.f;                                                                          \
+        } else if (g.epi == UNITER_EPI_DGELU) {                                                         \
+          _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) v[rr] *= dgelu_erf(AUXV(rr));               \
         }                                                                                               \
         if (!SK && g.colsum_part) {                                                                     \
+          float csum = 0.f;                                                                             \
+          _Pragma("unroll") for (int rr = 0; rr < 16; ++rr)                                             \
+            csum += (r0 + (rr & 3) + 8 * (rr >> 2) < g.M) ? v[rr] : 0.f;                                \
           csum += __shfl_xor(csum, 32, 64);                                                             \
           if (h == 0 && cok && (m0 + wm * WM + a * 32) < g.M)                                           \
             g.colsum_part[(size_t)((m0 + wm * WM + a * 32) >> 5) * g.N + col] = csum;                   \
         }                                                                                               \
+        if (SK || g.beta) {                                                                             \
+          int p_ = voC;                                                                                 \
+          _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                           \
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v[rr], rsC, p_, 0, 0);                      \
+            p_ += ((rr & 3) == 3 ? 5 : 1) * stC;                                                        \
+          }                                                                                             \
+        } else {                                                                                        \
+          if (g.C) {                                                                                    \
+            int p_ = voC;                                                                               \
+            _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                         \
+              buf_st_f32(v[rr], rsC, p_, 0);                                                            \
+              p_ += ((rr & 3) == 3 ? 5 : 1) * stC;                                                      \
+            }                                                                                           \
+          }                                                                                             \
+          if (g.Cb) {                                                                                   \
+            int p_ = voCb;                                                                              \
+            _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                         \
+              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v[rr]), rsCb, p_, 0, 0); \
+              p_ += ((rr & 3) == 3 ? 5 : 1) * stCb;                                                     \
+            }                                                                                           \
+          }                                                                                             \
+        }                                                                                               \
+        _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) v[rr] = 0.f;                                  \
       }                                                                                                 \
     }                                                                                                   \
   }
@@ -424,6 +485,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
   if (u < total_units) K_ITERATION_B(u, 0)
 #undef K_ITERATION_B
 #undef EPILOGUE_B
+#undef AUXV
 #undef MFMA_BLOCK
 #undef READ_FRAGS
 #undef LOAD_UNIT
@@ -431,8 +493,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgsB g) {
 
 template <int BM, int BN, bool AKM, bool BKM, bool RES = false>
 int launch_b(GemmArgsB g, hipStream_t st, int slots) {
-  // the k-major LDS images of the resident kernels are larger (43 - 49 KB per 64x64 workgroup): three fit a CU
-  if (RES && (AKM || BKM) && BM == 64 && BN == 64) slots = 768;
+  if (BM == 64 && BN == 64) slots = 768;     // three 64x64 workgroups per CU (wgs_per_cu)
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   const int tiles = g.tiles_m * g.tiles_n;
@@ -509,7 +570,10 @@ int gemm_bf16res_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, c
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
   if (cfg == 0) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    cfg = t128 >= 1024 ? 1 : 4;     // measured (r01_gemm_bf16_resident_vs_hybrid.txt): 64x64 wins on every model shape
+    // measured (tests/tools/gemm_lab.py, profiles/r01_gemm_bf16_resident_tiles.txt): with the drain-free epilogue
+    // 128x128 wins where the output is wide (QKV, FFN-up and its dgrad twin: N >= 2304), 64x64 on N = 768 and on
+    // the weight gradients
+    cfg = (t128 >= 1024 || (!a_kmajor && N >= 2048 && t128 >= 256)) ? 1 : 4;
   }
   hipStream_t st = (hipStream_t)stream;
   if (!a_kmajor && !b_kmajor) return dispatch_r<false, false>(cfg, g, st);
