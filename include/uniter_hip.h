@@ -298,7 +298,7 @@ int uniter_bce_logits(const float* logits, const int64_t* labels, float pos_weig
 
 /* ------------------------------------------------------------------------- *
  * Pretraining heads (BASELINE config 5: UniterForPretraining.forward_{mlm,mrfr,itm},
- * model/pretrain.py:107-203).  Dense / tied-decoder products are uniter_gemm_f32, the
+ * model/pretrain.py:107-203; and forward_mrc, :205-233).  Dense / tied-decoder products are uniter_gemm_f32, the
  * LayerNorm uniter_ln_*; these are the remaining pieces.
  * ------------------------------------------------------------------------- */
 /* dst[r,:] = src[idx[r],:]           (_compute_masked_hidden, model/pretrain.py:129-133) */
@@ -311,6 +311,15 @@ int uniter_cross_entropy_fwd(const float* logits, const int64_t* targets, float*
 /* dlogits[r,c] = (softmax(logits[r])[c] - [c == targets[r]]) * dloss[r]   (dlogits may alias logits) */
 int uniter_cross_entropy_bwd(const float* logits, const int64_t* targets, const float* lse,
                              const float* dloss, float* dlogits, int n, int C, int ld, void* stream);
+/* MRC-kl (model/pretrain.py:222-226): F.kl_div(F.log_softmax(logits, -1), target, reduction='none'):
+ * loss[r,c] = target > 0 ? target * (log target - (logits[r,c] - lse[r])) : 0;
+ * backward  dlogits[r,j] = softmax[r,j] * sum_c(dloss[r,c] target[r,c]) - dloss[r,j] target[r,j] */
+int uniter_kl_div_fwd(const float* logits, const float* target, float* loss, float* lse, int n, int C, int ld,
+                      void* stream);
+int uniter_kl_div_bwd(const float* logits, const float* target, const float* lse, const float* dloss,
+                      float* dlogits, int n, int C, int ld, void* stream);
+/* MRC (model/pretrain.py:227-228): out[r] = index of the first maximum of x[r, c0:C] (absolute column) */
+int uniter_row_argmax(const float* x, int n, int C, int ld, int c0, int64_t* out, void* stream);
 /* F.mse_loss(pred, target, reduction='none') and its backward dpred = 2 (pred - target) dloss */
 int uniter_mse_fwd(const float* pred, const float* target, float* loss, size_t n, void* stream);
 int uniter_mse_bwd(const float* pred, const float* target, const float* dloss, float* dpred, size_t n,

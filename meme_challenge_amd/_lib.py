@@ -92,6 +92,9 @@ _SIGS = {
     'uniter_row_scatter_add': (_I, [_P, _P, _P, _I, _I, _I, _P]),
     'uniter_cross_entropy_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'uniter_cross_entropy_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'uniter_kl_div_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'uniter_kl_div_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'uniter_row_argmax': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'uniter_mse_fwd': (_I, [_P, _P, _P, _SZ, _P]),
     'uniter_mse_bwd': (_I, [_P, _P, _P, _P, _SZ, _P]),
     'uniter_dgelu_mul': (_I, [_P, _P, _P, _SZ, _P]),

@@ -570,10 +570,14 @@ int gemm_bf16res_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, c
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
   if (cfg == 0) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    // measured (tests/tools/gemm_lab.py, profiles/r01_gemm_bf16_resident_tiles.txt): with the drain-free epilogue
-    // 128x128 wins where the output is wide (QKV, FFN-up and its dgrad twin: N >= 2304), 64x64 on N = 768 and on
-    // the weight gradients
-    cfg = (t128 >= 1024 || (!a_kmajor && N >= 2048 && t128 >= 256)) ? 1 : 4;
+    // measured (tests/tools/gemm_lab.py at M = 1424 / 2624 / 5248, profiles/r01_gemm_bf16_resident_tiles.txt): a
+    // full wave of 128x128 tiles moves ~1.45x the flops per unit time of a full wave of 64x64 ones (half the
+    // L2 -> LDS traffic per flop), so what decides is how well each tiling fills its last round of persistent
+    // slots (512 resp. 768).  The weight gradients (both operands k-major, stream-K) stay on 64x64.
+    const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+    const double e128 = 1.45 * (double)t128 / (512.0 * ((t128 + 511) / 512));
+    const double e64 = (double)t64 / (768.0 * ((t64 + 767) / 768));
+    cfg = (t128 >= 1024 || (!a_kmajor && e128 > e64)) ? 1 : 4;
   }
   hipStream_t st = (hipStream_t)stream;
   if (!a_kmajor && !b_kmajor) return dispatch_r<false, false>(cfg, g, st);

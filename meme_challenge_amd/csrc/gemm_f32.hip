@@ -488,6 +488,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
         g.aux_out, 0, g.aux_out ? g.M * g.ld_aux * 4 : 0, 0x00020000);                                  \
     const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(                                \
         const_cast<float*>(g.aux_in), 0, g.aux_in ? g.M * g.ld_aux * 4 : 0, 0x00020000);                \
+    /* loads and stores share vmcnt on gfx9: a bias load issued after a block's stores would wait for all of */ \
+    /* them, so the bias of every column block is fetched before the first store                            */ \
+    const bool has_bias = g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D; \
+    float bvv[TN];                                                                                      \
+    _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                    \
+      const int colb = n0 + wn * WN + b * 32 + i;                                                       \
+      bvv[b] = (has_bias && colb < g.N) ? g.bias[colb] : 0.f;                                           \
+    }                                                                                                   \
     _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                    \
       _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                  \
         const int col = n0 + wn * WN + b * 32 + i;                                                      \
@@ -495,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
         const int r0 = m0 + wm * WM + a * 32 + 4 * h;                                                   \
         const int voC = cok ? (r0 * g.ldc + col) * 4 : OOB;                                             \
         const int voX = cok ? (r0 * g.ld_aux + col) * 4 : OOB;                                          \
-        const float bv = (cok && (g.epi == UNITER_EPI_BIAS || g.epi == UNITER_EPI_BIAS_GELU || g.epi == UNITER_EPI_BIAS_GELU_D)) ? g.bias[col] : 0.f; \
+        const float bv = bvv[b];                                                                        \
         float csum = 0.f;                                                                               \
         _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                             \
           const int kr = (rr & 3) + 8 * (rr >> 2);                                                      \
@@ -515,10 +523,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
             buf_st_f32(dg_, rsX, voX, kr * g.ld_aux * 4, 0);                 \
           }                                                                                             \
           if (!SK && g.colsum_part) csum += (r0 + kr < g.M) ? v : 0.f;                                  \
-          if (SK) {                                                                                     \
+          if (SK || g.beta) {   /* C += without reading C: no load to wait for between the stores */   \
             __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsC, voC, kr * g.ldc * 4, 0);            \
           } else {                                                                                      \
-            if (g.beta) v += buf_ld_f32(rsC, voC, kr * g.ldc * 4, 0);         \
             buf_st_f32(v, rsC, voC, kr * g.ldc * 4, 0);                      \
           }                                                                                             \
           acc[a][b][rr] = 0.f;                                                                          \

@@ -1,14 +1,14 @@
-"""UNITER pretraining heads on the HIP path (BASELINE config 5: ITM / MLM / MRFR).
+"""UNITER pretraining heads on the HIP path (BASELINE config 5: ITM / MLM / MRFR; plus MRC / MRC-kl).
 
-Mirror of model/pretrain.py:19-203 and model/layer.py:188-233: `UniterForPretraining(config,
+Mirror of model/pretrain.py:19-233 and model/layer.py:188-233: `UniterForPretraining(config,
 img_dim, img_label_dim)` with the reference's module / state_dict names (`uniter.*`,
 `cls.predictions.*` with the decoder tied to `word_embeddings.weight`, `feat_regress.*` tied to
 `img_linear.weight` used transposed, `region_classifier.*`, `itm_output.*`) and
-`forward(batch, task, compute_loss=True)` for task in {'mlm', 'mrfr', 'itm'}.  The MRC tasks and
-the OT loss are out of scope and raise.
+`forward(batch, task, compute_loss=True)` for task in {'mlm', 'mrfr', 'itm', 'mrc', 'mrc-kl'}.  The OT
+loss (a value the reference computes and discards) is out of scope and raises.
 
 The heads are composed from small autograd nodes whose forward / backward are C-ABI calls
-(GEMM, LayerNorm, row gather, cross-entropy, MSE); parameter gradients accumulate directly into
+(GEMM, LayerNorm, row gather, cross-entropy, KL divergence, MSE); parameter gradients accumulate directly into
 the flat gradient buffer, including both tied weights.
 """
 from collections import defaultdict
@@ -198,6 +198,87 @@ class _MseFn(torch.autograd.Function):
         return dp, None
 
 
+class _LinearPadNFn(torch.autograd.Function):
+    """y = x @ W^T + b for an output width that is not a multiple of 4 (the region classifier's label
+    dimension, 1601 for the UNITER detectors): the GEMM's k-major operands need 4-element rows, so the
+    products run on copies padded with zero rows / columns; the padding never reaches the caller."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, owner):
+        x = x.contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        Np = (N + 3) // 4 * 4
+        wp = torch.zeros(Np, K, dtype=torch.float32, device=x.device)
+        wp[:N].copy_(weight.detach())
+        bp = torch.zeros(Np, dtype=torch.float32, device=x.device)
+        bp[:N].copy_(bias.detach())
+        yp = torch.empty(M, Np, dtype=torch.float32, device=x.device)
+        _gemm(0, 0, M, Np, K, x, K, wp, K, yp, Np, EPI_BIAS, bp)
+        ctx.save_for_backward(x, wp)
+        ctx.owner, ctx.wb, ctx.N = owner, (weight, bias), N
+        return yp[:, :N].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp = ctx.saved_tensors
+        weight, bias = ctx.wb
+        N, (M, K) = ctx.N, x.shape
+        Np = wp.shape[0]
+        _ensure_grad(weight)
+        _ensure_grad(bias)
+        dyp = torch.zeros(M, Np, dtype=torch.float32, device=x.device)
+        dyp[:, :N].copy_(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _gemm(0, 1, M, K, Np, dyp, Np, wp, K, dx, K)
+        dwp = torch.zeros(Np, K, dtype=torch.float32, device=x.device)
+        _gemm(1, 1, Np, K, M, dyp, Np, x, K, dwp, K, beta=1)
+        weight.grad.add_(dwp[:N])
+        dbp = torch.zeros(Np, dtype=torch.float32, device=x.device)
+        _colsum(dyp, M, Np, dbp)
+        bias.grad.add_(dbp[:N])
+        _mark_touched_names(ctx.owner, (weight, bias))
+        return dx, None, None, None
+
+
+class _KlDivFn(torch.autograd.Function):
+    """F.kl_div(F.log_softmax(logits, -1), target, reduction='none')   (model/pretrain.py:222-226)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits, target = logits.contiguous(), target.contiguous().to(torch.float32)
+        if logits.shape != target.shape:
+            raise ValueError('kl_div: shape mismatch %s vs %s' % (tuple(logits.shape), tuple(target.shape)))
+        n, Cn = logits.shape
+        loss = torch.empty_like(logits)
+        lse = torch.empty(n, dtype=torch.float32, device=logits.device)
+        check(_lib.lib().uniter_kl_div_fwd(ptr(logits), ptr(target), ptr(loss), ptr(lse), n, Cn, Cn,
+                                           _lib.cur_stream()), 'uniter_kl_div_fwd')
+        ctx.save_for_backward(logits, target, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, target, lse = ctx.saved_tensors
+        n, Cn = logits.shape
+        dl = torch.empty_like(logits)
+        check(_lib.lib().uniter_kl_div_bwd(ptr(logits), ptr(target), ptr(lse), ptr(dloss.contiguous()), ptr(dl),
+                                           n, Cn, Cn, _lib.cur_stream()), 'uniter_kl_div_bwd')
+        return dl, None
+
+
+def _hard_region_labels(label_targets):
+    """torch.max(label_targets[:, 1:], dim=-1)[1] + 1: the most likely non-background class
+    (model/pretrain.py:227-228; the first maximum on ties)."""
+    lt = label_targets.contiguous().to(torch.float32)
+    n, Cn = lt.shape
+    out = torch.empty(n, dtype=torch.int64, device=lt.device)
+    check(_lib.lib().uniter_row_argmax(ptr(lt), n, Cn, Cn, 1, ptr(out), _lib.cur_stream()), 'uniter_row_argmax')
+    return out
+
+
 def hip_linear(x, lin, owner, gelu=False):
     return _LinearFn.apply(x, lin.weight, lin.bias, owner, (lin.weight, lin.bias), gelu, False)
 
@@ -263,12 +344,20 @@ class RegionFeatureRegression(nn.Module):
 
 
 class RegionClassification(nn.Module):
-    """Parameter holder only (MRC is out of scope); keeps checkpoints loadable (model/pretrain.py:36-47)."""
+    """model/pretrain.py:36-47: Linear -> GELU -> LN -> Linear(hidden, label_dim), for MRC / MRC-kl."""
 
     def __init__(self, hidden_size, label_dim):
         super().__init__()
         self.net = nn.Sequential(_ParamLinear(hidden_size, hidden_size), GELU(), _ParamLayerNorm(hidden_size),
                                  _ParamLinear(hidden_size, label_dim))
+
+    def forward(self, x):
+        h = hip_linear(x, self.net[0], self, gelu=True)
+        h = _LayerNormFn.apply(h, self.net[2].weight, self.net[2].bias, self)
+        out = self.net[3]
+        if out.weight.shape[0] % 4 == 0:
+            return hip_linear(h, out, self)
+        return _LinearPadNFn.apply(h, out.weight, out.bias, self)
 
 
 class UniterForPretraining(UniterPreTrainedModel):
@@ -300,7 +389,8 @@ class UniterForPretraining(UniterPreTrainedModel):
         elif task == 'itm':
             return self.forward_itm(*common, batch['targets'], batch['ot_inputs'], compute_loss)
         elif task.startswith('mrc'):
-            raise NotImplementedError('MRC / MRC-kl are outside the built scope (SURVEY.md 2.1 row 4)')
+            return self.forward_mrc(*common, batch['img_masks'], batch['img_mask_tgt'], batch['label_targets'], task,
+                                    compute_loss)
         raise ValueError('invalid task')
 
     @staticmethod
@@ -335,6 +425,21 @@ class UniterForPretraining(UniterPreTrainedModel):
         if not compute_loss:
             return pred
         return _MseFn.apply(pred, feat_targets)
+
+    def forward_mrc(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                    img_masks, img_mask_tgt, label_targets, task, compute_loss=True):
+        """model/pretrain.py:205-233: region classification on the masked regions; 'mrc' trains against the most
+        likely non-background detector class, 'mrc-kl' against the detector's soft labels."""
+        seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                          output_all_encoded_layers=False, img_masks=img_masks)
+        masked = self._masked_rows(seq, img_mask_tgt)
+        scores = self.region_classifier(masked)
+        if not compute_loss:
+            return scores
+        if 'kl' in task:
+            return _KlDivFn.apply(scores, label_targets)
+        # ignore_index=0 (:231) never fires: the targets are 1 + an argmax over the non-background classes
+        return _CrossEntropyFn.apply(scores, _hard_region_labels(label_targets))
 
     def forward_itm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                     targets, ot_inputs=None, compute_loss=True):

@@ -1,8 +1,10 @@
 """TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
-CPU restatement of the pretraining heads used by BASELINE config 5 (ITM / MLM / MRFR):
-UniterForPretraining.forward_{mlm,mrfr,itm} (model/pretrain.py:107-203),
-RegionFeatureRegression (model/pretrain.py:19-33), BertOnlyMLMHead (model/layer.py:188-233).
+CPU restatement of the pretraining heads used by BASELINE config 5 (ITM / MLM / MRFR) and of the
+region-classification tasks next to them (MRC / MRC-kl):
+UniterForPretraining.forward_{mlm,mrfr,itm,mrc} (model/pretrain.py:107-233),
+RegionFeatureRegression (model/pretrain.py:19-33), RegionClassification (:36-47),
+BertOnlyMLMHead (model/layer.py:188-233).
 Weights use the reference's UniterForPretraining.state_dict() key names ("uniter." prefix)."""
 import torch
 import torch.nn.functional as F
@@ -59,6 +61,33 @@ def forward_itm(sd, cfg, batch, compute_loss=True, drop=None):
     if not compute_loss:
         return scores
     return F.cross_entropy(scores, batch['targets'], reduction='none')
+
+
+def forward_mrc(sd, cfg, batch, task='mrc', compute_loss=True, drop=None):
+    # model/pretrain.py:205-233
+    seq = _encode(sd, cfg, batch, drop, img_masks=batch['img_masks'])
+    h = _masked_hidden(seq, batch['img_mask_tgt'])
+    h = _head_transform(sd, ('region_classifier.net.0.', 'region_classifier.net.2.'), h)
+    scores = F.linear(h, sd['region_classifier.net.3.weight'], sd['region_classifier.net.3.bias'])
+    if not compute_loss:
+        return scores
+    lt = batch['label_targets']
+    if 'kl' in task:
+        return F.kl_div(F.log_softmax(scores, dim=-1), lt, reduction='none')
+    # the background class (column 0) is never the target (:227-230)
+    hard = torch.max(lt[:, 1:], dim=-1)[1] + 1
+    return F.cross_entropy(scores, hard, ignore_index=0, reduction='none')
+
+
+def synth_label_targets(n, label_dim, seed):
+    """Detector-style soft labels for n masked regions: rows of a softmax, a few exact zeros."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed + 11))
+    z = rng.standard_normal((n, label_dim)) * 2.0
+    p = np.exp(z - z.max(1, keepdims=True))
+    p[rng.random((n, label_dim)) < 0.1] = 0.0          # kl_div's xlogy(0, 0) = 0 branch
+    p /= p.sum(1, keepdims=True)
+    return torch.from_numpy(p.astype('float32'))
 
 
 def synth_pretrain_batch(B, T, R, seed, vocab, img_dim, txt_lens, num_bbs, mask_prob=0.3):

@@ -352,6 +352,7 @@ def gen_pretrain():
     tl, nbb = [10, 4, 7], [6, 6, 3]
     b = PO.synth_pretrain_batch(B, T, R, seed=9, vocab=TINY_PRE['vocab_size'], img_dim=TINY_IMG_DIM,
                                 txt_lens=tl, num_bbs=nbb)
+    b['label_targets'] = PO.synth_label_targets(int(b['img_masks'].sum()), 11, seed=9)
     for k, v in b.items():
         out['in/' + k] = v.numpy()
     keep = ['uniter.embeddings.word_embeddings.weight', 'uniter.img_embeddings.img_linear.weight',
@@ -359,11 +360,13 @@ def gen_pretrain():
             'cls.predictions.transform.dense.weight', 'cls.predictions.transform.LayerNorm.weight',
             'feat_regress.bias', 'feat_regress.net.0.weight', 'feat_regress.net.2.bias', 'itm_output.weight',
             'itm_output.bias', 'uniter.pooler.dense.weight', 'uniter.encoder.layer.0.attention.self.query.weight',
+            'region_classifier.net.0.weight', 'region_classifier.net.2.weight', 'region_classifier.net.3.weight',
+            'region_classifier.net.3.bias',
             'uniter.encoder.layer.1.output.LayerNorm.bias', 'uniter.embeddings.position_embeddings.weight']
     params = dict(m.named_parameters())
-    for task in ('mlm', 'mrfr', 'itm'):
+    for task in ('mlm', 'mrfr', 'itm', 'mrc', 'mrc-kl'):
         batch = dict(b)
-        if task == 'mrfr':
+        if task in ('mrfr', 'mrc', 'mrc-kl'):
             batch['img_feat'] = b['img_feat_masked']
         scores = m(batch, task, compute_loss=False)
         m.zero_grad()

@@ -25,11 +25,11 @@ def _model(pre):
     return m.cuda().eval()
 
 
-@pytest.mark.parametrize('task', ['mlm', 'mrfr', 'itm'])
+@pytest.mark.parametrize('task', ['mlm', 'mrfr', 'itm', 'mrc', 'mrc-kl'])
 def test_pretrain_task_matches_reference(pre, task):
     m = _model(pre)
     b = {k: v.cuda() for k, v in batch_from_npz(pre).items()}
-    if task == 'mrfr':
+    if task in ('mrfr', 'mrc', 'mrc-kl'):
         b['img_feat'] = b['img_feat_masked']
     with torch.no_grad():
         scores = m(b, task, compute_loss=False)
@@ -53,9 +53,66 @@ def test_pretrain_out_of_scope_tasks_raise(pre):
     m = _model(pre)
     b = {k: v.cuda() for k, v in batch_from_npz(pre).items()}
     with pytest.raises(NotImplementedError):
-        m(b, 'mrc-kl')
+        m(dict(b, ot_inputs={'ot_scatter': None}), 'itm')      # the OT branch (its value is discarded upstream)
     with pytest.raises(ValueError):
         m(b, 'nope')
+
+
+@pytest.mark.parametrize('n,Cn', [(23, 1601), (5, 11), (1, 4)])
+def test_kl_div_and_argmax_kernels(n, Cn):
+    """uniter_kl_div_fwd/bwd and uniter_row_argmax against torch float64 (label_dim 1601 = the UNITER detectors')."""
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(n * 7 + Cn)
+    x = torch.randn(n, Cn, generator=g) * 3
+    t = torch.softmax(torch.randn(n, Cn, generator=g) * 2, -1)
+    t[torch.rand(n, Cn, generator=g) < 0.1] = 0.0
+    dl = torch.randn(n, Cn, generator=g)
+    xr = x.double().requires_grad_(True)
+    ref = torch.nn.functional.kl_div(torch.log_softmax(xr, -1), t.double(), reduction='none')
+    ref.backward(dl.double())
+    dx, dt, ddl = x.cuda(), t.cuda(), dl.cuda()
+    loss, lse = torch.empty(n, Cn, device='cuda'), torch.empty(n, device='cuda')
+    L.check(lib.uniter_kl_div_fwd(L.ptr(dx), L.ptr(dt), L.ptr(loss), L.ptr(lse), n, Cn, Cn, L.cur_stream()))
+    assert maxdiff(loss, ref.detach()) < 2e-6
+    dlog = torch.empty_like(dx)
+    L.check(lib.uniter_kl_div_bwd(L.ptr(dx), L.ptr(dt), L.ptr(lse), L.ptr(ddl), L.ptr(dlog), n, Cn, Cn, L.cur_stream()))
+    assert maxdiff(dlog, xr.grad) < 2e-6
+    if Cn > 1:
+        t[0, 1:] = 0.0                       # ties: the first maximum wins, background column excluded
+        dt = t.cuda()
+        out = torch.empty(n, dtype=torch.int64, device='cuda')
+        L.check(lib.uniter_row_argmax(L.ptr(dt), n, Cn, Cn, 1, L.ptr(out), L.cur_stream()))
+        assert torch.equal(out.cpu(), torch.max(t[:, 1:], dim=-1)[1] + 1)
+
+
+def test_region_classifier_label_dim_1601():
+    """The padded-GEMM linear of the region classifier (label_dim % 4 != 0) against torch float64, fwd + bwd."""
+    from meme_challenge_amd.pretrain import RegionClassification
+    from meme_challenge_amd.model import ensure_store
+    torch.manual_seed(3)
+    rc = RegionClassification(64, 1601)
+    for p in rc.parameters():
+        torch.nn.init.normal_(p, std=0.3)
+    rc = rc.cuda()
+    ensure_store(rc)
+    x = torch.randn(37, 64)
+    xd = x.cuda().requires_grad_(True)
+    y = rc(xd)
+    dy = torch.randn(37, 1601)
+    y.backward(dy.cuda())
+    sd = {k: v.detach().cpu().double() for k, v in rc.state_dict().items()}
+    xr = x.double().requires_grad_(True)
+    h = torch.nn.functional.linear(xr, sd['net.0.weight'], sd['net.0.bias'])
+    h = h * 0.5 * (1 + torch.erf(h / 2 ** 0.5))
+    h = torch.nn.functional.layer_norm(h, (64,), sd['net.2.weight'], sd['net.2.bias'], 1e-12)
+    w3 = sd['net.3.weight'].requires_grad_(True)
+    yr = torch.nn.functional.linear(h, w3, sd['net.3.bias'])
+    yr.backward(dy.double())
+    assert maxdiff(y, yr.detach()) < 1e-4
+    assert maxdiff(xd.grad, xr.grad) < 2e-4 * xr.grad.abs().max().item() + 1e-5
+    assert maxdiff(rc.net[3].weight.grad, w3.grad) < 2e-4 * w3.grad.abs().max().item() + 1e-5
+    assert maxdiff(rc.net[3].bias.grad, dy.double().sum(0)) < 1e-4
 
 
 def test_cross_entropy_and_gather_kernels():

@@ -15,13 +15,17 @@ def pre():
     return load_golden('pretrain_tiny.npz')
 
 
-@pytest.mark.parametrize('task', ['mlm', 'mrfr', 'itm'])
+@pytest.mark.parametrize('task', ['mlm', 'mrfr', 'itm', 'mrc', 'mrc-kl'])
 def test_pretrain_heads_match_reference(pre, task):
     sd = {k: v.clone().requires_grad_(True) for k, v in sd_from_npz(pre).items()}
     b = batch_from_npz(pre)
-    if task == 'mrfr':
+    if task in ('mrfr', 'mrc', 'mrc-kl'):
         b['img_feat'] = b['img_feat_masked']
-    fn = getattr(PO, 'forward_' + task)
+    if task.startswith('mrc'):
+        import functools
+        fn = functools.partial(PO.forward_mrc, task=task)
+    else:
+        fn = getattr(PO, 'forward_' + task)
     with torch.no_grad():
         scores = fn(sd, TINY, b, compute_loss=False)
     assert maxdiff(scores, pre[task + '/scores']) < 2e-5

@@ -11,8 +11,9 @@ def timeit(run, iters=40):
     for _ in range(iters): run()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-shapes = [('qkv_fwd', 0, 0, 2624, 2304, 768, 1, 0), ('ffnup_fwd', 0, 0, 2624, 3072, 768, 5, 0), ('ffndown_fwd', 0, 0, 2624, 768, 3072, 1, 0),
-          ('ffndown_dgrad', 0, 1, 2624, 3072, 768, 6, 0), ('ffnup_dgrad', 0, 1, 2624, 768, 3072, 4, 0), ('ffn1_wgrad', 1, 1, 3072, 768, 2624, 0, 1)]
+MM = int(os.environ.get('LAB_M', '2624'))
+shapes = [('qkv_fwd', 0, 0, MM, 2304, 768, 1, 0), ('ffnup_fwd', 0, 0, MM, 3072, 768, 5, 0), ('ffndown_fwd', 0, 0, MM, 768, 3072, 1, 0),
+          ('ffndown_dgrad', 0, 1, MM, 3072, 768, 6, 0), ('ffnup_dgrad', 0, 1, MM, 768, 3072, 4, 0), ('qkv_dgrad', 0, 1, MM, 768, 2304, 4, 0), ('ffn1_wgrad', 1, 1, 3072, 768, MM, 0, 1), ('ffn2_wgrad', 1, 1, 768, 3072, MM, 0, 1)]
 cfgs = [int(c) for c in os.environ.get('LAB_CFGS', '1,4').split(',')]
 for name, akm, bkm, M, N, K, epi, beta in shapes:
     A = torch.randn((K, M) if akm else (M, K), device='cuda').bfloat16(); B = torch.randn((K, N) if bkm else (N, K), device='cuda').bfloat16()
