@@ -210,12 +210,14 @@ int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, const int32_t* 
 /* The same two operations on the bf16 matrix pipe (precision mode 2): Q, K, V rounded to bf16 while
  * staged, fp32 scores / softmax / dropout / LSE, probabilities and score gradients rounded to bf16 as
  * MFMA operands.  Same arguments and Philox element indices as the _ex forms; L <= 192;
- * ws: uniter_attn_bf16_bwd_ws_bytes (bf16 Pd / dS scratch, half of the fp32 kernels'). */
+ * qkv is fp32, or -- qkv_is_bf16 = 1 -- the bf16 output of the QKV GEMM read as stored (what the model passes).
+ * ws: uniter_attn_bf16_bwd_ws_bytes (bf16 Pd / dS scratch, half of the fp32 kernels').  The backward pass
+ * writes whichever of dqkv (fp32) / dqkv_bf16 is not NULL (at least one). */
 size_t uniter_attn_bf16_bwd_ws_bytes(int B, int L, int nh);
-int uniter_attn_bf16_fwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
-                         void* ctx_bf16, float* lse, void* keep_bits, int B, int L, int nh, float p_drop,
+int uniter_attn_bf16_fwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens,
+                         float* ctx, void* ctx_bf16, float* lse, void* keep_bits, int B, int L, int nh, float p_drop,
                          uint64_t seed, uint32_t offset, uint32_t site, void* stream);
-int uniter_attn_bf16_bwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
+int uniter_attn_bf16_bwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens,
                          const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16,
                          float* bias_part, const void* keep_bits, float* delta, int B, int L, int nh, float p_drop,
                          uint64_t seed, uint32_t offset, uint32_t site, void* ws, size_t ws_bytes, void* stream);

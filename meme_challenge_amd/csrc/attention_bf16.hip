@@ -36,7 +36,8 @@ constexpr int XROW = 34;         // floats exchanged per lane between the two ha
 constexpr float NEG_INF = -__builtin_huge_valf();
 
 struct Args {
-  const float* qkv;        // [rows, 3H]
+  const void* qkv;         // [rows, 3H] fp32, or bf16 when qb16 (the QKV GEMM's bf16 output, read as stored)
+  int qb16;
   const float* mask;       // [B, L] or NULL (varlen)
   const int* cu;           // [B+1] or NULL
   float* ctx; u16* ctx_b16;
@@ -89,6 +90,34 @@ __device__ __forceinline__ void stage_tr(u16* s, const float* __restrict__ base,
   }
 }
 
+// the same three for a bf16 source (no conversion: 16-byte pieces of 8 values)
+__device__ __forceinline__ void stage_rm(u16* s, const u16* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
+  for (int idx = tid; idx < Lr * 8; idx += nthr) {
+    const int r = idx >> 3, c8 = idx & 7;
+    bf16x8 v = {};
+    if (r < L) v = *reinterpret_cast<const bf16x8*>(base + (size_t)r * ld + c8 * 8);
+    *reinterpret_cast<bf16x8*>(s + r * KLD + c8 * 8) = v;
+  }
+}
+__device__ __forceinline__ void stage_tr(u16* s, const u16* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+  for (int idx = tid; idx < Lr * 8; idx += nthr) {
+    const int r = idx >> 3, c8 = idx & 7;
+    u16x8 v = {};
+    if (r < L) v = *reinterpret_cast<const u16x8*>(base + (size_t)r * ld + c8 * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[(c8 * 8 + e) * TLD + r] = v[e];
+  }
+}
+__device__ __forceinline__ void row_frags(bf16x8 (&f)[4], const u16* __restrict__ row, bool valid, int h) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    bf16x8 v = {};
+    if (valid) v = *reinterpret_cast<const bf16x8*>(row + 16 * s + 8 * h);
+    f[s] = v;
+  }
+}
+
 // B operand from a global fp32 row (64 values): step s, half h -> d = 16s + 8h .. +7
 __device__ __forceinline__ void row_frags(bf16x8 (&f)[4], const float* __restrict__ row, bool valid, int h) {
 #pragma unroll
@@ -136,8 +165,10 @@ __device__ __forceinline__ void store_rowT(float* __restrict__ row, u16* __restr
   for (int g = 0; g < 4; ++g) {
     const f32x4 v0 = {a0[4 * g] * mul, a0[4 * g + 1] * mul, a0[4 * g + 2] * mul, a0[4 * g + 3] * mul};
     const f32x4 v1 = {a1[4 * g] * mul, a1[4 * g + 1] * mul, a1[4 * g + 2] * mul, a1[4 * g + 3] * mul};
-    *reinterpret_cast<f32x4*>(row + 8 * g + 4 * h) = v0;
-    *reinterpret_cast<f32x4*>(row + 32 + 8 * g + 4 * h) = v1;
+    if (row) {
+      *reinterpret_cast<f32x4*>(row + 8 * g + 4 * h) = v0;
+      *reinterpret_cast<f32x4*>(row + 32 + 8 * g + 4 * h) = v1;
+    }
     if (row_b) {
       *reinterpret_cast<bf16x4*>(row_b + 8 * g + 4 * h) = bf16x4{(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3]};
       *reinterpret_cast<bf16x4*>(row_b + 32 + 8 * g + 4 * h) = bf16x4{(__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
@@ -183,14 +214,22 @@ __global__ __launch_bounds__(768) void attn_b16_fwd_kernel(const Args a, int Lr)
   const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
   const Span sp = span_of(a, b);
   const int Lb = sp.Lb, ld = 3 * a.H;
-  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
-  stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
-  stage_tr(Vt, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
-  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+  const size_t boff = (size_t)sp.row0 * ld + head * D;
   const int q = qb * 32 + i;
   const bool vq = q < Lb;
   bf16x8 qf[4];
-  row_frags(qf, base + (size_t)q * ld, vq, h);
+  if (a.qb16) {
+    const u16* base = static_cast<const u16*>(a.qkv) + boff;
+    stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
+    stage_tr(Vt, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+    row_frags(qf, base + (size_t)q * ld, vq, h);
+  } else {
+    const float* base = static_cast<const float*>(a.qkv) + boff;
+    stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
+    stage_tr(Vt, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+    row_frags(qf, base + (size_t)q * ld, vq, h);
+  }
+  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
   __syncthreads();
 
   const int kmid = ((sp.nb + 1) >> 1) * 32;
@@ -284,17 +323,26 @@ __global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr, 
   const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
   const Span sp = span_of(a, b);
   const int Lb = sp.Lb, ld = 3 * a.H;
-  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
-  stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
-  stage_rm(Vb, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
-  stage_tr(Kt, base + a.H, ld, Lb, Lr, tid, nthr);
-  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
-  float* red = reinterpret_cast<float*>(smem_raw + red_off);
-  for (int t = tid; t < 192; t += nthr) red[t] = 0.f;        // (a 32-row workgroup has only 128 threads)
+  const size_t boff = (size_t)sp.row0 * ld + head * D;
   const int q = qb * 32 + i;
   const bool vq = q < Lb;
   bf16x8 qf[4], dof[4];
-  row_frags(qf, base + (size_t)q * ld, vq, h);
+  if (a.qb16) {
+    const u16* base = static_cast<const u16*>(a.qkv) + boff;
+    stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
+    stage_rm(Vb, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+    stage_tr(Kt, base + a.H, ld, Lb, Lr, tid, nthr);
+    row_frags(qf, base + (size_t)q * ld, vq, h);
+  } else {
+    const float* base = static_cast<const float*>(a.qkv) + boff;
+    stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
+    stage_rm(Vb, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+    stage_tr(Kt, base + a.H, ld, Lb, Lr, tid, nthr);
+    row_frags(qf, base + (size_t)q * ld, vq, h);
+  }
+  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+  float* red = reinterpret_cast<float*>(smem_raw + red_off);
+  for (int t = tid; t < 192; t += nthr) red[t] = 0.f;        // (a 32-row workgroup has only 128 threads)
   const float* dorow = a.dctx + ((size_t)sp.row0 + q) * a.H + head * D;
   row_frags(dof, dorow, vq, h);
   float delta = 0.f;
@@ -367,7 +415,7 @@ __global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr, 
     for (int r = 0; r < 16; ++r) { dq0[r] += xb[r * 64 + lane]; dq1[r] += xb[(16 + r) * 64 + lane]; }
     if (vq) {
       const size_t off = ((size_t)sp.row0 + q) * ld + head * D;
-      store_rowT(a.dqkv + off, a.dqkv_b16 ? a.dqkv_b16 + off : nullptr, dq0, dq1, 1.0f, h);
+      store_rowT(a.dqkv ? a.dqkv + off : nullptr, a.dqkv_b16 ? a.dqkv_b16 + off : nullptr, dq0, dq1, 1.0f, h);
     }
     if (a.bias_part) acc_colsum(red, dq0, dq1, vq, i, h);
   }
@@ -389,8 +437,9 @@ __global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr,
   const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
   const Span sp = span_of(a, b);
   const int Lb = sp.Lb, ld = 3 * a.H;
-  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
-  stage_tr(Qt, base, ld, Lb, Lr, tid, nthr);
+  const size_t boff = (size_t)sp.row0 * ld + head * D;
+  if (a.qb16) stage_tr(Qt, static_cast<const u16*>(a.qkv) + boff, ld, Lb, Lr, tid, nthr);
+  else stage_tr(Qt, static_cast<const float*>(a.qkv) + boff, ld, Lb, Lr, tid, nthr);
   stage_tr(dOt, a.dctx + (size_t)sp.row0 * a.H + head * D, a.H, Lb, Lr, tid, nthr);
   float* red = reinterpret_cast<float*>(smem_raw + red_off);
   for (int t = tid; t < 192; t += nthr) red[t] = 0.f;        // (a 32-row workgroup has only 128 threads)
@@ -432,8 +481,8 @@ __global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr,
     }
     if (vk) {
       const size_t off = ((size_t)sp.row0 + key) * ld + head * D;
-      store_rowT(a.dqkv + off + a.H, a.dqkv_b16 ? a.dqkv_b16 + off + a.H : nullptr, dk0, dk1, 1.0f, h);
-      store_rowT(a.dqkv + off + 2 * a.H, a.dqkv_b16 ? a.dqkv_b16 + off + 2 * a.H : nullptr, dv0, dv1, 1.0f, h);
+      store_rowT(a.dqkv ? a.dqkv + off + a.H : nullptr, a.dqkv_b16 ? a.dqkv_b16 + off + a.H : nullptr, dk0, dk1, 1.0f, h);
+      store_rowT(a.dqkv ? a.dqkv + off + 2 * a.H : nullptr, a.dqkv_b16 ? a.dqkv_b16 + off + 2 * a.H : nullptr, dv0, dv1, 1.0f, h);
     }
     if (a.bias_part) { acc_colsum(red + 64, dk0, dk1, vk, i, h); acc_colsum(red + 128, dv0, dv1, vk, i, h); }
   }
@@ -470,14 +519,14 @@ extern "C" size_t uniter_attn_bf16_bwd_ws_bytes(int B, int L, int nh) {
   return (size_t)2 * B * nh * Lr * Lr * sizeof(unsigned short);
 }
 
-extern "C" int uniter_attn_bf16_fwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+extern "C" int uniter_attn_bf16_fwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
                                     void* ctx_bf16, float* lse, void* keep_bits, int B, int L, int nh, float p_drop,
                                     uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
   UCHECK_ARG(qkv && ctx && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_bf16_fwd: need attn_mask or cu_seqlens (not both)");
   Args a = {};
   UCHECK_RC(fill(a, B, L, nh, p_drop, seed, offset, site));
-  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_b16 = (u16*)ctx_bf16; a.lse = lse;
+  a.qkv = qkv; a.qb16 = qkv_is_bf16; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_b16 = (u16*)ctx_bf16; a.lse = lse;
   a.keep_bits = (u16*)keep_bits;
   const int Lr = (L + 31) / 32 * 32, nblk = Lr / 32;
   const size_t lds = max3((size_t)(Lr * KLD + D * TLD) * 2 + Lr * 4, (size_t)nblk * XROW * 64 * 4, 0);
@@ -487,17 +536,17 @@ extern "C" int uniter_attn_bf16_fwd(const float* qkv, const float* attn_mask, co
   return 0;
 }
 
-extern "C" int uniter_attn_bf16_bwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
+extern "C" int uniter_attn_bf16_bwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens,
                                     const float* ctx, const float* lse, const float* dctx, float* dqkv,
                                     void* dqkv_bf16, float* bias_part, const void* keep_bits, float* delta, int B, int L,
                                     int nh, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws,
                                     size_t ws_bytes, void* stream) {
-  UCHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta && ws && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
+  UCHECK_ARG(qkv && ctx && lse && dctx && (dqkv || dqkv_bf16) && delta && ws && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_bf16_bwd: null pointer, or not exactly one of attn_mask / cu_seqlens");
   UCHECK_ARG(ws_bytes >= uniter_attn_bf16_bwd_ws_bytes(B, L, nh), "attn_bf16_bwd: workspace too small");
   Args a = {};
   UCHECK_RC(fill(a, B, L, nh, p_drop, seed, offset, site));
-  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
+  a.qkv = qkv; a.qb16 = qkv_is_bf16; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
   a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (u16*)dqkv_bf16; a.bias_part = bias_part; a.keep_bits = (u16*)keep_bits; a.delta = delta;
   const int Lr = (L + 31) / 32 * 32, nblk = Lr / 32;
   a.pd_ws = (u16*)ws;

@@ -443,7 +443,10 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     LayerBufs& lb = pl.layers[l];
     if (gated) UCHECK_HIP(hipStreamWaitEvent(st, m->ready[1 + l], 0));
     float* y2 = packed ? lb.y2 : (all_layers ? hidden_out + l * PH : (l == nl - 1 ? hidden_out : lb.y2));
-    if (res)
+    if (attn_b16)      // the bf16 attention kernels read Q, K, V as bf16: write only that (in the qkv buffer's place)
+      UCHECK_RC(gemm_r(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, xb, H, m->WB(l, L_QW), H, nullptr, 3 * H,
+                       (unsigned short*)lb.qkv, 3 * H, UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
+    else if (res)
       UCHECK_RC(gemm_r(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, xb, H, m->WB(l, L_QW), H, lb.qkv, 3 * H,
                        nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
     else
@@ -452,7 +455,7 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     {
       ProfScope ps(m, UNITER_K_ATTN_FWD, st);
       if (attn_b16)      // precision 2: the attention products run on the bf16 pipe as well
-        UCHECK_RC(uniter_attn_bf16_fwd(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
+        UCHECK_RC(uniter_attn_bf16_fwd(lb.qkv, 1, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
                                        lb.ctx, lb.ctxb, lb.lse, save ? lb.keepb : nullptr, B, L, nh, pa, seed, offset,
                                        SITE_ATTN_PROBS(l), st));
       else if (packed || (save && L <= uniter_attn_varlen_max_len()))
@@ -607,8 +610,9 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   {
     ProfScope ps(m, UNITER_K_ATTN_BWD, st);
     if (attn_b16)
-      UCHECK_RC(uniter_attn_bf16_bwd(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
-                                     pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, lb.dqkv,
+      UCHECK_RC(uniter_attn_bf16_bwd(lb.qkv, 1, pl.packed ? nullptr : m->batch.attention_mask,
+                                     pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx,
+                                     nullptr /* fp32 dqkv has no reader in this mode: bias partials are fused */,
                                      lb.dqkvb, lb.qb_part, lb.keepb, lb.delta, B, L, nh, pa, m->seed, m->offset,
                                      SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
     else if (fused_qb)

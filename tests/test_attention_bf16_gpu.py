@@ -76,17 +76,29 @@ def test_attention_bf16_fwd_bwd(B, L, nh, p, lens, varlen):
     keep = torch.zeros(lib.uniter_attn_keep_bits_bytes(B, L, nh) // 2, dtype=torch.int16, device='cuda')
 
     def run(kp):
-        Lb.check(lib.uniter_attn_bf16_fwd(Lb.ptr(qd), mptr, cptr, Lb.ptr(ctx), Lb.ptr(ctxb), Lb.ptr(lse), kp, B, L, nh, p,
+        Lb.check(lib.uniter_attn_bf16_fwd(Lb.ptr(qsrc), qb16, mptr, cptr, Lb.ptr(ctx), Lb.ptr(ctxb), Lb.ptr(lse), kp, B, L, nh, p,
                                           seed, offset, site, Lb.cur_stream()))
-        Lb.check(lib.uniter_attn_bf16_bwd(Lb.ptr(qd), mptr, cptr, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), Lb.ptr(dqkv),
+        Lb.check(lib.uniter_attn_bf16_bwd(Lb.ptr(qsrc), qb16, mptr, cptr, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), Lb.ptr(dqkv),
                                           Lb.ptr(dqkvb), Lb.ptr(bpart), kp, Lb.ptr(delta), B, L, nh, p, seed, offset, site,
                                           Lb.ptr(ws), wsb, Lb.cur_stream()))
         torch.cuda.synchronize()
 
+    qsrc, qb16 = qd, 0
     run(None)                       # dQ evaluates Philox again
     plain = (ctx.clone(), dqkv.clone())
     run(Lb.ptr(keep))               # dQ reads the keep flags the forward pass stored: the same masks, bit for bit
     assert torch.equal(plain[0], ctx) and torch.equal(plain[1], dqkv)
+    # Q, K, V handed over as bf16 (the QKV GEMM's bf16 output): the kernels round fp32 input to exactly these values
+    qsrc, qb16 = qd.bfloat16(), 1
+    run(Lb.ptr(keep))
+    assert torch.equal(plain[0], ctx) and torch.equal(plain[1], dqkv)
+    # bf16-only output (what the model asks for: nothing reads the fp32 gradient in precision mode 2)
+    only_b = torch.zeros_like(dqkvb)
+    Lb.check(lib.uniter_attn_bf16_bwd(Lb.ptr(qsrc), qb16, mptr, cptr, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), None, Lb.ptr(only_b),
+                                      Lb.ptr(bpart), Lb.ptr(keep), Lb.ptr(delta), B, L, nh, p, seed, offset, site,
+                                      Lb.ptr(ws), wsb, Lb.cur_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(only_b, dqkvb)
     torch.cuda.synchronize()
     sel = slice(None) if varlen else rows
     got_ctx, got_d = ctx.cpu().double()[sel], dqkv.cpu().double()[sel]

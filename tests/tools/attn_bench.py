@@ -10,10 +10,11 @@ for p in (0.0, 0.1):
     dctx = torch.randn(B * Lq, H, device='cuda'); dqkv = torch.empty(B * Lq, 3 * H, device='cuda'); delta = torch.empty(B, nh, Lq, device='cuda')
     wsb = lib.uniter_attn_bwd_ws_bytes(B, Lq, nh); ws = torch.empty(max(wsb, 4) // 4, device='cuda')
     keep = torch.zeros(lib.uniter_attn_keep_bits_bytes(B, Lq, nh) // 2, dtype=torch.int16, device='cuda'); kp = L.ptr(keep)
+    qkvb = qkv.bfloat16()
     def fwd(): L.check(lib.uniter_attn_fwd(L.ptr(qkv), L.ptr(mask), L.ptr(ctx), L.ptr(lse), B, Lq, nh, p, 1, 2, 3, L.cur_stream()))
     def bwd(): L.check(lib.uniter_attn_bwd(L.ptr(qkv), L.ptr(mask), L.ptr(ctx), L.ptr(lse), L.ptr(dctx), L.ptr(dqkv), L.ptr(delta), B, Lq, nh, p, 1, 2, 3, L.ptr(ws), wsb, L.cur_stream()))
-    def fwd16(): L.check(lib.uniter_attn_bf16_fwd(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), None, L.ptr(lse), kp, B, Lq, nh, p, 1, 2, 3, L.cur_stream()))
-    def bwd16(): L.check(lib.uniter_attn_bf16_bwd(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(lse), L.ptr(dctx), L.ptr(dqkv), None, None, kp, L.ptr(delta), B, Lq, nh, p, 1, 2, 3, L.ptr(ws), wsb, L.cur_stream()))
+    def fwd16(): L.check(lib.uniter_attn_bf16_fwd(L.ptr(qkvb), 1, L.ptr(mask), None, L.ptr(ctx), None, L.ptr(lse), kp, B, Lq, nh, p, 1, 2, 3, L.cur_stream()))
+    def bwd16(): L.check(lib.uniter_attn_bf16_bwd(L.ptr(qkvb), 1, L.ptr(mask), None, L.ptr(ctx), L.ptr(lse), L.ptr(dctx), L.ptr(dqkv), None, None, kp, L.ptr(delta), B, Lq, nh, p, 1, 2, 3, L.ptr(ws), wsb, L.cur_stream()))
     for name, f in (('fwd', fwd), ('bwd(dq+dkv)', bwd), ('bf16 fwd', fwd16), ('bf16 bwd', bwd16)):
         for _ in range(3): f()
         torch.cuda.synchronize()
