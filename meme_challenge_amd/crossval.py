@@ -1,0 +1,118 @@
+"""Cross-validation driver (host side; mirrors utils/crossval.py of the reference).
+
+`generate_crossval_splits(data_path, dev_size)` writes `crossval_<dev_size>/{train,dev}_<kk>.jsonl`: the training
+list is shuffled once with `random.seed(42)`, split by label, and fold k takes `dev_size // 2` samples of each
+label as its validation set (utils/crossval.py:24-47,112-123) -- the same files the reference writes for the same
+input.  `train_crossval` runs one trainer per fold (seed + fold, `<name>_fold_<k>.<ext>` checkpoints), averages the
+folds' validation metrics and hands the per-fold prediction files to `ensemble.find_ensemble` (:132-215).
+The `use_dev_set` variant (half of dev_seen mixed into each fold's training set with balanced re-use counts,
+:49-110) is not built and raises.
+"""
+import json
+import logging
+import os
+import random
+from glob import glob
+from statistics import mean
+
+import numpy as np
+
+from .ensemble import find_ensemble
+from .utils import set_seed
+
+logger = logging.getLogger('CrossValLog')
+
+
+def export_jsonl(filepath, dict_list):
+    with open(filepath, 'w') as f:
+        f.write('\n'.join(json.dumps(d) for d in dict_list))
+
+
+def _read_jsonl(path):
+    with open(path) as f:
+        return [json.loads(line) for line in f.readlines()]
+
+
+def crossval_dir(data_path, dev_size, use_dev_set=False):
+    return os.path.join(data_path, 'crossval_%i%s' % (dev_size, '_usedevtest' if use_dev_set else ''))
+
+
+def generate_crossval_splits(data_path, dev_size=300, use_dev_set=False):
+    if use_dev_set:
+        raise NotImplementedError('crossval_use_dev (utils/crossval.py:49-110) is not built')
+    random.seed(42)
+    np.random.seed(42)
+    data_list = []
+    for name in ('train.jsonl', 'dev_seen.jsonl'):
+        path = os.path.join(data_path, name)
+        assert os.path.isfile(path), 'Tried to create cross validation splits, but file could not be found at %s' % path
+        items = _read_jsonl(path)
+        random.shuffle(items)           # one shuffle per file, in this order (the RNG stream is part of the format)
+        data_list += items
+    by_label = {l: [d for d in data_list if d['label'] == l] for l in (0, 1)}
+    num_splits = min(len(v) for v in by_label.values()) // dev_size
+    out_dir = crossval_dir(data_path, dev_size)
+    os.makedirs(out_dir, exist_ok=True)
+    half = dev_size // 2
+    for k in range(num_splits):
+        lo, hi = k * half, (k + 1) * half
+        dev_set = by_label[0][lo:hi] + by_label[1][lo:hi]
+        train_set = by_label[0][:lo] + by_label[0][hi:] + by_label[1][:lo] + by_label[1][hi:]
+        export_jsonl(os.path.join(out_dir, 'train_%s.jsonl' % str(k).zfill(2)), train_set)
+        export_jsonl(os.path.join(out_dir, 'dev_%s.jsonl' % str(k).zfill(2)), dev_set)
+        logger.info('Exported split %i with %4.2f%% hateful memes in validation set.'
+                    % (k, 100.0 * sum(d['label'] for d in dev_set) / max(len(dev_set), 1)))
+    return num_splits
+
+
+def _dataset_name(loader):
+    ds = getattr(loader, 'dataset', None)
+    if ds is None and hasattr(loader, 'loader'):
+        ds = getattr(loader.loader, 'dataset', None)
+    return getattr(ds, 'name', '')
+
+
+def train_crossval(trainer_class, config, data_loader_funcs, num_folds=0, dev_size=300, use_dev_set=False):
+    """num_folds = 0: one ordinary run on train.jsonl / dev_seen.jsonl.  Otherwise: the first num_folds folds
+    (-1 = all).  Returns the list of per-fold validation metrics (the single run's metrics for num_folds = 0)."""
+    if num_folds == 0:
+        config['train_loader'] = data_loader_funcs['train'](os.path.join(config['data_path'], 'train.jsonl'))
+        config['val_loader'] = data_loader_funcs['val'](os.path.join(config['data_path'], 'dev_seen.jsonl'))
+        return trainer_class(config).train_main()
+    if use_dev_set:
+        raise NotImplementedError('crossval_use_dev (utils/crossval.py:49-110) is not built')
+    cv = crossval_dir(config['data_path'], dev_size)
+    if not os.path.isdir(cv) or not glob(os.path.join(cv, '*.jsonl')):
+        logger.info('Creating cross-validation splits for dev size %i' % dev_size)
+        generate_crossval_splits(config['data_path'], dev_size=dev_size)
+    train_sets = sorted(glob(os.path.join(cv, 'train_??.jsonl')))
+    dev_sets = sorted(glob(os.path.join(cv, 'dev_??.jsonl')))
+    assert len(train_sets) == len(dev_sets), 'Found an inequal number of training and validation sets'
+    folds = len(dev_sets) if num_folds == -1 else min(num_folds, len(dev_sets))
+    base, ext = config['model_save_name'].rsplit('.', 1)
+    val_metrics = []
+    for k in range(folds):
+        set_seed(config['seed'] + k)
+        logger.info('Starting fold %i of %i' % (k, folds))
+        config['train_loader'] = data_loader_funcs['train'](train_sets[k])
+        config['val_loader'] = data_loader_funcs['val'](dev_sets[k])
+        config['model_save_name'] = '%s_fold_%i.%s' % (base, k, ext)
+        fold_metrics, _ = trainer_class(config).train_main()
+        val_metrics.append(fold_metrics)
+    config['model_save_name'] = base + '.' + ext
+    if not val_metrics:
+        return val_metrics
+    means = {key: mean(v[key] for v in val_metrics) for key in val_metrics[0]}
+    logger.info('Cross validation finished. Mean scores of validation folds:\n' + '\n'.join(
+        '%s: %s' % (k, ('%5.4f' % v) if k == 'loss' else ('%4.2f%%' % (100.0 * v))) for k, v in means.items()))
+    names = [_dataset_name(t) for t in config.get('test_loader', [])]
+    dev_names = sorted(n for n in names if n.startswith('dev'))
+    if not dev_names:
+        logger.warning('Skipping ensemble calculation as no predictions for a validation set could be found')
+        return val_metrics
+    pattern = os.path.join(config['model_path'], base + '_fold_*')
+    dev_files = sorted(glob(pattern + '_%s_preds.csv' % dev_names[0]))
+    test_files = [sorted(glob(pattern + '_%s_preds.csv' % n)) for n in names if n != dev_names[0]]
+    if dev_files:
+        find_ensemble(dev_files=dev_files, test_files=[t for t in test_files if t])
+    return val_metrics

@@ -382,8 +382,73 @@ def gen_pretrain():
     np.savez_compressed(os.path.join(HERE, 'pretrain_tiny.npz'), **out)
 
 
+def gen_crossval_ensemble():
+    """utils/crossval.py generate_crossval_splits and utils/ensemble.py (create_ensemble_prediction, find_ensemble
+    without deap) run on small synthetic inputs; inputs and the files they wrote are stored as arrays.
+    seaborn (imported by data/metrics.py for a plot helper) is not installed: an empty stand-in module is registered,
+    in this script only."""
+    import csv, glob, json, tempfile, types
+    sys.modules.setdefault('seaborn', types.ModuleType('seaborn'))
+    from utils.crossval import generate_crossval_splits
+    from utils import ensemble as E
+    rng = np.random.Generator(np.random.PCG64(77))
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        n_train, n_dev = 97, 20
+        ids = rng.permutation(90000)[:n_train + n_dev] + 1000
+        labels = (rng.random(n_train + n_dev) < 0.4).astype(np.int64)
+        for name, sl in (('train', slice(0, n_train)), ('dev_seen', slice(n_train, None))):
+            with open(os.path.join(tmp, name + '.jsonl'), 'w') as f:
+                f.write('\n'.join(json.dumps({'id': int(i), 'img': 'img/%05d.png' % i, 'label': int(l), 'text': 't%d' % i})
+                                  for i, l in zip(ids[sl], labels[sl])))
+        out['cv/ids'], out['cv/labels'], out['cv/n_train'] = ids, labels, np.int64(n_train)
+        generate_crossval_splits(tmp, dev_size=16)
+        files = sorted(glob.glob(os.path.join(tmp, 'crossval_16', '*.jsonl')))
+        out['cv/files'] = np.array([os.path.basename(f) for f in files])
+        for f in files:
+            with open(f) as fh:
+                out['cv/out/' + os.path.basename(f)] = np.array([json.loads(l)['id'] for l in fh.read().split('\n')])
+        # ---- ensemble ----
+        n = 60
+        eid = rng.permutation(5000)[:n] + 1
+        gt = (rng.random(n) < 0.45).astype(np.int64)
+        out['ens/id'], out['ens/gt'] = eid, gt
+        tid = rng.permutation(5000)[:40] + 6000
+        tgt = (rng.random(40) < 0.45).astype(np.int64)
+        out['ens/tid'], out['ens/tgt'] = tid, tgt
+        dev_files, test_files = [], []
+        for k in range(3):
+            keep = np.sort(rng.permutation(n)[:50])            # every fold misses 10 of the dev samples
+            proba = np.clip(0.5 + (gt[keep] - 0.5) * rng.uniform(0.1, 0.6) + rng.normal(0, 0.25, keep.size), 0.001, 0.999)
+            proba = np.round(proba, 6)
+            out['ens/fold%d/keep' % k], out['ens/fold%d/proba' % k] = keep, proba
+            fn = os.path.join(tmp, 'uniter_fold_%d_dev_seen_preds.csv' % k)
+            with open(fn, 'w') as f:
+                f.write('id,proba,label,gt\n' + ''.join('%i,%f,%i,%i\n' % (eid[j], p, p > 0.5, gt[j]) for j, p in zip(keep, proba)))
+            dev_files.append(fn)
+            tp = np.round(np.clip(0.5 + (tgt - 0.5) * rng.uniform(0.1, 0.6) + rng.normal(0, 0.25, 40), 0.001, 0.999), 6)
+            out['ens/fold%d/tproba' % k] = tp
+            fn = os.path.join(tmp, 'uniter_fold_%d_test_seen_preds.csv' % k)
+            with open(fn, 'w') as f:
+                f.write('id,proba,label,gt\n' + ''.join('%i,%f,%i,%i\n' % (tid[j], tp[j], tp[j] > 0.5, tgt[j]) for j in range(40)))
+            test_files.append(fn)
+        preds = np.stack([np.where(np.isin(np.arange(n), out['ens/fold%d/keep' % k]), 0.3 + 0.1 * k, -1.0) for k in range(3)])
+        for ol in (False, True):
+            out['ens/direct/%d' % ol] = E.create_ensemble_prediction(preds.copy(), [0.5, 1.0, 2.0], on_logits=ol)
+        E.find_ensemble(dev_files=dev_files, test_files=test_files, weight_range=(0.0, 0.5, 1.0, 2.0), max_weights=10000)
+        for name in ('uniter_dev_seen_ensemble.csv', 'uniter_test_seen_ensemble.csv'):
+            with open(os.path.join(tmp, name)) as f:
+                rows = list(csv.reader(f))
+            out['ens/out/%s/header' % name] = np.array(rows[0])
+            out['ens/out/%s/body' % name] = np.array([[float(v) for v in r] for r in rows[1:]])
+            print(name, rows[0], len(rows) - 1)
+    np.savez_compressed(os.path.join(HERE, 'crossval_ensemble.npz'), **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiny', 'host', 'trainer', 'base', 'large', 'pretrain']
+    which = sys.argv[1:] or ['tiny', 'host', 'trainer', 'base', 'large', 'pretrain', 'crossval']
+    if 'crossval' in which:
+        gen_crossval_ensemble()
     if 'pretrain' in which:
         gen_pretrain()
     if 'tiny' in which:

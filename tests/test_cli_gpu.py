@@ -98,3 +98,24 @@ def test_cli_with_shards_prefetch_and_packing(tmp_path):
         '--feature_shards', '--pack_padded'])
     assert os.path.isfile(os.path.join(data_dir, 'train_shard.feat.npy'))
     assert 0.5 < best['aucroc'] <= 1.0
+
+
+def test_cli_cross_validation_folds_and_ensemble(tmp_path):
+    """--num_folds 2: splits written in the reference's layout, one checkpoint and one set of prediction files per
+    fold, and the ensemble of the folds' dev_seen predictions (utils/crossval.py:132-215)."""
+    import train_uniter
+    cfg = tmp_path / 'tiny.json'
+    cfg.write_text(json.dumps(dict(TINY, vocab_size=28996, max_position_embeddings=64)))
+    data_dir, model_dir = str(tmp_path / 'data'), str(tmp_path / 'ckpt')
+    metrics = train_uniter.main([
+        '--config', str(cfg), '--data_path', data_dir, '--model_path', model_dir, '--vis_path', str(tmp_path / 'vis'),
+        '--synthetic', '64', '--batch_size', '8', '--max_epoch', '2', '--lr', '1e-3', '--warmup_steps', '2',
+        '--max_txt_len', '16', '--seed', '1', '--log_every', '50', '--num_folds', '2', '--crossval_dev_size', '16'])
+    assert len(metrics) == 2 and all('aucroc' in m for m in metrics)
+    cv = os.path.join(data_dir, 'crossval_16')
+    assert {'train_00.jsonl', 'dev_00.jsonl', 'train_01.jsonl', 'dev_01.jsonl'} <= set(os.listdir(cv))
+    for k in (0, 1):
+        assert os.path.isfile(os.path.join(model_dir, 'best_model_fold_%d.pt' % k))
+        assert os.path.isfile(os.path.join(model_dir, 'best_model_fold_%d_dev_seen_preds.csv' % k))
+    ens = open(os.path.join(model_dir, 'best_model_dev_seen_ensemble.csv')).read().splitlines()
+    assert ens[0] == 'id,gt,proba,label' and len(ens) == 65

@@ -131,13 +131,21 @@ def main(argv=None):
             else data.DataLoader(ds, **kw)
         return loader if config['no_prefetch'] else DevicePrefetcher(loader, config['device'])
 
-    config['train_loader'] = make('train.jsonl', train=True)
-    config['val_loader'] = make('dev_seen.jsonl')
     config['test_loader'] = [make(f, ids=True) for f in ('test_seen.jsonl', 'test_unseen.jsonl', 'dev_seen.jsonl',
                                                         'dev_unseen.jsonl')
                              if os.path.isfile(os.path.join(config['data_path'], f))]
-    trainer = TrainerUniter(config)
-    return trainer.train_main()
+    if config['num_folds'] == 0:
+        config['train_loader'] = make('train.jsonl', train=True)
+        config['val_loader'] = make('dev_seen.jsonl')
+        return TrainerUniter(config).train_main()
+    # --num_folds k (-1 = all): one run per cross-validation fold, then the ensemble of the folds' predictions
+    # (train_uniter.py:183-188 -> utils/crossval.py:132-215 in the reference)
+    from meme_challenge_amd.crossval import train_crossval
+    split = lambda path: os.path.relpath(path, config['data_path'])
+    funcs = {'train': lambda path: make(split(path), train=True), 'val': lambda path: make(split(path)),
+             'test': lambda path: make(split(path), ids=True)}
+    return train_crossval(TrainerUniter, config, funcs, num_folds=config['num_folds'],
+                          dev_size=config['crossval_dev_size'], use_dev_set=config['crossval_use_dev'])
 
 
 if __name__ == '__main__':
