@@ -110,7 +110,8 @@ def test_cli_cross_validation_folds_and_ensemble(tmp_path):
     metrics = train_uniter.main([
         '--config', str(cfg), '--data_path', data_dir, '--model_path', model_dir, '--vis_path', str(tmp_path / 'vis'),
         '--synthetic', '64', '--batch_size', '8', '--max_epoch', '2', '--lr', '1e-3', '--warmup_steps', '2',
-        '--max_txt_len', '16', '--seed', '1', '--log_every', '50', '--num_folds', '2', '--crossval_dev_size', '16'])
+        '--max_txt_len', '16', '--seed', '1', '--log_every', '50', '--num_folds', '2', '--crossval_dev_size', '16',
+        '--precision', 'bf16'])
     assert len(metrics) == 2 and all('aucroc' in m for m in metrics)
     cv = os.path.join(data_dir, 'crossval_16')
     assert {'train_00.jsonl', 'dev_00.jsonl', 'train_01.jsonl', 'dev_01.jsonl'} <= set(os.listdir(cv))

@@ -42,6 +42,7 @@ class TrainerUniter(TrainerTemplate):
         else:
             self.load_model()
         self.model.uniter_model.pack_padded = bool(self.config.get('pack_padded', False))
+        self.model.uniter_model.precision = self.config.get('precision', 'fp32')
 
     def load_model(self):
         uniter_config = resolve_config(self.config['config'])
@@ -90,6 +91,8 @@ def build_parser():
                              '(built next to the jsonl on first use) and read from it')
     parser.add_argument('--no_prefetch', action='store_true', help='copy each batch to the GPU synchronously (default: one batch ahead on a side stream)')
     parser.add_argument('--pack_padded', action='store_true', help='token packing: compute the valid positions only')
+    parser.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16', 'bf16_hybrid'],
+                        help="GEMM arithmetic: fp32 (the reference's), bf16 (bf16-resident operands) or bf16_hybrid")
     return parser
 
 
