@@ -71,7 +71,7 @@ __device__ __forceinline__ void gelu_pair_fast(float x, float& g, float& dg) {
   g = x * cdf;
   // one fused op on purpose: with separate mul + add the compiler pairs neighbouring elements into
   // v_pk_mul_f32 / v_pk_add_f32 (op_sel), and that sequence dropped the cdf term on a few lanes per launch in the
-  // 128x128 bf16 kernels on gfx950 (tests/tools/dbg_epi_res.py: 12 of 12 launches bad, 0 of 12 with the fma)
+  // 128x128 bf16 kernels on gfx950 (tests/tools/gemm_glitch_screen.py: 12 of 12 launches bad before, none with the fma)
   dg = __builtin_fmaf(x, pdf, cdf);
 }
 // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
