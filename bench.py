@@ -17,6 +17,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime initialises: see meme_challenge_amd/__init__.py
+
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))

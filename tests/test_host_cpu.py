@@ -211,3 +211,15 @@ def test_synthetic_pretrain_batch_layout(task):
         assert torch.equal(b['feat_targets'], base['img_feat'][m])
     else:
         assert b['targets'].shape == (B,) and set(b['targets'].tolist()) <= {0, 1}
+
+
+def test_package_import_sets_the_hardware_queue_default():
+    """Main / side stream overlap needs more HIP hardware queues than the default once RCCL has created its own
+    streams (meme_challenge_amd/__init__.py); a value chosen by the user is left alone."""
+    import os, subprocess, sys
+    code = "import os; import meme_challenge_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    assert subprocess.check_output([sys.executable, '-c', code], cwd=root, env=env).decode().strip() == '8'
+    env['GPU_MAX_HW_QUEUES'] = '4'
+    assert subprocess.check_output([sys.executable, '-c', code], cwd=root, env=env).decode().strip() == '4'
