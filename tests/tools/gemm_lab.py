@@ -12,8 +12,9 @@ def timeit(run, iters=40):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 MM = int(os.environ.get('LAB_M', '2624'))
-shapes = [('qkv_fwd', 0, 0, MM, 2304, 768, 1, 0), ('ffnup_fwd', 0, 0, MM, 3072, 768, 5, 0), ('ffndown_fwd', 0, 0, MM, 768, 3072, 1, 0),
-          ('ffndown_dgrad', 0, 1, MM, 3072, 768, 6, 0), ('ffnup_dgrad', 0, 1, MM, 768, 3072, 4, 0), ('qkv_dgrad', 0, 1, MM, 768, 2304, 4, 0), ('ffn1_wgrad', 1, 1, 3072, 768, MM, 0, 1), ('ffn2_wgrad', 1, 1, 768, 3072, MM, 0, 1)]
+HH = int(os.environ.get('LAB_H', '768')); II = 4 * HH
+shapes = [('qkv_fwd', 0, 0, MM, 3 * HH, HH, 1, 0), ('attnout_fwd', 0, 0, MM, HH, HH, 1, 0), ('ffnup_fwd', 0, 0, MM, II, HH, 5, 0), ('ffndown_fwd', 0, 0, MM, HH, II, 1, 0),
+          ('ffndown_dgrad', 0, 1, MM, II, HH, 6, 0), ('ffnup_dgrad', 0, 1, MM, HH, II, 4, 0), ('qkv_dgrad', 0, 1, MM, HH, 3 * HH, 4, 0), ('ffn1_wgrad', 1, 1, II, HH, MM, 0, 1), ('ffn2_wgrad', 1, 1, HH, II, MM, 0, 1)]
 cfgs = [int(c) for c in os.environ.get('LAB_CFGS', '1,4').split(',')]
 for name, akm, bkm, M, N, K, epi, beta in shapes:
     A = torch.randn((K, M) if akm else (M, K), device='cuda').bfloat16(); B = torch.randn((K, N) if bkm else (N, K), device='cuda').bfloat16()
