@@ -85,7 +85,10 @@ int uniter_gemm_bf16_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int 
 /* All-bf16 operands (resident bf16 activations / the bf16 mirror of the weights), fp32 accumulate;
  * writes C (fp32, may be NULL) and / or C_bf16 (bf16 copy for the next GEMM, may be NULL).  lda / ldb /
  * ldcb count bf16 elements.  Layouts: (0,0) x @ W^T, (0,1) dgrad, (1,1) wgrad.  cfg 0 / 1 / 4.
- * K % 64 == 0 (any K for (1,1): rows beyond K read as zero), leading dimensions % 8, 16-byte aligned operands. */
+ * K % 64 == 0 (any K for (1,1): rows beyond K read as zero), leading dimensions % 8, 16-byte aligned operands.
+ * beta = 1 (C += product) is formed with fp32 atomic adds -- no read of C in the kernel -- and has no bf16 copy
+ * (C_bf16 must be NULL).  In every epilogue the loads of a 32x32 output block (bias, aux_in) are issued before its
+ * first store: loads and stores share the vector-memory counter on gfx9. */
 int uniter_gemm_bf16res_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K,
                             const void* A, int lda, const void* B, int ldb,
                             float* C, int ldc, void* C_bf16, int ldcb, int epilogue, const float* bias,

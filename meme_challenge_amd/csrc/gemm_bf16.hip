@@ -555,7 +555,7 @@ int gemm_bf16res_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, c
   UCHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && (C || Cb), "gemm_bf16res: bad argument");
   UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_MUL, "gemm_bf16res: bad epilogue %d", epilogue);
   UCHECK_ARG(!(a_kmajor && !b_kmajor), "gemm_bf16res: layout (A k-major, B k-contiguous) is not built");
-  UCHECK_ARG(!beta || C, "gemm_bf16res: beta needs the fp32 output");
+  UCHECK_ARG(!beta || (C && !Cb), "gemm_bf16res: C += needs the fp32 output and has no bf16 copy (the sum is formed by atomics)");
   UCHECK_SHAPE((K % BKB == 0 || (a_kmajor && b_kmajor)) && lda % 8 == 0 && ldb % 8 == 0 &&
                (a_kmajor ? M % 8 == 0 : true) && (b_kmajor ? N % 8 == 0 : true) &&
                ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,

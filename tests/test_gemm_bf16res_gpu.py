@@ -72,6 +72,15 @@ def test_gemm_bf16res_model_shapes(cfg):
     _run(cfg, 1, 1, M=768, N=256, K=1458, epi=0, beta=1, want_bf16=False)       # ragged K
 
 
+def test_gemm_bf16res_rejects_beta_with_bf16_copy():
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    A = torch.zeros(64, 64, dtype=torch.bfloat16, device='cuda'); C = torch.zeros(64, 64, device='cuda')
+    rc = lib.uniter_gemm_bf16res_cfg(0, 0, 0, 64, 64, 64, L.ptr(A), 64, L.ptr(A), 64, L.ptr(C), 64, L.ptr(A), 64, 0, None, None,
+                                     None, 0, 1, L.cur_stream())
+    assert rc != 0
+
+
 def test_gemm_bf16res_rejects_misaligned():
     from meme_challenge_amd import _lib as L
     lib = L.lib()
