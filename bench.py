@@ -255,7 +255,8 @@ def main():
                                       else 'bf16 MFMA GEMMs / fp32 storage (BASELINE configs[2])'),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        'side_stream_wgrad': not args.no_side_stream,
-                       'optimizer_overlaps_next_forward': not args.no_adam_overlap},
+                       'optimizer_overlaps_next_forward': not args.no_adam_overlap,
+                       'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')},
             'step_mfma_frac': round(total / (ms * 1e-3) / world * world / (peak * 1e12), 4),
             'ffn_roofline_frac': round(ffn / (ms * 1e-3) / (peak * 1e12), 4),
             'final_loss': round(loss, 5),
