@@ -93,6 +93,20 @@ int uniter_gemm_bf16res_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, i
                             const void* A, int lda, const void* B, int ldb,
                             float* C, int ldc, void* C_bf16, int ldcb, int epilogue, const float* bias,
                             const float* aux_in, float* aux_out, int ld_aux, int beta, void* stream);
+/* Second-generation bf16-resident product for the forward and input-gradient GEMMs (csrc/gemm_bf16_dma.hip;
+ * replaces cuBLAS behind nn.Linear of model/layer.py:76-78,112,140,153 in the bf16 mode): operands reach LDS by
+ * LDS-DMA through a ring of stages with counted vmcnt waits; the accumulator is held transposed so outputs leave
+ * as 16-byte row stores.  Layouts (a_kmajor, b_kmajor): (0,0) x @ W^T, (0,1) dgrad.  cfg 1 = 128x128 tile
+ * (2 stages, two workgroups per CU), 2 = 128x256, 3 = 256x128 (8 waves, 3 stages), 4 = 128x128 (3 stages).
+ * nsplit > 1 cuts K into pieces computed by different workgroups: piece s stores its fp32 partial tile at
+ * C + s * c_split_stride (piece 0 applies the epilogue) and the CONSUMER adds the slabs (no bf16 output then).
+ * aux_in / aux_out are fp32 or bf16 ([M, ld_aux] elements) as the *_bf16 flags say.  beta = 1: C += product
+ * by fp32 atomics (epilogue NONE, no bf16 copy).  N % 8 == 0, K % 64 == 0, 16-byte aligned buffers. */
+int uniter_gemm_bf16v2_cfg(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K,
+                           const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                           long c_split_stride, void* C_bf16, int ldcb, int epilogue, const float* bias,
+                           const void* aux_in, int aux_in_bf16, void* aux_out, int aux_out_bf16,
+                           int ld_aux, int beta, void* stream);
 /* dst[i] = bf16(src[i]) (round to nearest even); n % 4 == 0 */
 int uniter_cast_bf16(const float* src, void* dst, size_t n, void* stream);
 
@@ -146,6 +160,11 @@ int uniter_ln_bwd(const float* dy, const float* z, const float* mean, const floa
 int uniter_ln_fwd_b16(const float* x, const float* res, const float* gamma, const float* beta,
                       float* z_out, float* y, void* y_bf16, float* mean, float* rstd, int M, int H,
                       float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream);
+/* uniter_ln_fwd_b16 whose input x is the SUM of nslab fp32 slabs x + s * slab_stride (split-K partial sums left by
+ * uniter_gemm_bf16v2_cfg: the reduction happens here, in the consumer's row pass, instead of in the GEMM). */
+int uniter_ln_fwd_slabs(const float* x, int nslab, size_t slab_stride, const float* res, const float* gamma,
+                        const float* beta, float* z_out, float* y, void* y_bf16, float* mean, float* rstd,
+                        int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream);
 int uniter_ln_bwd_b16(const float* dy, const float* z, const float* mean, const float* rstd,
                       const float* gamma, float* dz, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
                       float* dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
@@ -157,6 +176,14 @@ int uniter_ln_bwd_rows(const float* dy, const float* z, const float* mean, const
                        const float* gamma, float* dz, float* dx, void* dx_bf16, int want_dbias, int M, int H,
                        float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws, size_t ws_bytes,
                        void* stream);
+/* uniter_ln_bwd_rows whose upstream gradient dy is the sum of nslab fp32 slabs (see uniter_ln_fwd_slabs). */
+int uniter_ln_bwd_rows_slabs(const float* dy, int nslab, size_t slab_stride, const float* z, const float* mean,
+                             const float* rstd, const float* gamma, float* dz, float* dx, void* dx_bf16,
+                             int want_dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
+                             uint32_t site, void* ws, size_t ws_bytes, void* stream);
+/* out[n] += sum_m X[m, n] for a bf16 matrix X [M, ld] (bias gradient of a dense layer from the bf16 gradient of its
+ * output; replaces the autograd sum of model/layer.py:140 in the bf16 mode).  N % 8 == 0, ld % 8 == 0. */
+int uniter_colsum_bf16_add(const void* X, int M, int N, int ld, float* out, void* stream);
 int uniter_ln_bwd_finalize(const void* ws, size_t ws_bytes, int M, int H, float* dgamma, float* dbeta,
                            float* dbias, void* stream);
 size_t uniter_ln_bwd_ws_bytes(int M, int H);

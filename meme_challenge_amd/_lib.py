@@ -56,6 +56,9 @@ _SIGS = {
     'uniter_colsum_ws_bytes': (_SZ, [_I, _I]),
     'uniter_ln_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P]),
     'uniter_ln_fwd_b16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P]),
+    'uniter_ln_fwd_slabs': (_I, [_P, _I, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P]),
+    'uniter_ln_bwd_rows_slabs': (_I, [_P, _I, _SZ, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
+    'uniter_colsum_bf16_add': (_I, [_P, _I, _I, _I, _P, _P]),
     'uniter_ln_bwd_b16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_ln_bwd_rows': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_ln_bwd_finalize': (_I, [_P, _SZ, _I, _I, _P, _P, _P, _P]),
@@ -63,6 +66,7 @@ _SIGS = {
     'uniter_ln_bwd_ws_bytes': (_SZ, [_I, _I]),
     'uniter_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P]),
     'uniter_gemm_bf16res_cfg': (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
+    'uniter_gemm_bf16v2_cfg': (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, C.c_long, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
     'uniter_cast_bf16': (_I, [_P, _P, _SZ, _P]),
     'uniter_attn_bwd_ws_bytes': (_SZ, [_I, _I, _I]),
     'uniter_attn_varlen_max_len': (_I, []),

@@ -22,13 +22,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ z_out, float* __restrict__ y,
                                                      float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int M, int H,
-                                                     DropCfg drop, unsigned short* __restrict__ y_b16) {
+                                                     DropCfg drop, unsigned short* __restrict__ y_b16,
+                                                     int nslab, size_t slab_stride) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int H4 = H >> 2;
   f32x4 v[NV];
   row_load<NV>(v, x + (size_t)row * H, H4, lane);
+  for (int s = 1; s < nslab; ++s) {       // split-K partial sums of the producing GEMM (gemm_bf16_dma.hip)
+    f32x4 r[NV];
+    row_load<NV>(r, x + s * slab_stride + (size_t)row * H, H4, lane);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] += r[k];
+  }
   if (drop.active) row_dropout<NV>(v, drop, (uint64_t)row * H4, H4, lane);
   if (res) {
     f32x4 r[NV];
@@ -55,7 +62,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      float* __restrict__ dz, float* __restrict__ dx,
                                                      float* __restrict__ part, int M, int H,
                                                      DropCfg drop, int want_dbias,
-                                                     unsigned short* __restrict__ dx_b16) {
+                                                     unsigned short* __restrict__ dx_b16, int nslab,
+                                                     size_t slab_stride) {
   __shared__ __attribute__((aligned(16))) float red[4 * NV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H4 = H >> 2;
@@ -66,6 +74,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     f32x4 d[NV], xh[NV];
     row_load<NV>(d, dy + (size_t)row * H, H4, lane);
+    for (int s = 1; s < nslab; ++s) {
+      row_load<NV>(xh, dy + s * slab_stride + (size_t)row * H, H4, lane);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) d[k] += xh[k];
+    }
     row_load<NV>(xh, z + (size_t)row * H, H4, lane);
     const float mu = mean[row], rs = rstd[row];
     row_ln_bwd<NV>(d, xh, g, mu, rs, dg, db, H, H4, lane);      // d <- dz, accumulates dg/db
@@ -163,6 +176,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   }
 }
 
+// column sums of a bf16 matrix, added into out (fp32): block (bx, by) covers 512 columns (64 lanes x 8) and the rows
+// by*RPB .. +RPB; four row-lanes meet in LDS, then one fp32 atomic per column and block (the bias gradient of
+// intermediate.dense from the bf16 dU: 16 MB read once, on the side stream)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* __restrict__ X, int M, int N, int ld,
+                                                          float* __restrict__ out, int rows_per_block) {
+  __shared__ float red[4][64 * 8 + 8];
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 512 + lane * 8;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < N) {
+    const int r1 = min(M, (int)(blockIdx.y + 1) * rows_per_block);
+    for (int r = blockIdx.y * rows_per_block + wave; r < r1; r += 4) {
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(X + (size_t)r * ld + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s[2 * k] += __builtin_bit_cast(float, v[k] << 16);
+        s[2 * k + 1] += __builtin_bit_cast(float, v[k] & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = s[k];
+  __syncthreads();
+  for (int j = threadIdx.x; j < 512; j += 256) {
+    const int col = blockIdx.x * 512 + j;
+    if (col < N) atomicAdd(out + col, (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]));
+  }
+}
+
 __global__ void add_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, size_t n4) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
@@ -224,6 +267,17 @@ extern "C" int uniter_colsum_f32(const float* X, int M, int N, int ld, float* ou
   return finalize_partials((const float*)ws, splits, (size_t)N, out, N, beta, st);
 }
 
+// out[n] += sum_m X[m, n] for a bf16 X (N % 8 == 0, ld % 8 == 0, 16-byte aligned)
+extern "C" int uniter_colsum_bf16_add(const void* X, int M, int N, int ld, float* out, void* stream) {
+  UCHECK_ARG(X && out && M > 0 && N > 0, "colsum_bf16: bad argument");
+  UCHECK_SHAPE(N % 8 == 0 && ld % 8 == 0 && ((uintptr_t)X & 15) == 0, "colsum_bf16: N, ld multiples of 8 and a 16-byte aligned operand required");
+  const int rpb = 64;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N + 511) / 512, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)X, M, N, ld, out, rpb);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
 #define LN_DISPATCH(NVv, KERNEL, GRID, ...)                                                      \
   switch (NVv) {                                                                                 \
     case 1: hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(256), 0, st, __VA_ARGS__); break;         \
@@ -244,7 +298,15 @@ extern "C" int uniter_ln_fwd(const float* x, const float* res, const float* gamm
 extern "C" int uniter_ln_fwd_b16(const float* x, const float* res, const float* gamma, const float* beta,
                                  float* z_out, float* y, void* y_bf16, float* mean, float* rstd, int M, int H,
                                  float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
+  return uniter_ln_fwd_slabs(x, 1, 0, res, gamma, beta, z_out, y, y_bf16, mean, rstd, M, H, p_drop, seed, offset, site, stream);
+}
+
+extern "C" int uniter_ln_fwd_slabs(const float* x, int nslab, size_t slab_stride, const float* res, const float* gamma,
+                                   const float* beta, float* z_out, float* y, void* y_bf16, float* mean, float* rstd,
+                                   int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
+                                   void* stream) {
   UCHECK_ARG(x && gamma && beta && y, "ln_fwd: null pointer");
+  UCHECK_ARG(nslab >= 1 && (nslab == 1 || slab_stride >= (size_t)M * H), "ln_fwd: bad slab count / stride");
   UCHECK_ARG((mean == nullptr) == (rstd == nullptr), "ln_fwd: mean/rstd must both be given or NULL");
   UCHECK_SHAPE(H % 4 == 0 && H >= 4, "ln_fwd: H must be a multiple of 4");
   UCHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "ln_fwd: bad dropout p");
@@ -253,7 +315,7 @@ extern "C" int uniter_ln_fwd_b16(const float* x, const float* res, const float* 
   const DropCfg drop = make_drop(p_drop, seed, offset, site);
   const int nv = (H / 4 + 63) / 64;
   LN_DISPATCH(nv, ln_fwd_kernel, dim3((M + 3) / 4), x, res, gamma, beta, z_out, y, mean, rstd, M, H, drop,
-              (unsigned short*)y_bf16);
+              (unsigned short*)y_bf16, nslab, slab_stride);
   UCHECK_LAUNCH();
   return 0;
 }
@@ -287,7 +349,16 @@ extern "C" int uniter_ln_bwd_rows(const float* dy, const float* z, const float* 
                                   const float* gamma, float* dz, float* dx, void* dx_bf16, int want_dbias, int M,
                                   int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws,
                                   size_t ws_bytes, void* stream) {
+  return uniter_ln_bwd_rows_slabs(dy, 1, 0, z, mean, rstd, gamma, dz, dx, dx_bf16, want_dbias, M, H, p_drop, seed, offset,
+                                  site, ws, ws_bytes, stream);
+}
+
+extern "C" int uniter_ln_bwd_rows_slabs(const float* dy, int nslab, size_t slab_stride, const float* z, const float* mean,
+                                        const float* rstd, const float* gamma, float* dz, float* dx, void* dx_bf16,
+                                        int want_dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
+                                        uint32_t site, void* ws, size_t ws_bytes, void* stream) {
   UCHECK_ARG(dy && z && mean && rstd && gamma && ws, "ln_bwd: null pointer");
+  UCHECK_ARG(nslab >= 1 && (nslab == 1 || slab_stride >= (size_t)M * H), "ln_bwd: bad slab count / stride");
   UCHECK_ARG(dz || dx, "ln_bwd: need dz or dx");
   UCHECK_SHAPE(H % 4 == 0 && H >= 4, "ln_bwd: H must be a multiple of 4");
   UCHECK_ARG(ws_bytes >= uniter_ln_bwd_ws_bytes(M, H), "ln_bwd: workspace too small");
@@ -298,7 +369,7 @@ extern "C" int uniter_ln_bwd_rows(const float* dy, const float* z, const float* 
   const int nblk = ln_bwd_blocks(M);
   float* part = (float*)ws;
   LN_DISPATCH(nv, ln_bwd_kernel, dim3(nblk), dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop, want_dbias != 0,
-              (unsigned short*)dx_bf16);
+              (unsigned short*)dx_bf16, nslab, slab_stride);
   UCHECK_LAUNCH();
   return 0;
 }

@@ -26,6 +26,11 @@ int gemm_bf16_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, cons
 int gemm_bf16res_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B,
                      int ldb, float* C, int ldc, void* Cb, int ldcb, int epilogue, const float* bias,
                      const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part, void* stream);
+int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda,
+                    const void* B, int ldb, float* C, int ldc, long c_split_stride, void* Cb, int ldcb, int epilogue,
+                    const float* bias, const void* aux_in, int aux_in_bf16, void* aux_out, int aux_out_bf16,
+                    int ld_aux, int beta, void* stream);
+int gemm_bf16v2_pick_split(int M, int N, int K);
 int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta, hipStream_t st);
 int launch_masked_rowsum(const float* x, const int64_t* masks, float* out, int rows, int D, hipStream_t st);
 
@@ -78,6 +83,9 @@ struct Plan {
   float *dcat, *d_imgfc, *d_posfc, *d_feat, *dsum, *dpk;
   unsigned short* embb;   // precision 2: bf16 copy of the embedding output
   bool res;               // this plan was carved for precision 2
+  // precision 2: k-pieces of the GEMMs whose N is the hidden size (their fp32 outputs are that many slabs, summed by
+  // the LayerNorm row pass that consumes them): K = intermediate (FFN-down forward, FFN-up dgrad), K = 3 hidden (QKV dgrad)
+  int ns_ki, ns_k3h;
   bool packed;      // rows = valid positions only (uniter_batch_t::cu_seqlens)
   void *ln_ws, *col_ws, *emb_ws, *attn_ws;
   size_t ln_ws_bytes, col_ws_bytes, emb_ws_bytes, attn_ws_bytes;
@@ -154,12 +162,15 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
   pl.emb = cv.f(M * H);
   pl.res = m->precision == 2;
   pl.embb = pl.res ? cv.h(M * H) : nullptr;
+  pl.ns_ki = pl.res ? gemm_bf16v2_pick_split(pl.M, H, I) : 1;
+  pl.ns_k3h = pl.res ? gemm_bf16v2_pick_split(pl.M, H, 3 * H) : 1;
+  const size_t s_ki = (size_t)pl.ns_ki, s_k3h = (size_t)pl.ns_k3h;
   pl.layers.resize(nl);
   const bool save = mode != 0;
   auto alloc_fwd = [&](LayerBufs& b) {
     b.qkv = cv.f(M * 3 * H); b.lse = cv.f((size_t)B * nh * L); b.ctx = cv.f(M * H); b.t1 = cv.f(M * H);
     b.z1 = save ? cv.f(M * H) : nullptr; b.mean1 = cv.f(M); b.rstd1 = cv.f(M); b.y1 = cv.f(M * H);
-    b.u = save ? cv.f(M * I) : nullptr; b.hact = cv.f(M * I); b.t2 = cv.f(M * H);
+    b.u = save ? cv.f(M * I) : nullptr; b.hact = cv.f(M * I); b.t2 = cv.f(s_ki * M * H);
     b.z2 = save ? cv.f(M * H) : nullptr; b.mean2 = cv.f(M); b.rstd2 = cv.f(M); b.y2 = cv.f(M * H);
     if (pl.res) { b.ctxb = cv.h(M * H); b.y1b = cv.h(M * H); b.hactb = cv.h(M * I); b.y2b = cv.h(M * H); }
   };
@@ -168,9 +179,9 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
       LayerBufs& b = pl.layers[l];
       b = LayerBufs();
       alloc_fwd(b);
-      b.dz2 = cv.f(M * H); b.g2 = cv.f(M * H); b.du = cv.f(M * I); b.dy1 = cv.f(M * H); b.dz1 = cv.f(M * H);
+      b.dz2 = cv.f(M * H); b.g2 = cv.f(M * H); b.du = cv.f(M * I); b.dy1 = cv.f(s_ki * M * H); b.dz1 = cv.f(M * H);
       b.g1 = cv.f(M * H); b.dctx = cv.f(M * H); b.dqkv = cv.f(M * 3 * H); b.delta = cv.f((size_t)B * nh * L);
-      b.dx = cv.f(M * H);
+      b.dx = cv.f(s_k3h * M * H);
       b.du_csum = cv.f((size_t)((M + 31) / 32) * I);
       b.qb_part = cv.f((size_t)B * 3 * H);
       b.keepb = (unsigned short*)cv.raw(uniter_attn_keep_bits_bytes(B, L, nh));
@@ -233,7 +244,16 @@ int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int
                       aux_in, aux_out, ld_aux, beta, colsum_part, st);
 }
 
-// precision 2: both operands already bf16 in memory
+// precision 2: both operands already bf16 in memory.  Forward and input-gradient products run on the LDS-DMA kernel
+// (gemm_bf16_dma.hip); aux operands (gelu' in, gelu' out) are bf16 there, residual gradients fp32.
+int gemm_v2(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, int K, const void* A, int lda,
+            const void* B, int ldb, float* C, int ldc, int nsplit, unsigned short* Cb, int ldcb, int epi,
+            const float* bias, const void* aux_in, int aux_in_b16, void* aux_out, int aux_out_b16, int ld_aux) {
+  ProfScope ps(m, kind, st);
+  return gemm_bf16v2_run(0, nsplit, 0, bkm, M, N, K, A, lda, B, ldb, C, ldc, (long)M * ldc, Cb, ldcb, epi, bias, aux_in,
+                         aux_in_b16, aux_out, aux_out_b16, ld_aux, 0, st);
+}
+// weight gradients (both operands k-major, stream-K, fp32 atomics into the gradient buffer): gemm_bf16.hip
 int gemm_r(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int N, int K, const void* A, int lda,
            const void* B, int ldb, float* C, int ldc, unsigned short* Cb, int ldcb, int epi, const float* bias,
            const float* aux_in, float* aux_out, int ld_aux, int beta, float* colsum_part = nullptr) {
@@ -444,11 +464,11 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     if (gated) UCHECK_HIP(hipStreamWaitEvent(st, m->ready[1 + l], 0));
     float* y2 = packed ? lb.y2 : (all_layers ? hidden_out + l * PH : (l == nl - 1 ? hidden_out : lb.y2));
     if (attn_b16)      // the bf16 attention kernels read Q, K, V as bf16: write only that (in the qkv buffer's place)
-      UCHECK_RC(gemm_r(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, xb, H, m->WB(l, L_QW), H, nullptr, 3 * H,
-                       (unsigned short*)lb.qkv, 3 * H, UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
+      UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_QKV_FWD, st, 0, M, 3 * H, H, xb, H, m->WB(l, L_QW), H, nullptr, 3 * H, 1,
+                        (unsigned short*)lb.qkv, 3 * H, UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, 0, nullptr, 0, 0));
     else if (res)
-      UCHECK_RC(gemm_r(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, xb, H, m->WB(l, L_QW), H, lb.qkv, 3 * H,
-                       nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
+      UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_QKV_FWD, st, 0, M, 3 * H, H, xb, H, m->WB(l, L_QW), H, lb.qkv, 3 * H, 1,
+                        nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, 0, nullptr, 0, 0));
     else
       UCHECK_RC(gemm(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, x, H, m->LP(l, L_QW), H, lb.qkv, 3 * H,
                      UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
@@ -468,8 +488,8 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     }
     if (res) {
       if (!attn_b16) UCHECK_RC(cast_b(lb.ctx, lb.ctxb, (size_t)M * H, st));
-      UCHECK_RC(gemm_r(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, 0, M, H, H, lb.ctxb, H, m->WB(l, L_OW), H, lb.t1, H,
-                       nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, nullptr, 0, 0));
+      UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, M, H, H, lb.ctxb, H, m->WB(l, L_OW), H, lb.t1, H, 1,
+                        nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, 0, nullptr, 0, 0));
     } else {
       UCHECK_RC(gemm(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, 0, M, H, H, lb.ctx, H, m->LP(l, L_OW), H, lb.t1, H,
                      UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, nullptr, 0, 0));
@@ -481,12 +501,12 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
                                   SITE_ATTN_OUT(l), st));
     }
     if (res) {
-      // the activation only exists in bf16 (operand of FFN-down and of its weight gradient)
-      UCHECK_RC(gemm_r(m, UNITER_K_GEMM_FFN_UP_FWD, st, 0, 0, M, I, H, lb.y1b, H, m->WB(l, L_W1), H, nullptr, I,
-                       lb.hactb, I, gelu_d ? UNITER_EPI_BIAS_GELU_D : UNITER_EPI_BIAS_GELU, m->LP(l, L_B1), nullptr,
-                       lb.u, I, 0));
-      UCHECK_RC(gemm_r(m, UNITER_K_GEMM_FFN_DOWN_FWD, st, 0, 0, M, H, I, lb.hactb, I, m->WB(l, L_W2), I, lb.t2, H,
-                       nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_B2), nullptr, nullptr, 0, 0));
+      // the activation and gelu'(u) (or u) only exist in bf16: operand of FFN-down / of its weight gradient, factor of dU
+      UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_FFN_UP_FWD, st, 0, M, I, H, lb.y1b, H, m->WB(l, L_W1), H, nullptr, I, 1,
+                        lb.hactb, I, gelu_d ? UNITER_EPI_BIAS_GELU_D : UNITER_EPI_BIAS_GELU, m->LP(l, L_B1), nullptr, 0,
+                        save ? (void*)lb.u : (void*)lb.hact, 1, I));
+      UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_FFN_DOWN_FWD, st, 0, M, H, I, lb.hactb, I, m->WB(l, L_W2), I, lb.t2, H, pl.ns_ki,
+                        nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_B2), nullptr, 0, nullptr, 0, 0));
     } else {
       UCHECK_RC(gemm(m, UNITER_K_GEMM_FFN_UP_FWD, st, 0, 0, M, I, H, lb.y1, H, m->LP(l, L_W1), H, lb.hact, I,
                      gelu_d ? UNITER_EPI_BIAS_GELU_D : UNITER_EPI_BIAS_GELU, m->LP(l, L_B1), nullptr, lb.u, I, 0));
@@ -495,9 +515,9 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     }
     {
       ProfScope ps(m, UNITER_K_LN, st);
-      UCHECK_RC(uniter_ln_fwd_b16(lb.t2, lb.y1, m->LP(l, L_LN2_G), m->LP(l, L_LN2_B), lb.z2, y2, res ? lb.y2b : nullptr,
-                                  save ? lb.mean2 : nullptr, save ? lb.rstd2 : nullptr, M, H, ph, seed, offset,
-                                  SITE_FFN_OUT(l), st));
+      UCHECK_RC(uniter_ln_fwd_slabs(lb.t2, pl.ns_ki, (size_t)M * H, lb.y1, m->LP(l, L_LN2_G), m->LP(l, L_LN2_B), lb.z2, y2,
+                                    res ? lb.y2b : nullptr, save ? lb.mean2 : nullptr, save ? lb.rstd2 : nullptr, M, H,
+                                    ph, seed, offset, SITE_FFN_OUT(l), st));
     }
     lb.y2 = y2;
     x = y2;
@@ -569,10 +589,15 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   float* g2 = ph > 0.f ? lb.g2 : lb.dz2;
   float* g1 = ph > 0.f ? lb.g1 : lb.dz1;
+  // precision 2: the next layer's dx may be split-K slabs (summed here); never for the last layer (dy is the caller's
+  // gradient), with all_layers (dy is dsum) or in layer 0 (the embedding backward reads a plain dx)
+  const int ns_dy = (l == nl - 1 || m->all_layers) ? 1 : pl.ns_k3h;
+  const int ns_dx = (l == 0 || m->all_layers) ? 1 : pl.ns_k3h;
   {
     ProfScope ps(m, UNITER_K_LN, st);
-    UCHECK_RC(uniter_ln_bwd_rows(dy, lb.z2, lb.mean2, lb.rstd2, m->LP(l, L_LN2_G), lb.dz2, g2, pl.res ? lb.g2b : nullptr, 1,
-                                 M, H, ph, m->seed, m->offset, SITE_FFN_OUT(l), lb.ln_ws2, pl.ln_ws_bytes, st));
+    UCHECK_RC(uniter_ln_bwd_rows_slabs(dy, ns_dy, MH, lb.z2, lb.mean2, lb.rstd2, m->LP(l, L_LN2_G), lb.dz2, g2,
+                                       pl.res ? lb.g2b : nullptr, 1, M, H, ph, m->seed, m->offset, SITE_FFN_OUT(l),
+                                       lb.ln_ws2, pl.ln_ws_bytes, st));
   }
   // FFN down dgrad (+ GELU'), FFN up dgrad (+ residual grad)
   // the GEMM's epilogue also emits per-32-row column sums of du (= partial bias gradients of
@@ -585,10 +610,10 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   const bool fused_qb = L <= uniter_attn_varlen_max_len();
   const int epi_du = pl.gelu_d ? UNITER_EPI_MUL : UNITER_EPI_DGELU;
   if (res) {
-    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, lb.g2b, H, m->WB(l, L_W2), I, nullptr, I, lb.dub, I,
-                     epi_du, nullptr, lb.u, nullptr, I, 0, lb.du_csum));
-    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, I, lb.dub, I, m->WB(l, L_W1), H, lb.dy1, H, nullptr, 0,
-                     UNITER_EPI_ADD, nullptr, lb.dz2, nullptr, H, 0));
+    UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, I, H, lb.g2b, H, m->WB(l, L_W2), I, nullptr, I, 1, lb.dub, I,
+                      epi_du, nullptr, lb.u, 1, nullptr, 0, I));
+    UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, I, lb.dub, I, m->WB(l, L_W1), H, lb.dy1, H, pl.ns_ki, nullptr, 0,
+                      UNITER_EPI_ADD, nullptr, lb.dz2, 0, nullptr, 0, H));
   } else {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, g2, H, m->LP(l, L_W2), I, lb.du, I, epi_du,
                    nullptr, lb.u, nullptr, I, 0, fuse_db1 ? lb.du_csum : nullptr));
@@ -597,12 +622,13 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   {
     ProfScope ps(m, UNITER_K_LN, st);
-    UCHECK_RC(uniter_ln_bwd_rows(lb.dy1, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1, g1, res ? lb.g1b : nullptr, 1,
-                                 M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l), lb.ln_ws1, pl.ln_ws_bytes, st));
+    UCHECK_RC(uniter_ln_bwd_rows_slabs(lb.dy1, res ? pl.ns_ki : 1, MH, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1,
+                                       g1, res ? lb.g1b : nullptr, 1, M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l),
+                                       lb.ln_ws1, pl.ln_ws_bytes, st));
   }
   if (res) {
-    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, H, lb.g1b, H, m->WB(l, L_OW), H, lb.dctx, H, nullptr, 0,
-                     UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 0));
+    UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, H, lb.g1b, H, m->WB(l, L_OW), H, lb.dctx, H, 1, nullptr, 0,
+                      UNITER_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0));
   } else {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, H, g1, H, m->LP(l, L_OW), H, lb.dctx, H, UNITER_EPI_NONE,
                    nullptr, nullptr, nullptr, 0, 0));
@@ -626,8 +652,8 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   if (res) {
     if (!attn_b16) UCHECK_RC(cast_b(lb.dqkv, lb.dqkvb, (size_t)M * 3 * H, st));
-    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, 3 * H, lb.dqkvb, 3 * H, m->WB(l, L_QW), H, lb.dx, H,
-                     nullptr, 0, UNITER_EPI_ADD, nullptr, lb.dz1, nullptr, H, 0));
+    UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, 3 * H, lb.dqkvb, 3 * H, m->WB(l, L_QW), H, lb.dx, H, ns_dx,
+                      nullptr, 0, UNITER_EPI_ADD, nullptr, lb.dz1, 0, nullptr, 0, H));
   } else {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, 3 * H, lb.dqkv, 3 * H, m->LP(l, L_QW), H, lb.dx, H,
                    UNITER_EPI_ADD, nullptr, lb.dz1, nullptr, H, 0));
@@ -647,7 +673,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                      UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
     UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, I, H, M, lb.dub, I, lb.y1b, H, m->LG(l, L_W1), H, nullptr, 0,
                      UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
-    UCHECK_RC(finalize_partials(lb.du_csum, (M + 31) / 32, (size_t)I, m->LG(l, L_B1), I, 1, sd));
+    UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
     UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, H, M, lb.g1b, H, lb.ctxb, H, m->LG(l, L_OW), H, nullptr, 0,
                      UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
     UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkvb, 3 * H, xb, H, m->LG(l, L_QW), H, nullptr, 0,
@@ -760,6 +786,8 @@ extern "C" int uniter_model_set_weight_mirror(uniter_model_t* m, const float* fl
 extern "C" int uniter_model_set_precision(uniter_model_t* m, int precision) {
   UCHECK_ARG(m && precision >= 0 && precision <= 2, "set_precision: 0 (fp32), 1 (bf16 MFMA, fp32 operands) or 2 (bf16-resident operands)");
   UCHECK_ARG(precision != 2 || m->mirror, "set_precision: precision 2 needs uniter_model_set_weight_mirror first");
+  UCHECK_SHAPE(precision != 2 || m->cfg.intermediate_size % 64 == 0,
+               "set_precision: the bf16-resident mode needs intermediate_size %% 64 == 0 (got %d)", m->cfg.intermediate_size);
   m->precision = precision;
   return 0;
 }

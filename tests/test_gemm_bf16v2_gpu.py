@@ -1,0 +1,135 @@
+"""GPU: second-generation bf16-resident GEMM (LDS-DMA ring, transposed accumulator, split-K slabs).
+Reference: the same bf16 values multiplied in float64 (layouts and epilogues of model/layer.py:76-78,112,140,153
+forward and input-gradient products)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_gelu(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def _ref_dgelu(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+def _run(cfg, bkm, M, N, K, epi, nsplit=1, out='both', aux_in_bf16=False, aux_out_bf16=False, beta=0, seed=0):
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g).bfloat16()
+    B = torch.randn((K, N) if bkm else (N, K), generator=g).bfloat16()
+    bias = torch.randn(N, generator=g)
+    aux = torch.randn(M, N, generator=g)
+    if aux_in_bf16:
+        aux = aux.bfloat16().float()
+    C0 = torch.randn(M, N, generator=g)
+    ref = A.double() @ (B.double() if bkm else B.double().t())
+    pre = None
+    if epi in (1, 2, 5):
+        ref = ref + bias.double()
+    if epi == 2:
+        pre, ref = ref, _ref_gelu(ref)
+    if epi == 5:
+        pre, ref = _ref_dgelu(ref), _ref_gelu(ref)
+    if epi == 3:
+        ref = ref * _ref_dgelu(aux.double())
+    if epi == 4:
+        ref = ref + aux.double()
+    if epi == 6:
+        ref = ref * aux.double()
+    if beta:
+        ref = ref + C0.double()
+    dA, dB, dbias = A.cuda(), B.cuda(), bias.cuda()
+    daux = (aux.bfloat16() if aux_in_bf16 else aux).cuda().contiguous()
+    want_c = out in ('both', 'f32') or nsplit > 1 or beta
+    want_cb = out in ('both', 'bf16') and nsplit == 1 and not beta
+    dC = (C0.cuda().contiguous() if beta else torch.full((nsplit, M, N), float('nan'), device='cuda')) if want_c else None
+    dCb = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device='cuda') if want_cb else None
+    dauxo = torch.full((M, N), float('nan'), dtype=torch.bfloat16 if aux_out_bf16 else torch.float32, device='cuda')
+    L.check(lib.uniter_gemm_bf16v2_cfg(cfg, nsplit, 0, int(bkm), M, N, K, L.ptr(dA), K, L.ptr(dB), dB.shape[1],
+                                       L.ptr(dC), N, M * N, L.ptr(dCb), N, epi, L.ptr(dbias), L.ptr(daux),
+                                       int(aux_in_bf16), L.ptr(dauxo), int(aux_out_bf16), N, beta, L.cur_stream()),
+            'gemm_bf16v2')
+    torch.cuda.synchronize()
+    tol = 1e-4 * math.sqrt(K) * (1 + 0.1 * nsplit)
+    tag = (cfg, bkm, M, N, K, epi, nsplit, out, aux_in_bf16, aux_out_bf16, beta)
+    if want_c:
+        got = dC.cpu().double() if beta else dC.cpu().double().sum(0)
+        assert not torch.isnan(got).any(), tag
+        err = (got - ref).abs().max().item()
+        assert err < tol, tag + (err,)
+    if want_cb:
+        gb = dCb.cpu().double()
+        assert not torch.isnan(gb).any(), tag
+        rel = ((gb - ref).abs() / (ref.abs() + 1.0)).max().item()
+        assert rel < 2.0 ** -8, tag + (rel,)
+        if want_c:
+            assert torch.equal(dCb.cpu(), dC[0].cpu().bfloat16()), tag      # the bf16 copy is the rounded fp32 output
+    if epi in (2, 5):
+        ga = dauxo.cpu().double()
+        assert not torch.isnan(ga).any(), tag
+        if aux_out_bf16:
+            assert ((ga - pre).abs() / (pre.abs() + 1.0)).max().item() < 2.0 ** -8, tag
+        else:
+            assert (ga - pre).abs().max().item() < tol, tag
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
+@pytest.mark.parametrize('bkm', [0, 1])
+def test_layouts_and_edges(cfg, bkm):
+    _run(cfg, bkm, M=168, N=192, K=128, epi=0)                       # ragged M, N not a tile multiple
+    _run(cfg, bkm, M=320, N=264, K=192, epi=1 if not bkm else 4)     # N % 8 == 0 only
+    _run(cfg, bkm, M=64, N=128, K=64, epi=0, out='f32')
+    _run(cfg, bkm, M=1, N=8, K=64, epi=0)                            # one row, one 8-column group
+    _run(cfg, bkm, M=257, N=520, K=320, epi=1, out='bf16')
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
+def test_epilogues(cfg):
+    for epi in (0, 1, 2, 5):
+        _run(cfg, 0, M=200, N=256, K=128, epi=epi, aux_out_bf16=False)
+        _run(cfg, 0, M=200, N=256, K=128, epi=epi, aux_out_bf16=True, out='bf16')
+    for epi in (3, 4, 6):
+        _run(cfg, 1, M=200, N=256, K=128, epi=epi, aux_in_bf16=False)
+        _run(cfg, 1, M=200, N=256, K=128, epi=epi, aux_in_bf16=True, out='bf16')
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
+@pytest.mark.parametrize('nsplit', [2, 3, 4])
+def test_split_k_slabs(cfg, nsplit):
+    _run(cfg, 0, M=300, N=256, K=640, epi=1, nsplit=nsplit)
+    _run(cfg, 1, M=300, N=256, K=640, epi=4, nsplit=nsplit)
+    _run(cfg, 0, M=130, N=128, K=128, epi=1, nsplit=nsplit)          # fewer k-tiles than pieces: empty pieces store zeros
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
+def test_model_shapes(cfg):
+    _run(cfg, 0, M=2624, N=3072, K=768, epi=5, out='bf16', aux_out_bf16=True)     # FFN up
+    _run(cfg, 0, M=2624, N=2304, K=768, epi=1, out='bf16')                         # QKV
+    _run(cfg, 0, M=2624, N=768, K=3072, epi=1, out='f32', nsplit=2)                # FFN down
+    _run(cfg, 1, M=2624, N=3072, K=768, epi=6, out='bf16', aux_in_bf16=True)       # FFN down dgrad
+    _run(cfg, 1, M=2624, N=768, K=3072, epi=4, out='f32', nsplit=2)                # FFN up dgrad
+    _run(cfg, 1, M=1424, N=1024, K=3072, epi=4, out='f32')                         # UNITER-large
+    _run(cfg, 0, M=128, N=128, K=128, epi=0, beta=1)
+
+
+def test_rejects():
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    x = torch.zeros(64, 64, dtype=torch.bfloat16, device='cuda')
+    c = torch.zeros(64, 64, device='cuda')
+
+    def call(K=64, N=64, nsplit=1, cb=None, beta=0, akm=0):
+        return lib.uniter_gemm_bf16v2_cfg(1, nsplit, akm, 0, 64, N, K, L.ptr(x), 64, L.ptr(x), 64, L.ptr(c), 64, 64 * 64,
+                                          cb, 64, 0, None, None, 0, None, 0, 64, beta, L.cur_stream())
+    assert call() == 0
+    assert call(K=60) != 0 and b'gemm_bf16v2' in lib.uniter_last_error()
+    assert call(N=60) != 0
+    assert call(nsplit=2, cb=L.ptr(x)) != 0          # split-K has no bf16 output
+    assert call(beta=1, cb=L.ptr(x)) != 0
+    assert call(akm=1) != 0
