@@ -58,6 +58,120 @@ def gelu(x):
     return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
+# --- the bf16 precision mode of the HIP path (BASELINE configs[2..4]) ----------------------------
+# prec='bf16' rounds exactly what the bf16 kernels round (round-to-nearest-even, fp32 accumulation
+# everywhere) so that the HIP path can be held to a tight bar in that mode too:
+#   * every dense product (img_linear, query/key/value, attention output, intermediate, output):
+#     both operands rounded, forward and backward (dX = bf(dY) W_bf, dW = bf(dY)^T X_bf), bias
+#     gradient from the unrounded dY;
+#   * the fused query|key|value output is stored as bf16;
+#   * gelu(u) is stored as bf16, and dU = bf(dH * bf(gelu'(u))) (gelu' is kept as bf16);
+#   * attention: probabilities (after dropout) rounded where they multiply V; backward with dO,
+#     Pd = p * mask and dS rounded where they become matrix operands, delta = sum(O * dO) in fp32.
+#     The forward kernel rounds the UNNORMALISED probabilities of its blocked online softmax
+#     (exp(s - running max)): _online_softmax_pv_b16 restates that blocking, because any rounding
+#     that is modelled differently decorrelates every later bf16 rounding within a few layers.
+# Everything else (LayerNorm, softmax, dropout, residual adds, pooler, head, loss) is fp32 in both.
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _LinearB16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, round_out):
+        xb, wb = bf(x), bf(w)
+        y = F.linear(xb, wb, b)
+        ctx.save_for_backward(xb, wb)
+        ctx.has_bias = b is not None
+        return bf(y) if round_out else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        dyb = bf(dy)
+        dx = dyb @ wb
+        dw = dyb.reshape(-1, dyb.shape[-1]).t() @ xb.reshape(-1, xb.shape[-1])
+        db = dy.reshape(-1, dy.shape[-1]).sum(0) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+class _GeluB16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u):
+        cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
+        pdf = torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
+        ctx.save_for_backward(bf(cdf + u * pdf))
+        return bf(u * cdf)
+
+    @staticmethod
+    def backward(ctx, dh):
+        (dg,) = ctx.saved_tensors
+        return bf(dh * dg)
+
+
+def _online_softmax_pv_b16(s, keep, v):
+    """O = softmax(s) (x keep) V as csrc/attention_bf16.hip's forward kernel forms it: keys in blocks of 32, the
+    key range cut in two halves (first half = ceil(nblk / 2) blocks) that each run an online softmax; block j
+    multiplies V with bf16(exp(s - m_j) * keep), m_j = the half's running maximum after block j, and the fp32
+    accumulator is rescaled by exp(m_old - m_new) in between; the normaliser sums the UNROUNDED exp(s - m).
+    Returns (O, p) with p the exact softmax (what the backward kernel recomputes from the stored LSE)."""
+    B, nh, L, _ = s.shape
+    Lr = (L + 31) // 32 * 32
+    nblk = Lr // 32
+    hb = (nblk + 1) // 2
+    ninf = float('-inf')
+    sb = F.pad(s, (0, Lr - L), value=ninf).view(B, nh, L, nblk, 32)
+    bmax = sb.max(-1).values
+    halves = [torch.cummax(bmax[..., :hb], dim=-1).values]
+    if nblk > hb:
+        halves.append(torch.cummax(bmax[..., hb:], dim=-1).values)
+    mj = torch.cat(halves, -1)                                        # [B, nh, L, nblk]
+    mfin = mj.max(-1, keepdim=True).values
+    w = torch.exp(mj - mfin)                                          # rescale of block j's contribution
+    mj = torch.where(torch.isinf(mj), torch.zeros_like(mj), mj)      # a half whose keys are all masked: p = 0, w = 0
+    pt = torch.exp(sb - mj.unsqueeze(-1))                             # unnormalised probabilities
+    l = (pt.sum(-1) * w).sum(-1, keepdim=True)                        # [B, nh, L, 1]
+    if keep is not None:
+        pt = pt * F.pad(keep, (0, Lr - L), value=0.0).view(B, nh, L, nblk, 32)
+    peff = (bf(pt) * w.unsqueeze(-1)).view(B, nh, L, Lr)[..., :L] / l
+    return torch.matmul(peff, v), torch.softmax(s, dim=-1)
+
+
+class _AttnB16(torch.autograd.Function):
+    """q, k, v: [B, nh, L, d] holding bf16 values; ext_mask additive [B, 1, 1, L]; keep: dropout
+    multiplier (0 or 1/(1-p)) or None."""
+    @staticmethod
+    def forward(ctx, q, k, v, ext_mask, keep, scale):
+        s = torch.matmul(q, k.transpose(-1, -2)) * scale + ext_mask
+        o, p = _online_softmax_pv_b16(s, keep, v)
+        pd = p if keep is None else p * keep
+        ctx.save_for_backward(q, k, v, p, pd, o)
+        ctx.keep, ctx.scale = keep, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        # attn_b16_dq_kernel / attn_b16_dkv_kernel: p recomputed from the LSE (normalised), Pd = p * keep and
+        # dS = p (dP keep - delta) scale rounded to bf16 where they multiply dO, K and Q; dO rounded too
+        q, k, v, p, pd, o = ctx.saved_tensors
+        keep, scale = ctx.keep, ctx.scale
+        dob = bf(do)
+        delta = (o * do).sum(-1, keepdim=True)
+        dp = torch.matmul(dob, v.transpose(-1, -2))
+        ds = p * ((dp if keep is None else dp * keep) - delta) * scale
+        dsb, pdb = bf(ds), bf(pd)
+        dq = torch.matmul(dsb, k)
+        dk = torch.matmul(dsb.transpose(-1, -2), q)
+        dv = torch.matmul(pdb.transpose(-1, -2), dob)
+        return dq, dk, dv, None, None, None
+
+
+def linear(x, w, b, prec='fp32', round_out=False):
+    if prec == 'fp32':
+        return F.linear(x, w, b)
+    return _LinearB16.apply(x, w, b, round_out)
+
+
 def text_embeddings(sd, p, input_ids, position_ids, token_type_ids, cfg, drop):
     # UniterTextEmbeddings.forward, model/model.py:232-245
     if token_type_ids is None:
@@ -72,7 +186,7 @@ def text_embeddings(sd, p, input_ids, position_ids, token_type_ids, cfg, drop):
 
 
 def image_embeddings(sd, p, img_feat, img_pos_feat, img_type_ids, img_masks,
-                     cfg, drop):
+                     cfg, drop, prec='fp32'):
     # UniterModel._compute_img_embeddings, model/model.py:311-319 and
     # UniterImageEmbeddings.forward, model/model.py:261-272
     if img_type_ids is None:
@@ -84,8 +198,8 @@ def image_embeddings(sd, p, img_feat, img_pos_feat, img_type_ids, img_masks,
         mw = sd[q + 'mask_embedding.weight']
         mw = torch.cat([torch.zeros_like(mw[:1]), mw[1:]], 0)
         img_feat = img_feat + mw[img_masks.long()]
-    t_im = layer_norm(F.linear(img_feat, sd[q + 'img_linear.weight'],
-                               sd[q + 'img_linear.bias']),
+    t_im = layer_norm(linear(img_feat, sd[q + 'img_linear.weight'],
+                             sd[q + 'img_linear.bias'], prec),
                       sd[q + 'img_layer_norm.weight'],
                       sd[q + 'img_layer_norm.bias'])
     t_pos = layer_norm(F.linear(img_pos_feat, sd[q + 'pos_linear.weight'],
@@ -98,7 +212,7 @@ def image_embeddings(sd, p, img_feat, img_pos_feat, img_type_ids, img_masks,
                           philox.SITE_IMG_EMB)
 
 
-def self_attention(sd, lp, x, ext_mask, cfg, drop, layer):
+def self_attention(sd, lp, x, ext_mask, cfg, drop, layer, prec='fp32'):
     # BertSelfAttention.forward, model/layer.py:75-101
     B, L, H = x.shape
     nh = cfg['num_attention_heads']
@@ -108,9 +222,20 @@ def self_attention(sd, lp, x, ext_mask, cfg, drop, layer):
         return t.view(B, L, nh, d).permute(0, 2, 1, 3)
 
     a = lp + 'attention.self.'
-    q = heads(F.linear(x, sd[a + 'query.weight'], sd[a + 'query.bias']))
-    k = heads(F.linear(x, sd[a + 'key.weight'], sd[a + 'key.bias']))
-    v = heads(F.linear(x, sd[a + 'value.weight'], sd[a + 'value.bias']))
+    rnd = prec != 'fp32'
+    q = heads(linear(x, sd[a + 'query.weight'], sd[a + 'query.bias'], prec, rnd))
+    k = heads(linear(x, sd[a + 'key.weight'], sd[a + 'key.bias'], prec, rnd))
+    v = heads(linear(x, sd[a + 'value.weight'], sd[a + 'value.bias'], prec, rnd))
+    if rnd:
+        keep = None
+        if drop is not None and cfg['attention_probs_dropout_prob'] > 0.0:
+            Lp = (L + 3) // 4 * 4
+            idx = (torch.arange(B * nh * L, dtype=torch.int64).view(B, nh, L, 1)
+                   * Lp + torch.arange(L, dtype=torch.int64).view(1, 1, 1, L))
+            keep = _apply_dropout(torch.ones(B, nh, L, L), cfg['attention_probs_dropout_prob'], drop,
+                                  philox.site_attn_probs(layer), index=idx)
+        c = _AttnB16.apply(q, k, v, ext_mask, keep, 1.0 / math.sqrt(d))
+        return c.permute(0, 2, 1, 3).contiguous().view(B, L, H)
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d)
     s = s + ext_mask
     pr = torch.softmax(s, dim=-1)
@@ -124,21 +249,22 @@ def self_attention(sd, lp, x, ext_mask, cfg, drop, layer):
     return c
 
 
-def bert_layer(sd, lp, x, ext_mask, cfg, drop, layer):
+def bert_layer(sd, lp, x, ext_mask, cfg, drop, layer, prec='fp32'):
     # BertLayer.forward, model/layer.py:166-170
-    c = self_attention(sd, lp, x, ext_mask, cfg, drop, layer)
+    c = self_attention(sd, lp, x, ext_mask, cfg, drop, layer, prec)
     # BertSelfOutput.forward, model/layer.py:111-115
     o = lp + 'attention.output.'
-    h = F.linear(c, sd[o + 'dense.weight'], sd[o + 'dense.bias'])
+    h = linear(c, sd[o + 'dense.weight'], sd[o + 'dense.bias'], prec)
     h = _apply_dropout(h, cfg['hidden_dropout_prob'], drop,
                        philox.site_attn_out(layer))
     y1 = layer_norm(h + x, sd[o + 'LayerNorm.weight'], sd[o + 'LayerNorm.bias'])
     # BertIntermediate.forward, model/layer.py:139-142
-    u = gelu(F.linear(y1, sd[lp + 'intermediate.dense.weight'],
-                      sd[lp + 'intermediate.dense.bias']))
+    u = linear(y1, sd[lp + 'intermediate.dense.weight'],
+               sd[lp + 'intermediate.dense.bias'], prec)
+    u = gelu(u) if prec == 'fp32' else _GeluB16.apply(u)
     # BertOutput.forward, model/layer.py:152-156
     o = lp + 'output.'
-    h = F.linear(u, sd[o + 'dense.weight'], sd[o + 'dense.bias'])
+    h = linear(u, sd[o + 'dense.weight'], sd[o + 'dense.bias'], prec)
     h = _apply_dropout(h, cfg['hidden_dropout_prob'], drop,
                        philox.site_ffn_out(layer))
     return layer_norm(h + y1, sd[o + 'LayerNorm.weight'],
@@ -148,14 +274,16 @@ def bert_layer(sd, lp, x, ext_mask, cfg, drop, layer):
 def uniter_forward(sd, cfg, input_ids, position_ids, img_feat, img_pos_feat,
                    attention_mask, gather_index=None, img_masks=None,
                    output_all_encoded_layers=True, txt_type_ids=None,
-                   img_type_ids=None, drop=None, prefix='', return_embed=False):
-    """UniterModel.forward, model/model.py:336-367."""
+                   img_type_ids=None, drop=None, prefix='', return_embed=False, prec='fp32'):
+    """UniterModel.forward, model/model.py:336-367.  prec='bf16': the rounding points of the HIP
+    path's bf16 mode (see _LinearB16 above); 'fp32' is the reference arithmetic."""
+    assert prec in ('fp32', 'bf16')
     p = prefix
     ext = attention_mask.unsqueeze(1).unsqueeze(2).to(torch.float32)
     ext = (1.0 - ext) * -10000.0                      # model/model.py:342-345
     if input_ids is None:                              # image only, :348-351
         emb = image_embeddings(sd, p, img_feat, img_pos_feat, img_type_ids,
-                               img_masks, cfg, drop)
+                               img_masks, cfg, drop, prec)
     elif img_feat is None:                             # text only, :352-355
         emb = text_embeddings(sd, p, input_ids, position_ids, txt_type_ids,
                               cfg, drop)
@@ -163,13 +291,13 @@ def uniter_forward(sd, cfg, input_ids, position_ids, img_feat, img_pos_feat,
         txt = text_embeddings(sd, p, input_ids, position_ids, txt_type_ids,
                               cfg, drop)
         img = image_embeddings(sd, p, img_feat, img_pos_feat, img_type_ids,
-                               img_masks, cfg, drop)
+                               img_masks, cfg, drop, prec)
         gi = gather_index.unsqueeze(-1).expand(-1, -1, txt.shape[-1])
         emb = torch.gather(torch.cat([txt, img], dim=1), dim=1, index=gi)
     layers = []
     h = emb
     for i in range(cfg['num_hidden_layers']):          # model/model.py:282-292
-        h = bert_layer(sd, p + 'encoder.layer.%d.' % i, h, ext, cfg, drop, i)
+        h = bert_layer(sd, p + 'encoder.layer.%d.' % i, h, ext, cfg, drop, i, prec)
         if output_all_encoded_layers:
             layers.append(h)
     out = layers if output_all_encoded_layers else h
@@ -184,12 +312,12 @@ def pooler(sd, prefix, hidden):
                                sd[prefix + 'pooler.dense.bias']))
 
 
-def meme_uniter_forward(sd, cfg, drop=None, **kw):
+def meme_uniter_forward(sd, cfg, drop=None, prec='fp32', **kw):
     """MemeUniter.forward, model/meme_uniter.py:17-21 (kwargs as
     train_uniter.py:69-71 passes them)."""
     kw = dict(kw)
     kw.setdefault('output_all_encoded_layers', False)
-    h = uniter_forward(sd, cfg, drop=drop, prefix='uniter_model.', **kw)
+    h = uniter_forward(sd, cfg, drop=drop, prefix='uniter_model.', prec=prec, **kw)
     if isinstance(h, list):
         h = h[-1]
     pooled = pooler(sd, 'uniter_model.', h)

@@ -17,7 +17,7 @@ Outputs (all small):
                      and config-2 shapes with PCG64-synthesised weights
                      (oracle.synth_state_dict): logits, loss, per-parameter
                      gradient norms and a few gradient slices
-  shapes_large.npz   UNITER-large (config 4 shape): logits
+  shapes_large.npz   UNITER-large (config 4 shape): logits, loss, gradient norms and slices
   host_helpers.npz   get_gather_index / get_attention_mask outputs for ragged
                      lists; state_dict key names; LR-schedule values from
                      transformers; param-group split from get_optimizer
@@ -191,8 +191,7 @@ def gen_shapes(cfg_path, fname, cases, with_grads=True):
             for n in ('linear.weight',
                       'uniter_model.encoder.layer.0.attention.self.query.weight',
                       'uniter_model.img_embeddings.img_linear.weight',
-                      'uniter_model.encoder.layer.11.output.dense.weight'
-                      if cfg['num_hidden_layers'] >= 12 else 'linear.bias'):
+                      'uniter_model.encoder.layer.%d.output.dense.weight' % (cfg['num_hidden_layers'] - 1)):
                 g = dict(m.named_parameters())[n].grad
                 out[name + '/gslice/' + n] = g.reshape(-1)[:4096].numpy().copy()
             we = m.uniter_model.embeddings.word_embeddings.weight.grad
@@ -466,4 +465,4 @@ if __name__ == '__main__':
     if 'large' in which:
         gen_shapes(os.path.join(REF, 'config/uniter-large.json'), 'shapes_large.npz', {
             'cfg4_full': (8, 128, 50, None, None, 1234),
-        }, with_grads=False)
+        })

@@ -14,7 +14,7 @@ def _r(x):
     return x.float().bfloat16().double()
 
 
-def _reference(qkv, dctx, lens, B, L, nh, p, seed, offset, site):
+def _reference(qkv, dctx, lens, B, L, nh, p, seed, offset, site, emulate):
     H = nh * 64
     q, k, v = [_r(t).view(B, L, nh, 64).permute(0, 2, 1, 3) for t in qkv.split(H, dim=1)]
     do = _r(dctx).view(B, L, nh, 64).permute(0, 2, 1, 3)
@@ -33,7 +33,13 @@ def _reference(qkv, dctx, lens, B, L, nh, p, seed, offset, site):
         keep = torch.from_numpy(philox.keep_mask(int(idx.max()) + 1, p, seed, offset, site))[idx.reshape(-1)].view(idx.shape).double()
         keep = keep * float(np.float32(1.0) / np.float32(1.0 - p))
     pd = pr * keep
-    ctx = _r(pd) @ v                                             # P rounded as the MFMA operand
+    if emulate:
+        # P rounded as the MFMA operand: the kernel rounds exp(s - running max) block by block (oracle's restatement;
+        # padded batches only: with cu_seqlens the two key halves are cut per sample)
+        from oracle.uniter_oracle import _online_softmax_pv_b16
+        ctx = _online_softmax_pv_b16(s.float(), keep.float() if p > 0 else None, v.float())[0].double()
+    else:
+        ctx = _r(pd) @ v
     delta = (ctx * do).sum(-1, keepdim=True)
     dp = do @ v.transpose(-1, -2)
     ds = pr * (dp * keep - delta) / 8.0
@@ -55,7 +61,7 @@ def test_attention_bf16_fwd_bwd(B, L, nh, p, lens, varlen):
     qkv = torch.randn(B * L, 3 * H, generator=g)
     dctx = torch.randn(B * L, H, generator=g)
     seed, offset, site = 0xBEEF1234, 7, 10
-    ctx_ref, lse_ref, dqkv_ref, valid = _reference(qkv, dctx, lens, B, L, nh, p, seed, offset, site)
+    ctx_ref, lse_ref, dqkv_ref, valid = _reference(qkv, dctx, lens, B, L, nh, p, seed, offset, site, emulate=not varlen)
     rows = torch.nonzero(valid).view(-1)
     mask = valid.view(B, L).float()
     if varlen:
@@ -103,10 +109,12 @@ def test_attention_bf16_fwd_bwd(B, L, nh, p, lens, varlen):
     sel = slice(None) if varlen else rows
     got_ctx, got_d = ctx.cpu().double()[sel], dqkv.cpu().double()[sel]
     assert torch.isfinite(got_ctx).all() and torch.isfinite(got_d).all()
-    # the kernel rounds the UNNORMALISED exp(s - running max) to bf16 and rescales, the reference rounds the
-    # normalised probabilities: both are bf16-accurate (2^-9 relative per term), not bit-identical
-    assert (got_ctx - ctx_ref[rows]).abs().max() < 8e-3 * max(1.0, ctx_ref[rows].abs().max().item())
-    assert (got_ctx - ctx_ref[rows]).abs().mean() < 1e-3
+    # the reference rounds the UNNORMALISED exp(s - running max) block by block as the kernel does; what is left are
+    # the few probabilities whose rounding flips on the last bits of the fast exponential
+    # (with cu_seqlens the reference rounds the normalised probabilities: bf16-accurate, not the same bits)
+    cmax, cmean = (8e-3, 1e-3) if varlen else (1e-3, 2e-5)
+    assert (got_ctx - ctx_ref[rows]).abs().max() < cmax * max(1.0, ctx_ref[rows].abs().max().item())
+    assert (got_ctx - ctx_ref[rows]).abs().mean() < cmean
     for b, n in enumerate(lens):
         assert (lse.cpu().double()[b, :, :n] - lse_ref[b, :, :n]).abs().max() < 2e-4
     ref_d = dqkv_ref[rows]
