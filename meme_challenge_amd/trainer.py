@@ -153,7 +153,10 @@ class FusedAdam(torch.optim.Optimizer):
         return self._sumsq.sqrt()
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, max_grad_norm=0.0, zero_grads=True):
+    def step(self, closure=None, grad_scale=1.0, max_grad_norm=0.0, zero_grads=True, grad_ready=None):
+        """grad_ready(lo, hi): optional callable that makes the CURRENT stream wait until flat_grads[lo:hi] is final
+        (dp.GradSync.wait_range): each block launch then waits only for the gradient buckets that cover it.  Clipping
+        needs the norm of everything, so with max_grad_norm > 0 the whole buffer is waited for first."""
         if closure is not None:
             raise UniterHipError('FusedAdam does not support closures')
         st = self.store
@@ -166,6 +169,9 @@ class FusedAdam(torch.optim.Optimizer):
         flags = self._chunk_flags()
         lib = _lib.lib()
         if max_grad_norm and max_grad_norm > 0:
+            if grad_ready is not None:
+                grad_ready(0, st.numel)
+                grad_ready = None
             check(lib.uniter_grad_sumsq(ptr(st.flat_grads), ptr(flags), st.numel, ptr(self._sumsq),
                                         ptr(self._ws), self._ws_bytes, _lib.cur_stream()),
                   'uniter_grad_sumsq')
@@ -189,6 +195,8 @@ class FusedAdam(torch.optim.Optimizer):
         enc = self.overlap_encoder
         plan = self._overlap_plan(enc) if enc is not None else None
         if plan is None:
+            if grad_ready is not None:
+                grad_ready(0, st.numel)
             launch(0, st.numel, _lib.cur_stream())
         else:
             # The update is HBM-bound, the next forward MFMA-bound: run the encoder's blocks on the
@@ -197,6 +205,8 @@ class FusedAdam(torch.optim.Optimizer):
             head, blocks = plan
             main = torch.cuda.current_stream()
             for lo, hi in head:                                  # pooler / heads: tiny, stay on this stream
+                if grad_ready is not None:
+                    grad_ready(lo, hi)
                 launch(lo, hi, _lib.cur_stream())
             side = enc._side_stream
             if side is None:
@@ -205,6 +215,9 @@ class FusedAdam(torch.optim.Optimizer):
             events = []
             import ctypes as C
             for lo, hi in blocks:
+                if grad_ready is not None:
+                    with torch.cuda.stream(side):
+                        grad_ready(lo, hi)
                 launch(lo, hi, C.c_void_p(side.cuda_stream))
                 ev = torch.cuda.Event()
                 ev.record(side)
@@ -271,6 +284,24 @@ def get_scheduler(optimizer, config, steps_per_epoch):
 # --------------------------------------------------------------------------- #
 # the step
 # --------------------------------------------------------------------------- #
+def sync_step(optimizer, grad_sync, accum, max_grad_norm):
+    """average_gradients + clip + optimizer step + zero_grad behind the data-parallel exchange
+    (train_template.py:89-92,103-107).  With clipping the norm needs every bucket; without it each
+    optimizer block waits only for the buckets that cover it."""
+    world, ready = 1, None
+    if grad_sync is not None and grad_sync.active:
+        world = grad_sync.world
+        if max_grad_norm and max_grad_norm > 0:
+            grad_sync.finish()
+        else:
+            grad_sync.flush_all()
+            ready = grad_sync.wait_range
+    elif grad_sync is not None:
+        world = grad_sync.world
+    optimizer.step(grad_scale=1.0 / (accum * world), max_grad_norm=max_grad_norm, zero_grads=True, grad_ready=ready)
+
+
+
 class TrainStep(object):
     """`TrainerTemplate.calculate_loss` (train_template.py:95-126) + the forward of
     `TrainerUniter.train_iter_step` (train_uniter.py:67-72).
@@ -309,11 +340,7 @@ class TrainStep(object):
             self.grad_sync.prepare(will_step=stepping)
         loss.backward()
         if stepping:
-            if self.grad_sync is not None:
-                self.grad_sync.finish()
-            world = self.grad_sync.world if self.grad_sync is not None else 1
-            self.optimizer.step(grad_scale=1.0 / (accum * world), max_grad_norm=cfg['max_grad_norm'],
-                                zero_grads=True)
+            sync_step(self.optimizer, self.grad_sync, accum, cfg['max_grad_norm'])
             self.scheduler.step()
         self.last_loss, self.last_probs = loss.detach(), probs
         self.iters += 1

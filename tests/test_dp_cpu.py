@@ -98,17 +98,39 @@ def _worker(rank, world, port, out):
     sync.hook('embed', None, None)
     sync.finish()
     assert sync.launched == ranges
-    # (3) coalescing: one big bucket -> a single collective covering everything
+    # (3) coalescing: head + all layers travel as ONE collective, flushed when layer 0 completes (not held back for the
+    # embeddings), and the embeddings are a collective of their own
     flat2 = local.clone()
     sync2 = GradSync(flat2, ranges, bucket_bytes=1 << 40)
     sync2.prepare(True)
     sync2.hook('begin', None, None)
     for l in range(nl - 1, -1, -1):
         sync2.hook('layer', l, None)
+        assert sync2.launched == ([] if l > 0 else [(0, ranges[-1][0])])
     sync2.hook('embed', None, None)
+    assert sync2.launched == [(0, ranges[-1][0]), ranges[-1]]
+    # per-block waiting (the optimizer without clipping): only the buckets that overlap the block are waited for
+    sync2.wait_range(ranges[1][0], ranges[1][1])
+    assert [r[3] for r in sync2._inflight] == [True, False]
     sync2.finish()
-    assert sync2.launched == [(0, numel)]
+    assert [r[3] for r in sync2._inflight] == [True, True]
     assert torch.equal(flat2, flat)
+    # (3b) bf16 payload: the slices are rounded to bf16, summed in bf16 and widened back; local buffer stays fp32
+    flat4 = local.clone()
+    sync4 = GradSync(flat4, ranges, bucket_bytes=1, payload='bf16')
+    sync4.prepare(True)
+    sync4.hook('begin', None, None)
+    for l in range(nl - 1, -1, -1):
+        sync4.hook('layer', l, None)
+    sync4.hook('embed', None, None)
+    sync4.finish()
+    assert sync4.launched == ranges and flat4.dtype == torch.float32
+    parts = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(parts, local)
+    expect = sum(p_.to(torch.bfloat16) for p_ in parts[1:]) if world > 1 else 0
+    expect = (parts[0].to(torch.bfloat16) + expect).to(torch.float32) if world > 1 else parts[0].to(torch.bfloat16).float()
+    assert torch.equal(flat4, expect)
+    assert (flat4 - flat).abs().max().item() <= 2.0 ** -7 * flat.abs().max().item()
     # (4) finish() without hooks (e.g. frozen encoder) still reduces everything
     flat3 = local.clone()
     sync3 = GradSync(flat3, ranges, bucket_bytes=1)

@@ -1,0 +1,46 @@
+"""GPU: the data-parallel path on real hardware -- the model's backward hooks, dp.GradSync and an RCCL
+all-reduce (backend 'nccl', one rank, UNITER_DP_FORCE=1) in a child process (a process group cannot be
+created inside the pytest process without leaking into the other tests).
+
+With one rank the sum is the identity, so two training steps through the collective path must leave
+the parameters of the plain steps (fp32 payload) up to the summation order of the float-atomic weight
+gradients -- the same 1e-9 a plain re-run shows --, the buckets must be the backward-order slices
+(head + layers coalesced, flushed at layer 0; the embeddings alone), each collective must have been
+issued on the stream that produced its gradients, and the bf16 payload must change the result by no more than
+the rounding of the gradients (A16 / E1 of SURVEY.md section 8; reference mechanism train_template.py:58-59)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_single_rank_rccl_path_matches_plain_step():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'tests', 'tools', 'dp_single_rank_check.py')],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('DPCHECK ')][-1]
+    out = json.loads(line[len('DPCHECK '):])
+    noise = max(out['plain_rerun_maxdiff'], 2e-9)          # two plain runs differ by this much (fp32 atomics order)
+    assert out['fp32_clip_maxdiff'] <= 4 * noise, out
+    assert out['fp32_noclip_maxdiff'] <= 4 * noise, out     # per-block waits (no clipping) instead of one finish()
+    assert out['loss_diff'] <= 1e-6, out
+    info = out['info']
+    ranges = [tuple(r) for r in info['ranges']]
+    launched = [tuple(r) for r in info['launched']]
+    # head | layer nl-1 .. 0 coalesced into one collective (the tiny model is far below the bucket size) flushed when
+    # layer 0 completes, then the embeddings alone
+    assert launched == [(ranges[0][0], ranges[-1][0]), ranges[-1]], (launched, ranges)
+    # the layers' collective behind the weight-gradient kernels (side stream), the embeddings' behind the embedding
+    # backward (main stream)
+    assert info['on_side_stream'] == [True, False], info['on_side_stream']
+    assert out['bf16_info']['payload'] == 'bf16'
+    # bf16 payload: gradients rounded once (2^-9 relative) before Adam; after two steps at lr 1e-3 the parameters move by
+    # at most a few lr relative to the run without the collective
+    assert out['bf16_payload_maxdiff'] < 5e-3, out
