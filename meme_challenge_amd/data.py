@@ -140,7 +140,13 @@ class DevicePrefetcher(object):
 class MemeDataset(data.Dataset):
     def __init__(self, filepath, feature_dir=None, text_padding=None, return_ids=False, compact_batch=True,
                  confidence_threshold=0.0, preload_images=False, text_only=False, debug=False,
-                 feature_shard=None, **unused):
+                 feature_shard=None, ragged_regions=False, **unused):
+        """`ragged_regions=False` reproduces the reference's collate exactly: it measures the region count of every
+        sample on the already zero-padded stack (data/meme_dataset.py:161,191), so every sample of a batch carries the
+        batch's largest region count and the zero rows are attended like real regions (pinned by
+        tests/golden/data_pipeline.npz).  True masks each sample at its own region count instead (what
+        utils/utils.py:111-125 describes; fewer valid positions for token packing)."""
+        self.ragged_regions = ragged_regions
         assert os.path.isfile(filepath), "Dataset file cannot be found: \"%s\"." % filepath
         assert filepath.endswith(".jsonl"), "The filepath requires a JSON list file (\".jsonl\")."
         self.filepath, self.feature_dir = filepath, feature_dir
@@ -203,7 +209,7 @@ class MemeDataset(data.Dataset):
                 return batch
             img_feat = pad_sequence([s['img_feat'] for s in samples], batch_first=True, padding_value=0)
             img_pos = pad_sequence([s['img_pos_feat'] for s in samples], batch_first=True, padding_value=0)
-            img_len = [s['img_feat'].size(0) for s in samples]
+            img_len = [s['img_feat'].size(0) for s in samples] if self.ragged_regions else [img_feat.size(1)] * B
             if self.compact_batch:
                 attn = get_attention_mask(text_len, img_len)
             else:

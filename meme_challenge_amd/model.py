@@ -40,57 +40,54 @@ CHUNK = 64          # floats; granularity of the optimizer's per-chunk flags
 
 
 class UniterConfig(object):
-    """Configuration of a `UniterModel` (mirror of model/model.py:24-114)."""
+    """Hyper-parameters of a `UniterModel`.  Same construction surface as the reference's holder
+    (model/model.py:24-114: an int vocabulary size plus keyword overrides, or the path of a json
+    file; `from_dict`, `from_json_file`, `to_dict`, `to_json_string`) -- the attribute names are the
+    json schema of config/uniter-*.json."""
 
-    def __init__(self, vocab_size_or_config_json_file, hidden_size=768,
-                 num_hidden_layers=12, num_attention_heads=12,
-                 intermediate_size=3072, hidden_act="gelu",
-                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
-                 max_position_embeddings=512, type_vocab_size=2,
-                 initializer_range=0.02):
-        if isinstance(vocab_size_or_config_json_file, str):
-            with open(vocab_size_or_config_json_file, "r", encoding='utf-8') as reader:
-                json_config = json.loads(reader.read())
-            for key, value in json_config.items():
-                self.__dict__[key] = value
-        elif isinstance(vocab_size_or_config_json_file, int):
-            self.vocab_size = vocab_size_or_config_json_file
-            self.hidden_size = hidden_size
-            self.num_hidden_layers = num_hidden_layers
-            self.num_attention_heads = num_attention_heads
-            self.hidden_act = hidden_act
-            self.intermediate_size = intermediate_size
-            self.hidden_dropout_prob = hidden_dropout_prob
-            self.attention_probs_dropout_prob = attention_probs_dropout_prob
-            self.max_position_embeddings = max_position_embeddings
-            self.type_vocab_size = type_vocab_size
-            self.initializer_range = initializer_range
+    FIELDS = (('hidden_size', 768), ('num_hidden_layers', 12), ('num_attention_heads', 12),
+              ('intermediate_size', 3072), ('hidden_act', 'gelu'), ('hidden_dropout_prob', 0.1),
+              ('attention_probs_dropout_prob', 0.1), ('max_position_embeddings', 512),
+              ('type_vocab_size', 2), ('initializer_range', 0.02))
+
+    def __init__(self, vocab_size_or_config_json_file, **overrides):
+        src = vocab_size_or_config_json_file
+        if isinstance(src, bool) or not isinstance(src, (int, str)):
+            raise ValueError('UniterConfig needs a vocabulary size (int) or the path of a config json (str), '
+                             'got %s' % type(src).__name__)
+        unknown = set(overrides) - {k for k, _ in self.FIELDS}
+        if unknown:
+            raise TypeError('unknown UniterConfig fields: %s' % ', '.join(sorted(unknown)))
+        if isinstance(src, str):
+            with open(src, encoding='utf-8') as f:
+                self._absorb(json.load(f))
         else:
-            raise ValueError("First argument must be either a vocabulary size "
-                             "(int) or the path to a pretrained model config "
-                             "file (str)")
+            self.vocab_size = src
+            for name, default in self.FIELDS:
+                setattr(self, name, overrides.get(name, default))
+
+    def _absorb(self, mapping):
+        for key, value in mapping.items():
+            setattr(self, key, value)
+        return self
 
     @classmethod
     def from_dict(cls, json_object):
-        config = UniterConfig(vocab_size_or_config_json_file=-1)
-        for key, value in json_object.items():
-            config.__dict__[key] = value
-        return config
+        return cls(-1)._absorb(json_object)
 
     @classmethod
     def from_json_file(cls, json_file):
-        with open(json_file, "r", encoding='utf-8') as reader:
-            text = reader.read()
-        return cls.from_dict(json.loads(text))
-
-    def __repr__(self):
-        return str(self.to_json_string())
+        with open(json_file, encoding='utf-8') as f:
+            return cls.from_dict(json.load(f))
 
     def to_dict(self):
-        return copy.deepcopy(self.__dict__)
+        return copy.deepcopy(vars(self))
 
     def to_json_string(self):
         return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
+
+    def __repr__(self):
+        return self.to_json_string()
 
 
 # hyper-parameters of the two published UNITER sizes (the reference ships them as
@@ -582,50 +579,31 @@ class UniterPreTrainedModel(nn.Module):
 
     @classmethod
     def from_pretrained(cls, config_file, state_dict, *inputs, **kwargs):
-        """Instantiate from a config json and a state dict (model/model.py:148-214):
-        gamma/beta -> weight/bias renames, optional 'bert.' prefix, missing /
-        unexpected keys logged, shape errors raise RuntimeError."""
+        """Build the model from a config (json path, built-in name or UniterConfig) and fill it from
+        `state_dict` -- the loading contract of model/model.py:148-214: TF-era LayerNorm names
+        (`gamma` / `beta`) are accepted, a checkpoint saved under a `bert.` prefix is accepted by a
+        model that has no `bert` attribute, missing and unused keys are logged, tensors of the wrong
+        shape raise RuntimeError.  The caller's dict is not modified."""
         config = config_file if isinstance(config_file, UniterConfig) else resolve_config(config_file)
         logger.info("Model config {}".format(config))
         model = cls(config, *inputs, **kwargs)
-        old_keys, new_keys = [], []
-        for key in state_dict.keys():
-            new_key = None
-            if 'gamma' in key:
-                new_key = key.replace('gamma', 'weight')
-            if 'beta' in key:
-                new_key = key.replace('beta', 'bias')
-            if new_key:
-                old_keys.append(key)
-                new_keys.append(new_key)
-        for old_key, new_key in zip(old_keys, new_keys):
-            state_dict[new_key] = state_dict.pop(old_key)
-        missing_keys, unexpected_keys, error_msgs = [], [], []
-        metadata = getattr(state_dict, '_metadata', None)
-        state_dict = state_dict.copy()
-        if metadata is not None:
-            state_dict._metadata = metadata
-
-        def load(module, prefix=''):
-            local_metadata = ({} if metadata is None else metadata.get(prefix[:-1], {}))
-            module._load_from_state_dict(state_dict, prefix, local_metadata, True, missing_keys,
-                                         unexpected_keys, error_msgs)
-            for name, child in module._modules.items():
-                if child is not None:
-                    load(child, prefix + name + '.')
-        start_prefix = ''
-        if not hasattr(model, 'bert') and any(s.startswith('bert.') for s in state_dict.keys()):
-            start_prefix = 'bert.'
-        load(model, prefix=start_prefix)
-        if len(missing_keys) > 0:
+        strip = 'bert.' if (not hasattr(model, 'bert') and any(k.startswith('bert.') for k in state_dict)) else ''
+        cleaned, ignored = {}, []
+        for key, tensor in state_dict.items():
+            if strip and not key.startswith(strip):
+                ignored.append(key)              # outside the prefixed sub-tree: the checkpoint's other heads
+                continue
+            name = key[len(strip):]
+            head, _, leaf = name.rpartition('.')
+            leaf = {'gamma': 'weight', 'beta': 'bias'}.get(leaf, leaf)
+            cleaned[(head + '.' if head else '') + leaf] = tensor
+        result = model.load_state_dict(cleaned, strict=False)      # raises RuntimeError on a shape mismatch
+        if result.missing_keys:
             logger.info("Weights of {} not initialized from pretrained model: {}".format(
-                model.__class__.__name__, missing_keys))
-        if len(unexpected_keys) > 0:
-            logger.info("Weights from pretrained model not used in {}: {}".format(
-                model.__class__.__name__, unexpected_keys))
-        if len(error_msgs) > 0:
-            raise RuntimeError('Error(s) in loading state_dict for {}:\n\t{}'.format(
-                model.__class__.__name__, "\n\t".join(error_msgs)))
+                cls.__name__, list(result.missing_keys)))
+        unused = ignored + [strip + k for k in result.unexpected_keys]
+        if unused:
+            logger.info("Weights from pretrained model not used in {}: {}".format(cls.__name__, unused))
         return model
 
 

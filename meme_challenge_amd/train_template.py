@@ -1,19 +1,29 @@
-"""Trainer scaffolding around the HIP hot path: counterpart of the reference's
-`TrainerTemplate` (train_template.py:26-552) with the same hook contract
-(`init_model / load_model / train_iter_step / eval_iter_step / test_iter_step`),
-the same CLI flags (`add_default_argparse`), the same step semantics
-(`calculate_loss`), early stopping on the same metrics, the same checkpoint
-format (`{'model_state_dict': ...}`, utils/save.py:57-63) and the same
-prediction / metric exports (`id,proba,label[,gt]` CSV, `_metrics.json`).
+"""Training driver around the HIP hot path.
 
-Differences, all on purpose:
-  * per-iteration results (loss, probabilities, labels) stay on the GPU and are flushed
-    once per epoch -- the reference synchronises with `.item()`/`.cpu()` every iteration
-    (train_template.py:121-124);
-  * averaging, clipping, the optimizer update and zero_grad are one fused kernel;
-  * `--parallel_computing` selects one-process-per-GPU data parallelism over RCCL (launch
-    with torchrun) instead of single-process nn.DataParallel;
-  * tensorboard is optional (scalars are logged only when it is importable).
+What is kept from the reference's `TrainerTemplate` (train_template.py:26-552) is its CONTRACT, because
+`train_uniter.py`-style subclasses and the cross-validation driver are written against it:
+  * the hooks `init_model / load_model / train_iter_step / eval_iter_step / test_iter_step`,
+    the attributes they use (`self.model`, `self.batch`, `self.iters`, `self.preds`, `self.config`,
+    `self.model_file`, `self.pretrained_model_file`) and `calculate_loss(preds, labels, grad_step)`;
+  * the public entry points `train_main`, `eval_model`, `export_val_predictions`,
+    `export_test_predictions`, `export_metrics`;
+  * the CLI flags (`add_default_argparse`, same names / types / defaults) and `preprocess_args`;
+  * the artefacts: `{'model_state_dict': ...}` checkpoints (utils/save.py:57-63), `id,proba,label[,gt]`
+    prediction CSVs, `<name>_metrics.json`, early stopping on `optimize_for`.
+
+The loop itself is this package's own:
+  * per-iteration probabilities, labels and losses are written into preallocated DEVICE buffers
+    (`EpochLog`) and copied to the host once per epoch -- no `.item()` / `.cpu()` per iteration;
+  * averaging, clipping, the optimizer update and zero_grad are one fused launch behind the
+    data-parallel exchange (`trainer.sync_step`);
+  * `--parallel_computing` means one process per GPU over RCCL (launch with torchrun): every rank
+    trains on its own shard of each epoch's sample order, evaluates the full validation set (so
+    early stopping decides identically everywhere), rank 0 writes files, and the ranks leave
+    together (barrier) before anything downstream reads those files;
+  * `loss_func`: 'bce_logits' (one logit, pos_weight) is one fused kernel; 'bce' and 'ce'
+    (train_template.py:66-69) are formed by torch on the model's output and backpropagate into the
+    same HIP backward; `--optimizer adamax | sgd` use torch's update on the flat buffers
+    (trainer.TorchOptimizerStep) -- the fused step is built for the recipe the reference trains with.
 """
 import datetime
 import json
@@ -27,12 +37,23 @@ import torch.distributed as dist
 
 from . import dp
 from .metrics import standard_metrics, find_optimal_threshold
-from .trainer import bce_with_logits_loss, get_optimizer, get_scheduler
+from .trainer import bce_with_logits_loss, get_optimizer, get_scheduler, sync_step
 from .utils import set_seed
 
 LOGGER = logging.getLogger('TrainerLogger')
 logging.basicConfig(format='%(asctime)s : %(levelname)s - %(message)s', datefmt='%d/%m/%Y %I:%M:%S %p',
                     level=logging.INFO)
+
+METRIC_TAGS = (('F1', 'F1'), ('Precision', 'precision'), ('Recall', 'recall'), ('Accuracy', 'accuracy'),
+               ('AUC-ROC', 'aucroc'))
+
+
+def _distributed():
+    return dist.is_available() and dist.is_initialized()
+
+
+def _is_main():
+    return not _distributed() or dist.get_rank() == 0
 
 
 class _NullWriter(object):
@@ -52,53 +73,133 @@ def _make_writer(path):
 
 
 class ModelSaver(object):
-    """utils/save.py:53-63: torch.save({'model_state_dict': cpu tensors})."""
+    """Checkpoint format of utils/save.py:53-63: torch.save({'model_state_dict': cpu tensors})."""
 
     def __init__(self, output_path):
         self.output_path = output_path
 
     def save(self, model, optimizer=None):
         if optimizer is not None and hasattr(optimizer, 'join'):
-            optimizer.join()
-        state_dict = {k: v.detach().cpu().clone() if isinstance(v, torch.Tensor) else v
-                      for k, v in model.state_dict().items()}
-        torch.save({'model_state_dict': state_dict}, self.output_path)
+            optimizer.join()                 # an update overlapped with the next forward may still be running
+        tensors = {k: (v.detach().cpu().clone() if isinstance(v, torch.Tensor) else v)
+                   for k, v in model.state_dict().items()}
+        torch.save({'model_state_dict': tensors}, self.output_path)
+
+
+class EpochLog(object):
+    """Device-side record of one pass over a loader: probabilities, labels, per-iteration losses (and
+    sample ids when the dataset returns them).  Buffers grow geometrically and are reused across
+    epochs; `collect()` is the only host synchronisation."""
+
+    def __init__(self, device):
+        self.device = device
+        self._buf = {}
+        self.reset()
+
+    def reset(self):
+        self.n = 0              # samples
+        self.k = 0              # iterations
+        self.k_short = 0        # iterations since the last 'log_every' flush
+
+    def _room(self, name, need, dtype):
+        b = self._buf.get(name)
+        if b is None or b.numel() < need or b.dtype != dtype:
+            nb = torch.empty(max(need, 2 * (b.numel() if b is not None else 512)), dtype=dtype, device=self.device)
+            if b is not None and b.dtype == dtype:
+                nb[:b.numel()] = b
+            self._buf[name] = b = nb
+        return b
+
+    def add(self, probs, labels, loss, ids=None):
+        m = probs.numel()
+        self._room('probs', self.n + m, torch.float32)[self.n:self.n + m] = probs.detach().reshape(-1)
+        self._room('labels', self.n + m, torch.long)[self.n:self.n + m] = labels.detach().reshape(-1)
+        if ids is not None:
+            self._room('ids', self.n + m, torch.long)[self.n:self.n + m] = ids.detach().reshape(-1)
+        self._room('loss', self.k + 1, torch.float32)[self.k] = loss.detach()
+        self.n += m
+        self.k += 1
+        self.k_short += 1
+
+    def recent_loss(self):
+        """Mean loss of the iterations since the previous call (one scalar read, at the logging interval)."""
+        v = self._buf['loss'][self.k - self.k_short:self.k].mean().item() if self.k_short else float('nan')
+        self.k_short = 0
+        return v
+
+    def collect(self, with_ids=False):
+        if self.n == 0:
+            empty = torch.zeros(0)
+            return (empty, torch.zeros(0, dtype=torch.long), 0.0) + ((None,) if with_ids else ())
+        probs = self._buf['probs'][:self.n].cpu()
+        labels = self._buf['labels'][:self.n].cpu()
+        mean_loss = self._buf['loss'][:self.k].mean().item()
+        if not with_ids:
+            return probs, labels, mean_loss
+        ids = self._buf['ids'][:self.n].cpu() if 'ids' in self._buf else None
+        return probs, labels, mean_loss, ids
+
+
+class Plateau(object):
+    """Early stopping on one scalar: `better` = improvement over the best so far; stop after `patience`
+    evaluations that did not improve it by at least `min_delta`."""
+
+    def __init__(self, maximise, patience, min_delta, start):
+        self.sign = 1.0 if maximise else -1.0
+        self.patience, self.min_delta = patience, min_delta
+        self.best = start
+        self.stale = 0
+
+    def update(self, value):
+        gain = self.sign * (value - self.best)
+        improved = gain > 0
+        if improved:
+            self.best = value
+        self.stale = 0 if gain >= self.min_delta else self.stale + 1
+        return improved, self.stale >= self.patience
 
 
 class TrainerTemplate(object):
 
     def __init__(self, config):
-        self.probs_list, self.labels_list, self.loss_list, self.short_loss_list, self.id_list = [], [], [], [], []
-        self.best_val_metrics, self.train_metrics = defaultdict(int), {}
-        self.not_improved = 0
-        self.best_val_loss = 1000
-        self.total_iters = 0
-        self.terminate_training = False
+        self.config = config
+        self.device = config.get('device', torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))))
+        if not isinstance(config['test_loader'], list):
+            config['test_loader'] = [config['test_loader']]
         self.model_file = os.path.join(config['model_path'], config['model_save_name'])
         self.pretrained_model_file = None
         if config.get('pretrained_model_file') is not None:
             self.pretrained_model_file = os.path.join(config['model_path'], config['pretrained_model_file'])
         self.start_epoch = 1
-        self.config = config
-        self.device = config.get('device', torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))))
-        if not isinstance(self.config['test_loader'], list):
-            self.config['test_loader'] = [self.config['test_loader']]
+        self.total_iters = 0
+        self.terminate_training = False
+        self.best_val_metrics, self.train_metrics, self.test_metrics = defaultdict(int), {}, {}
+        self.best_val_loss = 1000
+        self.train_loss = float('nan')
         self.grad_sync = None
+        self._ids = None
+        self.log = EpochLog(self.device)
+        key = config['optimize_for']
+        self.plateau = Plateau(maximise=(key != 'loss'), patience=config['patience'],
+                               min_delta=config['early_stop_thresh'], start=(1000 if key == 'loss' else 0))
         self.init_training_params()
 
     # ------------------------------------------------------------------ set-up
     def init_training_params(self):
+        loss_func = self.config['loss_func']
+        if loss_func not in ('bce_logits', 'bce', 'ce'):
+            raise ValueError('invalid loss_func %r' % loss_func)
         self.init_model()
         self.model.to(self.device)
         self.model_saver = ModelSaver(self.model_file)
-        if self.config.get('parallel_computing') and dist.is_available() and dist.is_initialized() \
-                and dist.get_world_size() > 1:
+        if self.config.get('parallel_computing') and _distributed() and dist.get_world_size() > 1:
             dp.broadcast_parameters(self.model)
             self.grad_sync = dp.attach(self.model)
+            enc = getattr(self.model, 'uniter_model', None)
+            if enc is not None:          # different dropout masks on every rank (the batches differ as well)
+                enc.set_dropout_seed(int(self.config.get('seed', 0)) + 7919 * dist.get_rank())
         self.init_optimizer()
         self.init_scheduler()
-        if self.config['loss_func'] != 'bce_logits':
-            raise ValueError("loss_func=%r: only 'bce_logits' is built on the HIP path" % self.config['loss_func'])
 
     def init_scheduler(self):
         self.scheduler = get_scheduler(self.optimizer, self.config, len(self.config['train_loader']))
@@ -106,148 +207,167 @@ class TrainerTemplate(object):
     def init_optimizer(self):
         self.optimizer = get_optimizer(self.model, self.config)
         enc = getattr(self.model, 'uniter_model', None)
-        if enc is not None and self.config.get('overlap_optimizer', True):
+        if enc is not None and self.config.get('overlap_optimizer', True) and hasattr(self.optimizer, 'overlap_encoder'):
             # the update of step i runs beside the forward of step i+1 (trainer.FusedAdam.step);
-            # every other reader of the parameters joins first (ModelSaver.save below)
+            # every other reader of the parameters joins first (ModelSaver.save)
             self.optimizer.overlap_encoder = enc
 
     # --------------------------------------------------------------------- step
+    def _loss_and_probs(self, preds, labels):
+        kind = self.config['loss_func']
+        if kind == 'bce_logits':
+            return bce_with_logits_loss(preds.squeeze(1), labels, self.config['pos_wt'], return_probs=True)
+        if kind == 'bce':                # the model's output already is a probability (train_template.py:66-67)
+            p = preds.squeeze(1)
+            return torch.nn.functional.binary_cross_entropy(p, labels.float()), p
+        logp = torch.log_softmax(preds, dim=1)                                     # 'ce': two logits (:68-69)
+        return torch.nn.functional.nll_loss(logp, labels.long()), logp[:, 1].exp()
+
     def calculate_loss(self, preds, batch_label, grad_step):
-        """train_template.py:95-126.  The modulo test is on the per-epoch iteration index
-        (iteration 0 of every epoch steps with one micro-batch, still averaged over
-        `gradient_accumulation`)."""
-        cfg = self.config
-        loss, probs = bce_with_logits_loss(preds.squeeze(1), batch_label, cfg['pos_wt'], return_probs=True)
+        """Step semantics of train_template.py:95-126.  The modulo test is on the per-epoch iteration
+        index, so iteration 0 of every epoch steps with a single micro-batch that is still averaged
+        over `gradient_accumulation` (kept: it is what the reference trains with)."""
+        loss, probs = self._loss_and_probs(preds, batch_label)
         if grad_step:
-            accum = cfg['gradient_accumulation']
+            accum = self.config['gradient_accumulation']
             stepping = self.iters % accum == 0
             if self.grad_sync is not None:
                 self.grad_sync.prepare(will_step=stepping)
             loss.backward()
             if stepping:
-                world = 1
-                if self.grad_sync is not None:
-                    self.grad_sync.finish()
-                    world = self.grad_sync.world
-                self.optimizer.step(grad_scale=1.0 / (accum * world), max_grad_norm=cfg['max_grad_norm'],
-                                    zero_grads=True)
+                sync_step(self.optimizer, self.grad_sync, accum, self.config['max_grad_norm'])
                 self.scheduler.step()
-        # no host synchronisation here: flushed in _flush_epoch_lists()
-        self.probs_list.append(probs.detach())
-        self.labels_list.append(batch_label.detach())
-        self.loss_list.append(loss.detach())
-        if grad_step:
-            self.short_loss_list.append(loss.detach())
-
-    def _flush_epoch_lists(self):
-        probs = torch.cat(self.probs_list).float().cpu() if self.probs_list else torch.zeros(0)
-        labels = torch.cat(self.labels_list).cpu() if self.labels_list else torch.zeros(0, dtype=torch.long)
-        losses = torch.stack(self.loss_list).float().cpu().tolist() if self.loss_list else []
-        return probs, labels, losses
+        self.log.add(probs, batch_label, loss, ids=self._ids)
 
     # --------------------------------------------------------------------- eval
-    def eval_model(self, test=False, test_idx=0):
+    def _pass(self, loader, step):
+        """One no-grad pass over `loader` into the epoch log; `step(iters, batch)` is the subclass hook."""
         self.model.eval()
-        self.probs_list, self.labels_list, self.loss_list, self.id_list = [], [], [], []
-        loader = self.config['val_loader'] if not test else self.config['test_loader'][test_idx]
+        self.log.reset()
+        wants_ids = bool(getattr(loader.dataset, 'return_ids', False))
         with torch.no_grad():
             for iters, batch in enumerate(loader):
                 batch = self.batch_to_device(batch)
-                if getattr(loader.dataset, 'return_ids', False):
-                    self.id_list.append(batch['ids'])
-                self.eval_iter_step(iters, batch, test=test)
-        self.eval_probs, self.eval_labels, losses = self._flush_epoch_lists()
-        self.eval_ids = torch.cat(self.id_list).cpu() if self.id_list else None
-        val_loss = sum(losses) / max(len(losses), 1)
-        return standard_metrics(self.eval_probs, self.eval_labels, add_optimal_acc=True), val_loss
+                self._ids = batch['ids'] if wants_ids else None
+                step(iters, batch)
+        self._ids = None
+
+    def eval_model(self, test=False, test_idx=0):
+        loader = self.config['test_loader'][test_idx] if test else self.config['val_loader']
+        self._pass(loader, lambda iters, batch: self.eval_iter_step(iters, batch, test=test))
+        self.eval_probs, self.eval_labels, loss, self.eval_ids = self.log.collect(with_ids=True)
+        return standard_metrics(self.eval_probs, self.eval_labels, add_optimal_acc=True), loss
+
+    def _stem(self):
+        return os.path.join(self.config['model_path'], self.config['model_save_name'].rsplit('.', 1)[0])
+
+    def _write_predictions(self, name, ids, probs, threshold, labels=None):
+        with open('%s_%s_preds.csv' % (self._stem(), name), 'w') as f:
+            f.write('id,proba,label' + (',gt' if labels is not None else '') + '\n')
+            hard = (probs > threshold).long().tolist()
+            for row, (i, p) in enumerate(zip(ids.tolist(), probs.tolist())):
+                f.write('%i,%f,%i' % (i, p, hard[row]) + (',%i' % labels[row].item() if labels is not None else '') + '\n')
 
     @torch.no_grad()
     def export_test_predictions(self, test_idx=0, threshold=0.5):
-        self.model.eval()
         loader = self.config['test_loader'][test_idx]
         assert getattr(loader.dataset, 'return_ids', False), \
             "Can only export test results if the IDs are returned in the test dataset."
-        prob_list, id_list = [], []
+        self.model.eval()
+        ids, probs = [], []
         for batch in loader:
             batch = self.batch_to_device(batch)
-            id_list.append(batch['ids'])
-            prob_list.append(torch.sigmoid(self.test_iter_step(batch).reshape(-1)))
-        probs = torch.cat(prob_list).cpu()
-        ids = torch.cat(id_list).cpu()
-        self._export_preds(ids, probs, (probs > threshold).long(), file_postfix="_%s_preds.csv" % loader.dataset.name)
+            ids.append(batch['ids'])
+            probs.append(torch.sigmoid(self.test_iter_step(batch).reshape(-1)))
+        self._write_predictions(loader.dataset.name, torch.cat(ids).cpu(), torch.cat(probs).cpu(), threshold)
 
     @torch.no_grad()
     def export_val_predictions(self, test=False, test_idx=0, threshold=0.5):
-        loader = self.config['val_loader'] if not test else self.config['test_loader'][test_idx]
+        loader = self.config['test_loader'][test_idx] if test else self.config['val_loader']
         self.eval_model(test=test, test_idx=test_idx)
-        ids = self.eval_ids if self.eval_ids is not None else torch.zeros_like(self.eval_labels) - 1
-        self._export_preds(ids, self.eval_probs, (self.eval_probs > threshold).long(), labels=self.eval_labels,
-                           file_postfix="_%s_preds.csv" % getattr(loader.dataset, 'name', 'val'))
+        ids = self.eval_ids if self.eval_ids is not None else torch.full_like(self.eval_labels, -1)
+        self._write_predictions(getattr(loader.dataset, 'name', 'val'), ids, self.eval_probs, threshold,
+                                labels=self.eval_labels)
 
-    def _export_preds(self, ids, probs, preds, labels=None, file_postfix="_preds.csv"):
-        lines = ["id,proba,label%s" % (",gt" if labels is not None else "")]
-        for i in range(ids.shape[0]):
-            row = "%i,%f,%i" % (ids[i].item(), probs[i].item(), preds[i].item())
-            if labels is not None:
-                row += ",%i" % labels[i].item()
-            lines.append(row)
-        path = os.path.join(self.config['model_path'], self.config['model_save_name'].rsplit(".", 1)[0] + file_postfix)
-        with open(path, "w") as f:
-            f.write("\n".join(lines) + "\n")
-
-    # ---------------------------------------------------------- early stopping
-    def check_early_stopping(self):
-        key = self.config['optimize_for']
-        this = self.val_loss if key == 'loss' else self.val_metrics[key]
-        best = self.best_val_loss if key == 'loss' else self.best_val_metrics[key]
-        new_best = this < best if key == 'loss' else this > best
-        if new_best:
-            LOGGER.info("New High Score! Saving model...")
-            self.best_val_metrics = self.val_metrics
-            self.best_val_loss = self.val_loss
-            if not self.config["no_model_checkpoints"] and self._is_main():
-                self.model_saver.save(self.model, self.optimizer)
-        diff = best - this if key == 'loss' else this - best
-        if diff < self.config['early_stop_thresh']:
-            self.not_improved += 1
-            if self.not_improved >= self.config['patience']:
-                self.terminate_training = True
-        else:
-            self.not_improved = 0
-        LOGGER.info("current patience: {}".format(self.not_improved))
-
-    @staticmethod
-    def _is_main():
-        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+    def export_metrics(self):
+        report = {'dev': dict(self.best_val_metrics, loss=self.best_val_loss),
+                  'train': dict(self.train_metrics, loss=self.train_loss)}
+        if self.test_metrics:
+            report['test'] = self.test_metrics
+        with open(self._stem() + '_metrics.json', 'w') as f:
+            json.dump(report, f, indent=4)
 
     # ------------------------------------------------------------------- epochs
-    def train_epoch_step(self):
-        lr = self.scheduler.get_last_lr()
+    def _log_metrics(self, group, metrics, step):
+        w = self.config['writer']
+        for tag, key in METRIC_TAGS:
+            w.add_scalar('%s/%s' % (group, tag), metrics[key], step)
+
+    def _train_epoch(self):
+        self.log.reset()
+        self._ids = None
+        every = self.config['log_every']
+        for self.iters, self.batch in enumerate(self.config['train_loader']):
+            self.model.train()
+            self.batch = self.batch_to_device(self.batch)
+            self.train_iter_step()
+            done = self.total_iters + self.iters + 1
+            if done % every == 0:
+                w = self.config['writer']
+                w.add_scalar('Train/Loss', self.log.recent_loss(), done)
+                w.add_scalar('Stats/learning_rate', self.scheduler.get_last_lr()[0], done)
         self.total_iters += self.iters + 1
-        probs, labels, losses = self._flush_epoch_lists()
+        probs, labels, self.train_loss = self.log.collect()
         self.train_metrics = standard_metrics(probs, labels, add_optimal_acc=True)
-        self.train_loss = sum(losses) / max(len(losses), 1)
+
+    def _after_epoch(self):
+        lr = self.scheduler.get_last_lr()[0]
         w = self.config['writer']
         w.add_scalar('Train/Epoch_Loss', self.train_loss, self.total_iters)
-        for k_tb, k in (('F1', 'F1'), ('Precision', 'precision'), ('Recall', 'recall'), ('Accuracy', 'accuracy'),
-                        ('AUC-ROC', 'aucroc')):
-            w.add_scalar('Train/' + k_tb, self.train_metrics[k], self.epoch)
-        w.add_scalar("Train/learning_rate", lr[0], self.epoch)
+        self._log_metrics('Train', self.train_metrics, self.epoch)
+        w.add_scalar('Train/learning_rate', lr, self.epoch)
         t0 = time.time()
         self.val_metrics, self.val_loss = self.eval_model()
-        w.add_scalar("Stats/time_validation", time.time() - t0, self.total_iters)
+        w.add_scalar('Stats/time_validation', time.time() - t0, self.total_iters)
         w.add_scalar('Validation/Loss', self.val_loss, self.epoch)
-        for k_tb, k in (('F1', 'F1'), ('Precision', 'precision'), ('Recall', 'recall'), ('Accuracy', 'accuracy'),
-                        ('AUC-ROC', 'aucroc')):
-            w.add_scalar('Validation/' + k_tb, self.val_metrics[k], self.epoch)
-        if self._is_main():
+        self._log_metrics('Validation', self.val_metrics, self.epoch)
+        if _is_main():
             print("\nEpoch: {}/{},  train_loss = {:.4f}, train_acc = {:.4f}, train_aucroc = {:.4f}  |  "
                   "eval_loss = {:.4f}, eval_acc = {:.4f}, eval_aucroc = {:.4f}  |  lr = {:.8f}  elapsed {:.1f}s"
                   .format(self.epoch, self.config['max_epoch'], self.train_loss, self.train_metrics['accuracy'],
                           self.train_metrics['aucroc'], self.val_loss, self.val_metrics['accuracy'],
-                          self.val_metrics['aucroc'], lr[0], time.time() - self.start))
-        self.check_early_stopping()
-        self.probs_list, self.labels_list, self.loss_list, self.id_list = [], [], [], []
+                          self.val_metrics['aucroc'], lr, time.time() - self.start))
+        key = self.config['optimize_for']
+        improved, stop = self.plateau.update(self.val_loss if key == 'loss' else self.val_metrics[key])
+        if improved:
+            LOGGER.info("New High Score! Saving model...")
+            self.best_val_metrics, self.best_val_loss = self.val_metrics, self.val_loss
+            if not self.config['no_model_checkpoints'] and _is_main():
+                self.model_saver.save(self.model, self.optimizer)
+        LOGGER.info("current patience: {}".format(self.plateau.stale))
+        self.terminate_training = stop
+
+    def _final_evaluation(self):
+        """Reload the best checkpoint, pick the decision threshold on the validation set, score / export every test set."""
+        if not os.path.isfile(self.model_file):
+            raise ValueError("No Saved model state_dict found for the chosen model...!!! \n"
+                             "Aborting evaluation on test set...")
+        self.load_model()
+        self.model.to(self.device)
+        self.export_val_predictions()
+        threshold = find_optimal_threshold(self.eval_probs, self.eval_labels, metric="accuracy")
+        at_thr = standard_metrics(self.eval_probs, self.eval_labels, threshold=threshold, add_aucroc=False)
+        LOGGER.info("Optimal threshold on validation dataset: %.4f (accuracy=%4.2f%%)"
+                    % (threshold, 100.0 * at_thr["accuracy"]))
+        for idx, loader in enumerate(self.config['test_loader']):
+            name = getattr(loader.dataset, 'name', 'test%d' % idx)
+            table = getattr(loader.dataset, 'data', None)
+            if table is not None and hasattr(table, 'labels') and table.labels[0] == -1:     # unlabeled: predictions only
+                self.export_test_predictions(test_idx=idx, threshold=threshold)
+                self.test_metrics[name] = dict()
+            else:
+                self.test_metrics[name], _ = self.eval_model(test=True, test_idx=idx)
+                self.export_val_predictions(test=True, test_idx=idx, threshold=threshold)
 
     def end_training(self):
         if self.terminate_training:
@@ -256,63 +376,28 @@ class TrainerTemplate(object):
         else:
             LOGGER.info("Maximum epochs of {} reached. Finished training !!".format(self.config['max_epoch']))
         self.test_metrics = dict()
-        if not self.config["no_model_checkpoints"] and self._is_main():
-            if not os.path.isfile(self.model_file):
-                raise ValueError("No Saved model state_dict found for the chosen model...!!! \n"
-                                 "Aborting evaluation on test set...")
-            self.load_model()
-            self.model.to(self.device)
-            self.export_val_predictions()
-            threshold = find_optimal_threshold(self.eval_probs, self.eval_labels, metric="accuracy")
-            best = standard_metrics(self.eval_probs, self.eval_labels, threshold=threshold, add_aucroc=False)
-            LOGGER.info("Optimal threshold on validation dataset: %.4f (accuracy=%4.2f%%)"
-                        % (threshold, 100.0 * best["accuracy"]))
-            for test_idx, loader in enumerate(self.config['test_loader']):
-                name = getattr(loader.dataset, 'name', 'test%d' % test_idx)
-                data = getattr(loader.dataset, 'data', None)
-                unlabeled = data is not None and hasattr(data, 'labels') and data.labels[0] == -1
-                if unlabeled:
-                    self.export_test_predictions(test_idx=test_idx, threshold=threshold)
-                    self.test_metrics[name] = dict()
-                else:
-                    m, _ = self.eval_model(test=True, test_idx=test_idx)
-                    self.test_metrics[name] = m
-                    self.export_val_predictions(test=True, test_idx=test_idx, threshold=threshold)
-        else:
+        if self.config['no_model_checkpoints']:
             LOGGER.info("No model checkpoints were saved. Hence, testing will be skipped.")
-        if self._is_main():
+        elif _is_main():
+            self._final_evaluation()
+        if _is_main():
             self.export_metrics()
+            if self.config.get('remove_checkpoints') and os.path.isfile(self.model_file):
+                os.remove(self.model_file)
         self.config['writer'].close()
-        if self.config.get('remove_checkpoints') and self._is_main() and os.path.isfile(self.model_file):
-            os.remove(self.model_file)
-
-    def export_metrics(self):
-        path = os.path.join(self.config['model_path'], self.config['model_save_name'].rsplit(".", 1)[0] + "_metrics.json")
-        d = {"dev": dict(self.best_val_metrics), "train": dict(self.train_metrics)}
-        d["dev"]["loss"] = self.best_val_loss
-        d["train"]["loss"] = self.train_loss
-        if getattr(self, "test_metrics", None):
-            d["test"] = self.test_metrics
-        with open(path, "w") as f:
-            json.dump(d, f, indent=4)
+        if _distributed():
+            # rank 0 may still be scoring the test sets: nobody leaves (tears RCCL down, starts the next fold,
+            # globs the prediction files) before the files exist
+            dist.barrier()
 
     def train_main(self, cache=False):
         self.start = time.time()
-        if self._is_main():
+        if _is_main():
             print("\nBeginning training at:  {} \n".format(datetime.datetime.now()))
         self.model.to(self.device)
         for self.epoch in range(self.start_epoch, self.config['max_epoch'] + 1):
-            for self.iters, self.batch in enumerate(self.config['train_loader']):
-                self.model.train()
-                self.batch = self.batch_to_device(self.batch)
-                self.train_iter_step()
-                if (self.total_iters + self.iters + 1) % self.config['log_every'] == 0:
-                    sl = torch.stack(self.short_loss_list).mean().item()
-                    self.config['writer'].add_scalar('Train/Loss', sl, self.iters + 1 + self.total_iters)
-                    self.config['writer'].add_scalar('Stats/learning_rate', self.scheduler.get_last_lr()[0],
-                                                     self.iters + self.total_iters + 1)
-                    self.short_loss_list = []
-            self.train_epoch_step()
+            self._train_epoch()
+            self._after_epoch()
             if self.terminate_training:
                 break
         self.end_training()
@@ -339,58 +424,41 @@ class TrainerTemplate(object):
         raise NotImplementedError
 
     # --------------------------------------------------------------------- CLI
-    @staticmethod
-    def add_default_argparse(parser, defaults=dict()):
-        """The flags of train_template.py:424-506, same names / types / defaults."""
-        g = defaults.get
-        parser.add_argument('--data_path', type=str, default='./dataset')
-        parser.add_argument('--model_path', type=str, default='./model_checkpoints')
-        parser.add_argument('--vis_path', type=str, default='./vis_checkpoints')
-        parser.add_argument("--model_save_name", type=str, default='best_model.pt')
-        parser.add_argument("--no_model_checkpoints", action="store_true")
-        parser.add_argument("--remove_checkpoints", action="store_true")
-        parser.add_argument('--debug', action="store_true")
-        parser.add_argument('--pretrained_model_file', type=str)
-        parser.add_argument('--optimizer', type=str, default=g('optimizer', 'adam'))
-        parser.add_argument('--loss_func', type=str, default=g('loss_func', 'bce_logits'))
-        parser.add_argument('--optimize_for', type=str, default=g('optimize_for', 'aucroc'))
-        parser.add_argument('--scheduler', type=str, default=g('scheduler', 'warmup_cosine'))
-        parser.add_argument('--confounder_repeat', type=int, default=g('confounder_repeat', 1))
-        parser.add_argument('--object_conf_thresh', type=float, default=g('object_conf_thresh', 0.0))
-        parser.add_argument('--num_folds', type=int, default=g('num_folds', 0))
-        parser.add_argument('--crossval_dev_size', type=int, default=g('crossval_dev_size', 300))
-        parser.add_argument('--crossval_use_dev', action="store_true")
-        parser.add_argument('--beta1', type=float, default=g('beta1', 0.9))
-        parser.add_argument('--beta2', type=float, default=g('beta2', 0.999))
-        parser.add_argument('--batch_size', type=int, default=g('batch_size', 8))
-        parser.add_argument('--num_workers', type=int, default=g('num_workers', 0))
-        parser.add_argument('--gradient_accumulation', type=int, default=g('gradient_accumulation', 1))
-        parser.add_argument('--max_grad_norm', type=int, default=g('max_grad_norm', 5))
-        parser.add_argument('--pos_wt', type=float, default=g('pos_wt', 1))
-        parser.add_argument('--lr', type=float, default=g('lr', 1e-4))
-        parser.add_argument('--warmup_steps', type=int, default=g('warmup_steps', 50))
-        parser.add_argument('--weight_decay', type=float, default=g('weight_decay', 1e-3))
-        parser.add_argument('--max_epoch', type=int, default=g('max_epoch', 20))
-        parser.add_argument('--lr_decay_step', type=float, default=g('lr_decay_step', 3))
-        parser.add_argument('--lr_decay_factor', type=float, default=g('lr_decay_factor', 0.8))
-        parser.add_argument('--patience', type=float, default=g('patience', 5))
-        parser.add_argument('--early_stop_thresh', type=float, default=g('early_stop_thresh', 1e-3))
-        parser.add_argument('--seed', type=int, default=g('seed', 42))
-        parser.add_argument('--log_every', type=int, default=g('log_every', 2000))
-        parser.add_argument('--parallel_computing', type=bool, default=g('parallel_computing', False))
+    # (flag, type or None for store_true, default) of train_template.py:424-506
+    FLAGS = (('data_path', str, './dataset'), ('model_path', str, './model_checkpoints'),
+             ('vis_path', str, './vis_checkpoints'), ('model_save_name', str, 'best_model.pt'),
+             ('no_model_checkpoints', None, False), ('remove_checkpoints', None, False), ('debug', None, False),
+             ('pretrained_model_file', str, None), ('optimizer', str, 'adam'), ('loss_func', str, 'bce_logits'),
+             ('optimize_for', str, 'aucroc'), ('scheduler', str, 'warmup_cosine'), ('confounder_repeat', int, 1),
+             ('object_conf_thresh', float, 0.0), ('num_folds', int, 0), ('crossval_dev_size', int, 300),
+             ('crossval_use_dev', None, False), ('beta1', float, 0.9), ('beta2', float, 0.999),
+             ('batch_size', int, 8), ('num_workers', int, 0), ('gradient_accumulation', int, 1),
+             ('max_grad_norm', int, 5), ('pos_wt', float, 1), ('lr', float, 1e-4), ('warmup_steps', int, 50),
+             ('weight_decay', float, 1e-3), ('max_epoch', int, 20), ('lr_decay_step', float, 3),
+             ('lr_decay_factor', float, 0.8), ('patience', float, 5), ('early_stop_thresh', float, 1e-3),
+             ('seed', int, 42), ('log_every', int, 2000), ('parallel_computing', bool, False))
+
+    @classmethod
+    def add_default_argparse(cls, parser, defaults=dict()):
+        for name, kind, default in cls.FLAGS:
+            if kind is None:
+                parser.add_argument('--' + name, action='store_true')
+            else:
+                parser.add_argument('--' + name, type=kind, default=defaults.get(name, default))
 
     @staticmethod
     def preprocess_args(config, require_data_path=True):
-        """train_template.py:511-550: path checks, n_classes, writer, seed."""
+        """What train_template.py:511-550 derives from the parsed flags: device, n_classes, the directories,
+        the summary writer, the seed."""
         config['device'] = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
         config['n_classes'] = 2 if config['loss_func'] == 'ce' else 1
         if require_data_path and not os.path.exists(config['data_path']):
             raise ValueError("[!] ERROR: Dataset path does not exist")
-        os.makedirs(config['model_path'], exist_ok=True)
+        for key in ('model_path', 'vis_path'):
+            os.makedirs(config[key], exist_ok=True)
         if 'config' in config:
             from .model import resolve_config
             resolve_config(config['config'])          # raises ValueError if neither a file nor a built-in size
-        os.makedirs(config['vis_path'], exist_ok=True)
         config['writer'] = _make_writer(config['vis_path'])
         set_seed(config['seed'])
         return config

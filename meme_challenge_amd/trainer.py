@@ -232,16 +232,63 @@ class FusedAdam(torch.optim.Optimizer):
         self._flags_key = None
 
 
+class TorchOptimizerStep(object):
+    """`--optimizer adamax | sgd` (utils/optim_utils.py:36-43): the update itself is torch.optim's, on the views
+    into the flat buffers; averaging, global-norm clipping and zero_grad around it follow FusedAdam.step's
+    contract so the trainer drives both alike.  Not a fused kernel: the reference's recipe trains with Adam."""
+
+    def __init__(self, model, inner):
+        self.store = model.param_store() if hasattr(model, 'param_store') else ensure_store(model)
+        self.inner = inner
+        self.param_groups = inner.param_groups
+
+    def join(self):
+        pass
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0, max_grad_norm=0.0, zero_grads=True, grad_ready=None):
+        st = self.store
+        if grad_ready is not None:
+            grad_ready(0, st.numel)
+        g = st.flat_grads
+        if grad_scale != 1.0:
+            g.mul_(grad_scale)
+        if max_grad_norm and max_grad_norm > 0:
+            g.mul_(torch.clamp(float(max_grad_norm) / (g.norm() + 1e-6), max=1.0))
+        idle = [p for n, p in st.params.items() if n not in st.touched]     # no gradient this step: no update, no decay
+        for p in idle:
+            p.grad = None
+        self.inner.step()
+        st.reattach_grads(full=True)
+        st.mirror_dirty = True
+        if zero_grads:
+            g.zero_()
+            st.touched.clear()
+
+    def zero_grad(self, set_to_none=False):
+        self.store.zero_grads()
+
+
 def get_optimizer(model, config, group_param_func=None):
-    """utils/optim_utils.py:9-46 for the optimizers the HIP step implements."""
+    """utils/optim_utils.py:9-46: two parameter groups (weight decay off for biases and LayerNorm), then the
+    optimizer by name.  adam / adamw run as the fused HIP step."""
     if group_param_func is not None:
-        raise UniterHipError('custom parameter grouping is not supported by the fused optimizer')
+        raise UniterHipError('custom parameter grouping is not supported (INTEGRATION.md: out of scope)')
     name = config['optimizer']
-    if name not in ('adam', 'adamw'):
-        raise ValueError('invalid optimizer' if name not in ('adamax', 'sgd') else
-                         'optimizer %r is not built on the HIP path (adam / adamw are)' % name)
-    return FusedAdam(model, lr=config['lr'], betas=(config['beta1'], config['beta2']),
-                     weight_decay=config['weight_decay'], adamw=(name == 'adamw'))
+    if name in ('adam', 'adamw'):
+        return FusedAdam(model, lr=config['lr'], betas=(config['beta1'], config['beta2']),
+                         weight_decay=config['weight_decay'], adamw=(name == 'adamw'))
+    if name not in ('adamax', 'sgd'):
+        raise ValueError('invalid optimizer %r' % name)
+    store = model.param_store() if hasattr(model, 'param_store') else ensure_store(model)
+    named = list(store.params.items())
+    groups = [{'params': [p for n, p in named if not no_decay(n)], 'weight_decay': config['weight_decay']},
+              {'params': [p for n, p in named if no_decay(n)], 'weight_decay': 0.0}]
+    if name == 'adamax':
+        inner = torch.optim.Adamax(groups, lr=config['lr'], betas=(config['beta1'], config['beta2']))
+    else:
+        inner = torch.optim.SGD(groups, lr=config['lr'], momentum=0.9)
+    return TorchOptimizerStep(model, inner)
 
 
 # --------------------------------------------------------------------------- #
@@ -266,6 +313,7 @@ def linear_warmup_lambda(num_warmup_steps, num_training_steps):
 
 
 def get_scheduler(optimizer, config, steps_per_epoch):
+    optimizer = getattr(optimizer, 'inner', optimizer)        # TorchOptimizerStep wraps a torch optimizer
     total = steps_per_epoch * config['max_epoch']
     kind = config['scheduler']
     if kind == 'step':

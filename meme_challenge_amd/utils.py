@@ -6,39 +6,40 @@ import numpy as np
 import torch
 
 
-def get_gather_index(txt_lens, num_bbs, batch_size, max_len, out_size):
-    """utils/utils.py:111-117: identity, with [tl, tl+nbb) redirected to the
-    image rows (offset max_len) of cat([txt, img])."""
-    assert len(txt_lens) == len(num_bbs) == batch_size
-    gather_index = torch.arange(0, out_size, dtype=torch.long).unsqueeze(0).repeat(batch_size, 1)
-    for i, (tl, nbb) in enumerate(zip(txt_lens, num_bbs)):
-        gather_index.data[i, tl:tl + nbb] = torch.arange(max_len, max_len + nbb, dtype=torch.long).data
-    return gather_index
+def get_gather_index(txt_lens, num_bbs, batch_size, max_len, out_size, device=None):
+    """Row map of the joint sequence (contract of utils/utils.py:111-117): output position j of
+    sample b reads row gi[b, j] of cat([text (max_len rows), image]).  Positions [tl, tl + nbb) read
+    the image rows max_len .. max_len + nbb - 1, every other position reads row j (text, or padding
+    nothing looks at).  Vectorised: one comparison grid instead of a loop over the batch; can be
+    built directly on the device the model lives on."""
+    tl = torch.as_tensor(txt_lens, dtype=torch.long, device=device).reshape(-1, 1)
+    nbb = torch.as_tensor(num_bbs, dtype=torch.long, device=device).reshape(-1, 1)
+    if not (tl.shape[0] == nbb.shape[0] == batch_size):
+        raise ValueError('txt_lens / num_bbs must hold batch_size entries')
+    col = torch.arange(out_size, dtype=torch.long, device=device).unsqueeze(0)
+    in_img = (col >= tl) & (col < tl + nbb)
+    return torch.where(in_img, col - tl + max_len, col.expand(batch_size, out_size))
 
 
-def get_attention_mask(text_len, img_len):
-    """utils/utils.py:120-125: ones(tl+nbb) right-padded with zeros."""
-    n = [int(t) + int(i) for t, i in zip(text_len, img_len)]
-    mask = torch.zeros(len(n), max(n))
-    for r, k in enumerate(n):
-        mask[r, :k] = 1
-    return mask
+def get_attention_mask(text_len, img_len, device=None):
+    """[B, max(tl + nbb)] float mask, 1 on the tl + nbb valid positions of each row (contract of
+    utils/utils.py:120-125)."""
+    n = (torch.as_tensor(text_len, dtype=torch.long, device=device)
+         + torch.as_tensor(img_len, dtype=torch.long, device=device)).reshape(-1, 1)
+    col = torch.arange(int(n.max()), dtype=torch.long, device=device).unsqueeze(0)
+    return (col < n).to(torch.float32)
 
 
 def pad_tensors(tensors, lens=None, pad=0):
-    """B x [T, ...] -> [B, max_len, hid] (utils/utils.py:128-141)."""
+    """Stack B tensors [n_b, hid] into [B, max n_b, hid], filling with `pad` (contract of
+    utils/utils.py:128-141; `lens` may shorten a tensor's used part)."""
     if lens is None:
-        lens = [t.size(0) for t in tensors]
-    max_len = max(lens)
-    bs = len(tensors)
-    hid = tensors[0].size(-1)
-    dtype = tensors[0].dtype
-    output = torch.zeros(bs, max_len, hid, dtype=dtype)
-    if pad:
-        output.data.fill_(pad)
-    for i, (t, l) in enumerate(zip(tensors, lens)):
-        output.data[i, :l, ...] = t.data
-    return output
+        lens = [int(t.shape[0]) for t in tensors]
+    first = tensors[0]
+    out = first.new_full((len(tensors), max(lens), first.shape[-1]), pad)
+    for row, (t, n) in enumerate(zip(tensors, lens)):
+        out[row, :n] = t[:n]
+    return out
 
 
 def set_seed(seed):

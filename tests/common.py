@@ -43,3 +43,17 @@ def maxdiff(a, b):
     a = a.detach().cpu().double() if torch.is_tensor(a) else torch.as_tensor(a).double()
     b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(b).double()
     return (a - b).abs().max().item()
+
+
+def simple_tokenizer(texts, max_length=12):
+    """Deterministic offline tokenizer with the return fields of the BertTokenizer partial the reference builds
+    (train_uniter.py:124-126: input_ids padded to max_length, length, attention_mask, token_type_ids).  Used on BOTH
+    sides of the data-pipeline fixture (tests/golden/make_golden.py gen_data_pipeline)."""
+    ids = torch.zeros(len(texts), max_length, dtype=torch.long)
+    lens = []
+    for r, t in enumerate(texts):
+        toks = [101] + [1000 + sum(ord(c) * (i + 1) for i, c in enumerate(w)) % 20000 for w in str(t).split()][:max_length - 2] + [102]
+        ids[r, :len(toks)] = torch.tensor(toks)
+        lens.append(len(toks))
+    return {'input_ids': ids, 'length': torch.tensor(lens), 'attention_mask': (ids != 0).long(),
+            'token_type_ids': torch.zeros_like(ids)}

@@ -17,6 +17,8 @@ Outputs (all small):
                      and config-2 shapes with PCG64-synthesised weights
                      (oracle.synth_state_dict): logits, loss, per-parameter
                      gradient norms and a few gradient slices
+  data_pipeline.npz  MemeDataset.__getitem__ / collate_fn / ConfounderSampler of the reference on a small synthetic
+                     dataset in its on-disk format (raw content included so the test rebuilds the files)
   shapes_large.npz   UNITER-large (config 4 shape): logits, loss, gradient norms and slices
   host_helpers.npz   get_gather_index / get_attention_mask outputs for ragged
                      lists; state_dict key names; LR-schedule values from
@@ -444,8 +446,87 @@ def gen_crossval_ensemble():
     np.savez_compressed(os.path.join(HERE, 'crossval_ensemble.npz'), **out)
 
 
+def simple_tokenizer(texts, max_length=12):
+    """Offline stand-in for the BertTokenizer partial of train_uniter.py:124-126 (same return fields); the test
+    applies the SAME function (tests/common.py) on the other side."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+    from common import simple_tokenizer as tok
+    return tok(texts, max_length=max_length)
+
+
+def gen_data_pipeline():
+    """data/meme_dataset.py (MemeDataset.__getitem__, collate_fn, ConfounderSampler) and
+    data/dataset_template.py:_load_img_feature run on a small synthetic dataset in the reference's on-disk format.
+    The fixture holds the dataset's RAW content (so the test can rebuild the files) and what the reference made of it."""
+    import random
+    import tempfile
+    from data.meme_dataset import MemeDataset, ConfounderSampler
+    import torch.utils.data as tdata
+    tdata.Sampler.__init__ = lambda self, *a, **k: None     # torch 1.6's Sampler took the data source (meme_dataset.py:224)
+    rng = np.random.Generator(np.random.PCG64(2024))
+    n, dim = 14, 8
+    texts = ['look at this cat', 'when you see it', 'nobody : me', 'look at this cat', 'sky tree car', 'when you see it',
+             'a b c d e f g h i j k l m n', 'x', 'funny dog meme', 'nobody : me', 'tree', 'car car car', 'you and me', 'sky']
+    labels = [0, 1, 0, 1, 0, 0, 1, 0, 1, 1, 0, 1, 0, 0]        # 'look at this cat' and 'nobody : me' are confounders
+    out = {'raw/texts': np.array(texts), 'raw/labels': np.array(labels, np.int64), 'raw/ids': np.arange(100, 100 + n)}
+    with tempfile.TemporaryDirectory() as tmp:
+        fdir = os.path.join(tmp, 'img_feats')
+        os.makedirs(fdir)
+        with open(os.path.join(tmp, 'train.jsonl'), 'w') as f:
+            for i in range(n):
+                sid = str(100 + i).zfill(5)
+                nbb = int(rng.integers(2, 7))
+                feat = rng.standard_normal((nbb, dim)).astype(np.float32)
+                W, H = int(rng.integers(200, 800)), int(rng.integers(200, 800))
+                x1 = rng.random((nbb, 1)) * 0.6 * W; y1 = rng.random((nbb, 1)) * 0.6 * H
+                bw = (rng.random((nbb, 1)) * 0.3 + 0.05) * W; bh = (rng.random((nbb, 1)) * 0.3 + 0.05) * H
+                bbox = np.concatenate([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+                info = {'bbox': bbox.copy(), 'image_width': W, 'image_height': H, 'objects': rng.integers(0, 1600, nbb)}
+                if i % 2 == 0:
+                    info['objects_conf'] = rng.random(nbb).astype(np.float32)
+                else:                       # the other detector export: class probabilities (dataset_template.py:103-106)
+                    info['cls_prob'] = rng.random((nbb, 5)).astype(np.float32)
+                np.save(os.path.join(fdir, sid + '.npy'), feat)
+                np.save(os.path.join(fdir, sid + '_info.npy'), info, allow_pickle=True)
+                f.write(json.dumps({'id': 100 + i, 'img': 'img/%s.png' % sid, 'label': labels[i], 'text': texts[i]}) + '\n')
+                out['raw/%d/feat' % i] = feat
+                out['raw/%d/bbox' % i] = bbox
+                out['raw/%d/wh' % i] = np.array([W, H], np.int64)
+                out['raw/%d/objects' % i] = info['objects']
+                out['raw/%d/%s' % (i, 'objects_conf' if i % 2 == 0 else 'cls_prob')] = info.get('objects_conf', info.get('cls_prob'))
+        for thr in (0.0, 0.45):
+            ds = MemeDataset(filepath=os.path.join(tmp, 'train.jsonl'), feature_dir=fdir, preload_images=False, debug=False,
+                             text_padding=simple_tokenizer, return_ids=True, confidence_threshold=thr)
+            tag = 'thr%g' % thr
+            for i in range(n):
+                it = ds[i]
+                out['%s/item/%d/img_feat' % (tag, i)] = it['img_feat'].numpy()
+                out['%s/item/%d/img_pos_feat' % (tag, i)] = it['img_pos_feat'].numpy()
+                out['%s/item/%d/label_id' % (tag, i)] = np.array([int(it['label']), int(it['data_id'])])
+            collate = ds.get_collate_fn()
+            for bi, idxs in enumerate(([0, 1, 2, 3], [6, 7, 10], [13, 12, 11, 9, 8, 5])):
+                b = collate([ds[i] for i in idxs])
+                out['%s/batch/%d/idxs' % (tag, bi)] = np.array(idxs)
+                for k, v in b.items():
+                    if v is not None:
+                        out['%s/batch/%d/%s' % (tag, bi, k)] = v.numpy()
+        ds = MemeDataset(filepath=os.path.join(tmp, 'train.jsonl'), feature_dir=fdir, preload_images=False,
+                         text_padding=simple_tokenizer)
+        for rep in (1, 2, 3):
+            random.seed(1000 + rep)
+            sm = ConfounderSampler(ds, repeat_factor=rep)
+            out['sampler/%d/confounders' % rep] = np.array(sm.confounders)
+            out['sampler/%d/len' % rep] = np.array(len(sm))
+            out['sampler/%d/epoch0' % rep] = np.array(list(iter(sm)))
+            out['sampler/%d/epoch1' % rep] = np.array(list(iter(sm)))
+    np.savez_compressed(os.path.join(HERE, 'data_pipeline.npz'), **out)
+    print('data_pipeline.npz:', len(out), 'arrays; batch0 attn_mask', out['thr0/batch/0/attn_mask'].sum(1))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiny', 'host', 'trainer', 'base', 'large', 'pretrain', 'crossval']
+    which = sys.argv[1:] or ['tiny', 'host', 'trainer', 'base', 'large', 'pretrain', 'crossval', 'data']
+    if 'data' in which:
+        gen_data_pipeline()
     if 'crossval' in which:
         gen_crossval_ensemble()
     if 'pretrain' in which:

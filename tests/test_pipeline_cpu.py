@@ -14,7 +14,10 @@ def test_dataset_reads_reference_disk_format_and_collates(tmp_path):
     feat_dir = write_synthetic_dataset(root, n=9, num_bb=(3, 7), img_dim=16, seed=1, splits=('train',))
     tok = partial(HashTokenizer(vocab_size=2000), max_length=12, padding='max_length', truncation=True,
                   return_tensors='pt', return_length=True)
-    ds = MemeDataset(os.path.join(root, 'train.jsonl'), feature_dir=feat_dir, text_padding=tok, return_ids=True)
+    # ragged_regions=True: every sample masked at its own region count (the default reproduces the reference's collate,
+    # which counts the padded rows: tests/test_data_pipeline_cpu.py)
+    ds = MemeDataset(os.path.join(root, 'train.jsonl'), feature_dir=feat_dir, text_padding=tok, return_ids=True,
+                     ragged_regions=True)
     assert len(ds) == 9 and ds.name == 'train'
     s = ds[0]
     info = np.load(os.path.join(feat_dir, '00000_info.npy'), allow_pickle=True).item()

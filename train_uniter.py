@@ -24,6 +24,22 @@ from meme_challenge_amd.data import (MemeDataset, ConfounderSampler, HashTokeniz
 from meme_challenge_amd.meme_uniter import MemeUniter
 from meme_challenge_amd.model import UniterModel, UniterConfig, resolve_config
 from meme_challenge_amd.train_template import TrainerTemplate, LOGGER
+from meme_challenge_amd import dp
+
+
+class RankShard(data.Sampler):
+    """One rank's share of the epoch order an inner sampler draws.  Every rank runs the same inner sampler with
+    the same seed (set_seed + python's `random` in ConfounderSampler), so the orders agree; rank r takes every
+    world-th index, padded by wrap-around so that all ranks step equally often."""
+
+    def __init__(self, inner, rank, world):
+        self.inner, self.rank, self.world = inner, rank, world
+
+    def __iter__(self):
+        return iter(dp.shard_indices(list(self.inner), self.rank, self.world))
+
+    def __len__(self):
+        return (len(self.inner) + self.world - 1) // self.world
 
 IMG_DIM = 2048            # utils/const.py
 
@@ -41,6 +57,11 @@ class TrainerUniter(TrainerTemplate):
                                     n_classes=self.config['n_classes'])
         else:
             self.load_model()
+        self._apply_runtime_options()
+
+    def _apply_runtime_options(self):
+        """--precision / --pack_padded belong to the encoder object: every place that builds one applies them, so the
+        final reload in end_training scores with the arithmetic that was trained and validated."""
         self.model.uniter_model.pack_padded = bool(self.config.get('pack_padded', False))
         self.model.uniter_model.precision = self.config.get('precision', 'fp32')
 
@@ -53,6 +74,7 @@ class TrainerUniter(TrainerTemplate):
             checkpoint = torch.load(self.model_file, map_location='cpu')
             LOGGER.info('Using UNITER model {}'.format(self.model_file))
             self.model.load_state_dict(checkpoint['model_state_dict'])
+        self._apply_runtime_options()
 
     def _forward(self, batch):
         return self.model(img_feat=batch['img_feat'], img_pos_feat=batch['img_pos_feat'],
@@ -102,13 +124,18 @@ def main(argv=None):
     if config['parallel_computing'] and 'RANK' in os.environ and not torch.distributed.is_initialized():
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         torch.distributed.init_process_group('nccl')
+    ddp = torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    rank = torch.distributed.get_rank() if ddp else 0
+    world = torch.distributed.get_world_size() if ddp else 1
     if config['synthetic'] > 0:
-        os.makedirs(config['data_path'], exist_ok=True)
-        if not os.path.isfile(os.path.join(config['data_path'], 'train.jsonl')):
-            config['feature_path'] = write_synthetic_dataset(config['data_path'], n=config['synthetic'],
-                                                             splits=('train', 'dev_seen', 'test_seen'))
-        else:
-            config['feature_path'] = os.path.join(config['data_path'], 'img_feats')
+        if rank == 0:                    # one writer; the other ranks wait below before they open any file
+            os.makedirs(config['data_path'], exist_ok=True)
+            if not os.path.isfile(os.path.join(config['data_path'], 'train.jsonl')):
+                write_synthetic_dataset(config['data_path'], n=config['synthetic'],
+                                        splits=('train', 'dev_seen', 'test_seen'))
+        if ddp:
+            torch.distributed.barrier()
+        config['feature_path'] = os.path.join(config['data_path'], 'img_feats')
     config = TrainerTemplate.preprocess_args(config)
     if config['hash_tokenizer'] or config['synthetic'] > 0:
         tokenizer = HashTokenizer(max_length=config['max_txt_len'])
@@ -123,15 +150,22 @@ def main(argv=None):
         shard = None
         if config['feature_shards']:
             shard = os.path.splitext(path)[0] + '_shard'
-            if not os.path.isfile(shard + '.index.json'):
+            if rank == 0 and not os.path.isfile(shard + '.index.json'):
                 with open(path) as f:
                     build_feature_shard(config['feature_path'], [json.loads(l)['id'] for l in f if l.strip()], shard)
+            if ddp:
+                torch.distributed.barrier()
         ds = MemeDataset(filepath=path, feature_dir=config['feature_path'], feature_shard=shard,
                          text_padding=tokenizer_func, return_ids=ids, confidence_threshold=config['object_conf_thresh'])
         kw = dict(batch_size=config['batch_size'], num_workers=config['num_workers'], collate_fn=ds.get_collate_fn(),
                   pin_memory=True)
-        loader = data.DataLoader(ds, sampler=ConfounderSampler(ds, config['confounder_repeat']), **kw) if train \
-            else data.DataLoader(ds, **kw)
+        if train:
+            sampler = ConfounderSampler(ds, config['confounder_repeat'])
+            if ddp:                      # the reference's nn.DataParallel split every batch over the GPUs; here every rank draws its own batches
+                sampler = RankShard(sampler, rank, world)
+            loader = data.DataLoader(ds, sampler=sampler, **kw)
+        else:                            # validation / test: every rank scores everything (identical early-stopping decisions)
+            loader = data.DataLoader(ds, **kw)
         return loader if config['no_prefetch'] else DevicePrefetcher(loader, config['device'])
 
     config['test_loader'] = [make(f, ids=True) for f in ('test_seen.jsonl', 'test_unseen.jsonl', 'dev_seen.jsonl',
