@@ -441,6 +441,11 @@ typedef struct {
  * activation and its gradient exist only in bf16. */
 int  uniter_model_set_weight_mirror(uniter_model_t* m, const float* flat_base, const void* mirror_bf16, size_t numel);
 int  uniter_model_set_precision(uniter_model_t* m, int precision);
+/* Number of uniter_model_forward calls on this handle so far.  The handle keeps ONE plan (activations of the latest
+ * forward): a caller that wants to backpropagate records the value after its forward and must see the same value at
+ * backward time -- the reference's autograd allows several forwards per backward (model/model.py:336-367), this
+ * library does not, and the host mirror turns a mismatch into an error instead of wrong gradients. */
+uint64_t uniter_model_generation(const uniter_model_t* m);
 /* Overlap of the optimizer step with the next forward: `events` = hipEvent_t[num_hidden_layers + 1]
  * (embedding block, layer 0, layer 1, ..), each fired once that block's parameters (and zeroed
  * gradients) are final.  The next uniter_model_forward makes its stream wait for events[0] before

@@ -111,6 +111,7 @@ _SIGS = {
     'uniter_param_shape': (_I, [C.POINTER(UniterConfigC), _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'uniter_model_create': (_I, [C.POINTER(UniterConfigC), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p)]),
     'uniter_model_destroy': (None, [_P]),
+    'uniter_model_generation': (_U64, [_P]),
     'uniter_model_set_ready_events': (_I, [_P, _P, _I]),
     'uniter_model_set_weight_mirror': (_I, [_P, _P, _P, _SZ]),
     'uniter_model_set_precision': (_I, [_P, _I]),

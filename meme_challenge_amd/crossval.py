@@ -105,6 +105,9 @@ def train_crossval(trainer_class, config, data_loader_funcs, num_folds=0, dev_si
     means = {key: mean(v[key] for v in val_metrics) for key in val_metrics[0]}
     logger.info('Cross validation finished. Mean scores of validation folds:\n' + '\n'.join(
         '%s: %s' % (k, ('%5.4f' % v) if k == 'loss' else ('%4.2f%%' % (100.0 * v))) for k, v in means.items()))
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+        return val_metrics                 # the prediction files are rank 0's (written before end_training's barrier)
     names = [_dataset_name(t) for t in config.get('test_loader', [])]
     dev_names = sorted(n for n in names if n.startswith('dev'))
     if not dev_names:

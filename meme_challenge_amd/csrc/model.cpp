@@ -120,6 +120,7 @@ struct uniter_model {
   uint32_t offset = 0;
   hipStream_t st = nullptr, side = nullptr;
   bool bwd_open = false;
+  uint64_t generation = 0;   // bumped by every forward: a backward must belong to the LATEST forward (one plan / workspace per model)
 
   float* P(int i) const { return p[i]; }
   float* G(int i) const { return g[i]; }
@@ -420,6 +421,7 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   pl.gelu_d = gelu_d;
   m->batch = *b; m->hidden_out = hidden_out; m->all_layers = all_layers; m->seed = seed; m->offset = offset;
   m->bwd_open = false;
+  ++m->generation;
 
   // parameters still being written by an optimizer step on another stream (uniter_model_set_ready_events)
   const bool gated = (int)m->ready.size() == nl + 1;
@@ -754,6 +756,8 @@ extern "C" int uniter_model_backward(uniter_model_t* m, const uniter_batch_t* b,
   for (int l = m->cfg.num_hidden_layers - 1; l >= 0; --l) UCHECK_RC(uniter_model_backward_layer(m, l));
   return uniter_model_backward_embed(m);
 }
+
+extern "C" uint64_t uniter_model_generation(const uniter_model_t* m) { return m ? m->generation : 0; }
 
 extern "C" int uniter_model_set_ready_events(uniter_model_t* m, void* const* events, int n) {
   UCHECK_ARG(m && (n == 0 || (events && n == m->cfg.num_hidden_layers + 1)),

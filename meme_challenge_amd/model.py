@@ -539,12 +539,17 @@ class _UniterFn(torch.autograd.Function):
                                        mode, seed, offset, ptr(ws), nbytes, _lib.cur_stream()),
               'uniter_model_forward')
         ctx.model, ctx.batch, ctx.keep, ctx.ws, ctx.nbytes = model, batch, keep, ws, nbytes
+        ctx.generation = lib.uniter_model_generation(model._handle)
         ctx.all_layers, ctx.seed, ctx.offset = all_layers, seed, offset
         return hidden
 
     @staticmethod
     def backward(ctx, d_hidden):
         model = ctx.model
+        if _lib.lib().uniter_model_generation(model._handle) != ctx.generation:
+            raise UniterHipError('backward of a forward that is no longer the latest one on this UniterModel: the library '
+                                 'keeps the activations of ONE forward per model (run backward before the next forward, '
+                                 'or use torch.no_grad() for forwards that need no gradient)')
         d_hidden = d_hidden.contiguous()
         model._run_backward(ctx.batch, d_hidden, ctx.all_layers, ctx.seed, ctx.offset, ctx.ws,
                             ctx.nbytes)

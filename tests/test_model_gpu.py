@@ -244,3 +244,24 @@ def test_edge_shapes_match_oracle(B, T, R, tl, nbb, train):
         ref = sdo[n].grad if sdo[n].grad is not None else torch.zeros_like(sdo[n])
         tol = 3e-6 + 3e-4 * ref.abs().max().item()
         assert maxdiff(p.grad, ref) <= tol, (n, maxdiff(p.grad, ref), tol)
+
+
+@pytest.mark.parametrize('train', [True, False])
+def test_backward_of_a_stale_forward_fails_loudly(tiny, train):
+    """The library keeps the activations of ONE forward per model: backpropagating through an earlier forward after
+    another one has run must raise (train mode AND eval-with-grad), never return the other forward's gradients."""
+    from meme_challenge_amd._lib import UniterHipError
+    from meme_challenge_amd.trainer import bce_with_logits_loss
+    sd = sd_from_npz(tiny)
+    m = build(TINY, TINY_IMG_DIM, sd)
+    m = m.train() if train else m.eval()
+    b = to_dev(batch_from_npz(tiny))
+    first = bce_with_logits_loss(m(**model_kwargs(b)), b['labels'], 1.8)
+    second = bce_with_logits_loss(m(**model_kwargs(b)), b['labels'], 1.8)
+    with pytest.raises(UniterHipError):
+        first.backward()
+    second.backward()                      # the latest forward still backpropagates
+    with torch.no_grad():
+        m(**model_kwargs(b))               # no-grad forwards in between do count (they overwrite the plan) ...
+    third = bce_with_logits_loss(m(**model_kwargs(b)), b['labels'], 1.8)
+    third.backward()                       # ... and a fresh forward works again

@@ -115,3 +115,33 @@ def test_feature_shard_equals_per_sample_files(tmp_path):
     with pytest.raises(AssertionError):
         build_feature_shard(feat_dir, plain.data.ids.tolist()[:3], prefix + '_small')
         MemeDataset(os.path.join(root, 'train.jsonl'), text_padding=tok, feature_shard=prefix + '_small')
+
+
+def test_rank_shards_are_disjoint_cover_the_epoch_and_have_equal_length():
+    """train_uniter.RankShard / dp.shard_indices: with the same seed every rank draws the same epoch order from the
+    inner sampler and takes every world-th index of it -- disjoint, covering, padded to a common length."""
+    import random
+    from meme_challenge_amd.dp import shard_indices
+    import train_uniter
+    order = list(range(37))
+    random.Random(5).shuffle(order)
+    for world in (2, 3, 8):
+        shards = [shard_indices(order, r, world) for r in range(world)]
+        assert len({len(s) for s in shards}) == 1 and len(shards[0]) == -(-37 // world)
+        flat = [i for s in shards for i in s]
+        assert set(flat) == set(order)
+        core = [i for k in range(len(shards[0])) for s in shards for i in [s[k]]][:37]
+        assert core == order                                   # rank-major interleave reproduces the order: no sample skipped
+        assert len(flat) - len(set(flat)) == world * len(shards[0]) - 37      # only the wrap-around padding repeats
+
+    class Inner(object):
+        def __iter__(self):
+            random.seed(11)
+            o = list(range(10))
+            random.shuffle(o)
+            return iter(o)
+
+        def __len__(self):
+            return 10
+    a, b = train_uniter.RankShard(Inner(), 0, 2), train_uniter.RankShard(Inner(), 1, 2)
+    assert len(a) == len(b) == 5 and set(a).isdisjoint(set(b)) and set(a) | set(b) == set(range(10))
