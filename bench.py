@@ -49,44 +49,65 @@ def flops_per_step(cfg, B, T, R, L=None, lens=None):
     return 3 * fwd, 3 * nl * 2 * ffn_up_fwd, ffn_up_fwd
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """Reported baseline only: the CPU oracle (port of the reference forward; autograd
-    backward) on BASELINE config 1 (B=4, T=64, R=36, UNITER-base, dropout on), timed on this
-    box's host cores.  A bounded sample: 1 warm-up + up to 10 steps within the budget."""
+def _lscpu_model():
+    try:
+        import subprocess
+        for line in subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Reported baseline only: the CPU oracle (port of the reference forward; autograd backward) on
+    BASELINE config 1 (B=4, T=64, R=36, UNITER-base, dropout on), timed on this box's host cores: N threads
+    (3 warm-up + up to 10 timed steps) and one thread (1 warm-up + up to 2 timed steps), both bounded by the budget."""
     from oracle import uniter_oracle as O
     from oracle import step_oracle as S
-    nthreads = min(torch.get_num_threads(), 32)      # more threads than ~32 slow the small CPU ops down
-    torch.set_num_threads(nthreads)
     sd = {k: v.requires_grad_(True) for k, v in O.synth_state_dict(BASE, seed=0).items()}
     b = O.synth_batch(4, 64, 36, seed=1234)
     kw = dict(img_feat=b['img_feat'], img_pos_feat=b['img_pos_feat'], input_ids=b['input_ids'],
               position_ids=b['position_ids'], attention_mask=b['attn_mask'],
               gather_index=b['gather_index'], output_all_encoded_layers=False)
+    gf_per_sample = flops_per_step(BASE, 4, 64, 36)[0] / 4 / 1e9          # 52.411 (BASELINE.md section 3)
 
     def step(i):
         drop = O.DropSpec(1234, i, 0.1, 0.1)
         loss = S.bce_with_logits(O.meme_uniter_forward(sd, BASE, drop=drop, **kw), b['labels'], 1.8)
-        grads = torch.autograd.grad(loss, [v for v in sd.values()], allow_unused=True)
-        return grads
-    step(0)
-    t0 = time.perf_counter()
-    n = 0
-    while n < 10 and (time.perf_counter() - t0) < seconds_budget:
-        step(n + 1)
-        n += 1
-    dt = (time.perf_counter() - t0) / max(n, 1)
+        return torch.autograd.grad(loss, [v for v in sd.values()], allow_unused=True)
+
+    def timed(nthreads, warm, most, budget):
+        torch.set_num_threads(nthreads)
+        for i in range(warm):
+            step(i)
+        t0, n = time.perf_counter(), 0
+        while n < most and (time.perf_counter() - t0) < budget:
+            step(warm + n)
+            n += 1
+        return (time.perf_counter() - t0) / max(n, 1), n
+
+    hw = os.cpu_count() or 1
+    nthreads = min(torch.get_num_threads(), 32)      # more threads than ~32 slow the small CPU ops down
+    dt, n = timed(nthreads, 3, 10, seconds_budget * 0.6)
+    dt1, n1 = timed(1, 1, 2, seconds_budget * 0.4)
+    torch.set_num_threads(nthreads)
     return {'value': round(4.0 / dt, 3), 'unit': 'samples/s', 'cores': nthreads, 'kind': 'port',
-            'sample': 'config 1: UNITER-base B=4 T=64 R=36 fwd+bwd, %d steps after 1 warm-up, '
-                      'oracle/uniter_oracle.py (torch CPU fp32, dropout on), %.3f s/step' % (n, dt)}
+            'gflops': round(4.0 / dt * gf_per_sample, 1),
+            'single_thread': {'value': round(4.0 / dt1, 3), 'gflops': round(4.0 / dt1 * gf_per_sample, 1), 'steps': n1},
+            'cpu_model': _lscpu_model(), 'os_cpu_count': hw,
+            'sample': 'config 1: UNITER-base B=4 T=64 R=36 fwd+bwd, %d steps after 3 warm-ups on %d threads (%.3f s/step), '
+                      '%d steps after 1 warm-up on 1 thread (%.2f s/step); oracle/uniter_oracle.py (torch CPU fp32, dropout on)'
+                      % (n, nthreads, dt, n1, dt1)}
 
 
-def pmc_traffic(args, M, cfgd):
-    """Memory-side bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
-    (separate FETCH_SIZE / WRITE_SIZE runs of this same command, tests/tools/run_profile.sh ->
-    tests/tools/pmc_to_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    Counters cannot be read from inside a timed run, so the figure is a profile artefact: it is
-    reported only when the profiled shape is the one being benchmarked, else null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+def pmc_traffic(args, M, cfgd, build_info):
+    """Memory-side bytes per launch of the FFN-up forward GEMM from the committed rocprofv3 --pmc passes (separate
+    FETCH_SIZE / WRITE_SIZE runs of this command, tests/tools/run_profile.sh -> tests/tools/pmc_to_traffic.py;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside a timed
+    run, so this is a PROFILE ARTEFACT, reported only for the shape AND the library build it was taken on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_traffic.json')
     try:
         rec = json.load(open(path))['ffn_up_fwd']
     except (OSError, KeyError, ValueError):
@@ -95,14 +116,16 @@ def pmc_traffic(args, M, cfgd):
     if args.precision != 'fp32' or (shape.get('M'), shape.get('N'), shape.get('K')) != (
             M, cfgd['intermediate_size'], cfgd['hidden_size']):
         return None
+    if rec.get('build') and rec['build'] != build_info:
+        return None
     return int(rec['traffic_bytes'])
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--txt_len', type=int, default=128)
     ap.add_argument('--num_bb', type=int, default=36)
@@ -120,7 +143,7 @@ def main():
     ap.add_argument('--no_side_stream', action='store_true')
     ap.add_argument('--no_adam_overlap', action='store_true',
                     help='run the optimizer step as one launch on the main stream instead of block by block beside the next forward')
-    ap.add_argument('--prof_kind', type=int, default=1, help='UNITER_K_* kind timed with HIP events (1 = FFN-up fwd GEMM)')
+    ap.add_argument('--prof_kind', type=int, default=-1, help='UNITER_K_* kind timed with HIP events inside the timed region (-1 = every kind, 0 = none)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -212,15 +235,29 @@ def main():
     handle = encoder._handle
     barrier()
     if args.prof_kind:
-        _lib.check(lib.uniter_prof_enable(handle, args.prof_kind))
+        # in-kernel launch stamps of every GEMM (two atomics per wave, nothing added to the streams)
+        _lib.check(lib.uniter_prof_enable_stamps(handle, 1, None))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     barrier()
     dt = time.perf_counter() - t0
-    n_launch, tot_ms = C.c_int(0), C.c_double(0.0)
+    NK = 11
+    k_n, k_ms = (C.c_int * NK)(), (C.c_double * NK)()          # GEMM families: stamps taken INSIDE the timed region
+    e_n, e_ms = (C.c_int * NK)(), (C.c_double * NK)()          # attention / LayerNorm: HIP events in a separate pass
+    EV_STEPS = 5
     if args.prof_kind:
-        _lib.check(lib.uniter_prof_collect(handle, C.byref(n_launch), C.byref(tot_ms)))
+        _lib.check(lib.uniter_prof_collect_stamps(handle, k_n, k_ms, NK))
+        _lib.check(lib.uniter_prof_enable_stamps(handle, 0, None))
+        # event pairs around every launch cost ~7 us each and serialise the two backward streams (fp32 step +11 %,
+        # bf16 +27 %): they stay out of the timed region; this pass only times the kernels that carry no stamps
+        _lib.check(lib.uniter_prof_enable(handle, -1))
+        te = time.perf_counter()
+        for _ in range(EV_STEPS):
+            one_step()
+        torch.cuda.synchronize()
+        ev_ms = (time.perf_counter() - te) / EV_STEPS * 1e3
+        _lib.check(lib.uniter_prof_collect_kinds(handle, e_n, e_ms, NK))
         _lib.check(lib.uniter_prof_enable(handle, 0))
     loss = float((step.last_loss if args.workload == 'finetune' else last['loss']).item())
     if use_dist:
@@ -238,6 +275,35 @@ def main():
         M_eff = sum(cur['seq_lens']) if args.packed else B * L_eff
         dt_name = 'f32' if args.precision == 'fp32' else 'bf16'
         peak = PEAK_TFLOPS[dt_name]
+        H, I, nl = cfgd['hidden_size'], cfgd['intermediate_size'], cfgd['num_hidden_layers']
+        sq = sum(n * n for n in cur['seq_lens']) if args.packed else B * L_eff * L_eff
+        g_qkv, g_o, g_ffn = 2.0 * M_eff * H * 3 * H, 2.0 * M_eff * H * H, 2.0 * M_eff * H * I
+        att = 2.0 * 2 * sq * H
+        # algorithmic work per step of each timed family (BASELINE.md section 3 conventions; LayerNorm in bytes:
+        # forward reads x, residual and writes z, y = 16 B / element, backward reads dy, z and writes dz, dx = 16 B / element)
+        fam = {1: ('gemm_ffn_up_fwd', 'mfma', nl * g_ffn), 2: ('gemm_ffn_down_fwd', 'mfma', nl * g_ffn),
+               3: ('gemm_qkv_fwd', 'mfma', nl * g_qkv), 4: ('gemm_attn_out_fwd', 'mfma', nl * g_o),
+               5: ('attention_fwd', 'mfma', nl * att), 6: ('gemm_dgrad', 'mfma', nl * (g_qkv + g_o + 2 * g_ffn)),
+               7: ('gemm_wgrad', 'mfma', nl * (g_qkv + g_o + 2 * g_ffn)), 8: ('attention_bwd', 'mfma', nl * 2 * att),
+               9: ('layernorm_fwd', 'hbm', nl * 2 * 16.0 * M_eff * H), 10: ('layernorm_bwd', 'hbm', nl * 2 * 16.0 * M_eff * H)}
+        kernel_of = {'f32': {1: 'gemm_f32_v3_kernel<64,64,false,false,TAG=1>', 6: 'gemm_f32_v3_kernel<64,64,false,true,...>',
+                             7: 'gemm_f32_v3_kernel<64,64,true,true,0,SK> (stream-K)'},
+                     'bf16': {1: 'gemm_dma_kernel<128,128,false,false,SWAP,2,EPI=5> (bias + GELU + gelu\' bf16)',
+                              6: 'gemm_dma_kernel<128,128,false,true,SWAP,2,EPI>', 7: 'gemm_bf16_kernel<64,64,true,true,0,SK,RES> (stream-K)'}}
+        families = []
+        for k, (name, bound, work) in fam.items():
+            in_run = k_n[k] > 0
+            n, tot, steps = (k_n[k], k_ms[k], args.steps) if in_run else (e_n[k], e_ms[k], EV_STEPS)
+            if n == 0:
+                continue
+            sec = tot * 1e-3 / steps                   # seconds of this family per step
+            pk = peak * 1e12 if bound == 'mfma' else 8.0e12
+            families.append({'family': name, 'bound': bound, 'launches_per_step': n // steps,
+                             'avg_us': round(tot * 1e3 / n, 2), 'ms_per_step': round(sec * 1e3, 4),
+                             'achieved': round(work / sec / 1e12, 2), 'unit': 'TFLOP/s' if bound == 'mfma' else 'TB/s',
+                             'frac': round(work / sec / pk, 4), 'kernel': kernel_of[dt_name].get(k),
+                             'measured': 'in-kernel stamps inside the timed region' if in_run else
+                                         'HIP events, separate %d-step pass after the timed region (%.2f ms/step under events)' % (EV_STEPS, ev_ms)})
         out = {
             'metric': 'train samples/sec UNITER-%s (%d regions, %d tok)' % (args.model, R, T),
             'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
@@ -254,22 +320,46 @@ def main():
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        'side_stream_wgrad': not args.no_side_stream,
                        'optimizer_overlaps_next_forward': not args.no_adam_overlap,
+                       'grad_payload': sync.payload if sync is not None else None,
                        'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')},
-            'step_mfma_frac': round(total / (ms * 1e-3) / world * world / (peak * 1e12), 4),
+            'step_mfma_frac': round(total / (ms * 1e-3) / (peak * 1e12), 4),
             'ffn_roofline_frac': round(ffn / (ms * 1e-3) / (peak * 1e12), 4),
             'final_loss': round(loss, 5),
         }
-        if args.prof_kind and n_launch.value > 0:
-            avg_ms = tot_ms.value / n_launch.value
-            ach = ffn_up / (avg_ms * 1e-3) / 1e12 if args.prof_kind == 1 else None
-            out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2) if ach else None, 'peak': peak,
-                               'unit': 'TFLOP/s', 'frac': round(ach / peak, 4) if ach else None,
-                               'traffic': pmc_traffic(args, M_eff, cfgd),
-                               'kernel': ('gemm_f32_v3_kernel<64,64,false,false,TAG=1>' if args.precision == 'fp32'
-                                          else 'gemm_bf16_kernel<...,false,false>') +
-                                         ' (FFN-up fwd: M=%d N=%d K=%d, bias+GELU epilogue)'
-                                         % (M_eff, cfgd['intermediate_size'], cfgd['hidden_size']),
-                               'launches': n_launch.value, 'avg_ms': round(avg_ms, 4)}
+        if families:
+            # `roofline` = the GEMM family that takes the most time of the step (the weight- and input-gradient GEMMs
+            # run on two streams beside each other: their in-situ durations include that sharing); every timed family
+            # follows in `roofline_families`
+            gemms = [f for f in families if f['family'].startswith('gemm_')]
+            dom = max(gemms, key=lambda f: f['ms_per_step']) if gemms else families[0]
+            build_info = lib.uniter_build_info().decode()
+            out['roofline'] = {'bound': dom['bound'], 'achieved': dom['achieved'], 'peak': peak, 'unit': dom['unit'],
+                               'frac': dom['frac'], 'traffic': None, 'kernel': '%s: %s' % (dom['family'], dom['kernel']),
+                               'launches': dom['launches_per_step'] * args.steps, 'avg_ms': round(dom['avg_us'] * 1e-3, 4),
+                               'share_of_step_kernel_time': round(dom['ms_per_step'] / sum(f['ms_per_step'] for f in families), 3)}
+            out['roofline_families'] = families
+            tr = pmc_traffic(args, M_eff, cfgd, build_info)
+            if tr is not None:
+                out['traffic_from_profile'] = {'kernel': 'gemm_ffn_up_fwd', 'bytes_per_launch': tr,
+                                               'source': 'profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command)'}
+        # the optimizer step alone (HBM-bound: 32 B / parameter), measured after the timed region
+        opt.join()
+        torch.cuda.synchronize()
+        numel = model.param_store().numel
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        saved, opt.overlap_encoder = opt.overlap_encoder, None
+        e0.record()
+        for _ in range(5):
+            model.param_store().touch(model.param_store().names)       # every chunk takes the update path
+            opt.step(grad_scale=1.0, max_grad_norm=0.0, zero_grads=True)
+        e1.record()
+        torch.cuda.synchronize()
+        opt.overlap_encoder = saved
+        o_ms = e0.elapsed_time(e1) / 5
+        out['optimizer'] = {'bound': 'hbm', 'bytes': 32 * numel, 'ms': round(o_ms, 4),
+                            'achieved': round(32 * numel / (o_ms * 1e-3) / 1e12, 3), 'unit': 'TB/s', 'peak': 8.0,
+                            'frac': round(32 * numel / (o_ms * 1e-3) / 8.0e12, 4),
+                            'note': 'adam_kernel alone, 5 launches after the timed region (the step has no gradients then: lr-scaled decay only)'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

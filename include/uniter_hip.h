@@ -474,9 +474,19 @@ int uniter_model_backward(uniter_model_t* m, const uniter_batch_t* batch, const 
 enum { UNITER_K_NONE = 0, UNITER_K_GEMM_FFN_UP_FWD = 1, UNITER_K_GEMM_FFN_DOWN_FWD = 2,
        UNITER_K_GEMM_QKV_FWD = 3, UNITER_K_GEMM_ATTN_OUT_FWD = 4, UNITER_K_ATTN_FWD = 5,
        UNITER_K_GEMM_DGRAD = 6, UNITER_K_GEMM_WGRAD = 7, UNITER_K_ATTN_BWD = 8,
-       UNITER_K_LN = 9, UNITER_K_COUNT = 10 };
+       UNITER_K_LN = 9 /* LayerNorm forward */, UNITER_K_LN_BWD = 10, UNITER_K_COUNT = 11 };
 int uniter_prof_enable(uniter_model_t* m, int kind);             /* 0 disables */
-int uniter_prof_collect(uniter_model_t* m, int* n_launches, double* total_ms);  /* synchronises */
+int uniter_prof_collect(uniter_model_t* m, int* n_launches, double* total_ms);
+/* kind = -1 in uniter_prof_enable times EVERY kind; this returns launches and summed milliseconds per UNITER_K_* kind
+ * (arrays of n_kinds >= UNITER_K_COUNT entries). */
+int uniter_prof_collect_kinds(uniter_model_t* m, int* n_launches, double* total_ms, int n_kinds);
+/* In-kernel launch stamps: with stamps on, every workgroup of every GEMM of the model schedule stores its start and
+ * end time (100 MHz real-time clock) into its own words of a device buffer -- per-launch device durations (first start
+ * to last end, reduced on the host) with nothing added to the streams, so they can stay on inside a timed region
+ * (event pairs cost ~7 us each and serialise the two backward streams).  uniter_prof_collect_stamps synchronises the device and returns launches / summed milliseconds
+ * per GEMM kind (UNITER_K_GEMM_*).  Not a library-call path of the reference: measurement only. */
+int uniter_prof_enable_stamps(uniter_model_t* m, int on, void* stream);
+int uniter_prof_collect_stamps(uniter_model_t* m, int* n_launches, double* total_ms, int n_kinds);  /* synchronises */
 
 #ifdef __cplusplus
 }

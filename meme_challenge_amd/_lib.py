@@ -122,6 +122,9 @@ _SIGS = {
     'uniter_model_backward_embed': (_I, [_P]),
     'uniter_model_backward': (_I, [_P, C.POINTER(UniterBatchC), _P, _I, _U64, _U32, _P, _SZ, _P, _P]),
     'uniter_prof_enable': (_I, [_P, _I]),
+    'uniter_prof_enable_stamps': (_I, [_P, _I, _P]),
+    'uniter_prof_collect_stamps': (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), _I]),
+    'uniter_prof_collect_kinds': (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), _I]),
     'uniter_prof_collect': (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }
 

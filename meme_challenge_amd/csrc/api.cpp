@@ -17,3 +17,5 @@ extern "C" const char* uniter_last_error(void) { return g_err; }
 extern "C" const char* uniter_build_info(void) {
   return "libuniter_hip gfx950 fp32-mfma (built " __DATE__ " " __TIME__ ")";
 }
+
+unsigned long long* g_uniter_stamp_slot = nullptr;

@@ -26,10 +26,36 @@ void uniter_set_error(const char* fmt, ...);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// In-kernel launch stamps (uniter_prof_enable_stamps; bench.py's per-family roofline): when non-null, the NEXT GEMM
+// launch stores every workgroup's start and end time (100 MHz real-time clock) into its own words of this device slot
+// ([2][STAMP_WGS]: starts, then ends) -- two plain 8-byte stores per workgroup, reduced on the host afterwards.
+// Measured alternatives: a HIP event pair around each launch costs ~7 us on the stream and breaks the overlap of the
+// two backward streams (fp32 step +11 %, bf16 +27 %); 64-bit atomicMin / atomicMax into ONE slot serialise at the
+// memory side (~50 ns each, thousands per launch: +16 % / +35 %).  The launch that reads the pointer resets it.
+// One host thread per model (include/uniter_hip.h).
+#define STAMP_WGS 1024
+extern unsigned long long* g_uniter_stamp_slot;
+static inline unsigned long long* take_stamp_slot() {
+  unsigned long long* s = g_uniter_stamp_slot;
+  g_uniter_stamp_slot = nullptr;
+  return s;
+}
+
 #ifdef __HIPCC__
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ __forceinline__ void stamp_begin(unsigned long long* slot) {
+  if (slot && threadIdx.x == 0 && blockIdx.x < STAMP_WGS) slot[blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+}
+// call where every thread of the workgroup arrives (the end of the kernel): the barrier makes thread 0's clock read the
+// end of the workgroup's last wave (its LDS is held until then anyway); stores still in flight are not waited for
+__device__ __forceinline__ void stamp_end(unsigned long long* slot) {
+  if (slot) {
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < STAMP_WGS) slot[STAMP_WGS + blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+  }
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

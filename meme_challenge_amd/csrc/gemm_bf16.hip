@@ -38,6 +38,7 @@ struct GemmArgsB {
   int beta;
   int tiles_m, tiles_n, band_h;
   float* colsum_part;
+  unsigned long long* stamp;    // optional {first start, last end} slot (common.h)
 };
 
 __device__ __forceinline__ float buf_ld_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256, (wgs_per_cu<BM, BN, AKM || BKM, RES>())) void 
     t_first = idx; k_first = 0;
   }
   if (total_units == 0) return;
+  stamp_begin(g.stamp);
   const int t_step = SK ? 1 : per_xcd;
 
   using StA = Stager<BM, AKM, RES>;
@@ -489,6 +491,7 @@ __global__ __launch_bounds__(256, (wgs_per_cu<BM, BN, AKM || BKM, RES>())) void 
 #undef MFMA_BLOCK
 #undef READ_FRAGS
 #undef LOAD_UNIT
+  stamp_end(g.stamp);
 }
 
 template <int BM, int BN, bool AKM, bool BKM, bool RES = false>
@@ -568,6 +571,7 @@ int gemm_bf16res_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, c
   g.Cb = (unsigned short*)Cb; g.ldcb = ldcb;
   g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux; g.beta = beta;
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
+  g.stamp = take_stamp_slot();
   if (cfg == 0) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     // measured (tests/tools/gemm_lab.py at M = 1424 / 2624 / 5248, profiles/r01_gemm_bf16_resident_tiles.txt): a
@@ -633,6 +637,7 @@ int gemm_bf16_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, cons
   g.Cb = nullptr; g.ldcb = 0;
   g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux; g.beta = beta;
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
+  g.stamp = take_stamp_slot();
   if (cfg == 0) {
     // operand delivery bound: the biggest tile that still fills the chip
     // measured on MI355X (tests/tools/gemm_bf16_exp.py): 128x128 only pays once it fills the chip

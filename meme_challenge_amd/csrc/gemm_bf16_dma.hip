@@ -46,6 +46,7 @@ struct GArgsD {
   void* aux_out; int aux_out_bf16;
   int ld_aux;
   int tiles_m, tiles_n, band_h, nsplit;
+  unsigned long long* stamp;    // optional {first start, last end} slot (common.h)
   int dbg;       // measurement builds only (tests/tools/gemm_v2_lab.py): 1 = drop every output store, 2 = skip the k-loop
 };
 
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_dma_kernel
   const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
   const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
   if (idx >= chunk_n) return;
+  stamp_begin(g.stamp);
   const int w = chunk0 + idx;
   const int tile = w / g.nsplit, piece = w - tile * g.nsplit;
   int tmi, tni;
@@ -478,6 +480,7 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_dma_kernel
         }
       }
   }
+  stamp_end(g.stamp);
 #endif
 }
 
@@ -550,6 +553,7 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
   g.aux_in = aux_in; g.aux_in_bf16 = aux_in_bf16; g.aux_out = aux_out; g.aux_out_bf16 = aux_out_bf16; g.ld_aux = ld_aux;
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.nsplit = nsplit;
   g.dbg = cfg >> 8; cfg &= 0xff;
+  g.stamp = take_stamp_slot();
   if (cfg == 0) cfg = 1;
   hipStream_t st = (hipStream_t)stream;
   if (beta) return b_kmajor ? dispatch_cfg<true, false, UNITER_EPI_NONE>(cfg, g, st) : dispatch_cfg<false, false, UNITER_EPI_NONE>(cfg, g, st);

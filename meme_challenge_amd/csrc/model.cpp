@@ -107,9 +107,14 @@ struct uniter_model {
   const unsigned short* WB(int l, int k) const { return mirror + (LP(l, k) - mirror_base); }
   std::vector<hipEvent_t> ready;   // [embeddings, layer 0 .. nl-1]: parameters usable once the event has fired (consumed by the next forward)
   // profiling
-  int prof_kind = 0;
+  int prof_kind = 0;         // UNITER_K_* to time, or -1 = every kind
   std::vector<hipEvent_t> prof_ev;
+  std::vector<int> prof_tag;     // kind of each recorded event pair
   size_t prof_used = 0;
+  // in-kernel launch stamps of the GEMMs (uniter_prof_enable_stamps)
+  unsigned long long* stamp_buf = nullptr;   // device: [cap][2][STAMP_WGS] = per-workgroup start / end, 100 MHz ticks
+  size_t stamp_cap = 0, stamp_used = 0;
+  std::vector<int> stamp_tag;
   // state carried from forward to backward
   Plan plan;
   uniter_batch_t batch;
@@ -224,8 +229,14 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
 struct ProfScope {
   uniter_model* m; hipStream_t st; bool on;
   ProfScope(uniter_model* m_, int kind, hipStream_t st_) : m(m_), st(st_), on(false) {
-    if (m->prof_kind && m->prof_kind == kind && m->prof_used + 2 <= m->prof_ev.size()) {
+    if (m->stamp_buf && kind && kind != UNITER_K_ATTN_FWD && kind != UNITER_K_ATTN_BWD && kind != UNITER_K_LN &&
+        kind != UNITER_K_LN_BWD && m->stamp_used < m->stamp_cap) {
+      m->stamp_tag[m->stamp_used] = kind;                     // the GEMM launched inside this scope takes the slot
+      g_uniter_stamp_slot = m->stamp_buf + (size_t)2 * STAMP_WGS * m->stamp_used++;
+    }
+    if (m->prof_kind && kind && (m->prof_kind == kind || m->prof_kind < 0) && m->prof_used + 2 <= m->prof_ev.size()) {
       on = true;
+      m->prof_tag[m->prof_used / 2] = kind;
       hipEventRecord(m->prof_ev[m->prof_used], st);
     }
   }
@@ -376,6 +387,7 @@ extern "C" void uniter_model_destroy(uniter_model_t* m) {
   for (auto e : m->ev_main) if (e) hipEventDestroy(e);
   for (auto e : m->ev_side) if (e) hipEventDestroy(e);
   for (auto e : m->prof_ev) if (e) hipEventDestroy(e);
+  if (m->stamp_buf) (void)hipFree(m->stamp_buf);
   delete m;
 }
 
@@ -596,7 +608,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   const int ns_dy = (l == nl - 1 || m->all_layers) ? 1 : pl.ns_k3h;
   const int ns_dx = (l == 0 || m->all_layers) ? 1 : pl.ns_k3h;
   {
-    ProfScope ps(m, UNITER_K_LN, st);
+    ProfScope ps(m, UNITER_K_LN_BWD, st);
     UCHECK_RC(uniter_ln_bwd_rows_slabs(dy, ns_dy, MH, lb.z2, lb.mean2, lb.rstd2, m->LP(l, L_LN2_G), lb.dz2, g2,
                                        pl.res ? lb.g2b : nullptr, 1, M, H, ph, m->seed, m->offset, SITE_FFN_OUT(l),
                                        lb.ln_ws2, pl.ln_ws_bytes, st));
@@ -623,7 +635,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                    nullptr, lb.dz2, nullptr, H, 0));
   }
   {
-    ProfScope ps(m, UNITER_K_LN, st);
+    ProfScope ps(m, UNITER_K_LN_BWD, st);
     UCHECK_RC(uniter_ln_bwd_rows_slabs(lb.dy1, res ? pl.ns_ki : 1, MH, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1,
                                        g1, res ? lb.g1b : nullptr, 1, M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l),
                                        lb.ln_ws1, pl.ln_ws_bytes, st));
@@ -797,13 +809,74 @@ extern "C" int uniter_model_set_precision(uniter_model_t* m, int precision) {
 }
 
 extern "C" int uniter_prof_enable(uniter_model_t* m, int kind) {
-  UCHECK_ARG(m && kind >= 0 && kind < UNITER_K_COUNT, "prof_enable: bad argument");
+  UCHECK_ARG(m && kind >= -1 && kind < UNITER_K_COUNT, "prof_enable: bad argument");
   m->prof_kind = kind;
   m->prof_used = 0;
-  if (kind && m->prof_ev.empty()) {
-    m->prof_ev.resize(8192);
-    for (auto& e : m->prof_ev) UCHECK_HIP(hipEventCreate(&e));
+  const size_t want = kind < 0 ? 65536 : 8192;       // event pairs x 2: ~220 timed launches per step when every kind is on
+  if (kind && m->prof_ev.size() < want) {
+    const size_t have = m->prof_ev.size();
+    m->prof_ev.resize(want);
+    m->prof_tag.resize(want / 2);
+    for (size_t i = have; i < want; ++i) UCHECK_HIP(hipEventCreate(&m->prof_ev[i]));
   }
+  return 0;
+}
+
+extern "C" int uniter_prof_enable_stamps(uniter_model_t* m, int on, void* stream) {
+  UCHECK_ARG(m, "prof_enable_stamps: null model");
+  const size_t cap = 1 << 14;                        // launches; 16 KB each
+  const size_t bytes = cap * 2 * STAMP_WGS * sizeof(unsigned long long);
+  if (on && !m->stamp_buf) {
+    UCHECK_HIP(hipMalloc((void**)&m->stamp_buf, bytes));
+    m->stamp_cap = cap;
+    m->stamp_tag.resize(cap);
+  }
+  if (on) {
+    UCHECK_HIP(hipMemset(m->stamp_buf, 0, bytes));   // 0 = workgroup did not run (the clock never reads 0)
+    m->stamp_used = 0;
+  } else if (m->stamp_buf) {
+    (void)hipFree(m->stamp_buf);
+    m->stamp_buf = nullptr; m->stamp_cap = m->stamp_used = 0;
+  }
+  (void)stream;
+  g_uniter_stamp_slot = nullptr;
+  return 0;
+}
+
+extern "C" int uniter_prof_collect_stamps(uniter_model_t* m, int* n_launches, double* total_ms, int n_kinds) {
+  UCHECK_ARG(m && n_launches && total_ms && n_kinds >= UNITER_K_COUNT, "prof_collect_stamps: need UNITER_K_COUNT slots");
+  for (int k = 0; k < n_kinds; ++k) { n_launches[k] = 0; total_ms[k] = 0.0; }
+  if (!m->stamp_buf || m->stamp_used == 0) return 0;
+  UCHECK_HIP(hipDeviceSynchronize());
+  const size_t per = (size_t)2 * STAMP_WGS;
+  std::vector<unsigned long long> h(m->stamp_used * per);
+  UCHECK_HIP(hipMemcpy(h.data(), m->stamp_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < m->stamp_used; ++i) {
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int w = 0; w < STAMP_WGS; ++w) {
+      const unsigned long long a = h[i * per + w], b = h[i * per + STAMP_WGS + w];
+      if (a && a < t0) t0 = a;
+      if (b > t1) t1 = b;
+    }
+    if (t0 == ~0ull || t1 < t0) continue;                  // the scope launched no stamped kernel
+    n_launches[m->stamp_tag[i]] += 1;
+    total_ms[m->stamp_tag[i]] += (double)(t1 - t0) * 1e-5;  // 100 MHz ticks -> ms
+  }
+  return 0;
+}
+
+extern "C" int uniter_prof_collect_kinds(uniter_model_t* m, int* n_launches, double* total_ms, int n_kinds) {
+  UCHECK_ARG(m && n_launches && total_ms && n_kinds >= UNITER_K_COUNT, "prof_collect_kinds: need UNITER_K_COUNT slots");
+  for (int k = 0; k < n_kinds; ++k) { n_launches[k] = 0; total_ms[k] = 0.0; }
+  for (size_t i = 0; i + 1 < m->prof_used; i += 2) {
+    UCHECK_HIP(hipEventSynchronize(m->prof_ev[i + 1]));
+    float ms = 0.f;
+    UCHECK_HIP(hipEventElapsedTime(&ms, m->prof_ev[i], m->prof_ev[i + 1]));
+    const int k = m->prof_tag[i / 2];
+    n_launches[k] += 1;
+    total_ms[k] += ms;
+  }
+  m->prof_used = 0;
   return 0;
 }
 
