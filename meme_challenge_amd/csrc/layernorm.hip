@@ -8,6 +8,7 @@
 // statistics with a two-pass variance held in registers, wave-shuffle reduces.
 // Column reductions (dgamma, dbeta, bias grads) are two-stage and deterministic:
 // per-workgroup partial rows in a workspace, then a finalize kernel.
+#include <stdlib.h>
 #include "common.h"
 #include "philox.h"
 #include "rowops.h"
@@ -52,9 +53,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if (y_b16) row_store_bf16<NV>(v, y_b16 + (size_t)row * H, H4, lane);     // operand copy for a bf16-resident GEMM
 }
 
-// grid: nblk workgroups of 4 waves; wave w of block b walks rows b*4+w, +4*nblk, ...
-template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy,
+// grid: nblk workgroups of LNB_WAVES waves; wave w of block b walks rows b*W+w, +W*nblk, ...  Eight waves and (up to
+// 4096 rows) ONE row per wave: the pass is a latency-bound stream -- with two rows per wave on 4-wave workgroups only
+// 1312 waves (1.3 per SIMD) had loads in flight and it ran at 1.2 TB/s; the column partials stay one row per workgroup.
+template <int NV, int LNB_WAVES>
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __restrict__ dy,
                                                      const float* __restrict__ z,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd,
@@ -64,14 +67,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      DropCfg drop, int want_dbias,
                                                      unsigned short* __restrict__ dx_b16, int nslab,
                                                      size_t slab_stride) {
-  __shared__ __attribute__((aligned(16))) float red[4 * NV * 256];
+  __shared__ __attribute__((aligned(16))) float red[LNB_WAVES * NV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H4 = H >> 2;
   f32x4 g[NV], dg[NV], db[NV], dbx[NV];     // dbx: column sum of dx = bias gradient of the producing Linear
   row_load<NV>(g, gamma, H4, lane);
 #pragma unroll
   for (int k = 0; k < NV; ++k) { dg[k] = f32x4{0, 0, 0, 0}; db[k] = f32x4{0, 0, 0, 0}; dbx[k] = f32x4{0, 0, 0, 0}; }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * LNB_WAVES + wave; row < M; row += gridDim.x * LNB_WAVES) {
     f32x4 d[NV], xh[NV];
     row_load<NV>(d, dy + (size_t)row * H, H4, lane);
     for (int s = 1; s < nslab; ++s) {
@@ -92,9 +95,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
   }
   // cross-wave reduce of the column partials, then one partial row per workgroup
-  block_col_reduce_store<NV>(dg, red, part + (size_t)blockIdx.x * 3 * H, H4, lane, wave);
-  block_col_reduce_store<NV>(db, red, part + (size_t)blockIdx.x * 3 * H + H, H4, lane, wave);
-  if (want_dbias) block_col_reduce_store<NV>(dbx, red, part + (size_t)blockIdx.x * 3 * H + 2 * H, H4, lane, wave);
+  block_col_reduce_store<NV, LNB_WAVES>(dg, red, part + (size_t)blockIdx.x * 3 * H, H4, lane, wave);
+  block_col_reduce_store<NV, LNB_WAVES>(db, red, part + (size_t)blockIdx.x * 3 * H + H, H4, lane, wave);
+  if (want_dbias) block_col_reduce_store<NV, LNB_WAVES>(dbx, red, part + (size_t)blockIdx.x * 3 * H + 2 * H, H4, lane, wave);
 }
 
 // out[n] (+)= sum_p part[p*stride + n].  Block = 32 columns x 8 partial-slices: the slices
@@ -155,6 +158,47 @@ __global__ __launch_bounds__(256) void finalize_multi_kernel(const float* __rest
   }
 }
 
+// several independent column reductions in ONE launch (per encoder layer: the two LayerNorm backward passes'
+// [dgamma | dbeta | dbias] partial rows, the attention backward's per-sample query|key|value bias partials and, in the
+// fp32 mode, the dU column partials): out[c] += sum_p part[p * stride + c] for c < n.  Same 16 x 16 block shape as
+// finalize_multi_kernel; blocks are dealt to jobs by their prefix of block counts.
+struct FinJobs {
+  const float* part[4]; int nparts[4]; size_t stride[4]; int n[4];
+  float* out[4][3]; int seg[4];        // output j of a job covers columns [j * seg, (j + 1) * seg)
+  int first_block[5];
+};
+__global__ __launch_bounds__(256) void finalize_jobs_kernel(const FinJobs J, int njobs) {
+  __shared__ float red[16][17];
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
+  const int cx = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int n = (blockIdx.x - J.first_block[j]) * 16 + cx, N = J.n[j], nparts = J.nparts[j];
+  const float* __restrict__ part = J.part[j];
+  const size_t stride = J.stride[j];
+  float s = 0.f;
+  if (n < N) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int p = sl;
+    for (; p + 48 < nparts; p += 64) {
+      a0 += part[(size_t)p * stride + n];
+      a1 += part[(size_t)(p + 16) * stride + n];
+      a2 += part[(size_t)(p + 32) * stride + n];
+      a3 += part[(size_t)(p + 48) * stride + n];
+    }
+    for (; p < nparts; p += 16) a0 += part[(size_t)p * stride + n];
+    s = (a0 + a1) + (a2 + a3);
+  }
+  red[sl][cx] = s;
+  __syncthreads();
+  if (sl == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
+    float* o = J.out[j][n / J.seg[j]];
+    if (o) o[n % J.seg[j]] += t;
+  }
+}
+
 // column sums: block (bx, by) covers columns [bx*256, bx*256+256) and rows by, by+gridDim.y, ...
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ld,
                                                      float* __restrict__ part) {
@@ -211,9 +255,13 @@ __global__ void add_kernel(float* __restrict__ out, const float* __restrict__ a,
   if (i < n4) reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
 }
 
+// waves per workgroup / rows per wave of the backward row pass (A/B switches: UNITER_LNB_WAVES = 4 | 8, UNITER_LNB_ROWS)
+inline int lnb_waves() { static const int w = [] { const char* e = getenv("UNITER_LNB_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }(); return w; }
+inline int lnb_rows() { static const int r = [] { const char* e = getenv("UNITER_LNB_ROWS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }(); return r; }
 inline int ln_bwd_blocks(int M) {
-  int b = (M + 7) / 8;        // ~2 rows per wave: enough waves in flight for HBM, few partial rows
-  return b < 512 ? (b < 1 ? 1 : b) : 512;
+  const int per = lnb_waves() * lnb_rows();
+  int b = (M + per - 1) / per;
+  return b < 1024 ? (b < 1 ? 1 : b) : 1024;
 }
 inline int colsum_splits(int M) {
   int s = (M + 31) / 32;
@@ -238,6 +286,27 @@ int finalize_partials_multi(const float* part, int nparts, size_t stride, float*
   for (int j = 0; j < nout && j < 8; ++j) mo.out[j] = outs[j];
   hipLaunchKernelGGL(finalize_multi_kernel, dim3((nout * H + 15) / 16), dim3(256), 0, st, part, nparts, stride,
                      mo, nout, H);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+// Up to 4 jobs: job i accumulates nout[i] (<= 3) outputs of seg[i] columns each out of part[i] (nparts[i] rows of
+// `stride[i]` floats).  NULL outputs are skipped; jobs with part == NULL are dropped.
+int finalize_partials_jobs(int njobs, const float* const* part, const int* nparts, const size_t* stride,
+                           float* const (*outs)[3], const int* nout, const int* seg, hipStream_t st) {
+  FinJobs J = {};
+  int k = 0, blocks = 0;
+  for (int i = 0; i < njobs && k < 4; ++i) {
+    if (!part[i] || nparts[i] <= 0) continue;
+    J.part[k] = part[i]; J.nparts[k] = nparts[i]; J.stride[k] = stride[i]; J.seg[k] = seg[i]; J.n[k] = nout[i] * seg[i];
+    for (int o = 0; o < 3; ++o) J.out[k][o] = o < nout[i] ? outs[i][o] : nullptr;
+    J.first_block[k] = blocks;
+    blocks += (J.n[k] + 15) / 16;
+    ++k;
+  }
+  J.first_block[k] = blocks;
+  if (k == 0) return 0;
+  hipLaunchKernelGGL(finalize_jobs_kernel, dim3(blocks), dim3(256), 0, st, J, k);
   UCHECK_LAUNCH();
   return 0;
 }
@@ -278,12 +347,13 @@ extern "C" int uniter_colsum_bf16_add(const void* X, int M, int N, int ld, float
   return 0;
 }
 
-#define LN_DISPATCH(NVv, KERNEL, GRID, ...)                                                      \
+#define LN_DISPATCH(NVv, KERNEL, GRID, ...) LN_DISPATCH_T(NVv, KERNEL, GRID, 256, __VA_ARGS__)
+#define LN_DISPATCH_T(NVv, KERNEL, GRID, THREADS, ...)                                           \
   switch (NVv) {                                                                                 \
-    case 1: hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(256), 0, st, __VA_ARGS__); break;         \
-    case 2: hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(256), 0, st, __VA_ARGS__); break;         \
-    case 3: hipLaunchKernelGGL((KERNEL<3>), GRID, dim3(256), 0, st, __VA_ARGS__); break;         \
-    case 4: hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(256), 0, st, __VA_ARGS__); break;         \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(THREADS), 0, st, __VA_ARGS__); break;     \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(THREADS), 0, st, __VA_ARGS__); break;     \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), GRID, dim3(THREADS), 0, st, __VA_ARGS__); break;     \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(THREADS), 0, st, __VA_ARGS__); break;     \
     default: uniter_set_error("layernorm: hidden size %d unsupported (max 1024)", H);            \
              return UNITER_E_SHAPE;                                                              \
   }
@@ -368,11 +438,31 @@ extern "C" int uniter_ln_bwd_rows_slabs(const float* dy, int nslab, size_t slab_
   const int nv = (H / 4 + 63) / 64;
   const int nblk = ln_bwd_blocks(M);
   float* part = (float*)ws;
-  LN_DISPATCH(nv, ln_bwd_kernel, dim3(nblk), dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop, want_dbias != 0,
-              (unsigned short*)dx_bf16, nslab, slab_stride);
+#define LNB_ARGS dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop, want_dbias != 0, (unsigned short*)dx_bf16, nslab, slab_stride
+  if (lnb_waves() == 8) {
+    switch (nv) {
+      case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, 8>), dim3(nblk), dim3(512), 0, st, LNB_ARGS); break;
+      case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, 8>), dim3(nblk), dim3(512), 0, st, LNB_ARGS); break;
+      case 3: hipLaunchKernelGGL((ln_bwd_kernel<3, 8>), dim3(nblk), dim3(512), 0, st, LNB_ARGS); break;
+      case 4: hipLaunchKernelGGL((ln_bwd_kernel<4, 8>), dim3(nblk), dim3(512), 0, st, LNB_ARGS); break;
+      default: uniter_set_error("layernorm: hidden size %d unsupported (max 1024)", H); return UNITER_E_SHAPE;
+    }
+  } else {
+    switch (nv) {
+      case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, 4>), dim3(nblk), dim3(256), 0, st, LNB_ARGS); break;
+      case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, 4>), dim3(nblk), dim3(256), 0, st, LNB_ARGS); break;
+      case 3: hipLaunchKernelGGL((ln_bwd_kernel<3, 4>), dim3(nblk), dim3(256), 0, st, LNB_ARGS); break;
+      case 4: hipLaunchKernelGGL((ln_bwd_kernel<4, 4>), dim3(nblk), dim3(256), 0, st, LNB_ARGS); break;
+      default: uniter_set_error("layernorm: hidden size %d unsupported (max 1024)", H); return UNITER_E_SHAPE;
+    }
+  }
+#undef LNB_ARGS
   UCHECK_LAUNCH();
   return 0;
 }
+
+// internal: the partial-row count / row stride of a row pass over M rows (for finalize_partials_jobs)
+int ln_bwd_partial_rows(int M) { return ln_bwd_blocks(M); }
 
 extern "C" int uniter_ln_bwd_finalize(const void* ws, size_t ws_bytes, int M, int H, float* dgamma, float* dbeta,
                                       float* dbias, void* stream) {

@@ -32,6 +32,9 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
                     int ld_aux, int beta, void* stream);
 int gemm_bf16v2_pick_split(int M, int N, int K);
 int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta, hipStream_t st);
+int finalize_partials_jobs(int njobs, const float* const* part, const int* nparts, const size_t* stride,
+                           float* const (*outs)[3], const int* nout, const int* seg, hipStream_t st);
+int ln_bwd_partial_rows(int M);
 int launch_masked_rowsum(const float* x, const int64_t* masks, float* out, int rows, int D, hipStream_t st);
 
 namespace {
@@ -678,9 +681,22 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     UCHECK_HIP(hipEventRecord(m->ev_main[l], st));
     UCHECK_HIP(hipStreamWaitEvent(sd, m->ev_main[l], 0));
   }
-  // LayerNorm / dense-bias gradients: the column reductions of the two row passes above
-  UCHECK_RC(uniter_ln_bwd_finalize(lb.ln_ws2, pl.ln_ws_bytes, M, H, m->LG(l, L_LN2_G), m->LG(l, L_LN2_B), m->LG(l, L_B2), sd));
-  UCHECK_RC(uniter_ln_bwd_finalize(lb.ln_ws1, pl.ln_ws_bytes, M, H, m->LG(l, L_LN1_G), m->LG(l, L_LN1_B), m->LG(l, L_OB), sd));
+  // LayerNorm / dense-bias gradients: the column reductions of the two row passes above, the attention backward's
+  // per-sample query|key|value bias partials and (fp32 mode) the dU column partials -- ONE launch for all of them
+  {
+    const int lnp = ln_bwd_partial_rows(M);
+    const float* parts[4] = {(const float*)lb.ln_ws2, (const float*)lb.ln_ws1, fused_qb ? lb.qb_part : nullptr,
+                             (!res && fuse_db1) ? lb.du_csum : nullptr};
+    const int nparts[4] = {lnp, lnp, B, (M + 31) / 32};
+    const size_t strides[4] = {(size_t)3 * H, (size_t)3 * H, (size_t)3 * H, (size_t)I};
+    float* const outs[4][3] = {{m->LG(l, L_LN2_G), m->LG(l, L_LN2_B), m->LG(l, L_B2)},
+                               {m->LG(l, L_LN1_G), m->LG(l, L_LN1_B), m->LG(l, L_OB)},
+                               {m->LG(l, L_QB), nullptr, nullptr},
+                               {m->LG(l, L_B1), nullptr, nullptr}};
+    const int nout[4] = {3, 3, 1, 1};
+    const int seg[4] = {H, H, 3 * H, I};
+    UCHECK_RC(finalize_partials_jobs(4, parts, nparts, strides, outs, nout, seg, sd));
+  }
   if (res) {
     const unsigned short* xb = l == 0 ? pl.embb : pl.layers[l - 1].y2b;
     UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, lb.g2b, H, lb.hactb, I, m->LG(l, L_W2), I, nullptr, 0,
@@ -697,15 +713,13 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                    nullptr, nullptr, nullptr, 0, 1));
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, I, H, M, lb.du, I, lb.y1, H, m->LG(l, L_W1), H, UNITER_EPI_NONE,
                    nullptr, nullptr, nullptr, 0, 1));
-    if (fuse_db1) UCHECK_RC(finalize_partials(lb.du_csum, (M + 31) / 32, (size_t)I, m->LG(l, L_B1), I, 1, sd));
-    else UCHECK_RC(uniter_colsum_f32(lb.du, M, I, I, m->LG(l, L_B1), 1, pl.col_ws, pl.col_ws_bytes, sd));
+    if (!fuse_db1) UCHECK_RC(uniter_colsum_f32(lb.du, M, I, I, m->LG(l, L_B1), 1, pl.col_ws, pl.col_ws_bytes, sd));
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, H, M, g1, H, lb.ctx, H, m->LG(l, L_OW), H, UNITER_EPI_NONE,
                    nullptr, nullptr, nullptr, 0, 1));
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkv, 3 * H, x, H, m->LG(l, L_QW), H,
                    UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
   }
-  if (fused_qb) UCHECK_RC(finalize_partials(lb.qb_part, B, (size_t)3 * H, m->LG(l, L_QB), 3 * H, 1, sd));
-  else UCHECK_RC(uniter_colsum_f32(lb.dqkv, M, 3 * H, 3 * H, m->LG(l, L_QB), 1, pl.col_ws, pl.col_ws_bytes, sd));
+  if (!fused_qb) UCHECK_RC(uniter_colsum_f32(lb.dqkv, M, 3 * H, 3 * H, m->LG(l, L_QB), 1, pl.col_ws, pl.col_ws_bytes, sd));
   if (sd != st) UCHECK_HIP(hipEventRecord(m->ev_side[l], sd));
   return 0;
 }

@@ -111,9 +111,9 @@ __device__ __forceinline__ void row_ln_bwd(f32x4 (&d)[NV], f32x4 (&zx)[NV], cons
 #pragma unroll
     for (int e = 0; e < 4; ++e) d[k][e] = rs * (d[k][e] - c1 - zx[k][e] * c2);
 }
-// sum the per-wave column partials of a 4-wave workgroup and store one row of H floats.
-// red: >= 4*NV*256 floats of LDS.
-template <int NV>
+// sum the per-wave column partials of a WPB-wave workgroup and store one row of H floats.
+// red: >= WPB*NV*256 floats of LDS.
+template <int NV, int WPB = 4>
 __device__ __forceinline__ void block_col_reduce_store(const f32x4 (&acc)[NV], float* red,
                                                        float* __restrict__ out_row, int H4, int lane, int wave) {
   __syncthreads();
@@ -128,7 +128,7 @@ __device__ __forceinline__ void block_col_reduce_store(const f32x4 (&acc)[NV], f
       if (c < H4) {
         f32x4 t = acc[k];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + ((w * NV + k) * 64 + lane) * 4);
+        for (int w = 1; w < WPB; ++w) t += *reinterpret_cast<const f32x4*>(red + ((w * NV + k) * 64 + lane) * 4);
         reinterpret_cast<f32x4*>(out_row)[c] = t;
       }
     }
