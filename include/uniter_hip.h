@@ -184,6 +184,10 @@ int uniter_ln_bwd_rows_slabs(const float* dy, int nslab, size_t slab_stride, con
 /* out[n] += sum_m X[m, n] for a bf16 matrix X [M, ld] (bias gradient of a dense layer from the bf16 gradient of its
  * output; replaces the autograd sum of model/layer.py:140 in the bf16 mode).  N % 8 == 0, ld % 8 == 0. */
 int uniter_colsum_bf16_add(const void* X, int M, int N, int ld, float* out, void* stream);
+/* out[i] += sum_s slabs[s * slab_stride + i], i < n: folds the fp32 k-piece slabs of a split-K weight-gradient product
+ * (uniter_gemm_bf16v2_cfg with a_kmajor = b_kmajor = 1, nsplit > 1) into the gradient buffer -- what autograd's
+ * accumulation into .grad does for model/layer.py's nn.Linear weights.  n, slab_stride multiples of 4. */
+int uniter_slab_reduce_add(const float* slabs, int nslab, size_t slab_stride, float* out, size_t n, void* stream);
 int uniter_ln_bwd_finalize(const void* ws, size_t ws_bytes, int M, int H, float* dgamma, float* dbeta,
                            float* dbias, void* stream);
 size_t uniter_ln_bwd_ws_bytes(int M, int H);

@@ -173,6 +173,14 @@ __device__ __forceinline__ void wait_lgkm(u32x2_t& a, u32x2_t& b, u32x2_t& c, u3
 
 // BM x BN tile, one 64 x 64 sub-tile (2 x 2 accumulator blocks of 32 x 32) per wave, ST LDS stages.
 // SWAP: accumulator transposed (lane = output row); !SWAP: lane = output column (fp32 atomics for C +=).
+template <int N>
+__device__ __forceinline__ void wait_lgkm8(u32x2_t& a, u32x2_t& b, u32x2_t& c, u32x2_t& d, u32x2_t& e, u32x2_t& f,
+                                           u32x2_t& g, u32x2_t& h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N) : "memory");
+#endif
+}
+
 template <int BM, int BN, bool AKM, bool BKM, bool SWAP, int ST, int EPI>
 __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_dma_kernel(const GArgsD g) {
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtins / asm: the host pass gets an empty body (it only needs the launch stub)
@@ -239,7 +247,12 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_dma_kernel
 // s+1's six reads outstanding.
 #define RD_STEP(KS, BUF)                                                                                 \
   {                                                                                                      \
-    if constexpr (BKM) {                                                                                 \
+    if constexpr (AKM && BKM) {           /* weight gradients: both operands k-major, 8 transposed reads per step */ \
+      fa.template read_tr<KS>(sAaddr, 0, rA[BUF][0][0], rA[BUF][0][1]);                                  \
+      fa.template read_tr<KS>(sAaddr, 1, rA[BUF][1][0], rA[BUF][1][1]);                                  \
+      fb.template read_tr<KS>(sBaddr, 0, rb[BUF][0][0], rb[BUF][0][1]);                                  \
+      fb.template read_tr<KS>(sBaddr, 1, rb[BUF][1][0], rb[BUF][1][1]);                                  \
+    } else if constexpr (BKM) {                                                                          \
       fa.template read_asm<KS, 0>(sAaddr, ra[BUF][0]);                                                   \
       fa.template read_asm<KS, 1>(sAaddr, ra[BUF][1]);                                                   \
       fb.template read_tr<KS>(sBaddr, 0, rb[BUF][0][0], rb[BUF][0][1]);                                  \
@@ -251,7 +264,14 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_dma_kernel
   }
 #define MM_STEP(BUF, NLATER)                                                                             \
   {                                                                                                      \
-    if constexpr (BKM) {                                                                                 \
+    if constexpr (AKM && BKM) {                                                                          \
+      wait_lgkm8<(NLATER) ? 8 : 0>(rA[BUF][0][0], rA[BUF][0][1], rA[BUF][1][0], rA[BUF][1][1],           \
+                                   rb[BUF][0][0], rb[BUF][0][1], rb[BUF][1][0], rb[BUF][1][1]);          \
+      xa[BUF][0] = join_halves(rA[BUF][0][0], rA[BUF][0][1]);                                            \
+      xa[BUF][1] = join_halves(rA[BUF][1][0], rA[BUF][1][1]);                                            \
+      xb[BUF][0] = join_halves(rb[BUF][0][0], rb[BUF][0][1]);                                            \
+      xb[BUF][1] = join_halves(rb[BUF][1][0], rb[BUF][1][1]);                                            \
+    } else if constexpr (BKM) {                                                                          \
       wait_lgkm<NLATER>(rb[BUF][0][0], rb[BUF][0][1], rb[BUF][1][0], rb[BUF][1][1], ra[BUF][0], ra[BUF][1]); \
       xa[BUF][0] = __builtin_bit_cast(bf16x8, ra[BUF][0]);                                               \
       xa[BUF][1] = __builtin_bit_cast(bf16x8, ra[BUF][1]);                                               \
@@ -270,7 +290,7 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_dma_kernel
     const unsigned sAaddr = lds0 + (STG) * STAGE, sBaddr = sAaddr + IMG_A;                               \
     (void)sA; (void)sB; (void)sAaddr; (void)sBaddr;                                                      \
     bf16x8 xa[2][2], xb[2][2];                                                                           \
-    u32x2_t rb[2][2][2];                                                                                 \
+    u32x2_t rb[2][2][2], rA[2][2][2];                                                                    \
     u32x4_t ra[2][2];                                                                                    \
     RD_STEP(0, 0)                                                                                        \
     RD_STEP(1, 1) MM_STEP(0, 6)                                                                          \
@@ -499,6 +519,16 @@ int launch_d(GArgsD g, hipStream_t st) {
   return 0;
 }
 
+// weight gradients (both operands k-major): 128 x 128 tiles only
+template <bool SWAP>
+int dispatch_wgrad(int cfg, const GArgsD& g, hipStream_t st) {
+  switch (cfg) {
+    case 1: return launch_d<128, 128, true, true, SWAP, 2, UNITER_EPI_NONE>(g, st);
+    case 4: return launch_d<128, 128, true, true, SWAP, 3, UNITER_EPI_NONE>(g, st);
+    default: uniter_set_error("gemm_bf16v2: weight-gradient layout runs cfg 1 or 4 (got %d)", cfg); return UNITER_E_ARG;
+  }
+}
+
 template <bool BKM, bool SWAP, int EPI>
 int dispatch_cfg(int cfg, const GArgsD& g, hipStream_t st) {
   switch (cfg) {
@@ -534,11 +564,12 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
                     int ld_aux, int beta, void* stream) {
   UCHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && (C || Cb), "gemm_bf16v2: bad argument");
   UCHECK_ARG(epilogue >= 0 && epilogue <= UNITER_EPI_MUL, "gemm_bf16v2: bad epilogue %d", epilogue);
-  UCHECK_ARG(!a_kmajor, "gemm_bf16v2: A k-major (weight gradients) runs on gemm_bf16res");
+  UCHECK_ARG(!a_kmajor || (b_kmajor && epilogue == UNITER_EPI_NONE && !Cb),
+             "gemm_bf16v2: A k-major only as the weight-gradient layout (both operands k-major, no epilogue, fp32 output)");
   UCHECK_ARG(nsplit >= 1 && nsplit <= 8 && (nsplit == 1 || (C && !Cb && !beta && c_split_stride >= (long)M * ldc)),
              "gemm_bf16v2: split-K needs fp32 slabs (no bf16 output, no accumulate)");
   UCHECK_ARG(!beta || (C && !Cb && epilogue == UNITER_EPI_NONE), "gemm_bf16v2: C += has no epilogue and no bf16 copy");
-  UCHECK_SHAPE((K % KT == 0 || (a_kmajor && b_kmajor)) && lda % 8 == 0 && ldb % 8 == 0 && N % 8 == 0 &&
+  UCHECK_SHAPE((K % KT == 0 || (a_kmajor && b_kmajor)) && lda % 8 == 0 && ldb % 8 == 0 && N % 8 == 0 && (!a_kmajor || M % 8 == 0) &&
                ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && (ldc % 4 == 0) && (ldcb % 8 == 0) &&
                (ld_aux % 4 == 0) && ((uintptr_t)C & 15) == 0 && ((uintptr_t)Cb & 15) == 0 &&
                ((uintptr_t)aux_in & 15) == 0 && ((uintptr_t)aux_out & 15) == 0 && ((uintptr_t)bias & 15) == 0,
@@ -556,6 +587,7 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
   g.stamp = take_stamp_slot();
   if (cfg == 0) cfg = 1;
   hipStream_t st = (hipStream_t)stream;
+  if (a_kmajor) return beta ? dispatch_wgrad<false>(cfg, g, st) : dispatch_wgrad<true>(cfg, g, st);
   if (beta) return b_kmajor ? dispatch_cfg<true, false, UNITER_EPI_NONE>(cfg, g, st) : dispatch_cfg<false, false, UNITER_EPI_NONE>(cfg, g, st);
   return b_kmajor ? dispatch_epi<true>(cfg, g, st) : dispatch_epi<false>(cfg, g, st);
 }
@@ -571,6 +603,22 @@ int gemm_bf16v2_pick_split(int M, int N, int K) {
   if (tiles <= 128 && nk >= 48) return 4;
   if (tiles <= 320 && nk >= 24) return 2;
   return 1;
+}
+
+// Weight gradients dW[M, N] += dY^T X (both operands k-major, K = rows of the batch): pieces of the split-K slab form,
+// or 0 = keep the stream-K + float-atomics kernel of gemm_bf16.hip.  Measured at K = 2624
+// (profiles/r02_gemm_bf16_v2.txt): 768 x 3072 39.2 -> 30.9 us with two pieces, 2304 x 768 26.0 -> 24.7 (two),
+// 768 x 768 17.9 -> 16.8 (four); 3072 x 768 stays on stream-K (29.0 vs 31.2).
+// In the training step the gain does not survive (2870 -> 2855 samples/s: the weight gradients share the chip with the
+// input-gradient chain, whose idle slots the perfectly balanced stream-K pieces fill better), so the slab form is an
+// opt-in (UNITER_WGRAD_SLABS=1) and the default stays stream-K.
+int gemm_bf16v2_wgrad_pieces(int M, int N, int K) {
+  static const bool on = [] { const char* e = getenv("UNITER_WGRAD_SLABS"); return e && e[0] == '1'; }();
+  if (!on || K < 1024 || M % 8 || N % 8) return 0;
+  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles <= 48) return 4;
+  if (M <= N || tiles <= 128) return 2;
+  return 0;
 }
 
 extern "C" int uniter_gemm_bf16v2_cfg(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K,

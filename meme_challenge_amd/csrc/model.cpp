@@ -31,6 +31,7 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
                     const float* bias, const void* aux_in, int aux_in_bf16, void* aux_out, int aux_out_bf16,
                     int ld_aux, int beta, void* stream);
 int gemm_bf16v2_pick_split(int M, int N, int K);
+int gemm_bf16v2_wgrad_pieces(int M, int N, int K);
 int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta, hipStream_t st);
 int finalize_partials_jobs(int njobs, const float* const* part, const int* nparts, const size_t* stride,
                            float* const (*outs)[3], const int* nout, const int* seg, hipStream_t st);
@@ -90,6 +91,7 @@ struct Plan {
   // the LayerNorm row pass that consumes them): K = intermediate (FFN-down forward, FFN-up dgrad), K = 3 hidden (QKV dgrad)
   int ns_ki, ns_k3h;
   bool packed;      // rows = valid positions only (uniter_batch_t::cu_seqlens)
+  float* wg_slabs;        // precision 2: k-piece slabs of the split-K weight-gradient GEMMs (side stream, reused by every layer)
   void *ln_ws, *col_ws, *emb_ws, *attn_ws;
   size_t ln_ws_bytes, col_ws_bytes, emb_ws_bytes, attn_ws_bytes;
   size_t total;
@@ -225,6 +227,7 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
     pl.emb_ws = cv.raw(pl.emb_ws_bytes);
     pl.attn_ws_bytes = uniter_attn_bwd_ws_bytes(B, L, c.num_attention_heads);
     pl.attn_ws = cv.raw(pl.attn_ws_bytes);
+    pl.wg_slabs = pl.res ? cv.f((size_t)4 * 3 * H * (I > 3 * H ? I : 3 * H)) : nullptr;
   }
   pl.total = cv.off;
 }
@@ -275,6 +278,19 @@ int gemm_r(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, i
   ProfScope ps(m, kind, st);
   return gemm_bf16res_run(0, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, Cb, ldcb, epi, bias, aux_in, aux_out, ld_aux,
                           beta, colsum_part, st);
+}
+// dW[Mo, No] += A^T B with A [K, Mo], B [K, No] bf16: split-K slabs + one reduce pass where that beats stream-K atomics
+int wgrad_b16(uniter_model* m, const Plan& pl, hipStream_t st, int Mo, int No, int K, const void* A, const void* B, float* dW) {
+  const int pieces = gemm_bf16v2_wgrad_pieces(Mo, No, K);
+  if (pieces == 0 || !pl.wg_slabs)
+    return gemm_r(m, UNITER_K_GEMM_WGRAD, st, 1, 1, Mo, No, K, A, Mo, B, No, dW, No, nullptr, 0, UNITER_EPI_NONE, nullptr,
+                  nullptr, nullptr, 0, 1);
+  {
+    ProfScope ps(m, UNITER_K_GEMM_WGRAD, st);
+    UCHECK_RC(gemm_bf16v2_run(0, pieces, 1, 1, Mo, No, K, A, Mo, B, No, pl.wg_slabs, No, (long)Mo * No, nullptr, 0,
+                              UNITER_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0, 0, st));
+  }
+  return uniter_slab_reduce_add(pl.wg_slabs, pieces, (size_t)Mo * No, dW, (size_t)Mo * No, st);
 }
 int cast_b(const float* src, unsigned short* dst, size_t n, hipStream_t st) { return uniter_cast_bf16(src, dst, n, st); }
 
@@ -699,15 +715,11 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   if (res) {
     const unsigned short* xb = l == 0 ? pl.embb : pl.layers[l - 1].y2b;
-    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, lb.g2b, H, lb.hactb, I, m->LG(l, L_W2), I, nullptr, 0,
-                     UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
-    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, I, H, M, lb.dub, I, lb.y1b, H, m->LG(l, L_W1), H, nullptr, 0,
-                     UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+    UCHECK_RC(wgrad_b16(m, pl, sd, H, I, M, lb.g2b, lb.hactb, m->LG(l, L_W2)));
+    UCHECK_RC(wgrad_b16(m, pl, sd, I, H, M, lb.dub, lb.y1b, m->LG(l, L_W1)));
     UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
-    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, H, M, lb.g1b, H, lb.ctxb, H, m->LG(l, L_OW), H, nullptr, 0,
-                     UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
-    UCHECK_RC(gemm_r(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkvb, 3 * H, xb, H, m->LG(l, L_QW), H, nullptr, 0,
-                     UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+    UCHECK_RC(wgrad_b16(m, pl, sd, H, H, M, lb.g1b, lb.ctxb, m->LG(l, L_OW)));
+    UCHECK_RC(wgrad_b16(m, pl, sd, 3 * H, H, M, lb.dqkvb, xb, m->LG(l, L_QW)));
   } else {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, g2, H, lb.hact, I, m->LG(l, L_W2), I, UNITER_EPI_NONE,
                    nullptr, nullptr, nullptr, 0, 1));

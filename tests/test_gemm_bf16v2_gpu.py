@@ -133,3 +133,44 @@ def test_rejects():
     assert call(nsplit=2, cb=L.ptr(x)) != 0          # split-K has no bf16 output
     assert call(beta=1, cb=L.ptr(x)) != 0
     assert call(akm=1) != 0
+
+
+def _run_wgrad(cfg, M, N, K, nsplit, beta, seed=0):
+    """Weight-gradient layout: A [K, M] and B [K, N] both k-major, C [M, N] = A^T B (K = rows of the batch)."""
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(K, M, generator=g).bfloat16()
+    B = torch.randn(K, N, generator=g).bfloat16()
+    C0 = torch.randn(M, N, generator=g)
+    ref = A.double().t() @ B.double()
+    dA, dB = A.cuda(), B.cuda()
+    tol = 1e-4 * math.sqrt(K) * (1 + 0.1 * nsplit)
+    if beta:
+        dC = C0.cuda().contiguous()
+        L.check(lib.uniter_gemm_bf16v2_cfg(cfg, 1, 1, 1, M, N, K, L.ptr(dA), M, L.ptr(dB), N, L.ptr(dC), N, M * N, None, 0, 0,
+                                           None, None, 0, None, 0, 0, 1, L.cur_stream()), 'gemm_bf16v2 wgrad atomics')
+        torch.cuda.synchronize()
+        err = (dC.cpu().double() - (ref + C0.double())).abs().max().item()
+    else:
+        slabs = torch.full((nsplit, M, N), float('nan'), device='cuda')
+        L.check(lib.uniter_gemm_bf16v2_cfg(cfg, nsplit, 1, 1, M, N, K, L.ptr(dA), M, L.ptr(dB), N, L.ptr(slabs), N, M * N, None, 0,
+                                           0, None, None, 0, None, 0, 0, 0, L.cur_stream()), 'gemm_bf16v2 wgrad slabs')
+        out = C0.cuda().contiguous()
+        L.check(lib.uniter_slab_reduce_add(L.ptr(slabs), nsplit, M * N, L.ptr(out), M * N, L.cur_stream()), 'slab_reduce_add')
+        torch.cuda.synchronize()
+        assert not torch.isnan(slabs).any()
+        err = (out.cpu().double() - (ref + C0.double())).abs().max().item()
+    assert err < tol, (cfg, M, N, K, nsplit, beta, err)
+
+
+@pytest.mark.parametrize('cfg', [1, 4])
+def test_weight_gradient_layout(cfg):
+    _run_wgrad(cfg, M=128, N=128, K=128, nsplit=1, beta=0)
+    _run_wgrad(cfg, M=256, N=384, K=640, nsplit=3, beta=0)
+    _run_wgrad(cfg, M=256, N=128, K=200, nsplit=2, beta=0)          # ragged K (rows beyond K must read as zero)
+    _run_wgrad(cfg, M=128, N=256, K=1458, nsplit=4, beta=0)         # ragged K, several pieces
+    _run_wgrad(cfg, M=136, N=200, K=256, nsplit=1, beta=0)          # output edges
+    _run_wgrad(cfg, M=128, N=128, K=192, nsplit=1, beta=1)          # C += by atomics
+    _run_wgrad(cfg, M=768, N=3072, K=2624, nsplit=3, beta=0)        # FFN weight gradient of the model
+    _run_wgrad(cfg, M=2304, N=768, K=2624, nsplit=4, beta=0)

@@ -75,3 +75,26 @@ for name, bkm, M, N, K, epi, wc, wcb, abi, abo in shapes:
         for k, r in runs.items(): res[k].append(timeit(r, graphs[k]))
     fl = 2.0 * M * N * K
     print('%-14s %5dx%5dx%5d  ' % (name, M, N, K) + '  '.join('%s %.1fus %4.0fTF' % (k, statistics.median(v) * 1e3, fl / statistics.median(v) / 1e9) for k, v in res.items()), flush=True)
+
+# ---- weight gradients: both operands k-major; v1 = stream-K + atomics, v2 = split-K slabs + reduce pass ----
+if not only or 'wgrad' in only:
+    for name, M, N in (('ffn1_wgrad', II, HH), ('ffn2_wgrad', HH, II), ('qkv_wgrad', 3 * HH, HH), ('attnout_wgrad', HH, HH)):
+        K = MM
+        A = torch.randn(K, M, device='cuda').bfloat16(); B = torch.randn(K, N, device='cuda').bfloat16()
+        C = torch.zeros(M, N, device='cuda'); slabs = torch.zeros(8, M, N, device='cuda')
+        runs = {'v1': (lambda: lib.uniter_gemm_bf16res_cfg(0, 1, 1, M, N, K, L.ptr(A), M, L.ptr(B), N, L.ptr(C), N, None, 0, 0, None, None, None, 0, 1, L.cur_stream()))}
+        for cfg in (1, 4):
+            for ns in (1, 2, 3, 4, 6, 8):
+                def run(cfg=cfg, ns=ns):
+                    L.check(lib.uniter_gemm_bf16v2_cfg(cfg, ns, 1, 1, M, N, K, L.ptr(A), M, L.ptr(B), N, L.ptr(slabs), N, M * N, None, 0, 0, None, None, 0, None, 0, 0, 0, L.cur_stream()))
+                    L.check(lib.uniter_slab_reduce_add(L.ptr(slabs), ns, M * N, L.ptr(C), M * N, L.cur_stream()))
+                runs['v2c%ds%d' % (cfg, ns)] = run
+        runs['v2c1atomic'] = lambda: L.check(lib.uniter_gemm_bf16v2_cfg(1, 1, 1, 1, M, N, K, L.ptr(A), M, L.ptr(B), N, L.ptr(C), N, M * N, None, 0, 0, None, None, 0, None, 0, 0, 1, L.cur_stream()))
+        for r in runs.values(): r()
+        torch.cuda.synchronize()
+        graphs = {k: make_graph(r) for k, r in runs.items()}
+        res = {k: [] for k in runs}
+        for _ in range(ROUNDS):
+            for k, r in runs.items(): res[k].append(timeit(r, graphs[k]))
+        fl = 2.0 * M * N * K
+        print('%-14s %5dx%5dx%5d  ' % (name, M, N, K) + '  '.join('%s %.1fus %4.0fTF' % (k, statistics.median(v) * 1e3, fl / statistics.median(v) / 1e9) for k, v in res.items()), flush=True)

@@ -113,6 +113,8 @@ def build_parser():
                              '(built next to the jsonl on first use) and read from it')
     parser.add_argument('--no_prefetch', action='store_true', help='copy each batch to the GPU synchronously (default: one batch ahead on a side stream)')
     parser.add_argument('--pack_padded', action='store_true', help='token packing: compute the valid positions only')
+    parser.add_argument('--ragged_regions', action='store_true',
+                        help="mask every sample at its own region count (the reference's collate counts the zero-padded rows of the batch: data.MemeDataset)")
     parser.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16', 'bf16_hybrid'],
                         help="GEMM arithmetic: fp32 (the reference's), bf16 (bf16-resident operands) or bf16_hybrid")
     return parser
@@ -156,7 +158,8 @@ def main(argv=None):
             if ddp:
                 torch.distributed.barrier()
         ds = MemeDataset(filepath=path, feature_dir=config['feature_path'], feature_shard=shard,
-                         text_padding=tokenizer_func, return_ids=ids, confidence_threshold=config['object_conf_thresh'])
+                         text_padding=tokenizer_func, return_ids=ids, confidence_threshold=config['object_conf_thresh'],
+                         ragged_regions=config['ragged_regions'])
         kw = dict(batch_size=config['batch_size'], num_workers=config['num_workers'], collate_fn=ds.get_collate_fn(),
                   pin_memory=True)
         if train:
