@@ -110,27 +110,6 @@ int uniter_gemm_bf16v2_cfg(int cfg, int nsplit, int a_kmajor, int b_kmajor, int 
 /* dst[i] = bf16(src[i]) (round to nearest even); n % 4 == 0 */
 int uniter_cast_bf16(const float* src, void* dst, size_t n, void* stream);
 
-/* fp32-ACCURATE product on the bf16 matrix pipe: each fp32 operand is split exactly into three
- * bf16 pieces and the six significant piece products are accumulated in fp32 (error of the same
- * order as the native fp32 MFMA chain; see csrc/gemm_split.hip).  Same contract as
- * uniter_gemm_f32_cfg; shapes with K % 32 != 0 run on the native fp32 kernel. */
-int uniter_gemm_f32x3_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K,
-                    const float* A, int lda, const float* B, int ldb,
-                    float* C, int ldc, int epilogue, const float* bias,
-                    const float* aux_in, float* aux_out, int ld_aux,
-                    int beta, void* stream);
-
-/* Pre-split operands ("planes"): planes[p][r][c] (bf16, p = 0..2, plane p at + p*plane_stride
- * elements, row stride pld) hold the exact 3-way bf16 split of x[r][c]; transpose != 0 writes the
- * planes of x^T.  uniter_gemm_planes_cfg computes C = epi(A @ B^T) from the planes of A [M,K] and
- * B [N,K] with the six-product scheme at fp32 accuracy, with no split arithmetic in its loop. */
-int uniter_split_planes(const float* x, int rows, int cols, int ld, void* planes, int pld,
-                        size_t plane_stride, int transpose, void* stream);
-int uniter_gemm_planes_cfg(int cfg, int M, int N, int K, const void* A_planes, int lda, size_t a_plane_stride,
-                           const void* B_planes, int ldb, size_t b_plane_stride, float* C, int ldc,
-                           int epilogue, const float* bias, const float* aux_in, float* aux_out, int ld_aux,
-                           int beta, void* stream);
-
 /* out[n] (+)= sum_m X[m*ld + n]   (bias gradients of every nn.Linear) */
 int uniter_colsum_f32(const float* X, int M, int N, int ld, float* out, int beta,
                       void* ws, size_t ws_bytes, void* stream);

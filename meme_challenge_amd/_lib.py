@@ -49,9 +49,6 @@ _SIGS = {
     'uniter_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     'uniter_gemm_f32_cfg': (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     'uniter_gemm_bf16_cfg': (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
-    'uniter_gemm_f32x3_cfg': (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
-    'uniter_split_planes': (_I, [_P, _I, _I, _I, _P, _I, _SZ, _I, _P]),
-    'uniter_gemm_planes_cfg': (_I, [_I, _I, _I, _I, _P, _I, _SZ, _P, _I, _SZ, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     'uniter_colsum_f32': (_I, [_P, _I, _I, _I, _P, _I, _P, _SZ, _P]),
     'uniter_colsum_ws_bytes': (_SZ, [_I, _I]),
     'uniter_ln_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P]),

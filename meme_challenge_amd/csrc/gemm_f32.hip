@@ -3,24 +3,29 @@
 // Replaces the cuBLAS sgemm calls behind nn.Linear / its autograd in the
 // reference (model/layer.py:76-78,112,140,153; model/model.py:267).
 //
-// Design (MI355X_MICROARCH.md "Matrix cores", cdna_hip_programming.md 3):
-//  * v_mfma_f32_32x32x2_f32: exact fp32, 64 cycles/SIMD per instruction, peak
-//    157.3 TFLOP/s -- 1/16 of the bf16 rate, so the kernel is matrix-pipe bound
-//    and LDS / L2 traffic is secondary.  One wave per SIMD per workgroup,
-//    two workgroups per CU so that a barrier in one does not idle the pipe.
-//  * the MFMA K index is a free permutation: lane-half h of instruction t in an
-//    8-deep k-block takes k = 8*kb + 4*h + t for BOTH operands.  A k-contiguous
-//    operand fragment is then ONE ds_read_b128 (4 consecutive k) per 4 MFMAs.
-//  * k-contiguous tiles sit in LDS as [rows][32+4] floats: the 36-dword stride
-//    maps the 16 lanes of every ds_read_b128 lane group to 16 distinct 4-bank
-//    slots (9*i mod 16 is a bijection) -> conflict free.
-//  * k-major tiles (dgrad's W, wgrad's dY and X) sit as [32][cols+4]; a fragment
-//    is 4 ds_read_b32 with lanes 0..31 on consecutive dwords -> conflict free.
-//  * global -> registers -> LDS staging, double buffered, next tile's global
-//    loads issued before the MFMA block of the current one (T14), one
-//    __syncthreads per k-tile.
-//  * blockIdx -> tile map is XCD-aware (bijective chunking): blocks that share an
-//    XCD's L2 work on adjacent tiles.
+// Design (MI355X_MICROARCH.md "Matrix cores", cdna_hip_programming.md 3) of the kernel the model runs,
+// gemm_f32_v3_kernel (gemm_f32_kernel further down is the one-tile-per-workgroup fallback for K % 32 != 0):
+//  * v_mfma_f32_32x32x2_f32: exact fp32, 64 cycles/SIMD per instruction, peak 157.3 TFLOP/s -- 1/16 of the bf16
+//    rate and EQUAL to the fp32 vector rate, so the kernel is matrix-pipe bound and every VALU instruction beside
+//    the MFMAs costs its full issue time.
+//  * PERSISTENT 64 x 64 tiles: 256-thread workgroups (4 waves, one 32 x 32 accumulator each), four resident per CU
+//    (71 - 105 VGPRs, 36 KB LDS each; __launch_bounds__(256, 2) only states the floor of two), 1024 slots walking an
+//    XCD-chunked, L2-banded tile order; the k-tiles of all of a workgroup's tiles form one flat sequence of 32-deep
+//    units, so tiles finish out of phase and one tile's epilogue overlaps other tiles' MFMAs.  128 x 128 tiles
+//    (512 slots) from 3072 tiles of 64 x 64 up.
+//  * the MFMA K index is a free permutation: lane-half h of instruction t in an 8-deep k-block takes
+//    k = 8*kb + 4*h + t for BOTH operands.  A k-contiguous operand fragment is then ONE ds_read_b128 (4 consecutive
+//    k) per 4 MFMAs.
+//  * k-contiguous tiles sit in LDS as [rows][32+4] floats: the 36-dword stride maps the 16 lanes of every
+//    ds_read_b128 lane group to 16 distinct 4-bank slots (9*i mod 16 is a bijection) -> conflict free.
+//  * k-major tiles (dgrad's W, wgrad's dY and X) sit as [32][cols+4]; a fragment is 4 ds_read_b32 with lanes 0..31
+//    on consecutive dwords -> conflict free.
+//  * operands: buffer_load_dwordx4 with the hardware range check (no bounds branches) -> staging registers -> LDS,
+//    written mid-iteration, refetched three units ahead; the k-loop is unrolled by two so every LDS address is an
+//    immediate; one __syncthreads per unit.
+//  * stream-K (SK = true) for C += A.B with few tiles and a long K (weight gradients): an XCD's unit sequence is cut
+//    into equal pieces, partial tiles added with buffer_atomic_add_f32.
+//  * epilogues through buffer instructions with scalar row offsets; optional per-32-row column sums.
 #include <stdlib.h>
 #include "common.h"
 

@@ -409,6 +409,30 @@ def gen_crossval_ensemble():
         for f in files:
             with open(f) as fh:
                 out['cv/out/' + os.path.basename(f)] = np.array([json.loads(l)['id'] for l in fh.read().split('\n')])
+        # ---- use_dev_set variant: dev_seen with text confounders, rotated through the folds ----
+        tmp2 = os.path.join(tmp, 'usedev')
+        os.makedirs(tmp2)
+        n_dev2 = 26
+        rng2 = np.random.Generator(np.random.PCG64(78))        # its own stream: the inputs of the other parts stay as they were
+        ids2 = rng2.permutation(90000)[:n_train + n_dev2] + 100000
+        labels2 = (rng2.random(n_train + n_dev2) < 0.45).astype(np.int64)
+        texts2 = ['t%d' % i for i in ids2]
+        for a, b in ((n_train + 1, n_train + 7), (n_train + 3, n_train + 12), (n_train + 4, n_train + 20)):
+            texts2[b] = texts2[a]                      # three confounder groups inside dev_seen
+        texts2[n_train + 21] = texts2[n_train + 3]     # ... one of them with three members
+        for name, sl in (('train', slice(0, n_train)), ('dev_seen', slice(n_train, None))):
+            with open(os.path.join(tmp2, name + '.jsonl'), 'w') as f:
+                f.write('\n'.join(json.dumps({'id': int(i), 'img': 'img/%05d.png' % i, 'label': int(l), 'text': t})
+                                  for i, l, t in zip(ids2[sl], labels2[sl], texts2[sl])))
+        out['cvd/ids'], out['cvd/labels'], out['cvd/texts'] = ids2, labels2, np.array(texts2)
+        # two folds: with more, the reference's float32 choice probabilities (e.g. 2/3 + 1/3) are rejected by numpy
+        generate_crossval_splits(tmp2, dev_size=20, use_dev_set=True)
+        files = sorted(glob.glob(os.path.join(tmp2, 'crossval_20_usedevtest', '*.jsonl')))
+        out['cvd/files'] = np.array([os.path.basename(f) for f in files])
+        for f in files:
+            with open(f) as fh:
+                out['cvd/out/' + os.path.basename(f)] = np.array([json.loads(l)['id'] for l in fh.read().split('\n')])
+        print('use_dev_set files:', len(files))
         # ---- ensemble ----
         n = 60
         eid = rng.permutation(5000)[:n] + 1
