@@ -785,6 +785,10 @@ class UniterModel(UniterPreTrainedModel):
         downstream, so dropping those rows changes no valid output and no gradient."""
         B, L = b.B, b.L
         if seq_lens is None:
+            if not getattr(self, '_warned_pack_sync', False):
+                logger.warning('pack_padded without seq_lens: the lengths are read back from attention_mask (one device->host '
+                               'synchronisation per forward); the collate of data.MemeDataset provides batch["seq_lens"]')
+                self._warned_pack_sync = True
             lens = attention_mask.sum(dim=1).to(torch.int64).cpu().numpy()       # device -> host sync
         else:
             lens = np.asarray(torch.as_tensor(seq_lens).cpu().numpy(), dtype=np.int64).reshape(-1)

@@ -145,3 +145,21 @@ def test_rank_shards_are_disjoint_cover_the_epoch_and_have_equal_length():
             return 10
     a, b = train_uniter.RankShard(Inner(), 0, 2), train_uniter.RankShard(Inner(), 1, 2)
     assert len(a) == len(b) == 5 and set(a).isdisjoint(set(b)) and set(a) | set(b) == set(range(10))
+
+
+def test_runtime_options_survive_the_final_reload():
+    """--precision / --pack_padded belong to the encoder object; TrainerTemplate.end_training rebuilds the model through
+    load_model(), which must apply them again (the final validation / test scoring would otherwise run in fp32, padded)."""
+    import train_uniter
+    t = object.__new__(train_uniter.TrainerUniter)
+    t.config = {'config': 'uniter-base', 'n_classes': 1, 'precision': 'bf16', 'pack_padded': True}
+    t.model_file = '/nonexistent/best_model.pt'
+    import torch
+    base = dict(train_uniter.resolve_config('uniter-base').to_dict(), num_hidden_layers=1, vocab_size=200)
+    real = train_uniter.resolve_config
+    train_uniter.resolve_config = lambda _: train_uniter.UniterConfig.from_dict(base)
+    try:
+        t.load_model()
+    finally:
+        train_uniter.resolve_config = real
+    assert t.model.uniter_model.precision == 'bf16' and t.model.uniter_model.pack_padded is True
