@@ -23,7 +23,8 @@ def pick(rs, needle, counter):
 def main(src, out):
     f, w = rows(os.path.join(src, 'pmc_fetch.csv')), rows(os.path.join(src, 'pmc_write.csv'))
     res = {}
-    for name, needle in (('ffn_up_fwd', 'false, false, 1, false'), ('adam', 'adam_kernel')):
+    for name, needle in (('ffn_up_fwd', 'false, false, 1, false'), ('wgrad_stream_k', 'gemm_f32_v3_kernel<64, 64, true, true, 0, true>'),
+                         ('dgrad', 'gemm_f32_v3_kernel<64, 64, false, true, 0, false>'), ('adam', 'adam_kernel')):
         fk, n = pick(f, needle, 'FETCH_SIZE')
         wk, _ = pick(w, needle, 'WRITE_SIZE')
         res[name] = {'launches': n, 'fetch_size_kib': fk, 'write_size_kib': wk,
@@ -32,6 +33,19 @@ def main(src, out):
     M, N, K = 2624, 3072, 768
     res['ffn_up_fwd']['algorithmic_bytes'] = 4 * (M * K + N * K + N + 2 * M * N)
     res['ffn_up_fwd']['shape'] = {'M': M, 'N': N, 'K': K}
+    # weight gradients: 48 launches of four shapes per step ([768|3072|2304] x [768|3072], K = 2624): operands read once,
+    # outputs added with float atomics (WRITE_SIZE counts them exactly); algorithmic bytes averaged over the four shapes
+    H, I = 768, 3072
+    shapes = [(H, I), (I, H), (H, H), (3 * H, H)]
+    res['wgrad_stream_k']['algorithmic_bytes_avg'] = sum(4 * (M * a + M * b2 + a * b2) for a, b2 in shapes) / len(shapes)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+        from meme_challenge_amd import _lib
+        build = _lib.lib().uniter_build_info().decode()
+        for k in ('ffn_up_fwd', 'wgrad_stream_k', 'dgrad'):
+            res[k]['build'] = build
+    except Exception as e:          # the summary is still valid without the stamp
+        res['build_error'] = str(e)
     res['note'] = ('memory-side (L2 miss) bytes per launch; Infinity-Cache hits are included, so reads exceed the '
                    'algorithmic bytes by the per-XCD re-fetch of the weight panel (8 L2s)')
     json.dump(res, open(out, 'w'), indent=1)
