@@ -289,7 +289,7 @@ def main():
         kernel_of = {'f32': {1: 'gemm_f32_v3_kernel<64,64,false,false,TAG=1>', 6: 'gemm_f32_v3_kernel<64,64,false,true,...>',
                              7: 'gemm_f32_v3_kernel<64,64,true,true,0,SK> (stream-K)'},
                      'bf16': {1: 'gemm_dma_kernel<128,128,false,false,SWAP,2,EPI=5> (bias + GELU + gelu\' bf16)',
-                              6: 'gemm_dma_kernel<128,128,false,true,SWAP,2,EPI>', 7: 'gemm_bf16_kernel<64,64,true,true,0,SK,RES> (stream-K)'}}
+                              6: 'gemm_dma_kernel<128,128,false,true,SWAP,2,EPI>', 7: 'gemm_dma_wgrad_group_kernel<2> (the four weight gradients of a layer in one launch of whole-K 128x128 tiles)'}}
         families = []
         for k, (name, bound, work) in fam.items():
             in_run = k_n[k] > 0

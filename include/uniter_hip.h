@@ -160,6 +160,15 @@ int uniter_ln_bwd_rows_slabs(const float* dy, int nslab, size_t slab_stride, con
                              const float* rstd, const float* gamma, float* dz, float* dx, void* dx_bf16,
                              int want_dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
                              uint32_t site, void* ws, size_t ws_bytes, void* stream);
+/* The weight gradients of one encoder layer in ONE launch (csrc/gemm_bf16_dma.hip; replaces the autograd products
+ * dW = dY^T X behind nn.Linear of model/layer.py:76-78,112,140,153 in the bf16 mode): for p < n (n <= 4)
+ * dW[p] [M[p], N[p]] (fp32, leading dimension N[p]) += A[p]^T B[p] with A[p] [K, M[p]] and B[p] [K, N[p]] bf16
+ * row-major (both operands k-major, any K).  The 128 x 128 tiles of all products are numbered through; every tile is
+ * owned by one workgroup over the whole K, so dW += is a plain read-modify-write -- no atomics, no partial sums, and
+ * the result does not depend on the launch (bit-reproducible).  cfg 0/1 = two LDS stages, 4 = three.
+ * M[p] % 8 == 0, N[p] % 8 == 0, 16-byte aligned buffers; the dW[p] must not overlap. */
+int uniter_wgrad_bf16_group(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
+                            const void* const* B, float* const* dW, void* stream);
 /* out[n] += sum_m X[m, n] for a bf16 matrix X [M, ld] (bias gradient of a dense layer from the bf16 gradient of its
  * output; replaces the autograd sum of model/layer.py:140 in the bf16 mode).  N % 8 == 0, ld % 8 == 0. */
 int uniter_colsum_bf16_add(const void* X, int M, int N, int ld, float* out, void* stream);
@@ -368,6 +377,14 @@ int uniter_adam_step_mirror(float* params, float* grads, float* exp_avg, float* 
                             float grad_scale, float max_norm, float lr, float beta1, float beta2,
                             float eps, float weight_decay, int step, int adamw, int zero_grads,
                             void* mirror_bf16, void* stream);
+/* as uniter_adam_step_mirror with the grid capped at max_workgroups (0 = the default, which fills every wave slot of
+ * the chip): a launch that shares the GPU with the next forward (trainer.FusedAdam's per-layer blocks on the side
+ * stream) leaves the wave slots the forward's kernels need -- at full occupancy it slows them three-fold. */
+int uniter_adam_step_ex(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                        const uint8_t* chunk_flags, size_t n, const double* sumsq,
+                        float grad_scale, float max_norm, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int step, int adamw, int zero_grads,
+                        void* mirror_bf16, int max_workgroups, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Whole-model schedule: the library owns the kernel sequence of

@@ -57,6 +57,7 @@ _SIGS = {
     'uniter_ln_bwd_rows_slabs': (_I, [_P, _I, _SZ, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_slab_reduce_add': (_I, [_P, _I, _SZ, _P, _SZ, _P]),
     'uniter_colsum_bf16_add': (_I, [_P, _I, _I, _I, _P, _P]),
+    'uniter_wgrad_bf16_group': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _P]),
     'uniter_ln_bwd_b16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_ln_bwd_rows': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_ln_bwd_finalize': (_I, [_P, _SZ, _I, _I, _P, _P, _P, _P]),
@@ -104,6 +105,7 @@ _SIGS = {
     'uniter_grad_sumsq_ws_bytes': (_SZ, [_SZ]),
     'uniter_adam_step': (_I, [_P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P]),
     'uniter_adam_step_mirror': (_I, [_P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _P]),
+    'uniter_adam_step_ex': (_I, [_P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _I, _P]),
     'uniter_num_params': (_I, [C.POINTER(UniterConfigC)]),
     'uniter_param_name': (C.c_char_p, [C.POINTER(UniterConfigC), _I]),
     'uniter_param_shape': (_I, [C.POINTER(UniterConfigC), _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

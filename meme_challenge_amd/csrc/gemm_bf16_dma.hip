@@ -181,27 +181,29 @@ __device__ __forceinline__ void wait_lgkm8(u32x2_t& a, u32x2_t& b, u32x2_t& c, u
 #endif
 }
 
+// work item of this workgroup, XCD-chunked (blocks b and b + 8 share an XCD's L2: consecutive items go to one XCD);
+// -1 for the padding blocks of the grid
+__device__ __forceinline__ int xcd_work_item(int nwork) {
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int q8 = nwork >> 3, r8 = nwork & 7;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+  return idx < chunk_n ? chunk0 + idx : -1;
+}
+
+// one work item w = (tile, k-piece) of the product g
 template <int BM, int BN, bool AKM, bool BKM, bool SWAP, int ST, int EPI>
-__global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_dma_kernel(const GArgsD g) {
+__device__ __forceinline__ void gemm_dma_tile(const GArgsD& g, const int w, unsigned char* smem) {
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtins / asm: the host pass gets an empty body (it only needs the launch stub)
   constexpr int WNN = BN / 64, NW = (BM / 64) * WNN;
   constexpr int IMG_A = BM * 128, IMG_B = BN * 128, STAGE = IMG_A + IMG_B;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i5 = lane & 31, h = lane >> 5;
   const int wm = wave / WNN, wn = wave % WNN;
 
-  // work item -> (tile, k-piece): XCD-chunked (blocks b and b + 8 share an XCD's L2), banded tile order
-  const int nwork = g.tiles_m * g.tiles_n * g.nsplit;
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int q8 = nwork >> 3, r8 = nwork & 7;
-  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
-  if (idx >= chunk_n) return;
   stamp_begin(g.stamp);
-  const int w = chunk0 + idx;
   const int tile = w / g.nsplit, piece = w - tile * g.nsplit;
   int tmi, tni;
   tile_coords_d(tile, g.tiles_m, g.tiles_n, g.band_h, tmi, tni);
@@ -505,13 +507,46 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_dma_kernel
 }
 
 template <int BM, int BN, bool AKM, bool BKM, bool SWAP, int ST, int EPI>
-int launch_d(GArgsD g, hipStream_t st) {
+__global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_dma_kernel(const GArgsD g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * (BM + BN) * 128];
+  // work item -> (tile, k-piece), banded tile order inside an XCD's chunk
+  const int w = xcd_work_item(g.tiles_m * g.tiles_n * g.nsplit);
+  if (w < 0) return;
+  gemm_dma_tile<BM, BN, AKM, BKM, SWAP, ST, EPI>(g, w, smem);
+}
+
+// The weight gradients of one encoder layer as ONE launch: up to four products dW_p[M_p, N_p] += A_p^T B_p (both
+// operands k-major, K = rows of the batch) whose 128 x 128 tiles are numbered through.  A layer of UNITER-base has
+// 144 + 144 + 108 + 36 = 432 tiles for the chip's 512 workgroup slots: every tile is owned by one workgroup over
+// the whole K, so there are no partial sums to exchange (no atomics, no slabs) and dW += is a plain
+// read-modify-write in the epilogue (UNITER_EPI_ADD with the output as its own aux operand).
+struct GGroupD {
+  GArgsD p[4];
+  int start[5];     // first work item of product p; start[n..4] = total
+};
+
+template <int ST>
+__global__ __launch_bounds__(256, 2) void gemm_dma_wgrad_group_kernel(const GGroupD G) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * 256 * 128];
+  const int w = xcd_work_item(G.start[4]);
+  if (w < 0) return;
+  const int p = (w >= G.start[1]) + (w >= G.start[2]) + (w >= G.start[3]);
+  gemm_dma_tile<128, 128, true, true, true, ST, UNITER_EPI_ADD>(G.p[p], w - G.start[p], smem);
+}
+
+template <int BM>
+void plan_tiles(GArgsD& g, int BN) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   const long panel = (long)BM * g.K * 2;
   long bh = (3l << 19) / (panel > 0 ? panel : 1);
   g.band_h = (int)(bh < 1 ? 1 : (bh > 16 ? 16 : bh));
   if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
+}
+
+template <int BM, int BN, bool AKM, bool BKM, bool SWAP, int ST, int EPI>
+int launch_d(GArgsD g, hipStream_t st) {
+  plan_tiles<BM>(g, BN);
   const int nwork = g.tiles_m * g.tiles_n * g.nsplit;
   const int grid = (nwork + 7) / 8 * 8;
   hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, AKM, BKM, SWAP, ST, EPI>), dim3(grid), dim3(64 * (BM / 64) * (BN / 64)), 0, st, g);
@@ -590,6 +625,45 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
   if (a_kmajor) return beta ? dispatch_wgrad<false>(cfg, g, st) : dispatch_wgrad<true>(cfg, g, st);
   if (beta) return b_kmajor ? dispatch_cfg<true, false, UNITER_EPI_NONE>(cfg, g, st) : dispatch_cfg<false, false, UNITER_EPI_NONE>(cfg, g, st);
   return b_kmajor ? dispatch_epi<true>(cfg, g, st) : dispatch_epi<false>(cfg, g, st);
+}
+
+// dW_p[M_p, N_p] += A_p^T B_p for up to four products of one reduction length K (A_p [K, M_p], B_p [K, N_p] bf16,
+// dW_p fp32 with leading dimension N_p), one launch; cfg 1 = two LDS stages (two workgroups per CU), 4 = three.
+int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A,
+                            const void* const* B, float* const* dW, void* stream) {
+  UCHECK_ARG(n >= 1 && n <= 4 && K > 0 && Mo && No && A && B && dW, "wgrad_group: bad argument");
+  GGroupD G;
+  unsigned long long* stamp = take_stamp_slot();
+  int total = 0;
+  for (int p = 0; p < 4; ++p) {
+    G.start[p] = total;
+    if (p >= n) { G.p[p] = G.p[0]; continue; }
+    UCHECK_ARG(Mo[p] > 0 && No[p] > 0 && A[p] && B[p] && dW[p], "wgrad_group: bad product %d", p);
+    UCHECK_SHAPE(Mo[p] % 8 == 0 && No[p] % 8 == 0 && ((uintptr_t)A[p] & 15) == 0 && ((uintptr_t)B[p] & 15) == 0 &&
+                 ((uintptr_t)dW[p] & 15) == 0 && (size_t)(K + 64) * (Mo[p] > No[p] ? Mo[p] : No[p]) * 2 < (1ull << 31) &&
+                 ((size_t)Mo[p] + 256) * No[p] * 4 < (1ull << 31),
+                 "wgrad_group: M, N %% 8, 16-byte aligned buffers, 31-bit offsets (product %d: %d x %d, K=%d)", p, Mo[p], No[p], K);
+    GArgsD& g = G.p[p];
+    g.M = Mo[p]; g.N = No[p]; g.K = K; g.A = A[p]; g.lda = Mo[p]; g.B = B[p]; g.ldb = No[p]; g.C = dW[p]; g.ldc = No[p];
+    g.c_split_stride = 0; g.Cb = nullptr; g.ldcb = 0; g.epi = UNITER_EPI_ADD; g.bias = nullptr;
+    g.aux_in = dW[p]; g.aux_in_bf16 = 0; g.aux_out = nullptr; g.aux_out_bf16 = 0; g.ld_aux = No[p];
+    g.nsplit = 1; g.stamp = stamp; g.dbg = 0;
+    plan_tiles<128>(g, 128);
+    total += g.tiles_m * g.tiles_n;
+  }
+  G.start[4] = total;
+  for (int p = n; p < 4; ++p) G.start[p] = total;
+  const int grid = (total + 7) / 8 * 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (cfg == 4) hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<3>), dim3(grid), dim3(256), 0, st, G);
+  else hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<2>), dim3(grid), dim3(256), 0, st, G);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_wgrad_bf16_group(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
+                                       const void* const* B, float* const* dW, void* stream) {
+  return gemm_bf16v2_wgrad_group(cfg, n, M, N, K, A, B, dW, stream);
 }
 
 // Split-K choice for the GEMMs whose N is the hidden size (measured on MI355X, tests/tools/gemm_v2_lab.py,

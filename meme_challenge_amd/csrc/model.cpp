@@ -32,6 +32,8 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
                     int ld_aux, int beta, void* stream);
 int gemm_bf16v2_pick_split(int M, int N, int K);
 int gemm_bf16v2_wgrad_pieces(int M, int N, int K);
+int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A,
+                            const void* const* B, float* const* dW, void* stream);
 int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta, hipStream_t st);
 int finalize_partials_jobs(int njobs, const float* const* part, const int* nparts, const size_t* stride,
                            float* const (*outs)[3], const int* nout, const int* seg, hipStream_t st);
@@ -91,6 +93,7 @@ struct Plan {
   // the LayerNorm row pass that consumes them): K = intermediate (FFN-down forward, FFN-up dgrad), K = 3 hidden (QKV dgrad)
   int ns_ki, ns_k3h;
   bool packed;      // rows = valid positions only (uniter_batch_t::cu_seqlens)
+  int wg_group;           // precision 2: the layer's four weight gradients as one whole-K-tile launch (0 = stream-K, 1 / 4 = LDS stages cfg)
   float* wg_slabs;        // precision 2: k-piece slabs of the split-K weight-gradient GEMMs (side stream, reused by every layer)
   void *ln_ws, *col_ws, *emb_ws, *attn_ws;
   size_t ln_ws_bytes, col_ws_bytes, emb_ws_bytes, attn_ws_bytes;
@@ -104,7 +107,7 @@ struct uniter_model {
   int n_params;
   std::vector<float*> p, g;
   std::vector<std::string> names;
-  std::vector<hipEvent_t> ev_main, ev_side;
+  std::vector<hipEvent_t> ev_main, ev_side, ev_mid;
   int precision = 0;        // 0 = fp32 MFMA GEMMs, 1 = bf16 MFMA GEMMs (fp32 storage)
   const unsigned short* mirror = nullptr;   // bf16 copy of the flat parameter buffer (precision 2)
   const float* mirror_base = nullptr;
@@ -228,6 +231,11 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
     pl.attn_ws_bytes = uniter_attn_bwd_ws_bytes(B, L, c.num_attention_heads);
     pl.attn_ws = cv.raw(pl.attn_ws_bytes);
     pl.wg_slabs = pl.res ? cv.f((size_t)4 * 3 * H * (I > 3 * H ? I : 3 * H)) : nullptr;
+    // 1 (default): the four weight gradients of a layer as one launch of whole-K tiles (gemm_bf16_dma.hip); 0: four
+    // stream-K launches with float atomics; 2: as 1 with the three early products launched next to the attention
+    // backward (measured slower); 4: as 1 with three LDS stages (measured slower)
+    static const int wg_env = [] { const char* e = getenv("UNITER_WGRAD_GROUP"); return e ? atoi(e) : 1; }();
+    pl.wg_group = (pl.res && H % 8 == 0 && I % 8 == 0 && (wg_env == 1 || wg_env == 2 || wg_env == 4)) ? wg_env : 0;
   }
   pl.total = cv.off;
 }
@@ -388,9 +396,10 @@ extern "C" int uniter_model_create(const uniter_config_t* cfg, float* const* par
     }
   }
   const int nl = cfg->num_hidden_layers;
-  m->ev_main.resize(nl + 1); m->ev_side.resize(nl + 1);
+  m->ev_main.resize(nl + 1); m->ev_side.resize(nl + 1); m->ev_mid.resize(nl + 1);
   for (int i = 0; i <= nl; ++i) {
     hipError_t e1 = hipEventCreateWithFlags(&m->ev_main[i], hipEventDisableTiming);
+    if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&m->ev_mid[i], hipEventDisableTiming);
     hipError_t e2 = hipEventCreateWithFlags(&m->ev_side[i], hipEventDisableTiming);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       uniter_set_error("model_create: hipEventCreate failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
@@ -405,6 +414,7 @@ extern "C" void uniter_model_destroy(uniter_model_t* m) {
   if (!m) return;
   for (auto e : m->ev_main) if (e) hipEventDestroy(e);
   for (auto e : m->ev_side) if (e) hipEventDestroy(e);
+  for (auto e : m->ev_mid) if (e) hipEventDestroy(e);
   for (auto e : m->prof_ev) if (e) hipEventDestroy(e);
   if (m->stamp_buf) (void)hipFree(m->stamp_buf);
   delete m;
@@ -659,6 +669,22 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                                        g1, res ? lb.g1b : nullptr, 1, M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l),
                                        lb.ln_ws1, pl.ln_ws_bytes, st));
   }
+  const bool wg_early = res && pl.wg_group >= 2 && sd != st;
+  if (wg_early) {
+    // the three weight gradients whose operands exist now (FFN down / up, attention output: 324 whole-K tiles) start on
+    // the side stream here, next to the attention backward (192 workgroups with large LDS: a quarter of the CUs idle)
+    UCHECK_HIP(hipEventRecord(m->ev_mid[l], st));
+    UCHECK_HIP(hipStreamWaitEvent(sd, m->ev_mid[l], 0));
+    const int Mo[3] = {I, H, H}, No[3] = {H, I, H};
+    const void* const As[3] = {lb.dub, lb.g2b, lb.g1b};
+    const void* const Bs[3] = {lb.y1b, lb.hactb, lb.ctxb};
+    float* const dWs[3] = {m->LG(l, L_W1), m->LG(l, L_W2), m->LG(l, L_OW)};
+    {
+      ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
+      UCHECK_RC(gemm_bf16v2_wgrad_group(1, 3, Mo, No, M, As, Bs, dWs, sd));
+    }
+    UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
+  }
   if (res) {
     UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, H, lb.g1b, H, m->WB(l, L_OW), H, lb.dctx, H, 1, nullptr, 0,
                       UNITER_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0));
@@ -715,11 +741,31 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   if (res) {
     const unsigned short* xb = l == 0 ? pl.embb : pl.layers[l - 1].y2b;
-    UCHECK_RC(wgrad_b16(m, pl, sd, H, I, M, lb.g2b, lb.hactb, m->LG(l, L_W2)));
-    UCHECK_RC(wgrad_b16(m, pl, sd, I, H, M, lb.dub, lb.y1b, m->LG(l, L_W1)));
-    UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
-    UCHECK_RC(wgrad_b16(m, pl, sd, H, H, M, lb.g1b, lb.ctxb, m->LG(l, L_OW)));
-    UCHECK_RC(wgrad_b16(m, pl, sd, 3 * H, H, M, lb.dqkvb, xb, m->LG(l, L_QW)));
+    if (wg_early) {
+      const int Mo[1] = {3 * H}, No[1] = {H};
+      const void* const As[1] = {lb.dqkvb};
+      const void* const Bs[1] = {xb};
+      float* const dWs[1] = {m->LG(l, L_QW)};
+      ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
+      UCHECK_RC(gemm_bf16v2_wgrad_group(1, 1, Mo, No, M, As, Bs, dWs, sd));
+    } else if (pl.wg_group) {
+      // all four weight gradients of the layer as one launch: 432 whole-K tiles for 512 workgroup slots (UNITER-base)
+      const int Mo[4] = {I, H, 3 * H, H}, No[4] = {H, I, H, H};
+      const void* const As[4] = {lb.dub, lb.g2b, lb.dqkvb, lb.g1b};
+      const void* const Bs[4] = {lb.y1b, lb.hactb, xb, lb.ctxb};
+      float* const dWs[4] = {m->LG(l, L_W1), m->LG(l, L_W2), m->LG(l, L_QW), m->LG(l, L_OW)};
+      {
+        ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
+        UCHECK_RC(gemm_bf16v2_wgrad_group(pl.wg_group == 4 ? 4 : 1, 4, Mo, No, M, As, Bs, dWs, sd));
+      }
+      UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
+    } else {
+      UCHECK_RC(wgrad_b16(m, pl, sd, H, I, M, lb.g2b, lb.hactb, m->LG(l, L_W2)));
+      UCHECK_RC(wgrad_b16(m, pl, sd, I, H, M, lb.dub, lb.y1b, m->LG(l, L_W1)));
+      UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
+      UCHECK_RC(wgrad_b16(m, pl, sd, H, H, M, lb.g1b, lb.ctxb, m->LG(l, L_OW)));
+      UCHECK_RC(wgrad_b16(m, pl, sd, 3 * H, H, M, lb.dqkvb, xb, m->LG(l, L_QW)));
+    }
   } else {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, g2, H, lb.hact, I, m->LG(l, L_W2), I, UNITER_EPI_NONE,
                    nullptr, nullptr, nullptr, 0, 1));

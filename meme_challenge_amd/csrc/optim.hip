@@ -57,6 +57,36 @@ struct AdamArgs {
   unsigned short* mirror;     // optional bf16 copy of the updated parameters (precision 'bf16' weight mirror)
 };
 
+#define NT_LOAD(base, idx) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base) + (idx))
+__device__ __forceinline__ void adam_update4(const AdamArgs& a, float coef, float wd, f32x4& p, const f32x4& g, f32x4& m, f32x4& v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float gg = g[e] * coef;
+    float pp = p[e];
+    if (a.adamw) pp *= 1.0f - a.lr * wd;
+    else gg += wd * pp;
+    m[e] = a.b1 * m[e] + (1.0f - a.b1) * gg;
+    v[e] = a.b2 * v[e] + (1.0f - a.b2) * gg * gg;
+    const float denom = sqrtf(v[e]) * a.inv_sqrt_bc2 + a.eps;
+    p[e] = pp - a.step_size * (m[e] / denom);
+  }
+}
+__device__ __forceinline__ void adam_store4(const AdamArgs& a, size_t i, const f32x4& p, const f32x4& m, const f32x4& v) {
+  // the update streams 34 bytes per parameter once: non-temporal accesses, so that it does not evict the operand panels of
+  // the forward kernels that share the chip with it from the L2s
+  __builtin_nontemporal_store(p, reinterpret_cast<f32x4*>(a.p) + i);
+  if (a.mirror) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    reinterpret_cast<bf16x4_t*>(a.mirror)[i] = bf16x4_t{(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
+  }
+  __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(a.m) + i);
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.v) + i);
+  if (a.zero_grads) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(a.g) + i);
+}
+
+// Two 16-byte elements per thread and iteration, all eight loads issued before the arithmetic: a grid of one or two
+// workgroups per CU (the launch that shares the chip with the next forward, see trainer.FusedAdam) still keeps
+// 32-64 KB per CU in flight.
 __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
   float coef = a.gscale;
   if (a.max_norm > 0.f && a.sumsq) {
@@ -64,33 +94,21 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     const float c = a.max_norm / (total + 1e-6f);                   // clip_grad_norm_
     coef *= c < 1.0f ? c : 1.0f;
   }
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) {
-    const uint8_t f = a.flags[(i * 4) / CHUNK];
-    if (f == 0) continue;
-    const float wd = f == 2 ? a.wd : 0.f;
-    f32x4 p = reinterpret_cast<f32x4*>(a.p)[i];
-    f32x4 g = reinterpret_cast<f32x4*>(a.g)[i];
-    f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
-    f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float gg = g[e] * coef;
-      float pp = p[e];
-      if (a.adamw) pp *= 1.0f - a.lr * wd;
-      else gg += wd * pp;
-      m[e] = a.b1 * m[e] + (1.0f - a.b1) * gg;
-      v[e] = a.b2 * v[e] + (1.0f - a.b2) * gg * gg;
-      const float denom = sqrtf(v[e]) * a.inv_sqrt_bc2 + a.eps;
-      p[e] = pp - a.step_size * (m[e] / denom);
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += 2 * stride) {
+    const size_t j = i + stride;
+    const bool two = j < a.n4;
+    const uint8_t f0 = a.flags[(i * 4) / CHUNK];
+    const uint8_t f1 = two ? a.flags[(j * 4) / CHUNK] : 0;
+    f32x4 p0, g0, m0, v0, p1, g1, m1, v1;
+    if (f0) {
+      p0 = NT_LOAD(a.p, i); g0 = NT_LOAD(a.g, i); m0 = NT_LOAD(a.m, i); v0 = NT_LOAD(a.v, i);
     }
-    reinterpret_cast<f32x4*>(a.p)[i] = p;
-    if (a.mirror) {
-      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-      reinterpret_cast<bf16x4_t*>(a.mirror)[i] = bf16x4_t{(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
+    if (f1) {
+      p1 = NT_LOAD(a.p, j); g1 = NT_LOAD(a.g, j); m1 = NT_LOAD(a.m, j); v1 = NT_LOAD(a.v, j);
     }
-    reinterpret_cast<f32x4*>(a.m)[i] = m;
-    reinterpret_cast<f32x4*>(a.v)[i] = v;
-    if (a.zero_grads) reinterpret_cast<f32x4*>(a.g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (f0) { adam_update4(a, coef, f0 == 2 ? a.wd : 0.f, p0, g0, m0, v0); adam_store4(a, i, p0, m0, v0); }
+    if (f1) { adam_update4(a, coef, f1 == 2 ? a.wd : 0.f, p1, g1, m1, v1); adam_store4(a, j, p1, m1, v1); }
   }
 }
 
@@ -130,6 +148,15 @@ extern "C" int uniter_adam_step_mirror(float* params, float* grads, float* exp_a
                                        float max_norm, float lr, float beta1, float beta2, float eps,
                                        float weight_decay, int step, int adamw, int zero_grads,
                                        void* mirror_bf16, void* stream) {
+  return uniter_adam_step_ex(params, grads, exp_avg, exp_avg_sq, chunk_flags, n, sumsq, grad_scale, max_norm, lr, beta1,
+                             beta2, eps, weight_decay, step, adamw, zero_grads, mirror_bf16, 0, stream);
+}
+
+extern "C" int uniter_adam_step_ex(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                   const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale,
+                                   float max_norm, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, int step, int adamw, int zero_grads,
+                                   void* mirror_bf16, int max_workgroups, void* stream) {
   UCHECK_ARG(params && grads && exp_avg && exp_avg_sq && chunk_flags, "adam_step: null pointer");
   UCHECK_SHAPE(n % CHUNK == 0, "adam_step: n must be a multiple of 64");
   UCHECK_ARG(step >= 1, "adam_step: step must be >= 1");
@@ -143,7 +170,8 @@ extern "C" int uniter_adam_step_mirror(float* params, float* grads, float* exp_a
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   a.step_size = (float)((double)lr / bc1);
   a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-  const int nb = sumsq_blocks(n);
+  int nb = sumsq_blocks(n);
+  if (max_workgroups > 0 && nb > max_workgroups) nb = max_workgroups;
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
   UCHECK_LAUNCH();
   return 0;

@@ -24,6 +24,7 @@ must be built, otherwise a ``UniterHipError`` is raised.
 import copy
 import ctypes as C
 import json
+import os
 import logging
 
 import numpy as np

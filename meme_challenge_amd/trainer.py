@@ -15,6 +15,7 @@ iteration needs no host synchronisation (the reference does `.item()` /
 `.cpu()` every iteration, train_template.py:121-124).
 """
 import math
+import os
 
 import torch
 
@@ -102,6 +103,7 @@ class FusedAdam(torch.optim.Optimizer):
         # set to the UniterModel to overlap the update with the next forward (see step()); anything
         # else that reads parameters on the current stream must call join() first
         self.overlap_encoder = None
+        self.overlap_workgroups = int(os.environ.get('UNITER_ADAM_OVERLAP_WGS', '256'))
         self._pending = None
         self._plan_cache = None
 
@@ -180,16 +182,17 @@ class FusedAdam(torch.optim.Optimizer):
 
         mirror = getattr(st, 'mirror', None)
 
-        def launch(lo, hi, stream_ptr):
+        def launch(lo, hi, stream_ptr, max_wgs=0):
             off = lo * 4
             # the bf16 weight mirror (precision 'bf16') is written by the same kernel, on the same stream
-            check(lib.uniter_adam_step_mirror(st.flat_params.data_ptr() + off, st.flat_grads.data_ptr() + off,
-                                              self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
-                                              flags.data_ptr() + lo // CHUNK, hi - lo, ptr(self._sumsq),
-                                              float(grad_scale), float(max_grad_norm or 0.0), lr, float(b1), float(b2),
-                                              float(g0['eps']), float(g0['weight_decay']), self.step_count,
-                                              int(self.adamw), int(bool(zero_grads)),
-                                              (mirror.data_ptr() + lo * 2) if mirror is not None else None, stream_ptr),
+            check(lib.uniter_adam_step_ex(st.flat_params.data_ptr() + off, st.flat_grads.data_ptr() + off,
+                                          self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
+                                          flags.data_ptr() + lo // CHUNK, hi - lo, ptr(self._sumsq),
+                                          float(grad_scale), float(max_grad_norm or 0.0), lr, float(b1), float(b2),
+                                          float(g0['eps']), float(g0['weight_decay']), self.step_count,
+                                          int(self.adamw), int(bool(zero_grads)),
+                                          (mirror.data_ptr() + lo * 2) if mirror is not None else None, max_wgs,
+                                          stream_ptr),
                   'uniter_adam_step')
 
         enc = self.overlap_encoder
@@ -214,11 +217,13 @@ class FusedAdam(torch.optim.Optimizer):
             side.wait_stream(main)
             events = []
             import ctypes as C
-            for lo, hi in blocks:
+            for k, (lo, hi) in enumerate(blocks):
                 if grad_ready is not None:
                     with torch.cuda.stream(side):
                         grad_ready(lo, hi)
-                launch(lo, hi, C.c_void_p(side.cuda_stream))
+                # the embeddings' block has the chip to itself (the forward waits for it); the layers' blocks share it
+                # with the forward of the layers before them: a grid that leaves the forward its wave slots
+                launch(lo, hi, C.c_void_p(side.cuda_stream), 0 if k == 0 else self.overlap_workgroups)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 events.append(ev)

@@ -174,3 +174,48 @@ def test_weight_gradient_layout(cfg):
     _run_wgrad(cfg, M=128, N=128, K=192, nsplit=1, beta=1)          # C += by atomics
     _run_wgrad(cfg, M=768, N=3072, K=2624, nsplit=3, beta=0)        # FFN weight gradient of the model
     _run_wgrad(cfg, M=2304, N=768, K=2624, nsplit=4, beta=0)
+
+
+def _group_call(lib, L, cfg, Ms, Ns, K, As, Bs, Cs):
+    import ctypes
+    n = len(Ms)
+    IA = ctypes.c_int * n
+    PA = ctypes.c_void_p * n
+    return lib.uniter_wgrad_bf16_group(cfg, n, IA(*Ms), IA(*Ns), K, PA(*[a.data_ptr() for a in As]),
+                                       PA(*[b.data_ptr() for b in Bs]), PA(*[c.data_ptr() for c in Cs]), L.cur_stream())
+
+
+@pytest.mark.parametrize('cfg', [1, 4])
+@pytest.mark.parametrize('shapes,K', [([(128, 128)], 64), ([(136, 200), (256, 128), (8, 8)], 200),
+                                      ([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 2624),
+                                      ([(256, 64), (64, 256), (192, 64), (64, 64)], 1458)])
+def test_weight_gradient_group(cfg, shapes, K):
+    """Up to four dW += dY^T X products of one reduction length in ONE launch, whole-K tiles, read-modify-write of dW:
+    against fp64 on the same bf16 operands, and bit-identical when repeated (no atomics)."""
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(len(shapes) * 1000 + K)
+    As = [torch.randn(K, M, generator=g).bfloat16().cuda() for M, N in shapes]
+    Bs = [torch.randn(K, N, generator=g).bfloat16().cuda() for M, N in shapes]
+    C0 = [torch.randn(M, N, generator=g) for M, N in shapes]
+    outs = []
+    for rep in range(2):
+        Cs = [c.cuda().contiguous() for c in C0]
+        L.check(_group_call(lib, L, cfg, [m for m, _ in shapes], [n for _, n in shapes], K, As, Bs, Cs), 'wgrad group')
+        torch.cuda.synchronize()
+        outs.append([c.cpu() for c in Cs])
+    for (M, N), a, b, c0, c, c2 in zip(shapes, As, Bs, C0, outs[0], outs[1]):
+        ref = a.cpu().double().t() @ b.cpu().double() + c0.double()
+        assert (c.double() - ref).abs().max().item() < 1e-4 * math.sqrt(K), (M, N, K)
+        assert torch.equal(c, c2)
+
+
+def test_weight_gradient_group_rejects_bad_arguments():
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    a = torch.zeros(64, 12, dtype=torch.bfloat16, device='cuda')
+    c = torch.zeros(12, 12, device='cuda')
+    assert _group_call(lib, L, 1, [12], [12], 64, [a], [a], [c]) != 0          # M % 8
+    a = torch.zeros(64, 16, dtype=torch.bfloat16, device='cuda')
+    c = torch.zeros(16, 16, device='cuda')
+    assert _group_call(lib, L, 1, [16] * 5, [16] * 5, 64, [a] * 5, [a] * 5, [c] * 5) != 0     # more than four products

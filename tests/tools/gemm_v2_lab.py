@@ -98,3 +98,28 @@ if not only or 'wgrad' in only:
             for k, r in runs.items(): res[k].append(timeit(r, graphs[k]))
         fl = 2.0 * M * N * K
         print('%-14s %5dx%5dx%5d  ' % (name, M, N, K) + '  '.join('%s %.1fus %4.0fTF' % (k, statistics.median(v) * 1e3, fl / statistics.median(v) / 1e9) for k, v in res.items()), flush=True)
+
+# ---- the four weight gradients of a layer: separate stream-K launches vs one grouped whole-K-tile launch ----
+if not only or 'wgroup' in only:
+    import ctypes
+    K = MM
+    shp = [(II, HH), (HH, II), (3 * HH, HH), (HH, HH)]
+    As = [torch.randn(K, m, device='cuda').bfloat16() for m, n in shp]; Bs = [torch.randn(K, n, device='cuda').bfloat16() for m, n in shp]
+    Cs = [torch.zeros(m, n, device='cuda') for m, n in shp]
+    IA = ctypes.c_int * 4; PA = ctypes.c_void_p * 4
+    Ms = IA(*[m for m, n in shp]); Ns = IA(*[n for m, n in shp])
+    pa = PA(*[a.data_ptr() for a in As]); pb = PA(*[b.data_ptr() for b in Bs]); pc = PA(*[c.data_ptr() for c in Cs])
+    def sep():
+        for (m, n), a, b, c in zip(shp, As, Bs, Cs):
+            lib.uniter_gemm_bf16res_cfg(0, 1, 1, m, n, K, L.ptr(a), m, L.ptr(b), n, L.ptr(c), n, None, 0, 0, None, None, None, 0, 1, L.cur_stream())
+    runs = {'v1_4launches': sep,
+            'group_c1': lambda: L.check(lib.uniter_wgrad_bf16_group(1, 4, Ms, Ns, K, pa, pb, pc, L.cur_stream())),
+            'group_c4': lambda: L.check(lib.uniter_wgrad_bf16_group(4, 4, Ms, Ns, K, pa, pb, pc, L.cur_stream()))}
+    for r in runs.values(): r()
+    torch.cuda.synchronize()
+    graphs = {k: make_graph(r) for k, r in runs.items()}
+    res = {k: [] for k in runs}
+    for _ in range(ROUNDS):
+        for k, r in runs.items(): res[k].append(timeit(r, graphs[k]))
+    fl = sum(2.0 * m * n * K for m, n in shp)
+    print('%-14s K=%d  ' % ('layer_wgrads', K) + '  '.join('%s %.1fus %4.0fTF' % (k, statistics.median(v) * 1e3, fl / statistics.median(v) / 1e9) for k, v in res.items()), flush=True)
