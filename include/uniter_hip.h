@@ -97,7 +97,8 @@ int uniter_gemm_bf16res_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, i
  * replaces cuBLAS behind nn.Linear of model/layer.py:76-78,112,140,153 in the bf16 mode): operands reach LDS by
  * LDS-DMA through a ring of stages with counted vmcnt waits; the accumulator is held transposed so outputs leave
  * as 16-byte row stores.  Layouts (a_kmajor, b_kmajor): (0,0) x @ W^T, (0,1) dgrad.  cfg 1 = 128x128 tile
- * (2 stages, two workgroups per CU), 2 = 128x256, 3 = 256x128 (8 waves, 3 stages), 4 = 128x128 (3 stages).
+ * (2 stages, two workgroups per CU), 2 = 128x256, 3 = 256x128 (8 waves, 3 stages), 4 = 128x128 (3 stages),
+ * 5 = 64x128 (2 waves; the few-tile shapes), 0 = choose.
  * nsplit > 1 cuts K into pieces computed by different workgroups: piece s stores its fp32 partial tile at
  * C + s * c_split_stride (piece 0 applies the epilogue) and the CONSUMER adds the slabs (no bf16 output then).
  * aux_in / aux_out are fp32 or bf16 ([M, ld_aux] elements) as the *_bf16 flags say.  beta = 1: C += product

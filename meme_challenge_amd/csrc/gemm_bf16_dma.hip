@@ -571,7 +571,8 @@ int dispatch_cfg(int cfg, const GArgsD& g, hipStream_t st) {
     case 2: return launch_d<128, 256, false, BKM, SWAP, 3, EPI>(g, st);     // 8 waves, one workgroup per CU
     case 3: return launch_d<256, 128, false, BKM, SWAP, 3, EPI>(g, st);
     case 4: return launch_d<128, 128, false, BKM, SWAP, 3, EPI>(g, st);     // 4 waves, one workgroup per CU, deeper ring
-    default: uniter_set_error("gemm_bf16v2: bad cfg %d (1..4)", cfg); return UNITER_E_ARG;
+    case 5: return launch_d<64, 128, false, BKM, SWAP, 2, EPI>(g, st);      // 2 waves: twice the tiles for the few-tile shapes (N = hidden)
+    default: uniter_set_error("gemm_bf16v2: bad cfg %d (1..5)", cfg); return UNITER_E_ARG;
   }
 }
 
@@ -591,7 +592,7 @@ int dispatch_epi(int cfg, const GArgsD& g, hipStream_t st) {
 
 }  // namespace
 
-// cfg: 1 = 128x128 (2 stages), 2 = 128x256, 3 = 256x128, 4 = 128x128 (3 stages); 0 = choose.
+// cfg: 1 = 128x128 (2 stages), 2 = 128x256, 3 = 256x128, 4 = 128x128 (3 stages), 5 = 64x128 (2 waves); 0 = choose.
 // beta = 1: C += A.B through fp32 atomics (lane = column orientation; no epilogue, no bf16 output).
 int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda,
                     const void* B, int ldb, float* C, int ldc, long c_split_stride, void* Cb, int ldcb, int epilogue,
@@ -620,7 +621,12 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.nsplit = nsplit;
   g.dbg = cfg >> 8; cfg &= 0xff;
   g.stamp = take_stamp_slot();
-  if (cfg == 0) cfg = 1;
+  if (cfg == 0) {
+    // few tiles and one k-piece (the attention-output products: 126 tiles of 128 x 128 for 256 CUs): 64 x 128 tiles,
+    // twice the workgroups (12.0 -> 10.6 us forward, 11.7 -> 10.0 us input gradient; profiles/r02_gemm_bf16_v2.txt)
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    cfg = (!a_kmajor && nsplit == 1 && tiles <= 160) ? 5 : 1;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (a_kmajor) return beta ? dispatch_wgrad<false>(cfg, g, st) : dispatch_wgrad<true>(cfg, g, st);
   if (beta) return b_kmajor ? dispatch_cfg<true, false, UNITER_EPI_NONE>(cfg, g, st) : dispatch_cfg<false, false, UNITER_EPI_NONE>(cfg, g, st);

@@ -630,8 +630,10 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   } else {
     dy = pl.layers[l + 1].dx;
   }
-  float* g2 = ph > 0.f ? lb.g2 : lb.dz2;
-  float* g1 = ph > 0.f ? lb.g1 : lb.dz1;
+  // the dropped gradient in fp32: the operand of the fp32 GEMMs; the bf16-resident GEMMs read its bf16 copy only, so
+  // the fp32 store (8 MB per pass) is skipped there
+  float* g2 = ph > 0.f ? (pl.res ? nullptr : lb.g2) : lb.dz2;
+  float* g1 = ph > 0.f ? (pl.res ? nullptr : lb.g1) : lb.dz1;
   // precision 2: the next layer's dx may be split-K slabs (summed here); never for the last layer (dy is the caller's
   // gradient), with all_layers (dy is dsum) or in layer 0 (the embedding backward reads a plain dx)
   const int ns_dy = (l == nl - 1 || m->all_layers) ? 1 : pl.ns_k3h;

@@ -79,7 +79,7 @@ def _run(cfg, bkm, M, N, K, epi, nsplit=1, out='both', aux_in_bf16=False, aux_ou
             assert (ga - pre).abs().max().item() < tol, tag
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4, 5])
 @pytest.mark.parametrize('bkm', [0, 1])
 def test_layouts_and_edges(cfg, bkm):
     _run(cfg, bkm, M=168, N=192, K=128, epi=0)                       # ragged M, N not a tile multiple
@@ -89,7 +89,7 @@ def test_layouts_and_edges(cfg, bkm):
     _run(cfg, bkm, M=257, N=520, K=320, epi=1, out='bf16')
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4, 5])
 def test_epilogues(cfg):
     for epi in (0, 1, 2, 5):
         _run(cfg, 0, M=200, N=256, K=128, epi=epi, aux_out_bf16=False)
@@ -99,7 +99,7 @@ def test_epilogues(cfg):
         _run(cfg, 1, M=200, N=256, K=128, epi=epi, aux_in_bf16=True, out='bf16')
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4, 5])
 @pytest.mark.parametrize('nsplit', [2, 3, 4])
 def test_split_k_slabs(cfg, nsplit):
     _run(cfg, 0, M=300, N=256, K=640, epi=1, nsplit=nsplit)
@@ -107,7 +107,7 @@ def test_split_k_slabs(cfg, nsplit):
     _run(cfg, 0, M=130, N=128, K=128, epi=1, nsplit=nsplit)          # fewer k-tiles than pieces: empty pieces store zeros
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4, 5])
 def test_model_shapes(cfg):
     _run(cfg, 0, M=2624, N=3072, K=768, epi=5, out='bf16', aux_out_bf16=True)     # FFN up
     _run(cfg, 0, M=2624, N=2304, K=768, epi=1, out='bf16')                         # QKV
