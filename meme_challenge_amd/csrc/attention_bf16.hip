@@ -19,6 +19,7 @@
 //   * the dK/dV kernel contracts over queries with both operands in natural order: Q^T / dO^T
 //     transposed in LDS (one ds_read_b128 per MFMA) against Pd / dS read from the bf16 scratch the dQ
 //     kernel wrote ([B*nh][key][query], half the bytes of the fp32 kernels' scratch).
+#include <type_traits>
 #include "common.h"
 #include "philox.h"
 
@@ -68,47 +69,69 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-// rows [0, Lr) x 64 columns of an fp32 matrix (row stride ld) -> bf16 [row][KLD]; rows >= L are zero
-__device__ __forceinline__ void stage_rm(u16* s, const float* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
-  for (int idx = tid; idx < Lr * 16; idx += nthr) {
-    const int r = idx >> 4, c4 = idx & 15;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < L) v = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c4 * 4);
+// One [L, 64] operand on its way into LDS: the 16-byte pieces of this thread (blockDim.x = 4 Lr: four pieces of an fp32
+// source, two of a bf16 source) are ALL loaded before anything else happens -- the kernels issue the loads of every
+// operand and of their row fragments first and write LDS afterwards (piece by piece, each write waited for its own
+// load: ~10 us of memory latency in a row at the head of every attention kernel, tests/tools/attn_phase_lab.py).
+// store_rm: bf16 image [row][KLD] (rows >= L zero); store_tr: transposed image [d][TLD] (columns >= L zero).
+struct StageF {       // fp32 source, rounded to bf16 on the way
+  f32x4 v[4];
+  __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
+      v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < Lr * 16 && r < L) v[it] = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c4 * 4);
+    }
+  }
+  __device__ __forceinline__ void store_rm(u16* s, int Lr, int tid, int nthr) const {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-    *reinterpret_cast<u32x2*>(s + r * KLD + c4 * 4) = o;
-  }
-}
-// same source -> transposed bf16 [d][TLD] (column = row of the source); columns >= L are zero
-__device__ __forceinline__ void stage_tr(u16* s, const float* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
-  for (int idx = tid; idx < Lr * 16; idx += nthr) {
-    const int r = idx >> 4, c4 = idx & 15;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < L) v = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c4 * 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s[(c4 * 4 + e) * TLD + r] = __builtin_bit_cast(u16, (__bf16)v[e]);
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
+      if (idx < Lr * 16) *reinterpret_cast<u32x2*>(s + r * KLD + c4 * 4) = u32x2{pack2(v[it][0], v[it][1]), pack2(v[it][2], v[it][3])};
+    }
   }
-}
-
-// the same three for a bf16 source (no conversion: 16-byte pieces of 8 values)
-__device__ __forceinline__ void stage_rm(u16* s, const u16* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
-  for (int idx = tid; idx < Lr * 8; idx += nthr) {
-    const int r = idx >> 3, c8 = idx & 7;
-    bf16x8 v = {};
-    if (r < L) v = *reinterpret_cast<const bf16x8*>(base + (size_t)r * ld + c8 * 8);
-    *reinterpret_cast<bf16x8*>(s + r * KLD + c8 * 8) = v;
+  __device__ __forceinline__ void store_tr(u16* s, int Lr, int tid, int nthr) const {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
+      if (idx < Lr * 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[(c4 * 4 + e) * TLD + r] = __builtin_bit_cast(u16, (__bf16)v[it][e]);
+      }
+    }
   }
-}
-__device__ __forceinline__ void stage_tr(u16* s, const u16* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
+};
+struct StageH {       // bf16 source, copied as stored
   typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-  for (int idx = tid; idx < Lr * 8; idx += nthr) {
-    const int r = idx >> 3, c8 = idx & 7;
-    u16x8 v = {};
-    if (r < L) v = *reinterpret_cast<const u16x8*>(base + (size_t)r * ld + c8 * 8);
+  u16x8 v[2];
+  __device__ __forceinline__ void load(const u16* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[(c8 * 8 + e) * TLD + r] = v[e];
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 3, c8 = idx & 7;
+      v[it] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (idx < Lr * 8 && r < L) v[it] = *reinterpret_cast<const u16x8*>(base + (size_t)r * ld + c8 * 8);
+    }
   }
-}
+  __device__ __forceinline__ void store_rm(u16* s, int Lr, int tid, int nthr) const {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 3, c8 = idx & 7;
+      if (idx < Lr * 8) *reinterpret_cast<u16x8*>(s + r * KLD + c8 * 8) = v[it];
+    }
+  }
+  __device__ __forceinline__ void store_tr(u16* s, int Lr, int tid, int nthr) const {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 3, c8 = idx & 7;
+      if (idx < Lr * 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[(c8 * 8 + e) * TLD + r] = v[it][e];
+      }
+    }
+  }
+};
 __device__ __forceinline__ void row_frags(bf16x8 (&f)[4], const u16* __restrict__ row, bool valid, int h) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -220,16 +243,23 @@ __global__ __launch_bounds__(768) void attn_b16_fwd_kernel(const Args a, int Lr)
   bf16x8 qf[4];
   if (a.qb16) {
     const u16* base = static_cast<const u16*>(a.qkv) + boff;
-    stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
-    stage_tr(Vt, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+    StageH sk, sv;
+    sk.load(base + a.H, ld, Lb, Lr, tid, nthr);
+    sv.load(base + 2 * a.H, ld, Lb, Lr, tid, nthr);
     row_frags(qf, base + (size_t)q * ld, vq, h);
+    stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+    sk.store_rm(Kb, Lr, tid, nthr);
+    sv.store_tr(Vt, Lr, tid, nthr);
   } else {
     const float* base = static_cast<const float*>(a.qkv) + boff;
-    stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
-    stage_tr(Vt, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+    StageF sk, sv;
+    sk.load(base + a.H, ld, Lb, Lr, tid, nthr);
+    sv.load(base + 2 * a.H, ld, Lb, Lr, tid, nthr);
     row_frags(qf, base + (size_t)q * ld, vq, h);
+    stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+    sk.store_rm(Kb, Lr, tid, nthr);
+    sv.store_tr(Vt, Lr, tid, nthr);
   }
-  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
   __syncthreads();
 
   const int kmid = ((sp.nb + 1) >> 1) * 32;
@@ -311,6 +341,7 @@ __global__ __launch_bounds__(768) void attn_b16_fwd_kernel(const Args a, int Lr)
 
 // ------------------------------------------------- backward: dQ, delta, Pd / dS scratch ---
 // LDS: K row-major | V row-major | K transposed | mask bias
+template <bool QB16>
 __global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr, int red_off) {
   u16* Kb = reinterpret_cast<u16*>(smem_raw);
   u16* Vb = Kb + Lr * KLD;
@@ -327,33 +358,42 @@ __global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr, 
   const int q = qb * 32 + i;
   const bool vq = q < Lb;
   bf16x8 qf[4], dof[4];
-  if (a.qb16) {
-    const u16* base = static_cast<const u16*>(a.qkv) + boff;
-    stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
-    stage_rm(Vb, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
-    stage_tr(Kt, base + a.H, ld, Lb, Lr, tid, nthr);
-    row_frags(qf, base + (size_t)q * ld, vq, h);
-  } else {
-    const float* base = static_cast<const float*>(a.qkv) + boff;
-    stage_rm(Kb, base + a.H, ld, Lb, Lr, tid, nthr);
-    stage_rm(Vb, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
-    stage_tr(Kt, base + a.H, ld, Lb, Lr, tid, nthr);
-    row_frags(qf, base + (size_t)q * ld, vq, h);
-  }
-  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
-  float* red = reinterpret_cast<float*>(smem_raw + red_off);
-  for (int t = tid; t < 192; t += nthr) red[t] = 0.f;        // (a 32-row workgroup has only 128 threads)
   const float* dorow = a.dctx + ((size_t)sp.row0 + q) * a.H + head * D;
-  row_frags(dof, dorow, vq, h);
-  float delta = 0.f;
-  if (vq) {
-    const float* orow = a.ctx + ((size_t)sp.row0 + q) * a.H + head * D;
+  const float* orow = a.ctx + ((size_t)sp.row0 + q) * a.H + head * D;
+  // this lane's 32 of the 64 values of its dO and O rows (d = 16 s + 8 h + 4 j + 0..3 at index 2 s + j: the k-slots of the
+  // dO operand); delta = O . dO is the sum of both halves' partial dot products
+  f32x4 dob[8], ob[8];
+  float* red = reinterpret_cast<float*>(smem_raw + red_off);
+  typedef typename std::conditional<QB16, u16, float>::type src_t;
+  typename std::conditional<QB16, StageH, StageF>::type sk, sv;
+  {
+    // every global load of the prologue is issued before the first LDS write (K is loaded once for both of its images)
+    const src_t* base = static_cast<const src_t*>(a.qkv) + boff;
+    sk.load(base + a.H, ld, Lb, Lr, tid, nthr);
+    sv.load(base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+    row_frags(qf, base + (size_t)q * ld, vq, h);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const f32x4 o = *reinterpret_cast<const f32x4*>(orow + 32 * h + 4 * c);
-      const f32x4 d = *reinterpret_cast<const f32x4*>(dorow + 32 * h + 4 * c);
-      delta += o[0] * d[0] + o[1] * d[1] + o[2] * d[2] + o[3] * d[3];
+      dob[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      ob[c] = dob[c];
+      if (vq) {
+        dob[c] = *reinterpret_cast<const f32x4*>(dorow + 16 * (c >> 1) + 8 * h + 4 * (c & 1));
+        ob[c] = *reinterpret_cast<const f32x4*>(orow + 16 * (c >> 1) + 8 * h + 4 * (c & 1));
+      }
     }
+    stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+    for (int t = tid; t < 192; t += nthr) red[t] = 0.f;        // (a 32-row workgroup has only 128 threads)
+    sk.store_rm(Kb, Lr, tid, nthr);
+    sk.store_tr(Kt, Lr, tid, nthr);
+    sv.store_rm(Vb, Lr, tid, nthr);
+  }
+  float delta = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) delta += ob[c][0] * dob[c][0] + ob[c][1] * dob[c][1] + ob[c][2] * dob[c][2] + ob[c][3] * dob[c][3];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const f32x4 x = dob[2 * st], y = dob[2 * st + 1];
+    dof[st] = bf16x8{(__bf16)x[0], (__bf16)x[1], (__bf16)x[2], (__bf16)x[3], (__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
   }
   delta += __shfl_xor(delta, 32, 64);
   if (vq && h == 0 && half == 0) a.delta[(size_t)bh * a.L + q] = delta;
@@ -438,11 +478,22 @@ __global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr,
   const Span sp = span_of(a, b);
   const int Lb = sp.Lb, ld = 3 * a.H;
   const size_t boff = (size_t)sp.row0 * ld + head * D;
-  if (a.qb16) stage_tr(Qt, static_cast<const u16*>(a.qkv) + boff, ld, Lb, Lr, tid, nthr);
-  else stage_tr(Qt, static_cast<const float*>(a.qkv) + boff, ld, Lb, Lr, tid, nthr);
-  stage_tr(dOt, a.dctx + (size_t)sp.row0 * a.H + head * D, a.H, Lb, Lr, tid, nthr);
   float* red = reinterpret_cast<float*>(smem_raw + red_off);
-  for (int t = tid; t < 192; t += nthr) red[t] = 0.f;        // (a 32-row workgroup has only 128 threads)
+  {
+    StageF sdo;
+    sdo.load(a.dctx + (size_t)sp.row0 * a.H + head * D, a.H, Lb, Lr, tid, nthr);
+    if (a.qb16) {
+      StageH sq;
+      sq.load(static_cast<const u16*>(a.qkv) + boff, ld, Lb, Lr, tid, nthr);
+      sq.store_tr(Qt, Lr, tid, nthr);
+    } else {
+      StageF sq;
+      sq.load(static_cast<const float*>(a.qkv) + boff, ld, Lb, Lr, tid, nthr);
+      sq.store_tr(Qt, Lr, tid, nthr);
+    }
+    for (int t = tid; t < 192; t += nthr) red[t] = 0.f;        // (a 32-row workgroup has only 128 threads)
+    sdo.store_tr(dOt, Lr, tid, nthr);
+  }
   const int key = kb * 32 + i;
   const bool vk = key < Lb;
   const int qmid = ((sp.nb + 1) >> 1) * 32;
@@ -555,9 +606,14 @@ extern "C" int uniter_attn_bf16_bwd(const void* qkv, int qkv_is_bf16, const floa
   const size_t red_dq = max3((size_t)(2 * Lr * KLD + D * TLD) * 2 + Lr * 4, (size_t)nblk * XROW * 64 * 4, 0);
   const size_t red_dkv = max3((size_t)(2 * D * TLD) * 2, (size_t)nblk * 64 * 64 * 4, 0);
   const size_t lds_dq = red_dq + 192 * 4, lds_dkv = red_dkv + 192 * 4;
-  UCHECK_RC(set_lds(attn_b16_dq_kernel, lds_dq));
   UCHECK_RC(set_lds(attn_b16_dkv_kernel, lds_dkv));
-  hipLaunchKernelGGL(attn_b16_dq_kernel, dim3(B * nh), dim3(Lr * 4), lds_dq, (hipStream_t)stream, a, Lr, (int)red_dq);
+  if (a.qb16) {
+    UCHECK_RC(set_lds(attn_b16_dq_kernel<true>, lds_dq));
+    hipLaunchKernelGGL(attn_b16_dq_kernel<true>, dim3(B * nh), dim3(Lr * 4), lds_dq, (hipStream_t)stream, a, Lr, (int)red_dq);
+  } else {
+    UCHECK_RC(set_lds(attn_b16_dq_kernel<false>, lds_dq));
+    hipLaunchKernelGGL(attn_b16_dq_kernel<false>, dim3(B * nh), dim3(Lr * 4), lds_dq, (hipStream_t)stream, a, Lr, (int)red_dq);
+  }
   UCHECK_LAUNCH();
   hipLaunchKernelGGL(attn_b16_dkv_kernel, dim3(B * nh), dim3(Lr * 4), lds_dkv, (hipStream_t)stream, a, Lr, (int)red_dkv);
   UCHECK_LAUNCH();

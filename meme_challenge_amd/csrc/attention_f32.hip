@@ -344,14 +344,43 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
 // ---------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) float dyn_smem[];
 
-__device__ __forceinline__ void stage_rows(float* s, const float* __restrict__ base, int ld, int L, int Lr,
-                                           int tid, int nthr) {
-  for (int idx = tid; idx < Lr * 16; idx += nthr) {
-    const int r = idx >> 4, c4 = idx & 15;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < L) v = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c4 * 4);
-    *reinterpret_cast<f32x4*>(s + r * LDT + c4 * 4) = v;
+// Two [L, 64] operands -> LDS images [Lr][LDT] (rows >= L zero).  IT = Lr * 16 / blockDim.x 16-byte pieces per thread and
+// operand (4 with the split kernels' Lr * 4 threads, 8 with the resident kernels' Lr * 2): ALL 2 * IT loads are issued
+// before the first LDS write (and the split kernels issue their row-fragment loads in between) -- one piece at a time (load, wait, write) left 8 memory latencies in a row, 9.8 of the
+// 57 us of the dQ kernel (tests/tools/attn_phase_lab.py).
+template <int IT>
+struct Stage2 {
+  f32x4 v1[IT], v2[IT];
+  __device__ __forceinline__ void load(const float* __restrict__ base1, int ld1, const float* __restrict__ base2, int ld2,
+                                       int L, int Lr, int tid, int nthr) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
+      v1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      v2[it] = v1[it];
+      if (idx < Lr * 16 && r < L) {
+        v1[it] = *reinterpret_cast<const f32x4*>(base1 + (size_t)r * ld1 + c4 * 4);
+        v2[it] = *reinterpret_cast<const f32x4*>(base2 + (size_t)r * ld2 + c4 * 4);
+      }
+    }
   }
+  __device__ __forceinline__ void store(float* s1, float* s2, int Lr, int tid, int nthr) const {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
+      if (idx < Lr * 16) {
+        *reinterpret_cast<f32x4*>(s1 + r * LDT + c4 * 4) = v1[it];
+        *reinterpret_cast<f32x4*>(s2 + r * LDT + c4 * 4) = v2[it];
+      }
+    }
+  }
+};
+template <int IT>
+__device__ __forceinline__ void stage_rows2(float* s1, const float* __restrict__ base1, int ld1, float* s2,
+                                            const float* __restrict__ base2, int ld2, int L, int Lr, int tid, int nthr) {
+  Stage2<IT> st;
+  st.load(base1, ld1, base2, ld2, L, Lr, tid, nthr);
+  st.store(s1, s2, Lr, tid, nthr);
 }
 
 __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs a, int Lr) {
@@ -363,8 +392,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs a, int
   const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
   const int ld = 3 * a.H;
   const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
-  stage_rows(Ks, base + a.H, ld, a.L, Lr, tid, nthr);
-  stage_rows(Vs, base + 2 * a.H, ld, a.L, Lr, tid, nthr);
+  stage_rows2<8>(Ks, base + a.H, ld, Vs, base + 2 * a.H, ld, a.L, Lr, tid, nthr);
   for (int k = tid; k < Lr; k += nthr)
     mb[k] = k < a.L ? (1.0f - a.mask[(size_t)b * a.L + k]) * -10000.0f : NEG_INF;
   const int q = wave * 32 + i;
@@ -427,8 +455,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs a, 
   const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
   const int ld = 3 * a.H;
   const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
-  stage_rows(Ks, base + a.H, ld, a.L, Lr, tid, nthr);
-  stage_rows(Vs, base + 2 * a.H, ld, a.L, Lr, tid, nthr);
+  stage_rows2<8>(Ks, base + a.H, ld, Vs, base + 2 * a.H, ld, a.L, Lr, tid, nthr);
   for (int k = tid; k < Lr; k += nthr)
     mb[k] = k < a.L ? (1.0f - a.mask[(size_t)b * a.L + k]) * -10000.0f : NEG_INF;
   const int q = wave * 32 + i;
@@ -483,8 +510,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnArgs a,
   const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
   const int ld = 3 * a.H;
   const float* base = a.qkv + (size_t)b * a.L * ld + head * D;
-  stage_rows(Qs, base, ld, a.L, Lr, tid, nthr);
-  stage_rows(dOs, a.dctx + (size_t)b * a.L * a.H + head * D, a.H, a.L, Lr, tid, nthr);
+  stage_rows2<8>(Qs, base, ld, dOs, a.dctx + (size_t)b * a.L * a.H + head * D, a.H, a.L, Lr, tid, nthr);
   for (int k = tid; k < Lr; k += nthr) {
     lse_s[k] = k < a.L ? a.lse[(size_t)bh * a.L + k] : -NEG_INF;
     del_s[k] = k < a.L ? a.delta[(size_t)bh * a.L + k] : 0.f;
@@ -550,6 +576,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnArgs a,
 // products (dV = Pd^T dO, dK = dS^T Q) -- half the MFMAs of recomputing S and dP, no exp, no Philox.
 // ---------------------------------------------------------------------------
 constexpr int SPLIT_MAX_LR = 192;
+#ifdef ATTN_STAMPS      // measurement builds only (tests/tools/attn_phase_lab.py): per-workgroup phase clocks
+__device__ unsigned long long g_attn_stamps[3 * 8 * 1024];
+#define ASTAMP(kern, k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_attn_stamps[((kern) * 1024 + blockIdx.x) * 8 + (k)] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ASTAMP(kern, k) do { } while (0)
+#endif
 constexpr int XROW = 34;             // floats exchanged per lane: 32 accumulators + (m, l)
 
 // Packed (varlen) batches: with a.cu set, sample b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx / dqkv,
@@ -600,13 +632,14 @@ __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, i
   const int Lb = sp.Lb;
   const int ld = 3 * a.H;
   const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
-  stage_rows(Ks, base + a.H, ld, Lb, Lr, tid, nthr);
-  stage_rows(Vs, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
-  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+  Stage2<4> stg;
+  stg.load(base + a.H, ld, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
   const int q = qb * 32 + i;
   const bool vq = q < Lb;
   f32x4 qf[8];
   load_row_frags(qf, base + (size_t)q * ld, vq, h);
+  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+  stg.store(Ks, Vs, Lr, tid, nthr);
   __syncthreads();
 
   const int kmid = ((sp.nb + 1) >> 1) * 32;
@@ -697,10 +730,9 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
   const int Lb = sp.Lb;
   const int ld = 3 * a.H;
   const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
-  stage_rows(Ks, base + a.H, ld, Lb, Lr, tid, nthr);
-  stage_rows(Vs, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
-  stage_mask(mb, a, b, Lb, Lr, tid, nthr);
-  for (int t = tid; t < 192; t += nthr) dyn_smem[2 * Lr * LDT + 2 * Lr + t] = 0.f;      // (a 32-row workgroup has only 128 threads)
+  ASTAMP(1, 0);
+  Stage2<4> stg;
+  stg.load(base + a.H, ld, base + 2 * a.H, ld, Lb, Lr, tid, nthr);
   const int q = qb * 32 + i;
   const bool vq = q < Lb;
   f32x4 qf[8], dof[8];
@@ -710,6 +742,9 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
   {
     f32x4 of[8];
     load_row_frags(of, a.ctx + ((size_t)sp.row0 + q) * a.H + head * D, vq, h);
+    stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+    for (int t = tid; t < 192; t += nthr) dyn_smem[2 * Lr * LDT + 2 * Lr + t] = 0.f;      // (a 32-row workgroup has only 128 threads)
+    stg.store(Ks, Vs, Lr, tid, nthr);
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
@@ -719,7 +754,9 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
   }
   // an out-of-range query has lse = +inf: every probability (and so Pd, dS) of its column is 0
   const float lse = vq ? a.lse[(size_t)bh * a.L + q] : -NEG_INF;
+  ASTAMP(1, 1);
   __syncthreads();
+  ASTAMP(1, 2);
 
   // blocks [0, nb) x [0, nb) of the scratch are written in full (zeros where query or key >= Lb):
   // that is exactly what the dK/dV kernel reads
@@ -759,13 +796,16 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
     }
     tileT_times_acc(Ks + k0 * LDT, s, dq0, dq1, i, h);
   }
+  ASTAMP(1, 3);
   __syncthreads();
+  ASTAMP(1, 4);
   float* xb = dyn_smem + (size_t)qb * XROW * 64;
   if (half) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { xb[r * 64 + lane] = dq0[r]; xb[(16 + r) * 64 + lane] = dq1[r]; }
   }
   __syncthreads();
+  ASTAMP(1, 5);
   float* red = dyn_smem + 2 * Lr * LDT + 2 * Lr;        // 192 floats behind everything else (res_lds_bytes)
   if (!half) {
 #pragma unroll
@@ -780,6 +820,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
     __syncthreads();
     if (tid < 64) a.bias_part[(size_t)b * 3 * a.H + head * D + tid] = red[tid];
   }
+  ASTAMP(1, 6);
 }
 
 // dV^T[d][key] = sum_q dO[q][d] Pd[q][key],  dK^T[d][key] = sum_q Q[q][d] dS[q][key]
@@ -797,8 +838,8 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs 
   const int Lb = sp.Lb;
   const int ld = 3 * a.H;
   const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
-  stage_rows(Qs, base, ld, Lb, Lr, tid, nthr);
-  stage_rows(dOs, a.dctx + (size_t)sp.row0 * a.H + head * D, a.H, Lb, Lr, tid, nthr);
+  Stage2<4> stg;
+  stg.load(base, ld, a.dctx + (size_t)sp.row0 * a.H + head * D, a.H, Lb, Lr, tid, nthr);
   for (int t = tid; t < 192; t += nthr) dyn_smem[2 * Lr * LDT + 2 * Lr + t] = 0.f;      // (a 32-row workgroup has only 128 threads)
   const int key = kb * 32 + i;
   const bool vk = key < Lb;
@@ -817,6 +858,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs 
       wd[g] = *reinterpret_cast<const f32x4*>(dsr + qbeg + 8 * g);
     }
   }
+  stg.store(Qs, dOs, Lr, tid, nthr);
   __syncthreads();
 
   f32x16 dk0, dk1, dv0, dv1;
@@ -1068,3 +1110,10 @@ extern "C" int uniter_attn_bwd(const float* qkv, const float* attn_mask, const f
   UCHECK_LAUNCH();
   return 0;
 }
+
+#ifdef ATTN_STAMPS
+extern "C" int uniter_dbg_attn_stamps(unsigned long long* out, size_t n) {
+  UCHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), n * sizeof(unsigned long long)));
+  return 0;
+}
+#endif
