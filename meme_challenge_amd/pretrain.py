@@ -13,6 +13,8 @@ the flat gradient buffer, including both tied weights.
 """
 from collections import defaultdict
 
+import logging
+
 import torch
 from torch import nn
 
@@ -20,6 +22,8 @@ from . import _lib
 from ._lib import check, ptr, UniterHipError
 from .model import (UniterModel, UniterPreTrainedModel, HipLinear, ensure_store, _ensure_grad,
                     _mark_touched, _ParamLinear, _ParamLayerNorm)
+
+logger = logging.getLogger(__name__)
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_ADD = range(5)
 
@@ -443,9 +447,12 @@ class UniterForPretraining(UniterPreTrainedModel):
 
     def forward_itm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                     targets, ot_inputs=None, compute_loss=True):
-        if ot_inputs is not None:
-            raise NotImplementedError('the OT branch computes a value the reference discards '
-                                      '(model/pretrain.py:197-203); it is outside the built scope')
+        if ot_inputs is not None and not getattr(self, '_warned_ot', False):
+            # model/pretrain.py:168-203 computes the optimal-transport distance of the batch and then returns the ITM
+            # loss / scores alone (both `return ..., ot_loss` lines are commented out there): nothing a caller sees
+            # depends on it, so the IPOT iterations of model/ot.py are not run here
+            logger.info('forward_itm: ot_inputs given -- the reference discards the OT distance it computes from them; skipped')
+            self._warned_ot = True
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                           output_all_encoded_layers=False)
         pooled = self.uniter.pooler(seq)

@@ -49,11 +49,17 @@ def test_pretrain_task_matches_reference(pre, task):
     assert m.feat_regress.weight is m.uniter.img_embeddings.img_linear.weight
 
 
-def test_pretrain_out_of_scope_tasks_raise(pre):
-    m = _model(pre)
+def test_itm_with_ot_inputs_returns_what_the_reference_returns(pre):
+    """model/pretrain.py:168-203 computes an OT distance from ot_inputs and returns the ITM loss alone: the presence of
+    ot_inputs changes nothing a caller sees."""
+    m = _model(pre).eval()
     b = {k: v.cuda() for k, v in batch_from_npz(pre).items()}
-    with pytest.raises(NotImplementedError):
-        m(dict(b, ot_inputs={'ot_scatter': None}), 'itm')      # the OT branch (its value is discarded upstream)
+    with torch.no_grad():
+        plain = m(b, 'itm')
+        with_ot = m(dict(b, ot_inputs={'ot_scatter': None, 'scatter_max': 0, 'txt_pad': None, 'img_pad': None}), 'itm')
+        scores = m(dict(b, ot_inputs={'ot_scatter': None}), 'itm', compute_loss=False)
+    assert torch.equal(plain, with_ot)
+    assert scores.shape == (plain.shape[0], 2)
     with pytest.raises(ValueError):
         m(b, 'nope')
 

@@ -3,11 +3,11 @@ run() { echo "--- $*"; timeout 600 "$@" | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print(d['value'], d['ms_per_step'], [(f['family'], f['avg_us']) for f in d['roofline_families'] if 'attention' in f['family']])
+        d = json.loads(l); print(d['value'], d['ms_per_step'])
 "; }
-{ UNITER_LIB_VARIANT=stamps UNITER_DEV_PARTIAL_LIB=1 python tests/tools/attn_phase_lab.py
-  timeout 1200 python -m pytest tests/test_attention_gpu.py tests/test_attention_bf16_gpu.py tests/test_packed_gpu.py tests/test_parity_configs_gpu.py -q -x 2>&1 | tail -3
+{ for rep in 1 2 3; do for f in 0 1; do export UNITER_FIN_LATE=$f; echo "== FIN_LATE=$f"
   run python bench.py --precision bf16 --no_cpu_baseline
-  run python bench.py --no_cpu_baseline
+  run python bench.py --no_cpu_baseline --steps 40
+  done; done
 } > gpurun_out/prio.log 2>&1
 cat gpurun_out/prio.log
