@@ -11,9 +11,8 @@ The heads are composed from small autograd nodes whose forward / backward are C-
 (GEMM, LayerNorm, row gather, cross-entropy, KL divergence, MSE); parameter gradients accumulate directly into
 the flat gradient buffer, including both tied weights.
 """
-from collections import defaultdict
-
 import logging
+from collections import defaultdict
 
 import torch
 from torch import nn
