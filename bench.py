@@ -109,16 +109,23 @@ def pmc_traffic(args, M, cfgd, build_info):
     run, so this is a PROFILE ARTEFACT, reported only for the shape AND the library build it was taken on."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_traffic.json')
     try:
-        rec = json.load(open(path))['ffn_up_fwd']
+        allrec = json.load(open(path))
+        rec = allrec['ffn_up_fwd']
     except (OSError, KeyError, ValueError):
         return None
     shape = rec.get('shape', {})
-    if args.precision != 'fp32' or (shape.get('M'), shape.get('N'), shape.get('K')) != (
+    if args.precision != 'fp32' or args.workload != 'finetune' or (shape.get('M'), shape.get('N'), shape.get('K')) != (
             M, cfgd['intermediate_size'], cfgd['hidden_size']):
         return None
     if rec.get('build') and rec['build'] != build_info:
         return None
-    return int(rec['traffic_bytes'])
+    out = {'gemm_ffn_up_fwd': {'bytes_per_launch': int(rec['traffic_bytes']), 'algorithmic_bytes': int(rec['algorithmic_bytes'])}}
+    wg = allrec.get('wgrad_stream_k')
+    if wg and wg.get('build') == rec.get('build'):
+        # the time-dominant family of the fp32 step (average over its four shapes)
+        out['gemm_wgrad'] = {'bytes_per_launch': int(wg['traffic_bytes']), 'algorithmic_bytes': int(wg['algorithmic_bytes_avg']),
+                             'note': 'reads served by L2 misses: the operand set stays in the Infinity Cache (FETCH_SIZE counts L2 fills)'}
+    return out
 
 
 def main():
@@ -340,8 +347,9 @@ def main():
             out['roofline_families'] = families
             tr = pmc_traffic(args, M_eff, cfgd, build_info)
             if tr is not None:
-                out['traffic_from_profile'] = {'kernel': 'gemm_ffn_up_fwd', 'bytes_per_launch': tr,
-                                               'source': 'profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command)'}
+                out['traffic_from_profile'] = dict(tr, source='profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this '
+                                                              'command on this library build; FETCH_SIZE doubled per the gfx950 '
+                                                              'correction, WRITE_SIZE exact)')
         # the optimizer step alone (HBM-bound: 32 B / parameter), measured after the timed region
         opt.join()
         torch.cuda.synchronize()
