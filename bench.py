@@ -148,6 +148,7 @@ def main():
                     help='token packing: compute the valid positions only (pays off with --ragged; identical results)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_side_stream', action='store_true')
+    ap.add_argument('--prewarm_s', type=float, default=1.0, help='seconds of untimed steps before the W warm-up steps (clock ramp)')
     ap.add_argument('--no_adam_overlap', action='store_true',
                     help='run the optimizer step as one launch on the main stream instead of block by block beside the next forward')
     ap.add_argument('--prof_kind', type=int, default=-1, help='UNITER_K_* kind timed with HIP events inside the timed region (-1 = every kind, 0 = none)')
@@ -236,6 +237,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock warm-up (untimed, not part of W): a GPU that idled through the imports starts at its lowest clocks; about a
+    # second of steps before the W warm-up steps keeps the ramp out of the timed region
+    t_pre = time.perf_counter()
+    while args.prewarm_s > 0 and time.perf_counter() - t_pre < args.prewarm_s:
+        for _ in range(5):
+            one_step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         one_step()
     lib = _lib.lib()
