@@ -507,7 +507,7 @@ __device__ __forceinline__ void gemm_dma_tile(const GArgsD& g, const int w, unsi
 }
 
 template <int BM, int BN, bool AKM, bool BKM, bool SWAP, int ST, int EPI>
-__global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_dma_kernel(const GArgsD g) {
+__global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), (ST * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) void gemm_dma_kernel(const GArgsD g) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * (BM + BN) * 128];
   // work item -> (tile, k-piece), banded tile order inside an XCD's chunk
   const int w = xcd_work_item(g.tiles_m * g.tiles_n * g.nsplit);
@@ -526,7 +526,7 @@ struct GGroupD {
 };
 
 template <int ST>
-__global__ __launch_bounds__(256, 2) void gemm_dma_wgrad_group_kernel(const GGroupD G) {
+__global__ __launch_bounds__(256, (ST == 2 ? 2 : 1)) void gemm_dma_wgrad_group_kernel(const GGroupD G) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * 256 * 128];
   const int w = xcd_work_item(G.start[4]);
   if (w < 0) return;
