@@ -236,6 +236,8 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
     // backward (measured slower); 4: as 1 with three LDS stages (measured slower)
     static const int wg_env = [] { const char* e = getenv("UNITER_WGRAD_GROUP"); return e ? atoi(e) : 1; }();
     pl.wg_group = (pl.res && H % 8 == 0 && I % 8 == 0 && (wg_env == 1 || wg_env == 2 || wg_env == 4)) ? wg_env : 0;
+    // the grouped kernel addresses its operands with 31-bit buffer offsets: very long batches keep the stream-K launches
+    if ((size_t)(M + 64) * (I > 3 * H ? I : 3 * H) * 2 >= (1ull << 31)) pl.wg_group = 0;
   }
   pl.total = cv.off;
 }
