@@ -44,12 +44,32 @@ class _BceLogitsFn(torch.autograd.Function):
         ctx.save_for_backward(dlog)
         ctx.shape = logits.shape
         ctx.mark_non_differentiable(probs)
+        ctx.set_materialize_grads(False)           # no zero tensor for the probabilities' (absent) gradient
         return loss, probs
 
     @staticmethod
     def backward(ctx, dloss, _dprobs):
         (dlog,) = ctx.saved_tensors
+        if dloss is None:
+            return None, None, None
+        unit = _UNIT.get(dlog.device)
+        if unit is not None and dloss.data_ptr() == unit.data_ptr():
+            return dlog.view(ctx.shape), None, None          # loss.backward(unit_gradient(..)): d loss = 1, nothing to multiply
         return (dlog * dloss).view(ctx.shape), None, None
+
+
+_UNIT = {}
+
+
+def unit_gradient(device):
+    """A cached scalar 1.0 to pass as loss.backward(gradient=...): saves the ones_like fill autograd would launch for the
+    root and (recognised by its address in _BceLogitsFn.backward) the multiply by it -- two launch-latency-sized kernels
+    in the host-bound stretch between forward and backward."""
+    device = torch.device(device)
+    t = _UNIT.get(device)
+    if t is None:
+        t = _UNIT[device] = torch.ones((), dtype=torch.float32, device=device)
+    return t
 
 
 def bce_with_logits_loss(logits, labels, pos_weight=1.0, return_probs=False):
@@ -391,7 +411,7 @@ class TrainStep(object):
         stepping = self.iters % accum == 0
         if self.grad_sync is not None:
             self.grad_sync.prepare(will_step=stepping)
-        loss.backward()
+        loss.backward(unit_gradient(loss.device))
         if stepping:
             sync_step(self.optimizer, self.grad_sync, accum, cfg['max_grad_norm'])
             self.scheduler.step()
