@@ -262,9 +262,11 @@ def main():
     e_n, e_ms = (C.c_int * NK)(), (C.c_double * NK)()          # attention / LayerNorm: HIP events in a separate pass
     EV_STEPS = 5
     prof_error = None
+    bwd_union_ms = C.c_double(0.0)       # time with an input- or weight-gradient GEMM running (the two share the chip)
     if args.prof_kind:
         try:      # per-family figures are auxiliary: a failure here is reported in the line, it does not lose the line
             _lib.check(lib.uniter_prof_collect_stamps(handle, k_n, k_ms, NK))
+            _lib.check(lib.uniter_prof_stamps_union(handle, (1 << 6) | (1 << 7), C.byref(bwd_union_ms)))
             _lib.check(lib.uniter_prof_enable_stamps(handle, 0, None))
             # event pairs around every launch cost ~7 us each and serialise the two backward streams (fp32 step +11 %,
             # bf16 +27 %): they stay out of the timed region; this pass only times the kernels that carry no stamps
@@ -362,6 +364,15 @@ def main():
                                'launches': dom['launches_per_step'] * args.steps, 'avg_ms': round(dom['avg_us'] * 1e-3, 4),
                                'share_of_step_kernel_time': round(dom['ms_per_step'] / sum(f['ms_per_step'] for f in families), 3)}
             out['roofline_families'] = families
+            if bwd_union_ms.value > 0:
+                # the input- and weight-gradient GEMMs run beside each other on two streams: each family's in-situ rate
+                # above includes that sharing; this is the rate of both together over the time either of them ran
+                wk = 2 * fam[6][2]
+                sec_u = bwd_union_ms.value * 1e-3 / args.steps
+                out['backward_gemms_together'] = {'bound': 'mfma', 'ms_per_step': round(sec_u * 1e3, 4),
+                                                  'achieved': round(wk / sec_u / 1e12, 2), 'unit': 'TFLOP/s', 'peak': peak,
+                                                  'frac': round(wk / sec_u / (peak * 1e12), 4),
+                                                  'measured': 'union of the stamped launch intervals of gemm_dgrad and gemm_wgrad inside the timed region'}
             tr = pmc_traffic(args, M_eff, cfgd, build_info)
             if tr is not None:
                 out['traffic_from_profile'] = dict(tr, source='profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this '

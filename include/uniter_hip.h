@@ -488,6 +488,10 @@ int uniter_prof_collect_kinds(uniter_model_t* m, int* n_launches, double* total_
  * per GEMM kind (UNITER_K_GEMM_*).  Not a library-call path of the reference: measurement only. */
 int uniter_prof_enable_stamps(uniter_model_t* m, int on, void* stream);
 int uniter_prof_collect_stamps(uniter_model_t* m, int* n_launches, double* total_ms, int n_kinds);  /* synchronises */
+/* milliseconds during which at least one stamped launch of a kind in kind_mask (bit k = UNITER_K_* k) was running: the
+ * union of the launches' intervals, e.g. what the input- and weight-gradient GEMMs, which share the chip on two streams,
+ * took together.  Call before uniter_prof_enable_stamps(m, 0, ..) discards the stamps. */
+int uniter_prof_stamps_union(uniter_model_t* m, unsigned kind_mask, double* union_ms);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@
 // of each GEMM leaves idle.  Every layer owns its backward scratch, so the two
 // streams never race on a buffer (288 GB of HBM: ~3 GB for UNITER-base B=16).
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "common.h"
@@ -938,6 +939,40 @@ extern "C" int uniter_prof_collect_stamps(uniter_model_t* m, int* n_launches, do
     n_launches[m->stamp_tag[i]] += 1;
     total_ms[m->stamp_tag[i]] += (double)(t1 - t0) * 1e-5;  // 100 MHz ticks -> ms
   }
+  return 0;
+}
+
+// milliseconds during which at least one stamped launch of a kind in `kind_mask` (bit k = UNITER_K_* k) was running:
+// the union of the launches' [first start, last end] intervals -- what two streams that share the chip took TOGETHER
+extern "C" int uniter_prof_stamps_union(uniter_model_t* m, unsigned kind_mask, double* union_ms) {
+  UCHECK_ARG(m && union_ms, "prof_stamps_union: null pointer");
+  *union_ms = 0.0;
+  if (!m->stamp_buf || m->stamp_used == 0) return 0;
+  UCHECK_HIP(hipDeviceSynchronize());
+  const size_t per = (size_t)2 * STAMP_WGS;
+  std::vector<unsigned long long> h(m->stamp_used * per);
+  UCHECK_HIP(hipMemcpy(h.data(), m->stamp_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::vector<std::pair<unsigned long long, unsigned long long>> iv;
+  for (size_t i = 0; i < m->stamp_used; ++i) {
+    if (!((kind_mask >> m->stamp_tag[i]) & 1u)) continue;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int w = 0; w < STAMP_WGS; ++w) {
+      const unsigned long long a = h[i * per + w], b = h[i * per + STAMP_WGS + w];
+      if (a && a < t0) t0 = a;
+      if (b > t1) t1 = b;
+    }
+    if (t0 != ~0ull && t1 >= t0) iv.emplace_back(t0, t1);
+  }
+  std::sort(iv.begin(), iv.end());
+  unsigned long long tot = 0, cs = 0, ce = 0;
+  bool open = false;
+  for (auto& p : iv) {
+    if (!open) { cs = p.first; ce = p.second; open = true; }
+    else if (p.first > ce) { tot += ce - cs; cs = p.first; ce = p.second; }
+    else if (p.second > ce) ce = p.second;
+  }
+  if (open) tot += ce - cs;
+  *union_ms = (double)tot * 1e-5;
   return 0;
 }
 

@@ -42,6 +42,10 @@ def test_bench_default_contract():
     for f in fams.values():
         assert 0.0 < f['frac'] < 1.0, f
     assert d['optimizer']['bound'] == 'hbm' and 0.05 < d['optimizer']['frac'] < 1.0
+    # both gradient GEMM families over the time either of them ran: above each family's own in-situ rate, below the peak
+    t = d['backward_gemms_together']
+    assert max(fams['gemm_dgrad']['frac'], fams['gemm_wgrad']['frac']) < t['frac'] < 1.0
+    assert t['ms_per_step'] <= fams['gemm_dgrad']['ms_per_step'] + fams['gemm_wgrad']['ms_per_step'] + 1e-6
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'samples/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']
     assert c['single_thread']['value'] > 0 and c['gflops'] > 0 and c['cpu_model'] and c['os_cpu_count'] >= c['cores']
