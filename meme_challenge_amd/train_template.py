@@ -376,6 +376,7 @@ class TrainerTemplate(object):
         else:
             LOGGER.info("Maximum epochs of {} reached. Finished training !!".format(self.config['max_epoch']))
         self.test_metrics = dict()
+        self._check_replicas()
         if self.config['no_model_checkpoints']:
             LOGGER.info("No model checkpoints were saved. Hence, testing will be skipped.")
         elif _is_main():
@@ -389,6 +390,22 @@ class TrainerTemplate(object):
             # rank 0 may still be scoring the test sets: nobody leaves (tears RCCL down, starts the next fold,
             # globs the prediction files) before the files exist
             dist.barrier()
+
+    def _check_replicas(self):
+        """Data parallel: every rank applied the same update to the same reduced gradients, so the replicas hold the same
+        bits.  A difference means a gradient slice missed its collective -- fail loudly instead of exporting one rank's model."""
+        if not (_distributed() and dist.get_world_size() > 1 and hasattr(self.model, 'param_store')):
+            return
+        flat = self.model.param_store().flat_params
+        mine = torch.stack([flat.double().sum(), flat.double().abs().sum()])
+        every = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        ref = every[0]
+        for r, t in enumerate(every):
+            if not torch.allclose(t, ref, rtol=1e-12, atol=0.0):
+                raise RuntimeError('data-parallel replicas diverged: rank %d holds parameter sums %s, rank 0 %s'
+                                   % (r, t.tolist(), ref.tolist()))
+        LOGGER.info('data-parallel replicas agree (parameter checksum %.9e on %d ranks)' % (float(ref[1]), len(every)))
 
     def train_main(self, cache=False):
         self.start = time.time()

@@ -125,3 +125,43 @@ def test_cli_cross_validation_folds_and_ensemble(tmp_path):
         assert os.path.isfile(os.path.join(model_dir, 'best_model_fold_%d_dev_seen_preds.csv' % k))
     ens = open(os.path.join(model_dir, 'best_model_dev_seen_ensemble.csv')).read().splitlines()
     assert ens[0] == 'id,gt,proba,label' and len(ens) == 65
+
+
+def test_cli_two_ranks_shard_the_data_and_keep_their_replicas_equal(tmp_path):
+    """train_uniter.py --parallel_computing on two ranks (gloo, both on cuda:0): rank 0 writes the dataset while rank 1
+    waits, every rank draws its own batches, gradients are exchanged bucket by bucket, the replicas end with identical
+    parameters (TrainerTemplate._check_replicas raises otherwise), rank 0 alone exports, nobody leaves early."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = tmp_path / 'tiny.json'
+    cfg.write_text(json.dumps(dict(TINY, vocab_size=28996, max_position_embeddings=64)))
+    data_dir, model_dir = str(tmp_path / 'data'), str(tmp_path / 'ckpt')
+    args = [sys.executable, os.path.join(repo, 'train_uniter.py'), '--config', str(cfg), '--data_path', data_dir,
+            '--model_path', model_dir, '--vis_path', str(tmp_path / 'vis'), '--synthetic', '64', '--batch_size', '8',
+            '--max_epoch', '4', '--lr', '1e-3', '--warmup_steps', '2', '--pos_wt', '1.8', '--max_txt_len', '16',
+            '--seed', '1', '--log_every', '3', '--ragged_regions', '--parallel_computing', 'True']
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29551', WORLD_SIZE='2', LOCAL_RANK='0',
+               UNITER_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen(args, env=dict(env, RANK=str(r)), cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-4000:]
+    assert 'data-parallel replicas agree' in outs[0] + outs[1]
+    assert os.path.isfile(os.path.join(model_dir, 'best_model.pt'))
+    json.load(open(os.path.join(model_dir, 'best_model_metrics.json')))
+    # two ranks x batch 8 = one process x batch 16: the validation loss follows the same trajectory epoch by epoch (the
+    # ranks draw the same 16 samples per step the single process draws; only the dropout streams differ)
+    import re
+    single = subprocess.run([a if a != '8' else '16' for a in args[:-2]] + ['--data_path', str(tmp_path / 'data1'),
+                             '--model_path', str(tmp_path / 'ckpt1')],
+                            env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE')}, cwd=repo,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert single.returncode == 0, single.stdout[-4000:]
+    ev = lambda text: [float(x) for x in re.findall(r'eval_loss = ([0-9.]+)', text)]
+    dp_loss, sp_loss = ev(outs[0]), ev(single.stdout)
+    assert len(dp_loss) == len(sp_loss) == 4
+    assert max(abs(a - b) for a, b in zip(dp_loss, sp_loss)) < 0.02, (dp_loss, sp_loss)
+    csv = open(os.path.join(model_dir, 'best_model_dev_seen_preds.csv')).read().splitlines()
+    assert csv[0] == 'id,proba,label,gt' and len(csv) == 65

@@ -125,7 +125,8 @@ def main(argv=None):
     config = args.__dict__
     if config['parallel_computing'] and 'RANK' in os.environ and not torch.distributed.is_initialized():
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        torch.distributed.init_process_group('nccl')
+        # RCCL; UNITER_DIST_BACKEND=gloo lets several ranks share one GPU (tests: RCCL wants one device per rank)
+        torch.distributed.init_process_group(os.environ.get('UNITER_DIST_BACKEND', 'nccl'))
     ddp = torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
     rank = torch.distributed.get_rank() if ddp else 0
     world = torch.distributed.get_world_size() if ddp else 1
