@@ -64,6 +64,8 @@ def test_two_ranks_share_the_batch():
     # measured: 3e-8 absolute / 8e-8 rms-relative in both modes.  A sample's forward and input gradients do not depend on
     # which other samples share its batch (so the bf16 mode rounds exactly the same values on both sides); only the sums
     # over the batch -- weight and bias gradients, here split in two and added by the collective -- change their order
+    # bf16 payload: every rank's gradients rounded to bf16 (2^-9 relative) before the sum
+    assert out['bf16_payload']['rel_rms'] < 4e-3 and out['bf16_payload']['rel_rms'] > 1e-5, out['bf16_payload']
     for r in (f32, b16):
         assert r['maxdiff'] <= 1e-6 * max(r['scale'], 1.0), r
         assert r['rel_rms'] < 1e-6, r

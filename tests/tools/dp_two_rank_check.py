@@ -57,10 +57,10 @@ def main():
     if 'seq_lens' in shard and not torch.is_tensor(shard['seq_lens']):
         shard['seq_lens'] = list(full['seq_lens'])[rank * per:(rank + 1) * per]
     out = {}
-    for prec in ('fp32', 'bf16'):
+    for name, prec, payload in (('fp32', 'fp32', 'fp32'), ('bf16', 'bf16', 'fp32'), ('bf16_payload', 'bf16', 'bf16')):
         model = build(cfgd)
         model.uniter_model.precision = prec
-        sync = dp.attach(model, payload='fp32')
+        sync = dp.attach(model, payload=payload)
         g, loss = grads_of(model, shard, sync)
         g = g / world                                       # what the optimizer's grad_scale = 1 / world applies
         losses = [None] * world
@@ -70,7 +70,7 @@ def main():
             ref_model.uniter_model.precision = prec
             g_ref, loss_ref = grads_of(ref_model, full, None)
             scale = g_ref.abs().max().item()
-            out[prec] = dict(maxdiff=(g - g_ref).abs().max().item(), scale=scale,
+            out[name] = dict(maxdiff=(g - g_ref).abs().max().item(), scale=scale,
                              rel_rms=((g - g_ref).norm() / g_ref.norm()).item(),
                              loss_mean=sum(losses) / world, loss_ref=loss_ref, buckets=len(sync.launched))
         dist.barrier()
