@@ -126,14 +126,23 @@ def _cap_cpu_threads():
     assemble instead of 2.3 ms with eight threads (MI355X box, 16 samples, 36 regions) -- seven times the bf16 training
     step.  UNITER_CPU_THREADS overrides."""
     want = int(os.environ.get('UNITER_CPU_THREADS', '8'))
-    if want > 0 and torch.get_num_threads() > want:
+    had = torch.get_num_threads()
+    if want > 0 and had > want:
         torch.set_num_threads(want)
+    return had
 
 
 def main(argv=None):
+    had_threads = _cap_cpu_threads()
+    try:
+        return _main(argv)
+    finally:
+        torch.set_num_threads(had_threads)       # a caller that runs main() in its own process keeps its pool
+
+
+def _main(argv=None):
     args, _ = build_parser().parse_known_args(argv)
     config = args.__dict__
-    _cap_cpu_threads()
     if config['parallel_computing'] and 'RANK' in os.environ and not torch.distributed.is_initialized():
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         # RCCL; UNITER_DIST_BACKEND=gloo lets several ranks share one GPU (tests: RCCL wants one device per rank)
