@@ -386,6 +386,16 @@ int uniter_adam_step_ex(float* params, float* grads, float* exp_avg, float* exp_
                         float grad_scale, float max_norm, float lr, float beta1, float beta2,
                         float eps, float weight_decay, int step, int adamw, int zero_grads,
                         void* mirror_bf16, int max_workgroups, void* stream);
+/* Data parallel with a bf16 gradient payload (dp.GradSync): the reduced gradients ARE a bf16 buffer; these two read them
+ * from there (widened on the fly) instead of from an fp32 copy somebody would have to write first.  uniter_adam_step_g16 still
+ * zeroes the fp32 `grads` (the buffer the next backward accumulates into) when zero_grads is set; grads_bf16 NULL = read
+ * `grads` (= uniter_adam_step_ex).  Replaces nothing in the reference (its nn.DataParallel reduces fp32 gradients). */
+int uniter_grad_sumsq_bf16(const void* grads_bf16, const uint8_t* chunk_flags, size_t n, double* sumsq, void* ws,
+                           size_t ws_bytes, void* stream);
+int uniter_adam_step_g16(float* params, float* grads, const void* grads_bf16, float* exp_avg, float* exp_avg_sq,
+                         const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale,
+                         float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int step, int adamw, int zero_grads, void* mirror_bf16, int max_workgroups, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Whole-model schedule: the library owns the kernel sequence of

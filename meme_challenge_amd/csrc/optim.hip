@@ -18,9 +18,18 @@ namespace {
 
 constexpr int CHUNK = 64;
 
+__device__ __forceinline__ f32x4 widen4(const unsigned short* __restrict__ g16, size_t i) {
+  typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+  const u32x2_t w = reinterpret_cast<const u32x2_t*>(g16)[i];
+  return f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+               __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+}
+
+// g16 (optional): the gradients as bf16 (the data-parallel exchange's reduced payload) instead of the fp32 buffer
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
                                                     const uint8_t* __restrict__ flags, size_t n4,
-                                                    double* __restrict__ part) {
+                                                    double* __restrict__ part,
+                                                    const unsigned short* __restrict__ g16) {
   __shared__ double red[4];
   double acc = 0.0;
   // two 16-byte pieces per thread and iteration, both loads issued first (the pass is a pure HBM stream: 440 MB)
@@ -29,8 +38,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     const size_t j = i + stride;
     const bool f0 = flags[(i * 4) / CHUNK] != 0, f1 = j < n4 && flags[(j * 4) / CHUNK] != 0;
     f32x4 v = {0.f, 0.f, 0.f, 0.f}, w = v;
-    if (f0) v = reinterpret_cast<const f32x4*>(g)[i];
-    if (f1) w = reinterpret_cast<const f32x4*>(g)[j];
+    if (f0) v = g16 ? widen4(g16, i) : reinterpret_cast<const f32x4*>(g)[i];
+    if (f1) w = g16 ? widen4(g16, j) : reinterpret_cast<const f32x4*>(g)[j];
     acc += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
     acc += (double)(w[0] * w[0] + w[1] * w[1]) + (double)(w[2] * w[2] + w[3] * w[3]);
   }
@@ -61,6 +70,7 @@ struct AdamArgs {
   float gscale, max_norm, lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2;
   int adamw, zero_grads;
   unsigned short* mirror;     // optional bf16 copy of the updated parameters (precision 'bf16' weight mirror)
+  const unsigned short* g16;  // optional: read the gradient from this bf16 buffer (reduced data-parallel payload); g is still zeroed
 };
 
 #define NT_LOAD(base, idx) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base) + (idx))
@@ -108,10 +118,10 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     const uint8_t f1 = two ? a.flags[(j * 4) / CHUNK] : 0;
     f32x4 p0, g0, m0, v0, p1, g1, m1, v1;
     if (f0) {
-      p0 = NT_LOAD(a.p, i); g0 = NT_LOAD(a.g, i); m0 = NT_LOAD(a.m, i); v0 = NT_LOAD(a.v, i);
+      p0 = NT_LOAD(a.p, i); g0 = a.g16 ? widen4(a.g16, i) : NT_LOAD(a.g, i); m0 = NT_LOAD(a.m, i); v0 = NT_LOAD(a.v, i);
     }
     if (f1) {
-      p1 = NT_LOAD(a.p, j); g1 = NT_LOAD(a.g, j); m1 = NT_LOAD(a.m, j); v1 = NT_LOAD(a.v, j);
+      p1 = NT_LOAD(a.p, j); g1 = a.g16 ? widen4(a.g16, j) : NT_LOAD(a.g, j); m1 = NT_LOAD(a.m, j); v1 = NT_LOAD(a.v, j);
     }
     if (f0) { adam_update4(a, coef, f0 == 2 ? a.wd : 0.f, p0, g0, m0, v0); adam_store4(a, i, p0, m0, v0); }
     if (f1) { adam_update4(a, coef, f1 == 2 ? a.wd : 0.f, p1, g1, m1, v1); adam_store4(a, j, p1, m1, v1); }
@@ -134,7 +144,22 @@ extern "C" int uniter_grad_sumsq(const float* grads, const uint8_t* chunk_flags,
   UCHECK_ARG(ws_bytes >= uniter_grad_sumsq_ws_bytes(n), "grad_sumsq: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int nb = sumsq_blocks(n);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, grads, chunk_flags, n / 4, (double*)ws);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, grads, chunk_flags, n / 4, (double*)ws, (const unsigned short*)nullptr);
+  UCHECK_LAUNCH();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, sumsq);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_grad_sumsq_bf16(const void* grads_bf16, const uint8_t* chunk_flags, size_t n, double* sumsq,
+                                      void* ws, size_t ws_bytes, void* stream) {
+  UCHECK_ARG(grads_bf16 && chunk_flags && sumsq && ws, "grad_sumsq_bf16: null pointer");
+  UCHECK_SHAPE(n % CHUNK == 0 && ((uintptr_t)grads_bf16 & 7) == 0, "grad_sumsq_bf16: n must be a multiple of 64, 8-byte aligned");
+  UCHECK_ARG(ws_bytes >= uniter_grad_sumsq_ws_bytes(n), "grad_sumsq_bf16: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = sumsq_blocks(n);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, (const float*)nullptr, chunk_flags, n / 4, (double*)ws,
+                     (const unsigned short*)grads_bf16);
   UCHECK_LAUNCH();
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, sumsq);
   UCHECK_LAUNCH();
@@ -163,7 +188,17 @@ extern "C" int uniter_adam_step_ex(float* params, float* grads, float* exp_avg, 
                                    float max_norm, float lr, float beta1, float beta2, float eps,
                                    float weight_decay, int step, int adamw, int zero_grads,
                                    void* mirror_bf16, int max_workgroups, void* stream) {
+  return uniter_adam_step_g16(params, grads, nullptr, exp_avg, exp_avg_sq, chunk_flags, n, sumsq, grad_scale, max_norm, lr,
+                              beta1, beta2, eps, weight_decay, step, adamw, zero_grads, mirror_bf16, max_workgroups, stream);
+}
+
+extern "C" int uniter_adam_step_g16(float* params, float* grads, const void* grads_bf16, float* exp_avg,
+                                    float* exp_avg_sq, const uint8_t* chunk_flags, size_t n, const double* sumsq,
+                                    float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
+                                    int max_workgroups, void* stream) {
   UCHECK_ARG(params && grads && exp_avg && exp_avg_sq && chunk_flags, "adam_step: null pointer");
+  UCHECK_SHAPE(((uintptr_t)grads_bf16 & 7) == 0, "adam_step: bf16 gradients must be 8-byte aligned");
   UCHECK_SHAPE(n % CHUNK == 0, "adam_step: n must be a multiple of 64");
   UCHECK_ARG(step >= 1, "adam_step: step must be >= 1");
   UCHECK_ARG(max_norm <= 0.f || sumsq, "adam_step: clipping needs sumsq");
@@ -172,6 +207,7 @@ extern "C" int uniter_adam_step_ex(float* params, float* grads, float* exp_avg, 
   a.sumsq = sumsq; a.gscale = grad_scale; a.max_norm = max_norm; a.lr = lr; a.b1 = beta1; a.b2 = beta2;
   a.eps = eps; a.wd = weight_decay; a.adamw = adamw; a.zero_grads = zero_grads;
   a.mirror = (unsigned short*)mirror_bf16;
+  a.g16 = (const unsigned short*)grads_bf16;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   a.step_size = (float)((double)lr / bc1);

@@ -21,7 +21,8 @@ transfers beat many small ones, but whatever is still in flight when backward en
     backward compute.
 
 Payload (``payload='bf16'``): the slice is rounded to bf16 into a communication buffer, summed by
-RCCL in bf16 and widened back to fp32 before the optimizer reads it -- half the bytes on every
+RCCL in bf16 and read by the fused optimizer (and the clip norm) straight from there, widened on the
+fly (any other consumer gets it widened back into the fp32 buffer) -- half the bytes on every
 link; local accumulation over micro-batches, the clip norm and the optimizer stay fp32.  The
 default is 'fp32' (bit-identical to a single-process run on the concatenated batch, up to the
 summation order); the bf16 precision mode of the model selects 'bf16'.
@@ -50,6 +51,9 @@ class GradSync(object):
         self.payload = payload
         self.comm = torch.empty_like(flat_grads, dtype=torch.bfloat16) if payload == 'bf16' else None
         self.solo = {len(self.ranges) - 1} if len(self.ranges) > 2 else set()     # the embeddings: never coalesced
+        # True (set by trainer.sync_step for the fused optimizer): the consumer reads the reduced bf16 sums straight from
+        # `comm` (uniter_adam_step_g16 / uniter_grad_sumsq_bf16), wait_range does not widen them back into the fp32 buffer
+        self.consumer_reads_comm = False
         self.active = True
         self._inflight = []                       # [work, start, end, unpacked]
         self._pending = None                      # (start, end) accumulated but not yet launched
@@ -91,7 +95,7 @@ class GradSync(object):
             if e <= lo or s >= hi or done:
                 continue
             work.wait()
-            if self.comm is not None:
+            if self.comm is not None and not self.consumer_reads_comm:
                 self.flat[s:e].copy_(self.comm[s:e])
             rec[3] = True
 

@@ -175,8 +175,10 @@ class FusedAdam(torch.optim.Optimizer):
         return self._sumsq.sqrt()
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, max_grad_norm=0.0, zero_grads=True, grad_ready=None):
-        """grad_ready(lo, hi): optional callable that makes the CURRENT stream wait until flat_grads[lo:hi] is final
+    def step(self, closure=None, grad_scale=1.0, max_grad_norm=0.0, zero_grads=True, grad_ready=None, grad_bf16=None):
+        """grad_bf16: optional bf16 tensor holding the gradients to apply (the reduced data-parallel payload, dp.GradSync.comm)
+        in place of the fp32 gradient buffer, which is still zeroed.
+        grad_ready(lo, hi): optional callable that makes the CURRENT stream wait until flat_grads[lo:hi] is final
         (dp.GradSync.wait_range): each block launch then waits only for the gradient buckets that cover it.  Clipping
         needs the norm of everything, so with max_grad_norm > 0 the whole buffer is waited for first."""
         if closure is not None:
@@ -194,9 +196,14 @@ class FusedAdam(torch.optim.Optimizer):
             if grad_ready is not None:
                 grad_ready(0, st.numel)
                 grad_ready = None
-            check(lib.uniter_grad_sumsq(ptr(st.flat_grads), ptr(flags), st.numel, ptr(self._sumsq),
-                                        ptr(self._ws), self._ws_bytes, _lib.cur_stream()),
-                  'uniter_grad_sumsq')
+            if grad_bf16 is not None:
+                check(lib.uniter_grad_sumsq_bf16(ptr(grad_bf16), ptr(flags), st.numel, ptr(self._sumsq),
+                                                 ptr(self._ws), self._ws_bytes, _lib.cur_stream()),
+                      'uniter_grad_sumsq_bf16')
+            else:
+                check(lib.uniter_grad_sumsq(ptr(st.flat_grads), ptr(flags), st.numel, ptr(self._sumsq),
+                                            ptr(self._ws), self._ws_bytes, _lib.cur_stream()),
+                      'uniter_grad_sumsq')
         self.step_count += 1
         b1, b2 = g0['betas']
 
@@ -205,14 +212,15 @@ class FusedAdam(torch.optim.Optimizer):
         def launch(lo, hi, stream_ptr, max_wgs=0):
             off = lo * 4
             # the bf16 weight mirror (precision 'bf16') is written by the same kernel, on the same stream
-            check(lib.uniter_adam_step_ex(st.flat_params.data_ptr() + off, st.flat_grads.data_ptr() + off,
-                                          self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
-                                          flags.data_ptr() + lo // CHUNK, hi - lo, ptr(self._sumsq),
-                                          float(grad_scale), float(max_grad_norm or 0.0), lr, float(b1), float(b2),
-                                          float(g0['eps']), float(g0['weight_decay']), self.step_count,
-                                          int(self.adamw), int(bool(zero_grads)),
-                                          (mirror.data_ptr() + lo * 2) if mirror is not None else None, max_wgs,
-                                          stream_ptr),
+            check(lib.uniter_adam_step_g16(st.flat_params.data_ptr() + off, st.flat_grads.data_ptr() + off,
+                                           (grad_bf16.data_ptr() + lo * 2) if grad_bf16 is not None else None,
+                                           self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
+                                           flags.data_ptr() + lo // CHUNK, hi - lo, ptr(self._sumsq),
+                                           float(grad_scale), float(max_grad_norm or 0.0), lr, float(b1), float(b2),
+                                           float(g0['eps']), float(g0['weight_decay']), self.step_count,
+                                           int(self.adamw), int(bool(zero_grads)),
+                                           (mirror.data_ptr() + lo * 2) if mirror is not None else None, max_wgs,
+                                           stream_ptr),
                   'uniter_adam_step')
 
         enc = self.overlap_encoder
@@ -361,9 +369,13 @@ def sync_step(optimizer, grad_sync, accum, max_grad_norm):
     """average_gradients + clip + optimizer step + zero_grad behind the data-parallel exchange
     (train_template.py:89-92,103-107).  With clipping the norm needs every bucket; without it each
     optimizer block waits only for the buckets that cover it."""
-    world, ready = 1, None
+    world, ready, g16 = 1, None, None
     if grad_sync is not None and grad_sync.active:
         world = grad_sync.world
+        # bf16 payload + the fused optimizer: the reduced sums are consumed where RCCL left them
+        grad_sync.consumer_reads_comm = grad_sync.comm is not None and isinstance(optimizer, FusedAdam)
+        if grad_sync.consumer_reads_comm:
+            g16 = grad_sync.comm
         if max_grad_norm and max_grad_norm > 0:
             grad_sync.finish()
         else:
@@ -371,7 +383,11 @@ def sync_step(optimizer, grad_sync, accum, max_grad_norm):
             ready = grad_sync.wait_range
     elif grad_sync is not None:
         world = grad_sync.world
-    optimizer.step(grad_scale=1.0 / (accum * world), max_grad_norm=max_grad_norm, zero_grads=True, grad_ready=ready)
+    if g16 is not None:
+        optimizer.step(grad_scale=1.0 / (accum * world), max_grad_norm=max_grad_norm, zero_grads=True, grad_ready=ready,
+                       grad_bf16=g16)
+    else:
+        optimizer.step(grad_scale=1.0 / (accum * world), max_grad_norm=max_grad_norm, zero_grads=True, grad_ready=ready)
 
 
 
