@@ -274,6 +274,10 @@ int uniter_gather_rows(const float* cat, const int64_t* gather_index, float* out
 int uniter_gather_rows_bwd(const float* dout, const int64_t* gather_index, float* dcat,
                            int B, int S, int Lout, int H, void* stream);
 /* feat_out = feat + mask_emb[img_masks] with mask_emb row 0 treated as zero (model/model.py:262-265) */
+/* out[m][:] = bias (m < M; N % 4 == 0): the starting value of x @ W^T + b where the product is accumulated on top by the
+ * stream-K form of uniter_gemm_f32 (beta = 1), which has no bias epilogue -- the image projection of model/model.py:267,
+ * too few tiles (108) for the tile-per-workgroup form to fill the chip. */
+int uniter_bias_rows(const float* bias, float* out, int M, int N, void* stream);
 int uniter_img_mask_add(const float* feat, const int64_t* img_masks, const float* mask_emb,
                         float* feat_out, int rows, int D, void* stream);
 /* backward of the text embedding: accumulates into dword/dpos/dtype/dgamma/dbeta */

@@ -464,6 +464,24 @@ extern "C" int uniter_gather_rows_bwd(const float* dout, const int64_t* gather_i
   return 0;
 }
 
+// out[m][:] = bias for m < M: the starting value of a product that is then ACCUMULATED on top (C += x W^T by the stream-K
+// form of the GEMM, which has no bias epilogue)
+__global__ __launch_bounds__(256) void bias_rows_kernel(const float* __restrict__ bias, float* __restrict__ out, int M, int N4) {
+  const size_t n = (size_t)M * N4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(bias)[i % N4];
+}
+
+extern "C" int uniter_bias_rows(const float* bias, float* out, int M, int N, void* stream) {
+  UCHECK_ARG(bias && out && M > 0 && N > 0, "bias_rows: bad argument");
+  UCHECK_SHAPE(N % 4 == 0, "bias_rows: N must be a multiple of 4");
+  const size_t n = (size_t)M * (N / 4);
+  const int nb = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(bias_rows_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, bias, out, M, N / 4);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int uniter_img_mask_add(const float* feat, const int64_t* img_masks, const float* mask_emb,
                                    float* feat_out, int rows, int D, void* stream) {
   UCHECK_ARG(feat && img_masks && mask_emb && feat_out, "img_mask_add: null pointer");

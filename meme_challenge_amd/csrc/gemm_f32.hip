@@ -586,7 +586,12 @@ int launch_v3(GemmArgs g, hipStream_t st, int slots) {
     const int rounds = (tiles + slots - 1) / slots;
     const bool uneven = (long)tiles * 100 < (long)rounds * slots * 88;
     const long units = (long)tiles * ((g.K + BK - 1) / BK);
-    if ((uneven || sk_mode == 2) && units >= 8l * slots) {    // >= 8 k-iterations per piece
+    // >= 8 k-iterations per piece; a product too small for that on every slot (the image projection: 108 tiles x 64 units)
+    // takes as many slots, in steps of 256, as get eight units each
+    int sk_n = slots;
+    if (units < 8l * slots) sk_n = (int)(units / 8 / 256) * 256;
+    if ((uneven || sk_mode == 2) && sk_n >= 256) {
+      slots = sk_n;
       static const int sk_slots = env_int("UNITER_WGRAD_SLOTS_F32", 0);      // A/B: pieces of the stream-K form
       if (sk_slots > 0) slots = sk_slots;
       hipLaunchKernelGGL((gemm_f32_v3_kernel<BM, BN, AKM, BKM, 0, true>), dim3(slots), dim3(256), 0, st, g);

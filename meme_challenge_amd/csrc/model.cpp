@@ -483,8 +483,20 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
       UCHECK_RC(uniter_img_mask_add(b->img_feat, b->img_masks, m->P(P_MASK_EMB), pl.feat_eff, B * R, c.img_dim, st));
       feat = pl.feat_eff;
     }
-    UCHECK_RC(gemm(m, 0, st, 0, 0, B * R, H, c.img_dim, feat, c.img_dim, m->P(P_IMG_W), c.img_dim, pl.imgfc, H,
-                   UNITER_EPI_BIAS, m->P(P_IMG_B), nullptr, nullptr, 0, 0));
+    // region-feature projection (model/model.py:267): 576 x 768 outputs are 108 tiles of 64 x 64 for 1024 workgroup slots
+    // with K = 2048 -- as a stream-K accumulation on top of the bias rows it fills the chip (fp32: 58 -> 25 us)
+    const long t64 = (long)((B * R + 63) / 64) * ((H + 63) / 64);
+    static const bool img_sk = [] { const char* e = getenv("UNITER_IMG_SK"); return !e || e[0] != '0'; }();
+    // (fp32 only: the float atomics make the sum's order vary from run to run -- 1e-7 in fp32, but the bf16 mode amplifies any
+    // such difference through its rounding stages, DESIGN.md section 2, and its forward is otherwise deterministic)
+    if (img_sk && m->precision == 0 && t64 >= 8 && t64 <= 600 && c.img_dim >= 1024 && c.img_dim % 64 == 0 && H % 4 == 0) {
+      UCHECK_RC(uniter_bias_rows(m->P(P_IMG_B), pl.imgfc, B * R, H, st));
+      UCHECK_RC(gemm(m, 0, st, 0, 0, B * R, H, c.img_dim, feat, c.img_dim, m->P(P_IMG_W), c.img_dim, pl.imgfc, H,
+                     UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+    } else {
+      UCHECK_RC(gemm(m, 0, st, 0, 0, B * R, H, c.img_dim, feat, c.img_dim, m->P(P_IMG_W), c.img_dim, pl.imgfc, H,
+                     UNITER_EPI_BIAS, m->P(P_IMG_B), nullptr, nullptr, 0, 0));
+    }
     UCHECK_RC(uniter_img_embed_fwd(pl.imgfc, b->img_pos_feat, b->img_type_ids, m->P(P_POSL_W), m->P(P_POSL_B),
                                    m->P(P_TYPE), m->P(P_ILN_G), m->P(P_ILN_B), m->P(P_PLN_G), m->P(P_PLN_B),
                                    m->P(P_FLN_G), m->P(P_FLN_B), pl.cat, save ? pl.img_stats : nullptr, B, R,
