@@ -4,6 +4,8 @@ and matrix-pipe busy (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x duration x
 Usage: python tests/tools/pmc_table.py profiles/r02 [bf16] > profiles/r02_kernel_table[_bf16].md"""
 import csv, sys, re
 pre = sys.argv[1]; suf = ('_' + sys.argv[2]) if len(sys.argv) > 2 else ''
+if not pre.endswith('/'):
+    pre += '_'          # profiles/r02 -> profiles/r02_pmc_fetch.csv; a directory (gpurun_out/r02/) -> .../pmc_fetch.csv
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
     n = n[:n.index('(')] if '(' in n else n
@@ -17,12 +19,12 @@ def pmc(path, counter):
     except OSError:
         pass
     return out
-fetch = pmc('%s_pmc_fetch%s.csv' % (pre, suf), 'FETCH_SIZE')
-write = pmc('%s_pmc_write%s.csv' % (pre, suf), 'WRITE_SIZE')
-mfma = pmc('%s_pmc_mfma.csv' % pre, 'SQ_VALU_MFMA_BUSY_CYCLES') if not suf else {}
+fetch = pmc('%spmc_fetch%s.csv' % (pre, suf), 'FETCH_SIZE')
+write = pmc('%spmc_write%s.csv' % (pre, suf), 'WRITE_SIZE')
+mfma = pmc('%spmc_mfma.csv' % pre, 'SQ_VALU_MFMA_BUSY_CYCLES') if not suf else {}
 stats = {}
 tot = 0.0
-for r in csv.DictReader(open('%s_bench%s_kernel_stats.csv' % (pre, suf))):
+for r in csv.DictReader(open('%sbench%s_kernel_stats.csv' % (pre, suf))):
     k = short(r['Name'])
     stats[k] = (int(r['Calls']), float(r['AverageNs']), float(r['Percentage']))
 print('| kernel | launches | avg µs | % of kernel time | read MB / launch | written MB / launch | GB/s | of 8 TB/s | MFMA busy |')

@@ -24,7 +24,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_bf16 -o w -- python3 bench.py --precision bf16 --no_cpu_baseline --steps 3 --warmup 1 --prof_kind 0 > /dev/null 2>$O/pmc5.err
 for d in fetch write mfma fetch_bf16 write_bf16; do python tests/tools/pmc_summary.py $O/pmc_$d $O/pmc_$d.csv; head -6 $O/pmc_$d.csv | cut -c1-200; done
 python tests/tools/pmc_to_traffic.py $O $O/pmc_traffic.json
-python tests/tools/pmc_table.py $O > $O/kernel_table.md; python tests/tools/pmc_table.py $O bf16 > $O/kernel_table_bf16.md
+python tests/tools/pmc_table.py $O/ > $O/kernel_table.md; python tests/tools/pmc_table.py $O/ bf16 > $O/kernel_table_bf16.md
 # keep the merge-back small
 find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
 du -sh $O
