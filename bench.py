@@ -14,12 +14,11 @@ resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime initialises: see meme_challenge_amd/__init__.py
-
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -64,6 +63,7 @@ def cpu_baseline(seconds_budget=30.0):
     """Reported baseline only: the CPU oracle (port of the reference forward; autograd backward) on
     BASELINE config 1 (B=4, T=64, R=36, UNITER-base, dropout on), timed on this box's host cores: N threads
     (3 warm-up + up to 10 timed steps) and one thread (1 warm-up + up to 2 timed steps), both bounded by the budget."""
+    import torch
     from oracle import uniter_oracle as O
     from oracle import step_oracle as S
     sd = {k: v.requires_grad_(True) for k, v in O.synth_state_dict(BASE, seed=0).items()}
@@ -128,7 +128,7 @@ def pmc_traffic(args, M, cfgd, build_info):
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -137,7 +137,7 @@ def main():
     ap.add_argument('--txt_len', type=int, default=128)
     ap.add_argument('--num_bb', type=int, default=36)
     ap.add_argument('--model', choices=['base', 'large'], default='base')
-    ap.add_argument('--precision', choices=['fp32', 'bf16', 'bf16_hybrid'], default='fp32',
+    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
                     help="fp32 (BASELINE configs[1], default) or bf16: bf16 MFMA for the dense GEMMs, fp32 elsewhere (configs[2])")
     ap.add_argument('--workload', choices=['finetune', 'multitask'], default='finetune',
                     help='finetune = MemeUniter step (BASELINE configs[1-3], default); multitask = UNITER + ITM/MLM/MRFR '
@@ -152,22 +152,93 @@ def main():
     ap.add_argument('--no_adam_overlap', action='store_true',
                     help='run the optimizer step as one launch on the main stream instead of block by block beside the next forward')
     ap.add_argument('--prof_kind', type=int, default=-1, help='UNITER_K_* kind timed with HIP events inside the timed region (-1 = every kind, 0 = none)')
-    args = ap.parse_args()
+    ap.add_argument('--dp_sparse_embeddings', action='store_true',
+                    help='N > 1: exchange the touched word-embedding gradient rows (all-gather of ids + rows) instead of '
+                         'all-reducing the whole 28996 x 768 table')
+    return ap.parse_args(argv)
 
+
+def launch_ranks(n, cmd, env=None, poll_s=0.2):
+    """`python bench.py --gpus N` outside a launcher: THIS process -- which has made no GPU call and makes none -- starts N
+    fresh rank processes (one per device; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them),
+    relays rank 0's stdout (the JSON line), sends the other ranks' stdout to stderr, and returns 0 only if every rank
+    did.  A rank that fails takes the others down with it (exact PIDs, no pattern kill) instead of leaving them in a
+    collective.  Nothing is re-executed: the parent stays a plain supervisor."""
+    import socket
+    with socket.socket() as s:                       # a free rendezvous port on the loopback interface
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: the only form this pool's driver supports
+    base['UNITER_BENCH_LAUNCHER'] = 'self'
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(list(cmd), env=e, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(poll_s)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:
+                    rc = code if code > 0 else 1
+                    print('bench.py: rank %d exited with code %d; stopping the other ranks' % (procs.index(p), code),
+                          file=sys.stderr)
+                    break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # no launcher environment: be the launcher (N = 1 stays in this process: the driver's BENCH line is unchanged)
+        return launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv))
+    return run_rank(args)
+
+
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         if rank == 0:
             print('warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # RCCL ('nccl'); UNITER_DIST_BACKEND=gloo lets several ranks share one GPU (tests: RCCL wants one device per rank)
+    backend = os.environ.get('UNITER_DIST_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()                  # does not initialise the GPU
+    if ndev == 0:
+        raise SystemExit('bench.py needs an MI355X: no GPU visible (there is no CPU path)')
+    if local_rank >= ndev and backend == 'nccl':
+        raise SystemExit('bench.py: rank %d has no device (%d visible); RCCL needs one GPU per rank' % (local_rank, ndev))
+    local_dev = local_rank % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     use_dist = world > 1 or 'RANK' in os.environ
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from meme_challenge_amd import _lib
     from meme_challenge_amd.model import UniterConfig, UniterModel
@@ -213,7 +284,7 @@ def main():
     sync = None
     if use_dist:
         dp.broadcast_parameters(model)
-        sync = dp.attach(model)
+        sync = dp.attach(model, sparse_embeddings=args.dp_sparse_embeddings)
     if args.workload == 'finetune':
         step = TrainStep(model, opt, sched, config, grad_sync=sync)
 
@@ -224,8 +295,8 @@ def main():
 
         def one_step():
             task = task_rng.choice(tasks)
-            if sync is not None:
-                sync.prepare(True)
+            if sync is not None:     # the MLM task's tied decoder makes the word-embedding gradient dense
+                sync.prepare(True, token_ids=None if task == 'mlm' else batches[task]['input_ids'])
             loss = model(batches[task], task, compute_loss=True).mean()
             loss.backward()
             sync_step(opt, sync, 1, config['max_grad_norm'])
@@ -344,9 +415,15 @@ def main():
                                       'fp32 (BASELINE configs[1])' if args.precision == 'fp32'
                                       else 'bf16 MFMA GEMMs / fp32 storage (BASELINE configs[2])'),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                       # what torch.distributed itself reports (not the flag): lets the driver verify the collective saw N ranks
+                       'ranks_seen': dist.get_world_size() if use_dist else 1,
+                       'dist_backend': dist.get_backend() if use_dist else None,
+                       'launcher': ('bench.py (self-spawned ranks)' if os.environ.get('UNITER_BENCH_LAUNCHER') == 'self' else
+                                    'external (RANK in the environment)') if use_dist else 'none (single process)',
                        'side_stream_wgrad': not args.no_side_stream,
                        'optimizer_overlaps_next_forward': not args.no_adam_overlap,
                        'grad_payload': sync.payload if sync is not None else None,
+                       'dp_sparse_embedding_steps': sync.sparse_steps if sync is not None else 0,
                        'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')},
             'step_mfma_frac': round(total / (ms * 1e-3) / (peak * 1e12), 4),
             'ffn_roofline_frac': round(ffn / (ms * 1e-3) / (peak * 1e12), 4),
@@ -394,10 +471,12 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    return 0
 
 
 def optimizer_alone(out, opt, model):
     """adam_kernel alone: 10 launches behind 2 warm-ups, every chunk on the update path (bytes / time against 8 TB/s)"""
+    import torch
     opt.join()
     torch.cuda.synchronize()
     numel = model.param_store().numel
@@ -419,4 +498,4 @@ def optimizer_alone(out, opt, model):
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

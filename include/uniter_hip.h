@@ -396,6 +396,9 @@ int uniter_adam_step_ex(float* params, float* grads, float* exp_avg, float* exp_
  * `grads` (= uniter_adam_step_ex).  Replaces nothing in the reference (its nn.DataParallel reduces fp32 gradients). */
 int uniter_grad_sumsq_bf16(const void* grads_bf16, const uint8_t* chunk_flags, size_t n, double* sumsq, void* ws,
                            size_t ws_bytes, void* stream);
+/* out[0] = parts[0] + .. + parts[n-1]: the clip norm (train_template.py:104, clip_grad_norm_ over ALL parameters) reduced
+ * slice by slice -- one uniter_grad_sumsq per data-parallel collective as it lands, each into its own slot -- and joined here */
+int uniter_sumsq_combine(const double* parts, int n, double* out, void* stream);
 int uniter_adam_step_g16(float* params, float* grads, const void* grads_bf16, float* exp_avg, float* exp_avg_sq,
                          const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale,
                          float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,

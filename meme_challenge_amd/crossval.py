@@ -139,9 +139,14 @@ def train_crossval(trainer_class, config, data_loader_funcs, num_folds=0, dev_si
         config['val_loader'] = data_loader_funcs['val'](os.path.join(config['data_path'], 'dev_seen.jsonl'))
         return trainer_class(config).train_main()
     cv = crossval_dir(config['data_path'], dev_size, use_dev_set)
-    if not os.path.isdir(cv) or not glob(os.path.join(cv, '*.jsonl')):
-        logger.info('Creating cross-validation splits for dev size %i' % dev_size)
-        generate_crossval_splits(config['data_path'], dev_size=dev_size, use_dev_set=use_dev_set)
+    import torch.distributed as dist
+    ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not ddp or dist.get_rank() == 0:          # one writer: the files are opened with 'w' (truncated) while they are written
+        if not os.path.isdir(cv) or not glob(os.path.join(cv, '*.jsonl')):
+            logger.info('Creating cross-validation splits for dev size %i' % dev_size)
+            generate_crossval_splits(config['data_path'], dev_size=dev_size, use_dev_set=use_dev_set)
+    if ddp:                                      # nobody globs or opens a fold file before rank 0 has closed them all
+        dist.barrier()
     train_sets = sorted(glob(os.path.join(cv, 'train_??.jsonl')))
     dev_sets = sorted(glob(os.path.join(cv, 'dev_??.jsonl')))
     test_sets = sorted(glob(os.path.join(cv, 'dev_seen_??.jsonl')))        # use_dev_set: the fold's half of dev_seen
@@ -169,7 +174,6 @@ def train_crossval(trainer_class, config, data_loader_funcs, num_folds=0, dev_si
     means = {key: mean(v[key] for v in val_metrics) for key in val_metrics[0]}
     logger.info('Cross validation finished. Mean scores of validation folds:\n' + '\n'.join(
         '%s: %s' % (k, ('%5.4f' % v) if k == 'loss' else ('%4.2f%%' % (100.0 * v))) for k, v in means.items()))
-    import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
         return val_metrics                 # the prediction files are rank 0's (written before end_training's barrier)
     names = [_dataset_name(t) for t in config.get('test_loader', [])]

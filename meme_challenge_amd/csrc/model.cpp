@@ -9,6 +9,7 @@
 // overlap layer l-1's dgrad chain and fill the CUs that the partial last wave
 // of each GEMM leaves idle.  Every layer owns its backward scratch, so the two
 // streams never race on a buffer (288 GB of HBM: ~3 GB for UNITER-base B=16).
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -269,7 +270,10 @@ int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int
   if (m->precision >= 1)      // embeddings' projections (fp32 inputs) also run on the bf16 pipe in mode 2
     return gemm_bf16_run(0, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux_in, aux_out, ld_aux, beta,
                          colsum_part, st);
-  return gemm_f32_run(0, kind == UNITER_K_GEMM_FFN_UP_FWD, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias,
+  // weight gradients (stream-K): UNITER_WGRAD_CFG = 21 selects 128 x 128 tiles (half the operand bytes per FLOP), 24 the 64 x 64 ones
+  static const int wg_cfg = [] { const char* e = getenv("UNITER_WGRAD_CFG"); return e ? atoi(e) : 0; }();
+  const int cfg = (kind == UNITER_K_GEMM_WGRAD && akm && bkm && beta == 1) ? wg_cfg : 0;
+  return gemm_f32_run(cfg, kind == UNITER_K_GEMM_FFN_UP_FWD, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias,
                       aux_in, aux_out, ld_aux, beta, colsum_part, st);
 }
 

@@ -166,6 +166,13 @@ extern "C" int uniter_grad_sumsq_bf16(const void* grads_bf16, const uint8_t* chu
   return 0;
 }
 
+extern "C" int uniter_sumsq_combine(const double* parts, int n, double* out, void* stream) {
+  UCHECK_ARG(parts && out && n >= 1, "sumsq_combine: bad argument");
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, parts, n, out);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int uniter_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                                 const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale,
                                 float max_norm, float lr, float beta1, float beta2, float eps,

@@ -29,8 +29,23 @@ summation order); the bf16 precision mode of the model selects 'bf16'.
 
 Averaging (1/world) is folded into the optimizer's ``grad_scale``; the gradient
 norm for clipping is computed on the reduced buffer, identical on every rank,
-so no second collective is needed.  Without clipping the optimizer's per-block launches wait
-only for the buckets that cover their block (``wait_range``).
+so no second collective is needed.  The norm is reduced PIECE BY PIECE (``pieces``: one per
+collective, in issue order): the optimizer waits for a collective, reduces its slice into a slot,
+goes on to the next -- so when backward ends only the embeddings' collective and the 20-us partial
+norm of its slice are still ahead of the update, not a pass over all 440 MB.  Without clipping
+the optimizer's per-block launches wait only for the buckets that cover their block (``wait_range``).
+
+Sparse word-embedding exchange (``sparse_embeddings=True``): a fine-tuning step touches at most
+B*T of the 28996 rows of the word-embedding table, yet its gradient is 89 of the 98 MB of the one
+collective that cannot hide behind backward.  With the flag the table leaves the dense exchange:
+every rank sorts its token ids (at ``prepare`` time, during the forward), marks the first
+occurrence of each, all-gathers (ids, rows of its local gradient at the first occurrences, zero
+rows elsewhere) -- B*T*H elements per rank instead of V*H -- then clears its own touched rows and
+adds every rank's rows IN RANK ORDER (each rank's ids are unique among its non-zero rows, so the
+adds of one rank never collide; the order over ranks is the same everywhere): all replicas hold
+bit-identical sums, as after an all-reduce.  The rest of the embeddings bucket (position / type /
+image projections, 2 M parameters) stays a dense collective.  A step whose word-embedding gradient
+is dense (the MLM task's tied decoder) passes ``token_ids=None`` and takes the dense path.
 """
 import contextlib
 import os
@@ -40,17 +55,36 @@ import torch.distributed as dist
 
 
 class GradSync(object):
-    def __init__(self, flat_grads, bucket_ranges, group=None, bucket_bytes=32 << 20, payload='fp32'):
+    def __init__(self, flat_grads, bucket_ranges, group=None, bucket_bytes=32 << 20, payload='fp32', word_table=None):
+        """word_table: (start, rows, row_len) of the word-embedding gradient inside the LAST bucket (it must open that
+        bucket) -- enables the sparse exchange for steps that announce their token ids to ``prepare``."""
         if payload not in ('fp32', 'bf16'):
             raise ValueError("payload must be 'fp32' or 'bf16'")
         self.flat = flat_grads
         self.ranges = list(bucket_ranges)         # per ParamStore bucket: (start, end)
+        self.word_table = None
+        if word_table is not None:
+            ws, V, H = word_table
+            ls, le = self.ranges[-1]
+            if ws != ls or ws + V * H > le:
+                raise ValueError('word_table must open the last (embeddings) bucket')
+            self.word_table = (ws, V, H)
+            # the table becomes a range of its own (up to the 64-element boundary the next tensor starts on: the padding
+            # holds zeros); what follows it in the bucket stays a dense collective
+            we = (ws + V * H + 63) // 64 * 64
+            self.ranges[-1:] = [(ws, we)] + ([(we, le)] if we < le else [])
+        self._tokens = []                         # token ids of the micro-batches accumulated since the last exchange
+        self._tokens_dense = False                # one of them had a dense word-embedding gradient
+        self._cap = None                          # ids per rank and exchange, agreed over the ranks at the first sparse step
+        self.sparse_steps = 0                     # exchanges that took the sparse path (for tests / the bench line)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_bytes = bucket_bytes
         self.payload = payload
         self.comm = torch.empty_like(flat_grads, dtype=torch.bfloat16) if payload == 'bf16' else None
-        self.solo = {len(self.ranges) - 1} if len(self.ranges) > 2 else set()     # the embeddings: never coalesced
+        # the embeddings (with a word table: the table and the rest of the bucket): never coalesced
+        n_emb = 1 if self.word_table is None else len(self.ranges) - len(bucket_ranges) + 1
+        self.solo = set(range(len(self.ranges) - n_emb, len(self.ranges))) if len(bucket_ranges) > 2 else set()
         # True (set by trainer.sync_step for the fused optimizer): the consumer reads the reduced bf16 sums straight from
         # `comm` (uniter_adam_step_g16 / uniter_grad_sumsq_bf16), wait_range does not widen them back into the fp32 buffer
         self.consumer_reads_comm = False
@@ -62,12 +96,44 @@ class GradSync(object):
         self.launch_streams = []                  # the stream each of them was issued on (for tests)
 
     # -- driven by the trainer ---------------------------------------------------
-    def prepare(self, will_step=True):
+    def prepare(self, will_step=True, token_ids=None):
         """Call before backward.  Gradients are exchanged only on the micro-batch that
-        steps; earlier micro-batches accumulate locally."""
+        steps; earlier micro-batches accumulate locally.
+        token_ids (sparse word-embedding exchange only): the int64 ids this micro-batch looks up in the word-embedding
+        table -- the rows its gradient can touch; None = the gradient of the table is dense this time."""
         # UNITER_DP_FORCE=1 exercises the collective path on a single rank (testing only)
         self.active = bool(will_step) and (self.world > 1 or os.environ.get('UNITER_DP_FORCE') == '1')
         self._inflight, self._pending, self._next, self.launched, self.launch_streams = [], None, 0, [], []
+        if self.word_table is not None:
+            if token_ids is None:
+                self._tokens_dense = True
+            else:
+                self._tokens.append(token_ids.reshape(-1).to(torch.int64))
+            self._sorted = None
+            if self.active and not self._tokens_dense:
+                # sorted ids and first-occurrence marks now, next to the forward: nothing of it waits for the backward
+                ids = self._tokens[0] if len(self._tokens) == 1 else torch.cat(self._tokens)
+                if self._cap is None:             # once: the ranks agree on a capacity (the only host synchronisation)
+                    cap = torch.tensor([ids.numel()], dtype=torch.int64, device=ids.device)
+                    if self.world > 1:
+                        dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=self.group)
+                    self._cap = int(cap.item())
+                if ids.numel() > self._cap:
+                    raise ValueError('sparse embedding exchange: %d token ids in a step, capacity agreed at the first '
+                                     'step is %d (same batch shape on every rank and step)' % (ids.numel(), self._cap))
+                srt = ids.sort().values
+                first = torch.ones_like(srt, dtype=torch.bool)
+                first[1:] = srt[1:] != srt[:-1]
+                if srt.numel() < self._cap:       # a short last batch: pad with id 0 / no row
+                    pad = self._cap - srt.numel()
+                    srt = torch.cat([srt, srt.new_zeros(pad)])
+                    first = torch.cat([first, first.new_zeros(pad)])
+                self._sorted = (srt, first)
+
+    def pieces(self):
+        """(start, end) of every collective issued this step, in issue order (flush_all first): the slices a consumer
+        can wait for one by one (``wait_range``) -- the clip norm is reduced that way."""
+        return [(s, e) for _, s, e, _ in self._inflight]
 
     def finish(self):
         """Call after backward, before anything reads the whole gradient buffer (clip norm, a
@@ -84,6 +150,7 @@ class GradSync(object):
         while self._next < len(self.ranges):
             self._add_bucket(self._next, None)
         self._flush(None)
+        self._tokens, self._tokens_dense = [], False
 
     def wait_range(self, lo, hi):
         """Make the CURRENT stream wait for the buckets that overlap flat[lo:hi] (and widen their bf16
@@ -93,6 +160,9 @@ class GradSync(object):
         for rec in self._inflight:
             work, s, e, done = rec
             if e <= lo or s >= hi or done:
+                continue
+            if work is None:                      # the sparse exchange: summed in place on the issuing stream
+                rec[3] = True
                 continue
             work.wait()
             if self.comm is not None and not self.consumer_reads_comm:
@@ -112,9 +182,60 @@ class GradSync(object):
             if index == 0:
                 self._flush(stream)               # layer 0 goes now, not together with the embeddings
         elif kind == 'embed':
-            while self._next < len(self.ranges):
-                self._add_bucket(self._next, stream)
-            self._flush(stream)
+            self._finish_embeddings(stream)
+
+    def _finish_embeddings(self, stream):
+        sparse = self.word_table is not None and self._sorted is not None and not self._tokens_dense
+        word_idx = None
+        if sparse:
+            ws = self.word_table[0]
+            word_idx = next(i for i, (s, _) in enumerate(self.ranges) if s == ws)
+        while self._next < len(self.ranges):
+            if self._next == word_idx:
+                self._flush(stream)
+                self._next += 1                   # the table does not join the dense exchange this step
+                continue
+            self._add_bucket(self._next, stream)
+        self._flush(stream)
+        if sparse:
+            self._exchange_rows(stream)
+        self._tokens, self._tokens_dense = [], False
+
+    def _exchange_rows(self, stream):
+        """The word-embedding table's gradient: all-gather (sorted ids, rows at first occurrences), then the sum in rank
+        order over cleared rows (module docstring)."""
+        ws, V, H = self.word_table
+        srt, first = self._sorted
+        on_gpu = self.flat.is_cuda
+        ctx = torch.cuda.stream(stream) if (stream is not None and on_gpu) else contextlib.nullcontext()
+        with ctx:
+            table = self.flat[ws:ws + V * H].view(V, H)
+            rows = table.index_select(0, srt)
+            rows.masked_fill_(~first.unsqueeze(1), 0.0)
+            if self.comm is not None:
+                rows = rows.to(torch.bfloat16)
+            n = srt.numel()
+            all_ids = torch.empty(self.world * n, dtype=srt.dtype, device=srt.device)
+            all_rows = torch.empty(self.world * n, H, dtype=rows.dtype, device=rows.device)
+            if self.world > 1:
+                w_ids = dist.all_gather_into_tensor(all_ids, srt, group=self.group, async_op=True)
+                w_rows = dist.all_gather_into_tensor(all_rows, rows, group=self.group, async_op=True)
+                w_ids.wait()
+                w_rows.wait()
+            else:
+                all_ids.copy_(srt)
+                all_rows.copy_(rows)
+            table.index_fill_(0, srt, 0.0)
+            for r in range(self.world):           # rank order: the same sequence of fp32 adds on every replica
+                table.index_add_(0, all_ids[r * n:(r + 1) * n], all_rows[r * n:(r + 1) * n].to(torch.float32))
+            we = (ws + V * H + 63) // 64 * 64
+            if self.comm is not None:             # a consumer that reads the bf16 sums finds the table there as well
+                self.comm[ws:we].copy_(self.flat[ws:we])
+            self.launch_streams.append(torch.cuda.current_stream().cuda_stream if on_gpu else None)
+        self._inflight.append([None, ws, we, False])
+        self.launched.append((ws, we))
+        self.sparse_steps += 1
+        self.last_sparse_rows = n
 
     # -- internals ------------------------------------------------------------------
     def _payload_bytes(self, n):
@@ -156,9 +277,11 @@ class GradSync(object):
         self.launched.append((s, e))
 
 
-def attach(model, group=None, bucket_bytes=32 << 20, payload=None):
+def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embeddings=None):
     """Wire a GradSync to a MemeUniter, UniterForPretraining or UniterModel and return it.
-    payload None: 'bf16' when the encoder runs in the bf16 precision mode, else 'fp32'."""
+    payload None: 'bf16' when the encoder runs in the bf16 precision mode, else 'fp32'.
+    sparse_embeddings (None: UNITER_DP_SPARSE_EMB=1): exchange the touched rows of the word-embedding gradient instead
+    of the table (GradSync docstring); the trainer then passes each micro-batch's token ids to ``prepare``."""
     store = model.param_store() if hasattr(model, 'param_store') else None
     if store is None:
         from .model import ensure_store
@@ -166,7 +289,16 @@ def attach(model, group=None, bucket_bytes=32 << 20, payload=None):
     um = getattr(model, 'uniter_model', None) or getattr(model, 'uniter', None) or model   # MemeUniter / UniterForPretraining / UniterModel
     if payload is None:
         payload = 'bf16' if getattr(um, 'precision', 'fp32') == 'bf16' else 'fp32'
-    gs = GradSync(store.flat_grads, store.bucket_ranges, group=group, bucket_bytes=bucket_bytes, payload=payload)
+    if sparse_embeddings is None:
+        sparse_embeddings = os.environ.get('UNITER_DP_SPARSE_EMB') == '1'
+    word_table = None
+    if sparse_embeddings:
+        name = next((n for n in store.names if n.endswith('embeddings.word_embeddings.weight')), None)
+        if name is not None and store.bucket_ranges and store.offsets[name] == store.bucket_ranges[-1][0]:
+            V, H = store.params[name].shape
+            word_table = (store.offsets[name], int(V), int(H))
+    gs = GradSync(store.flat_grads, store.bucket_ranges, group=group, bucket_bytes=bucket_bytes, payload=payload,
+                  word_table=word_table)
     um._grad_hook = gs.hook
     return gs
 

@@ -217,8 +217,8 @@ class TrainerTemplate(object):
         kind = self.config['loss_func']
         if kind == 'bce_logits':
             return bce_with_logits_loss(preds.squeeze(1), labels, self.config['pos_wt'], return_probs=True)
-        if kind == 'bce':                # the model's output already is a probability (train_template.py:66-67)
-            p = preds.squeeze(1)
+        if kind == 'bce':                # nn.BCELoss on torch.sigmoid(preds): the head emits logits (train_template.py:66-67,96-97)
+            p = torch.sigmoid(preds.squeeze(1))
             return torch.nn.functional.binary_cross_entropy(p, labels.float()), p
         logp = torch.log_softmax(preds, dim=1)                                     # 'ce': two logits (:68-69)
         return torch.nn.functional.nll_loss(logp, labels.long()), logp[:, 1].exp()
@@ -232,7 +232,7 @@ class TrainerTemplate(object):
             accum = self.config['gradient_accumulation']
             stepping = self.iters % accum == 0
             if self.grad_sync is not None:
-                self.grad_sync.prepare(will_step=stepping)
+                self.grad_sync.prepare(will_step=stepping, token_ids=getattr(self, 'batch', {}).get('input_ids'))
             loss.backward()
             if stepping:
                 sync_step(self.optimizer, self.grad_sync, accum, self.config['max_grad_norm'])
@@ -339,6 +339,16 @@ class TrainerTemplate(object):
                           self.val_metrics['aucroc'], lr, time.time() - self.start))
         key = self.config['optimize_for']
         improved, stop = self.plateau.update(self.val_loss if key == 'loss' else self.val_metrics[key])
+        if _distributed() and dist.get_world_size() > 1:
+            # every rank scored the validation set itself, and kernels that sum with float atomics differ between runs
+            # in the last bits: a metric that sits on a threshold could let ONE rank stop (or not) and strand the others
+            # in the next epoch's first collective.  Rank 0's verdict and plateau state are everybody's.
+            verdict = torch.tensor([float(improved), float(stop), float(self.plateau.best), float(self.plateau.stale),
+                                    float(self.val_loss)], dtype=torch.float64, device=self.device)
+            dist.broadcast(verdict, src=0)
+            v = verdict.tolist()
+            improved, stop = bool(v[0]), bool(v[1])
+            self.plateau.best, self.plateau.stale, self.val_loss = v[2], int(v[3]), v[4]
         if improved:
             LOGGER.info("New High Score! Saving model...")
             self.best_val_metrics, self.best_val_loss = self.val_metrics, self.val_loss
@@ -377,19 +387,26 @@ class TrainerTemplate(object):
             LOGGER.info("Maximum epochs of {} reached. Finished training !!".format(self.config['max_epoch']))
         self.test_metrics = dict()
         self._check_replicas()
-        if self.config['no_model_checkpoints']:
-            LOGGER.info("No model checkpoints were saved. Hence, testing will be skipped.")
-        elif _is_main():
-            self._final_evaluation()
-        if _is_main():
-            self.export_metrics()
-            if self.config.get('remove_checkpoints') and os.path.isfile(self.model_file):
-                os.remove(self.model_file)
+        failure = None
+        try:
+            if self.config['no_model_checkpoints']:
+                LOGGER.info("No model checkpoints were saved. Hence, testing will be skipped.")
+            elif _is_main():
+                self._final_evaluation()
+            if _is_main():
+                self.export_metrics()
+                if self.config.get('remove_checkpoints') and os.path.isfile(self.model_file):
+                    os.remove(self.model_file)
+        except Exception as e:                   # noqa: BLE001 -- re-raised below, behind the barrier
+            failure = e
         self.config['writer'].close()
         if _distributed():
             # rank 0 may still be scoring the test sets: nobody leaves (tears RCCL down, starts the next fold,
-            # globs the prediction files) before the files exist
+            # globs the prediction files) before the files exist -- and a rank 0 that failed still reaches the barrier,
+            # it does not strand the others in it
             dist.barrier()
+        if failure is not None:
+            raise failure
 
     def _check_replicas(self):
         """Data parallel: every rank applied the same update to the same reduced gradients, so the replicas hold the same

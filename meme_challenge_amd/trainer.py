@@ -114,6 +114,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(st.flat_params)
         self.exp_avg_sq = torch.zeros_like(st.flat_params)
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=st.device)
+        self._parts = None          # per-slice partial sums of the clip norm (data parallel: one per collective)
         n_ws = _lib.lib().uniter_grad_sumsq_ws_bytes(st.numel)
         self._ws = torch.empty(n_ws, dtype=torch.uint8, device=st.device)
         self._ws_bytes = n_ws
@@ -175,12 +176,16 @@ class FusedAdam(torch.optim.Optimizer):
         return self._sumsq.sqrt()
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, max_grad_norm=0.0, zero_grads=True, grad_ready=None, grad_bf16=None):
+    def step(self, closure=None, grad_scale=1.0, max_grad_norm=0.0, zero_grads=True, grad_ready=None, grad_bf16=None,
+             grad_pieces=None):
         """grad_bf16: optional bf16 tensor holding the gradients to apply (the reduced data-parallel payload, dp.GradSync.comm)
         in place of the fp32 gradient buffer, which is still zeroed.
         grad_ready(lo, hi): optional callable that makes the CURRENT stream wait until flat_grads[lo:hi] is final
         (dp.GradSync.wait_range): each block launch then waits only for the gradient buckets that cover it.  Clipping
-        needs the norm of everything, so with max_grad_norm > 0 the whole buffer is waited for first."""
+        needs the norm of everything: with max_grad_norm > 0 it is reduced slice by slice over `grad_pieces` (the
+        collectives' slices in issue order, tiling the buffer) -- wait for one, reduce it into its slot, go on -- so
+        that behind the backward only the last collective and the norm of ITS slice are ahead of the update; without
+        `grad_pieces` the whole buffer is waited for and reduced in one pass."""
         if closure is not None:
             raise UniterHipError('FusedAdam does not support closures')
         st = self.store
@@ -193,17 +198,33 @@ class FusedAdam(torch.optim.Optimizer):
         flags = self._chunk_flags()
         lib = _lib.lib()
         if max_grad_norm and max_grad_norm > 0:
-            if grad_ready is not None:
-                grad_ready(0, st.numel)
-                grad_ready = None
-            if grad_bf16 is not None:
-                check(lib.uniter_grad_sumsq_bf16(ptr(grad_bf16), ptr(flags), st.numel, ptr(self._sumsq),
-                                                 ptr(self._ws), self._ws_bytes, _lib.cur_stream()),
-                      'uniter_grad_sumsq_bf16')
+            def sumsq(lo, hi, out_ptr):
+                if grad_bf16 is not None:
+                    check(lib.uniter_grad_sumsq_bf16(grad_bf16.data_ptr() + 2 * lo, flags.data_ptr() + lo // CHUNK, hi - lo,
+                                                     out_ptr, ptr(self._ws), self._ws_bytes, _lib.cur_stream()),
+                          'uniter_grad_sumsq_bf16')
+                else:
+                    check(lib.uniter_grad_sumsq(st.flat_grads.data_ptr() + 4 * lo, flags.data_ptr() + lo // CHUNK, hi - lo,
+                                                out_ptr, ptr(self._ws), self._ws_bytes, _lib.cur_stream()),
+                          'uniter_grad_sumsq')
+
+            pieces = sorted(grad_pieces) if (grad_ready is not None and grad_pieces) else None
+            if pieces is not None and not (pieces[0][0] == 0 and pieces[-1][1] == st.numel and
+                                           all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))):
+                pieces = None                     # the slices do not tile the buffer: one pass over all of it
+            if pieces is None or len(pieces) == 1:
+                if grad_ready is not None:
+                    grad_ready(0, st.numel)
+                sumsq(0, st.numel, self._sumsq.data_ptr())
             else:
-                check(lib.uniter_grad_sumsq(ptr(st.flat_grads), ptr(flags), st.numel, ptr(self._sumsq),
-                                            ptr(self._ws), self._ws_bytes, _lib.cur_stream()),
-                      'uniter_grad_sumsq')
+                if self._parts is None or self._parts.numel() < len(pieces):
+                    self._parts = torch.zeros(max(16, len(pieces)), dtype=torch.float64, device=st.device)
+                for k, (lo, hi) in enumerate(grad_pieces):        # issue order: the early collectives have landed long ago
+                    grad_ready(lo, hi)
+                    sumsq(lo, hi, self._parts.data_ptr() + 8 * k)
+                check(lib.uniter_sumsq_combine(ptr(self._parts), len(pieces), ptr(self._sumsq), _lib.cur_stream()),
+                      'uniter_sumsq_combine')
+            grad_ready = None
         self.step_count += 1
         b1, b2 = g0['betas']
 
@@ -317,10 +338,10 @@ def get_optimizer(model, config, group_param_func=None):
     named = list(store.params.items())
     groups = [{'params': [p for n, p in named if not no_decay(n)], 'weight_decay': config['weight_decay']},
               {'params': [p for n, p in named if no_decay(n)], 'weight_decay': 0.0}]
-    if name == 'adamax':
-        inner = torch.optim.Adamax(groups, lr=config['lr'], betas=(config['beta1'], config['beta2']))
-    else:
-        inner = torch.optim.SGD(groups, lr=config['lr'], momentum=0.9)
+    if name == 'adamax':             # utils/optim_utils.py:36-37: torch's default betas, the config's are not passed
+        inner = torch.optim.Adamax(groups, lr=config['lr'])
+    else:                            # :41-43: momentum = beta1
+        inner = torch.optim.SGD(groups, lr=config['lr'], momentum=config['beta1'])
     return TorchOptimizerStep(model, inner)
 
 
@@ -369,25 +390,24 @@ def sync_step(optimizer, grad_sync, accum, max_grad_norm):
     """average_gradients + clip + optimizer step + zero_grad behind the data-parallel exchange
     (train_template.py:89-92,103-107).  With clipping the norm needs every bucket; without it each
     optimizer block waits only for the buckets that cover it."""
-    world, ready, g16 = 1, None, None
+    world, ready, g16, kw = 1, None, None, {}
     if grad_sync is not None and grad_sync.active:
         world = grad_sync.world
+        fused = isinstance(optimizer, FusedAdam)
         # bf16 payload + the fused optimizer: the reduced sums are consumed where RCCL left them
-        grad_sync.consumer_reads_comm = grad_sync.comm is not None and isinstance(optimizer, FusedAdam)
+        grad_sync.consumer_reads_comm = grad_sync.comm is not None and fused
         if grad_sync.consumer_reads_comm:
-            g16 = grad_sync.comm
-        if max_grad_norm and max_grad_norm > 0:
-            grad_sync.finish()
-        else:
-            grad_sync.flush_all()
+            kw['grad_bf16'] = grad_sync.comm
+        grad_sync.flush_all()
+        if fused:
             ready = grad_sync.wait_range
+            if max_grad_norm and max_grad_norm > 0:
+                kw['grad_pieces'] = grad_sync.pieces()     # the clip norm, slice by slice as the collectives land
+        else:
+            grad_sync.finish()
     elif grad_sync is not None:
         world = grad_sync.world
-    if g16 is not None:
-        optimizer.step(grad_scale=1.0 / (accum * world), max_grad_norm=max_grad_norm, zero_grads=True, grad_ready=ready,
-                       grad_bf16=g16)
-    else:
-        optimizer.step(grad_scale=1.0 / (accum * world), max_grad_norm=max_grad_norm, zero_grads=True, grad_ready=ready)
+    optimizer.step(grad_scale=1.0 / (accum * world), max_grad_norm=max_grad_norm, zero_grads=True, grad_ready=ready, **kw)
 
 
 
@@ -426,7 +446,7 @@ class TrainStep(object):
         accum = cfg['gradient_accumulation']
         stepping = self.iters % accum == 0
         if self.grad_sync is not None:
-            self.grad_sync.prepare(will_step=stepping)
+            self.grad_sync.prepare(will_step=stepping, token_ids=batch['input_ids'])
         loss.backward(unit_gradient(loss.device))
         if stepping:
             sync_step(self.optimizer, self.grad_sync, accum, cfg['max_grad_norm'])

@@ -1,0 +1,62 @@
+"""CPU: `python bench.py --gpus N` outside a launcher starts N fresh rank processes itself (bench.launch_ranks): each
+child gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, only rank 0's stdout reaches the caller's stdout
+(ONE JSON line), a failing rank stops the others and makes the launcher exit non-zero.  The parent makes no GPU call:
+it is exercised here with stand-in children (the real ranks need an MI355X: tests/test_bench_gpu.py)."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+CHILD = r'''
+import json, os, sys, time
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+assert os.environ['LOCAL_RANK'] == os.environ['RANK'] and os.environ['MASTER_ADDR'] == '127.0.0.1'
+assert int(os.environ['MASTER_PORT']) > 0 and os.environ['UNITER_BENCH_LAUNCHER'] == 'self'
+mode = sys.argv[1]
+if mode == 'fail' and rank == 1:
+    sys.exit(7)
+if mode == 'fail':
+    time.sleep(60)          # would hang in a collective: the launcher must stop it
+print(json.dumps({'rank': rank, 'n_gpus': world, 'port': os.environ['MASTER_PORT']}), flush=True)
+'''
+
+
+def _run(mode, n):
+    code = ('import sys; sys.path.insert(0, %r); import bench; '
+            'sys.exit(bench.launch_ranks(%d, [sys.executable, "-c", %r, %r]))' % (REPO, n, CHILD, mode))
+    return subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+
+
+def test_launcher_starts_n_ranks_and_relays_rank0():
+    out = _run('ok', 3)
+    assert out.returncode == 0, out.stderr
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
+    assert lines == [{'rank': 0, 'n_gpus': 3, 'port': lines[0]['port']}]          # rank 0 only on stdout
+    others = sorted(json.loads(l)['rank'] for l in out.stderr.splitlines() if l.startswith('{'))
+    assert others == [1, 2]                                                         # the rest went to stderr
+
+
+def test_launcher_fails_when_a_rank_fails_and_stops_the_others():
+    t0 = time.time()
+    out = _run('fail', 2)
+    assert out.returncode == 7 and 'rank 1 exited with code 7' in out.stderr
+    assert time.time() - t0 < 45          # rank 0 (sleeping for 60 s) was terminated, not waited for
+
+
+def test_single_gpu_run_stays_in_process(monkeypatch):
+    """N = 1 (the driver's BENCH line) never goes through the launcher; neither does a rank started by torch.distributed.run."""
+    import bench
+    called = []
+    monkeypatch.setattr(bench, 'launch_ranks', lambda *a, **k: called.append(a) or 0)
+    monkeypatch.setattr(bench, 'run_rank', lambda args: 0)
+    monkeypatch.delenv('RANK', raising=False)
+    assert bench.main(['--gpus', '1']) == 0 and called == []
+    assert bench.main(['--gpus', '4', '--steps', '3']) == 0
+    assert called and called[0][0] == 4 and called[0][1][-4:] == ['--gpus', '4', '--steps', '3']
+    called.clear()
+    monkeypatch.setenv('RANK', '2')
+    assert bench.main(['--gpus', '4']) == 0 and called == []

@@ -137,6 +137,51 @@ def _worker(rank, world, port, out):
     sync3.prepare(True)
     sync3.finish()
     assert torch.equal(flat3, flat)
+    # (5) sparse word-embedding exchange: the table leaves the dense collectives; (sorted ids, rows at first occurrences)
+    # are all-gathered and summed in rank order over cleared rows -- bit-identical to the all-reduce for two ranks
+    # (0 + a + b), identical on every rank for any world size, and the clip-norm pieces tile the buffer
+    wname = 'uniter_model.embeddings.word_embeddings.weight'
+    V, H = sd[wname].shape
+    for payload in ('fp32', 'bf16'):
+        flat5 = local.clone()
+        sync5 = GradSync(flat5, ranges, bucket_bytes=1, payload=payload, word_table=(offs[wname], V, H))
+        assert len(sync5.ranges) == len(ranges) + 1 and sync5.ranges[-2] == (offs[wname], offs[wname] + V * H)
+        # micro-batch 1 accumulates locally (its ids are remembered), micro-batch 2 steps: the union of both is exchanged
+        extra = torch.tensor([[3, 3, 96, 0]]) if rank == 0 else torch.tensor([[5, 1, 1, 0]])
+        sync5.prepare(will_step=False, token_ids=extra)
+        sync5.prepare(will_step=True, token_ids=batch['input_ids'])
+        sync5.hook('begin', None, None)
+        for l in range(nl - 1, -1, -1):
+            sync5.hook('layer', l, None)
+        sync5.hook('embed', None, None)
+        assert sync5.sparse_steps == 1 and sync5.launched[-1] == sync5.ranges[-2]      # dense rest first, then the rows
+        pieces = sorted(sync5.pieces())
+        assert pieces[0][0] == 0 and pieces[-1][1] == numel and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+        sync5.finish()
+        if payload == 'fp32':
+            # rows no rank announced are untouched by the exchange: they hold the LOCAL gradient -- zero, as nobody looked them up
+            assert torch.equal(flat5, flat), (flat5 - flat).abs().max()
+        else:
+            # bf16 rows summed in fp32: the table holds the unrounded sum, its bf16 copy (what the fused optimizer reads) is
+            # what the dense bf16 all-reduce leaves (two ranks: one rounding of an exact sum either way)
+            w0, w1 = offs[wname], offs[wname] + V * H
+            assert torch.equal(flat5[:w0], flat4[:w0]) and torch.equal(flat5[w1:], flat4[w1:])
+            assert torch.equal(flat5[w0:w1].to(torch.bfloat16).float(), flat4[w0:w1])
+            assert torch.equal(sync5.comm[w0:w1].float(), flat4[w0:w1])
+        chk5 = [torch.zeros_like(flat5) for _ in range(world)]
+        dist.all_gather(chk5, flat5)
+        assert all(torch.equal(c, chk5[0]) for c in chk5)
+        # a step whose table gradient is dense (the MLM task's tied decoder) announces no ids: dense path, same sums
+        flat6 = local.clone()
+        sync6 = GradSync(flat6, ranges, bucket_bytes=1, payload=payload, word_table=(offs[wname], V, H))
+        sync6.prepare(will_step=True, token_ids=None)
+        sync6.hook('begin', None, None)
+        for l in range(nl - 1, -1, -1):
+            sync6.hook('layer', l, None)
+        sync6.hook('embed', None, None)
+        sync6.finish()
+        assert sync6.sparse_steps == 0 and torch.equal(flat6, flat if payload == 'fp32' else flat4)
+        assert sync6.launched == sync6.ranges
     if rank == 0:
         torch.save({'reduced': flat, 'offs': offs}, out)
     # every rank holds identical reduced gradients

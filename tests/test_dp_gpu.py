@@ -66,7 +66,11 @@ def test_two_ranks_share_the_batch():
     # over the batch -- weight and bias gradients, here split in two and added by the collective -- change their order
     # bf16 payload: every rank's gradients rounded to bf16 (2^-9 relative) before the sum
     assert out['bf16_payload']['rel_rms'] < 4e-3 and out['bf16_payload']['rel_rms'] > 1e-5, out['bf16_payload']
-    for r in (f32, b16):
+    # sparse word-embedding exchange (ids + touched rows all-gathered, summed in rank order): the same gradients
+    sp, sp16 = out['fp32_sparse'], out['bf16_payload_sparse']
+    assert sp['sparse_steps'] == 1 and sp16['sparse_steps'] == 1 and f32['sparse_steps'] == 0
+    assert sp16['rel_rms'] < 4e-3, sp16
+    for r in (f32, b16, sp):
         assert r['maxdiff'] <= 1e-6 * max(r['scale'], 1.0), r
         assert r['rel_rms'] < 1e-6, r
         assert abs(r['loss_mean'] - r['loss_ref']) < 1e-6, r

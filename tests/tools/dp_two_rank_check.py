@@ -29,7 +29,7 @@ def grads_of(model, batch, sync):
     store = model.param_store()
     store.zero_grads()
     if sync is not None:
-        sync.prepare(True)
+        sync.prepare(True, token_ids=batch['input_ids'])
     preds = model(**TrainStep.forward_kwargs(batch))
     loss = bce_with_logits_loss(preds.squeeze(1), batch['labels'], 1.8)
     loss.backward()
@@ -57,10 +57,12 @@ def main():
     if 'seq_lens' in shard and not torch.is_tensor(shard['seq_lens']):
         shard['seq_lens'] = list(full['seq_lens'])[rank * per:(rank + 1) * per]
     out = {}
-    for name, prec, payload in (('fp32', 'fp32', 'fp32'), ('bf16', 'bf16', 'fp32'), ('bf16_payload', 'bf16', 'bf16')):
+    for name, prec, payload, sparse in (('fp32', 'fp32', 'fp32', False), ('bf16', 'bf16', 'fp32', False),
+                                        ('bf16_payload', 'bf16', 'bf16', False), ('fp32_sparse', 'fp32', 'fp32', True),
+                                        ('bf16_payload_sparse', 'bf16', 'bf16', True)):
         model = build(cfgd)
         model.uniter_model.precision = prec
-        sync = dp.attach(model, payload=payload)
+        sync = dp.attach(model, payload=payload, sparse_embeddings=sparse)
         g, loss = grads_of(model, shard, sync)
         g = g / world                                       # what the optimizer's grad_scale = 1 / world applies
         losses = [None] * world
@@ -72,7 +74,8 @@ def main():
             scale = g_ref.abs().max().item()
             out[name] = dict(maxdiff=(g - g_ref).abs().max().item(), scale=scale,
                              rel_rms=((g - g_ref).norm() / g_ref.norm()).item(),
-                             loss_mean=sum(losses) / world, loss_ref=loss_ref, buckets=len(sync.launched))
+                             loss_mean=sum(losses) / world, loss_ref=loss_ref, buckets=len(sync.launched),
+                             sparse_steps=sync.sparse_steps)
         dist.barrier()
     if rank == 0:
         print('DP2CHECK ' + json.dumps(out), flush=True)
