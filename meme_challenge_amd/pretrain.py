@@ -27,12 +27,34 @@ logger = logging.getLogger(__name__)
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_ADD = range(5)
 
 
+# Precision of the heads' dense products: follows the encoder's (UniterForPretraining.forward sets it for the autograd
+# nodes built during that call; each node keeps the value it was built with for its backward).  'bf16': both operands
+# rounded to bf16 while they are staged, products on the bf16 matrix pipe, fp32 accumulation / epilogue / output
+# (uniter_gemm_bf16_cfg) -- the tied MLM decoder [n_masked, 768] x [768, 28996] is 82 GFLOP per MLM step at B = 32.
+_HEAD_PRECISION = ['fp32']
+
+
 def _gemm(akm, bkm, M, N, K, A, lda, B, ldb, Cc, ldc, epi=EPI_NONE, bias=None, aux_in=None, aux_out=None,
-          ld_aux=0, beta=0):
+          ld_aux=0, beta=0, prec='fp32'):
     if M == 0 or N == 0 or K == 0:
         return
-    check(_lib.lib().uniter_gemm_f32(akm, bkm, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(Cc), ldc, epi, ptr(bias),
-                                     ptr(aux_in), ptr(aux_out), ld_aux, beta, _lib.cur_stream()), 'uniter_gemm_f32')
+    lib, st = _lib.lib(), _lib.cur_stream()
+    if prec != 'bf16':
+        check(lib.uniter_gemm_f32(akm, bkm, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(Cc), ldc, epi, ptr(bias),
+                                  ptr(aux_in), ptr(aux_out), ld_aux, beta, st), 'uniter_gemm_f32')
+        return
+    K1 = K if (K % 64 == 0 or (akm and bkm)) else K // 64 * 64
+    if K1 != K and not (epi == EPI_NONE and not akm and K1 > 0 and A.is_contiguous() and B.is_contiguous()):
+        K1 = K              # (uniter_gemm_bf16_cfg itself runs such a shape on the exact fp32 kernel)
+    check(lib.uniter_gemm_bf16_cfg(0, akm, bkm, M, N, K1, ptr(A), lda, ptr(B), ldb, ptr(Cc), ldc, epi, ptr(bias),
+                                   ptr(aux_in), ptr(aux_out), ld_aux, beta, st), 'uniter_gemm_bf16_cfg')
+    if K1 != K:
+        # the bf16 kernel stages 64-deep k-tiles of a k-contiguous operand: the last K % 64 terms of the contraction (the
+        # vocabulary size 28996 = 453 * 64 + 4 in the decoder's input gradient) are added by the fp32 kernel
+        a_off = A.data_ptr() + 4 * K1
+        b_off = B.data_ptr() + 4 * K1 * (ldb if bkm else 1)
+        check(lib.uniter_gemm_f32(akm, bkm, M, N, K - K1, a_off, lda, b_off, ldb, ptr(Cc), ldc, EPI_NONE, None, None, None,
+                                  0, 1, st), 'uniter_gemm_f32')
 
 
 def _colsum(X, M, N, out):
@@ -55,11 +77,12 @@ class _LinearFn(torch.autograd.Function):
         N = weight.shape[1] if w_t else weight.shape[0]
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
         u = torch.empty_like(y) if gelu else None
+        prec = ctx.prec = _HEAD_PRECISION[0]
         if w_t:
-            _gemm(0, 1, M, N, K, x, K, weight, N, y, N, EPI_BIAS, bias)
+            _gemm(0, 1, M, N, K, x, K, weight, N, y, N, EPI_BIAS, bias, prec=prec)
         else:
             _gemm(0, 0, M, N, K, x, K, weight, K, y, N, EPI_BIAS_GELU if gelu else EPI_BIAS, bias,
-                  aux_out=u, ld_aux=N)
+                  aux_out=u, ld_aux=N, prec=prec)
         ctx.save_for_backward(x, u)
         ctx.owner, ctx.names, ctx.w_t = owner, names, w_t
         ctx.wb = (weight, bias)
@@ -81,16 +104,17 @@ class _LinearFn(torch.autograd.Function):
                   'uniter_dgelu_mul')
             dy = g
         dx = None
+        prec = ctx.prec
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if w_t:      # dx[m,k] = sum_n dy[m,n] W[k,n]
-                _gemm(0, 0, M, K, N, dy, N, weight, N, dx, K)
+                _gemm(0, 0, M, K, N, dy, N, weight, N, dx, K, prec=prec)
             else:        # dx[m,k] = sum_n dy[m,n] W[n,k]
-                _gemm(0, 1, M, K, N, dy, N, weight, K, dx, K)
+                _gemm(0, 1, M, K, N, dy, N, weight, K, dx, K, prec=prec)
         if w_t:          # dW[k,n] += sum_m x[m,k] dy[m,n]
-            _gemm(1, 1, K, N, M, x, K, dy, N, weight.grad, N, beta=1)
+            _gemm(1, 1, K, N, M, x, K, dy, N, weight.grad, N, beta=1, prec=prec)
         else:            # dW[n,k] += sum_m dy[m,n] x[m,k]
-            _gemm(1, 1, N, K, M, dy, N, x, K, weight.grad, K, beta=1)
+            _gemm(1, 1, N, K, M, dy, N, x, K, weight.grad, K, beta=1, prec=prec)
         _colsum(dy, M, N, bias.grad)
         _mark_touched_names(ctx.owner, ctx.names)
         return dx, None, None, None, None, None, None
@@ -381,6 +405,7 @@ class UniterForPretraining(UniterPreTrainedModel):
 
     def forward(self, batch, task, compute_loss=True):
         ensure_store(self)
+        _HEAD_PRECISION[0] = 'bf16' if self.uniter.precision == 'bf16' else 'fp32'
         batch = defaultdict(lambda: None, batch)
         common = (batch['input_ids'], batch['position_ids'], batch['img_feat'], batch['img_pos_feat'],
                   batch['attn_masks'], batch['gather_index'])

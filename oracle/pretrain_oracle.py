@@ -5,7 +5,13 @@ region-classification tasks next to them (MRC / MRC-kl):
 UniterForPretraining.forward_{mlm,mrfr,itm,mrc} (model/pretrain.py:107-233),
 RegionFeatureRegression (model/pretrain.py:19-33), RegionClassification (:36-47),
 BertOnlyMLMHead (model/layer.py:188-233).
-Weights use the reference's UniterForPretraining.state_dict() key names ("uniter." prefix)."""
+Weights use the reference's UniterForPretraining.state_dict() key names ("uniter." prefix).
+
+prec='bf16' (the bf16 precision mode of the HIP path, BASELINE configs[2..4]): the encoder rounds what
+uniter_oracle's bf16 mode rounds, and every dense product of the heads that runs on the bf16 matrix pipe --
+the head transforms, the tied MLM decoder, the tied MRFR projection -- rounds both operands, forward and
+backward (uniter_oracle._LinearB16); GELU, LayerNorm, the losses, the pooler and the two-way ITM head stay
+fp32, as in meme_challenge_amd/pretrain.py."""
 import torch
 import torch.nn.functional as F
 
@@ -18,44 +24,45 @@ def _masked_hidden(hidden, mask):
     return hidden[m].contiguous().view(-1, hidden.size(-1))
 
 
-def _head_transform(sd, p, x):
+def _head_transform(sd, p, x, prec='fp32'):
     # dense -> erf-GELU -> LayerNorm(eps 1e-12)   (model/layer.py:188-204; model/pretrain.py:22-25)
-    return O.layer_norm(O.gelu(F.linear(x, sd[p[0] + 'weight'], sd[p[0] + 'bias'])),
+    return O.layer_norm(O.gelu(O.linear(x, sd[p[0] + 'weight'], sd[p[0] + 'bias'], prec)),
                         sd[p[1] + 'weight'], sd[p[1] + 'bias'])
 
 
-def _encode(sd, cfg, batch, drop, img_masks=None):
+def _encode(sd, cfg, batch, drop, img_masks=None, prec='fp32'):
     return O.uniter_forward(sd, cfg, batch['input_ids'], batch['position_ids'], batch['img_feat'],
                             batch['img_pos_feat'], batch['attn_masks'], batch['gather_index'],
-                            img_masks=img_masks, output_all_encoded_layers=False, drop=drop, prefix='uniter.')
+                            img_masks=img_masks, output_all_encoded_layers=False, drop=drop, prefix='uniter.',
+                            prec=prec)
 
 
-def forward_mlm(sd, cfg, batch, compute_loss=True, drop=None):
-    seq = _encode(sd, cfg, batch, drop)
+def forward_mlm(sd, cfg, batch, compute_loss=True, drop=None, prec='fp32'):
+    seq = _encode(sd, cfg, batch, drop, prec=prec)
     seq = seq[:, :batch['input_ids'].size(1), :]
     h = _masked_hidden(seq, batch['txt_labels'] != -1)
-    h = _head_transform(sd, ('cls.predictions.transform.dense.', 'cls.predictions.transform.LayerNorm.'), h)
+    h = _head_transform(sd, ('cls.predictions.transform.dense.', 'cls.predictions.transform.LayerNorm.'), h, prec)
     # tied decoder (model/layer.py:212-226): word_embeddings.weight + separate bias
-    scores = F.linear(h, sd['uniter.embeddings.word_embeddings.weight']) + sd['cls.predictions.bias']
+    scores = O.linear(h, sd['uniter.embeddings.word_embeddings.weight'], None, prec) + sd['cls.predictions.bias']
     if not compute_loss:
         return scores
     tl = batch['txt_labels']
     return F.cross_entropy(scores, tl[tl != -1], reduction='none')
 
 
-def forward_mrfr(sd, cfg, batch, compute_loss=True, drop=None):
-    seq = _encode(sd, cfg, batch, drop, img_masks=batch['img_masks'])
+def forward_mrfr(sd, cfg, batch, compute_loss=True, drop=None, prec='fp32'):
+    seq = _encode(sd, cfg, batch, drop, img_masks=batch['img_masks'], prec=prec)
     h = _masked_hidden(seq, batch['img_mask_tgt'])
-    h = _head_transform(sd, ('feat_regress.net.0.', 'feat_regress.net.2.'), h)
+    h = _head_transform(sd, ('feat_regress.net.0.', 'feat_regress.net.2.'), h, prec)
     # F.linear(hidden, img_linear.weight.t(), bias), model/pretrain.py:27,32
-    pred = F.linear(h, sd['uniter.img_embeddings.img_linear.weight'].t(), sd['feat_regress.bias'])
+    pred = O.linear(h, sd['uniter.img_embeddings.img_linear.weight'].t(), sd['feat_regress.bias'], prec)
     if not compute_loss:
         return pred
     return F.mse_loss(pred, batch['feat_targets'], reduction='none')
 
 
-def forward_itm(sd, cfg, batch, compute_loss=True, drop=None):
-    seq = _encode(sd, cfg, batch, drop)
+def forward_itm(sd, cfg, batch, compute_loss=True, drop=None, prec='fp32'):
+    seq = _encode(sd, cfg, batch, drop, prec=prec)
     pooled = O.pooler(sd, 'uniter.', seq)
     scores = F.linear(pooled, sd['itm_output.weight'], sd['itm_output.bias'])
     if not compute_loss:
@@ -63,9 +70,10 @@ def forward_itm(sd, cfg, batch, compute_loss=True, drop=None):
     return F.cross_entropy(scores, batch['targets'], reduction='none')
 
 
-def forward_mrc(sd, cfg, batch, task='mrc', compute_loss=True, drop=None):
-    # model/pretrain.py:205-233
-    seq = _encode(sd, cfg, batch, drop, img_masks=batch['img_masks'])
+def forward_mrc(sd, cfg, batch, task='mrc', compute_loss=True, drop=None, prec='fp32'):
+    # model/pretrain.py:205-233 (the region classifier's products stay fp32 in both modes: its label width, 1601, is
+    # no multiple of 4 and the task is not part of BASELINE config 5)
+    seq = _encode(sd, cfg, batch, drop, img_masks=batch['img_masks'], prec=prec)
     h = _masked_hidden(seq, batch['img_mask_tgt'])
     h = _head_transform(sd, ('region_classifier.net.0.', 'region_classifier.net.2.'), h)
     scores = F.linear(h, sd['region_classifier.net.3.weight'], sd['region_classifier.net.3.bias'])

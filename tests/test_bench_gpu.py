@@ -66,8 +66,8 @@ def test_bench_starts_its_own_ranks(extra):
     per rank) -- the launcher, the rendezvous, the exchange and the line are the ones an 8-GPU run uses."""
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     env.update(UNITER_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-                          '--prewarm_s', '0', '--no_cpu_baseline', *extra], cwd=ROOT, env=env, capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                          '--prewarm_s', '0', '--prof_kind', '0', '--no_cpu_baseline', *extra], cwd=ROOT, env=env, capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -75,9 +75,10 @@ def test_bench_starts_its_own_ranks(extra):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['ranks_seen'] == 2 and d['config']['dist_backend'] == 'gloo'
     assert d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp2' and 'self-spawned' in d['config']['launcher']
-    assert abs(d['value'] - 32 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3 and d['final_loss'] == d['final_loss']
+    # (gloo moves 440 MB of gradients through the host: seconds per step -- the value is rounded to two decimals)
+    assert abs(d['value'] - 32 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-2 and d['final_loss'] == d['final_loss']
     n_sparse = d['config']['dp_sparse_embedding_steps']            # every step took the sparse path (warm-up and the events pass included)
-    assert (n_sparse == 0) if not extra else (n_sparse >= 3 + 1)
+    assert (n_sparse == 0) if not extra else (n_sparse == 2 + 1)
 
 
 def test_graft_entry_smoke():

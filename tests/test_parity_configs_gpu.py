@@ -5,7 +5,10 @@
   configs[3]  UNITER-large B=8  T=128 R=50  fp32 against the reference golden WITH gradients
               (tests/golden/shapes_large.npz) and bf16 against the bf16-rounding oracle
   configs[4]  UNITER-base + ITM / MLM / MRFR heads, B=32 T=128 R=36, fp32 against the oracle on
-              PCG64 weights: per-element losses and gradient slices, both tied weights included
+              PCG64 weights: per-element losses and gradient slices, both tied weights included;
+              and in the bf16 mode (encoder AND the heads' dense products -- the tied MLM decoder, the
+              tied MRFR projection -- on the bf16 pipe), two-sided against the bf16-rounding and the
+              fp32 oracle like the fine-tuning step
 
 What the bf16 bar is, and why.  The oracle's bf16 mode rounds the same operands the kernels round (GEMM
 inputs, the stored query|key|value, gelu / gelu', the blocked online-softmax probabilities, dO / Pd / dS), so ONE
@@ -255,3 +258,86 @@ def test_config5_multitask_b32_matches_oracle(task, train):
         assert (g.abs().sum(1) > 0).sum().item() > 20000          # the decoder touches every vocabulary row
     if task == 'mrfr':
         assert m.feat_regress.weight is m.uniter.img_embeddings.img_linear.weight
+
+
+@pytest.mark.parametrize('task,train', [('mlm', True), ('mrfr', False), ('itm', True)])
+def test_config5_multitask_b32_bf16_two_sided(task, train):
+    """BASELINE configs[4] in the arithmetic its bench line runs in (precision='bf16'): per-element losses and the
+    gradients of the embeddings, two encoder layers, the pooler and every head parameter (both tied weights) of the
+    HIP path are no further from the fp32 oracle than the bf16-rounding oracle itself is -- the bar of
+    _check_bf16_step_against_bf16_oracle -- and they differ from the fp32 oracle at all (the bf16 kernels really ran,
+    in the heads too: the decoder-only parameters are held to the same bar)."""
+    from meme_challenge_amd.model import UniterConfig
+    from meme_challenge_amd.pretrain import UniterForPretraining
+    from meme_challenge_amd.utils import make_synthetic_pretrain_batch
+    B, T, R = 32, 128, 36
+    m = UniterForPretraining(UniterConfig.from_dict(BASE), img_dim=2048, img_label_dim=1601)
+    sd = _pretrain_state(m)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    m = m.train() if train else m.eval()
+    m.uniter.precision = 'bf16'
+    dseed, doff = 0x5E5E, 2
+    m.uniter.set_dropout_seed(dseed, doff)
+    b = make_synthetic_pretrain_batch(task, B, T, R, seed=77)
+    seq_lens = b.pop('seq_lens')
+    bd = {k: v.cuda() for k, v in b.items()}
+    bd['seq_lens'] = seq_lens
+    loss = m(bd, task, compute_loss=True)
+    loss.mean().backward()
+    torch.cuda.synchronize()
+    drop = O.DropSpec(dseed, doff, BASE['hidden_dropout_prob'], BASE['attention_probs_dropout_prob']) if train else None
+    fwd = {'mlm': P.forward_mlm, 'mrfr': P.forward_mrfr, 'itm': P.forward_itm}[task]
+
+    def oracle(prec):
+        uniq, sdo = {}, {}
+        for k, v in sd.items():          # tied keys must stay one leaf
+            if id(v) not in uniq:
+                uniq[id(v)] = v.clone().requires_grad_(True)
+            sdo[k] = uniq[id(v)]
+        lo = fwd(sdo, BASE, dict(b), compute_loss=True, drop=drop, prec=prec)
+        lo.mean().backward()
+        return lo.detach(), {k: v.grad for k, v in sdo.items()}
+
+    lb, gb = oracle('bf16')
+    lf, gf = oracle('fp32')
+    assert tuple(loss.shape) == tuple(lf.shape)
+    noise = maxdiff(lb, lf)                      # what the rounding model alone does to the per-element losses
+    scale = max(1.0, lf.abs().max().item())
+    assert 1e-5 * scale < noise < 5e-2 * scale, noise
+    assert maxdiff(loss, lf) <= 2.0 * noise + 2e-4 * scale, (maxdiff(loss, lf), noise)
+    assert maxdiff(loss, lb) <= 2.0 * noise + 2e-4 * scale, (maxdiff(loss, lb), noise)
+    assert maxdiff(loss, lf) > 1e-5 * scale      # really ran the bf16 path
+    assert _rms_rel(loss, lf) <= 1.6 * _rms_rel(lb, lf) + 1e-5
+    params = dict(m.named_parameters())
+    checked, ratios, head_ratios = 0, [], []
+    for n, p in params.items():
+        ref = gf[n]
+        if ref is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, n
+            continue
+        if not (n.startswith('uniter.encoder.layer.0.') or n.startswith('uniter.encoder.layer.11.')
+                or 'embeddings' in n or not n.startswith('uniter.encoder')):
+            continue
+        if n.endswith('attention.self.key.bias'):
+            qb = params[n.replace('key.bias', 'query.bias')].grad
+            assert p.grad.abs().max().item() <= 0.2 * qb.abs().max().item() + 1e-12, n
+            continue
+        if ref.abs().max().item() == 0.0:
+            assert p.grad.abs().max().item() == 0.0, n
+            continue
+        eh, eo = _rms_rel(p.grad, ref), _rms_rel(gb[n], ref)
+        assert eh <= 1.6 * eo + 2e-4, (task, n, eh, eo)
+        assert _rms_rel(p.grad, gb[n]) <= 2.0 * eo + 2e-4, (task, n, _rms_rel(p.grad, gb[n]), eo)
+        ratios.append(eh / max(eo, 1e-30))
+        if not n.startswith('uniter.'):
+            head_ratios.append((n, eh, eo))
+        checked += 1
+    assert checked > 30
+    med = float(np.median(ratios))
+    assert 0.8 < med < 1.2, med
+    if task in ('mlm', 'mrfr'):
+        # the heads' own products ran on the bf16 pipe: their weight gradients carry bf16-sized noise (an fp32 head would
+        # sit at 1e-6 against the fp32 oracle's head given the same inputs; here both are ~1e-3)
+        dense = [r for r in head_ratios if r[0].endswith('dense.weight') or r[0].endswith('net.0.weight')]
+        assert dense and all(eh > 1e-4 for _, eh, _ in dense), dense
