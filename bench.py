@@ -292,6 +292,8 @@ def run_rank(args):
             step.train_iter(batch, iters=0)
     else:
         last = {}
+        if sync is None:
+            opt.attach_norm_hooks(encoder)
 
         def one_step():
             task = task_rng.choice(tasks)

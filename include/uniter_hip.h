@@ -399,6 +399,12 @@ int uniter_grad_sumsq_bf16(const void* grads_bf16, const uint8_t* chunk_flags, s
 /* out[0] = parts[0] + .. + parts[n-1]: the clip norm (train_template.py:104, clip_grad_norm_ over ALL parameters) reduced
  * slice by slice -- one uniter_grad_sumsq per data-parallel collective as it lands, each into its own slot -- and joined here */
 int uniter_sumsq_combine(const double* parts, int n, double* out, void* stream);
+/* the same norm taken DURING the backward pass: as soon as a slice of the gradient buffer is final (a layer's weight
+ * gradients, on the stream that wrote them) `nblocks` workgroups leave their unreduced partial sums of it in
+ * parts[0 .. nblocks) (chunk_flags NULL = every element counts); one uniter_sumsq_combine over all slices' partials
+ * ends it.  Behind the backward pass only the embeddings' slice is left instead of a pass over every gradient. */
+int uniter_grad_sumsq_part(const float* grads, const uint8_t* chunk_flags, size_t n, double* parts, int nblocks,
+                           void* stream);
 int uniter_adam_step_g16(float* params, float* grads, const void* grads_bf16, float* exp_avg, float* exp_avg_sq,
                          const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale,
                          float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
@@ -467,7 +473,11 @@ uint64_t uniter_model_generation(const uniter_model_t* m);
 /* Overlap of the optimizer step with the next forward: `events` = hipEvent_t[num_hidden_layers + 1]
  * (embedding block, layer 0, layer 1, ..), each fired once that block's parameters (and zeroed
  * gradients) are final.  The next uniter_model_forward makes its stream wait for events[0] before
- * the embeddings and events[1 + l] before layer l, then forgets them.  n = 0 clears. */
+ * the embeddings and events[1 + l] before layer l, then forgets them.  n = 0 clears.
+ * n = num_hidden_layers + 2: events[0] covers the embeddings' parameters WITHOUT the word-embedding table and the last
+ * event the table alone (22 of the embeddings' 24 M parameters): the forward then runs its image branch (region
+ * projection, the three LayerNorms of model/model.py:261-272), which reads no word embedding, behind events[0] and
+ * only the text embeddings wait for the table. */
 int  uniter_model_set_ready_events(uniter_model_t* m, void* const* events, int n);
 size_t uniter_model_ws_bytes(const uniter_model_t* m, int B, int T, int R, int L, int train);
 /* hidden_out: [B,L,H] last layer (all_layers = 0) or [nl,B,L,H] (all_layers = 1).

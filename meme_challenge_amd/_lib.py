@@ -110,6 +110,7 @@ _SIGS = {
     'uniter_adam_step_g16': (_I, [_P, _P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _I, _P]),
     'uniter_grad_sumsq_bf16': (_I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
     'uniter_sumsq_combine': (_I, [_P, _I, _P, _P]),
+    'uniter_grad_sumsq_part': (_I, [_P, _P, _SZ, _P, _I, _P]),
     'uniter_num_params': (_I, [C.POINTER(UniterConfigC)]),
     'uniter_param_name': (C.c_char_p, [C.POINTER(UniterConfigC), _I]),
     'uniter_param_shape': (_I, [C.POINTER(UniterConfigC), _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

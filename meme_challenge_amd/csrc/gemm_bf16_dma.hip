@@ -182,9 +182,10 @@ __device__ __forceinline__ void wait_lgkm8(u32x2_t& a, u32x2_t& b, u32x2_t& c, u
 }
 
 // work item of this workgroup, XCD-chunked (blocks b and b + 8 share an XCD's L2: consecutive items go to one XCD);
-// -1 for the padding blocks of the grid
-__device__ __forceinline__ int xcd_work_item(int nwork) {
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+// -1 for the padding blocks of the grid.  round > 0: the items a workgroup of a grid SMALLER than the work takes after
+// its first one (the grouped weight-gradient launch on a capped grid), still inside its XCD's chunk
+__device__ __forceinline__ int xcd_work_item(int nwork, int round = 0) {
+  const int xcd = blockIdx.x & 7, idx = (blockIdx.x >> 3) + round * (int)(gridDim.x >> 3);
   const int q8 = nwork >> 3, r8 = nwork & 7;
   const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
   const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
@@ -203,7 +204,6 @@ __device__ __forceinline__ void gemm_dma_tile(const GArgsD& g, const int w, unsi
   const int i5 = lane & 31, h = lane >> 5;
   const int wm = wave / WNN, wn = wave % WNN;
 
-  stamp_begin(g.stamp);
   const int tile = w / g.nsplit, piece = w - tile * g.nsplit;
   int tmi, tni;
   tile_coords_d(tile, g.tiles_m, g.tiles_n, g.band_h, tmi, tni);
@@ -502,7 +502,6 @@ __device__ __forceinline__ void gemm_dma_tile(const GArgsD& g, const int w, unsi
         }
       }
   }
-  stamp_end(g.stamp);
 #endif
 }
 
@@ -512,7 +511,9 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), (ST * (BM + BN) * 128 <
   // work item -> (tile, k-piece), banded tile order inside an XCD's chunk
   const int w = xcd_work_item(g.tiles_m * g.tiles_n * g.nsplit);
   if (w < 0) return;
+  stamp_begin(g.stamp);
   gemm_dma_tile<BM, BN, AKM, BKM, SWAP, ST, EPI>(g, w, smem);
+  stamp_end(g.stamp);
 }
 
 // The weight gradients of one encoder layer as ONE launch: up to four products dW_p[M_p, N_p] += A_p^T B_p (both
@@ -528,10 +529,19 @@ struct GGroupD {
 template <int ST>
 __global__ __launch_bounds__(256, (ST == 2 ? 2 : 1)) void gemm_dma_wgrad_group_kernel(const GGroupD G) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * 256 * 128];
-  const int w = xcd_work_item(G.start[4]);
-  if (w < 0) return;
-  const int p = (w >= G.start[1]) + (w >= G.start[2]) + (w >= G.start[3]);
-  gemm_dma_tile<128, 128, true, true, true, ST, UNITER_EPI_ADD>(G.p[p], w - G.start[p], smem);
+  // a grid smaller than the tile count (G.max_wgs): the workgroup walks its XCD's chunk in strides of the grid -- fewer
+  // workgroups of this launch resident per CU, so the input-gradient chain on the other stream finds free slots
+  bool any = false;
+  for (int round = 0;; ++round) {
+    const int w = xcd_work_item(G.start[4], round);
+    if (w < 0) break;
+    if (!any) stamp_begin(G.p[0].stamp);
+    else __syncthreads();                 // the slowest wave has left the previous tile's last LDS stage
+    any = true;
+    const int p = (w >= G.start[1]) + (w >= G.start[2]) + (w >= G.start[3]);
+    gemm_dma_tile<128, 128, true, true, true, ST, UNITER_EPI_ADD>(G.p[p], w - G.start[p], smem);
+  }
+  if (any) stamp_end(G.p[0].stamp);
 }
 
 template <int BM>
@@ -659,7 +669,12 @@ int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K,
   }
   G.start[4] = total;
   for (int p = n; p < 4; ++p) G.start[p] = total;
-  const int grid = (total + 7) / 8 * 8;
+  int grid = (total + 7) / 8 * 8;
+  // UNITER_WGRAD_GROUP_WGS: cap of the grid (a multiple of 8; 0 = one workgroup per tile).  256 = one workgroup of this
+  // launch per CU: the launch alone takes what two co-resident workgroups take (a lone 4-wave tile runs its k-loop at
+  // 0.57 us per k-tile against 0.93 for two), and every CU keeps a slot for the other stream's kernels
+  static const int cap = [] { const char* e = getenv("UNITER_WGRAD_GROUP_WGS"); return e ? atoi(e) / 8 * 8 : 0; }();
+  if (cap >= 8 && grid > cap) grid = cap;
   hipStream_t st = (hipStream_t)stream;
   if (cfg == 4) hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<3>), dim3(grid), dim3(256), 0, st, G);
   else hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<2>), dim3(grid), dim3(256), 0, st, G);

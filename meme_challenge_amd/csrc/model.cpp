@@ -472,15 +472,13 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   ++m->generation;
 
   // parameters still being written by an optimizer step on another stream (uniter_model_set_ready_events)
-  const bool gated = (int)m->ready.size() == nl + 1;
+  // ready = [embeddings, layer 0 .. nl-1] or, with one more event, [embeddings WITHOUT the word table, layers.., word table]:
+  // the image branch (region projection, 3 LayerNorms) then runs while the optimizer still streams the 89-MB word table
+  const bool gated = (int)m->ready.size() == nl + 1 || (int)m->ready.size() == nl + 2;
+  const bool word_split = (int)m->ready.size() == nl + 2;
   if (gated) UCHECK_HIP(hipStreamWaitEvent(st, m->ready[0], 0));
 
   // ---- embeddings (model/model.py:321-334) ----
-  if (has_txt)
-    UCHECK_RC(uniter_txt_embed_fwd(b->input_ids, b->position_ids, b->txt_type_ids, m->P(P_WORD), m->P(P_POS),
-                                   m->P(P_TYPE), m->P(P_ELN_G), m->P(P_ELN_B), pl.cat, B, T, S, H,
-                                   c.vocab_size, c.max_position_embeddings, c.type_vocab_size, b->pos_bcast,
-                                   ph, seed, offset, st));
   if (has_img) {
     const float* feat = b->img_feat;
     if (b->img_masks) {
@@ -505,6 +503,13 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
                                    m->P(P_TYPE), m->P(P_ILN_G), m->P(P_ILN_B), m->P(P_PLN_G), m->P(P_PLN_B),
                                    m->P(P_FLN_G), m->P(P_FLN_B), pl.cat, save ? pl.img_stats : nullptr, B, R,
                                    pl.T0, S, H, c.type_vocab_size, ph, seed, offset, st));
+  }
+  if (has_txt) {
+    if (word_split) UCHECK_HIP(hipStreamWaitEvent(st, m->ready[nl + 1], 0));
+    UCHECK_RC(uniter_txt_embed_fwd(b->input_ids, b->position_ids, b->txt_type_ids, m->P(P_WORD), m->P(P_POS),
+                                   m->P(P_TYPE), m->P(P_ELN_G), m->P(P_ELN_B), pl.cat, B, T, S, H,
+                                   c.vocab_size, c.max_position_embeddings, c.type_vocab_size, b->pos_bcast,
+                                   ph, seed, offset, st));
   }
   const bool joint = has_txt && has_img;
   if (packed) UCHECK_RC(uniter_row_gather(pl.cat, b->pack_src, pl.emb, M, H, B * S, st));
@@ -865,8 +870,8 @@ extern "C" int uniter_model_backward(uniter_model_t* m, const uniter_batch_t* b,
 extern "C" uint64_t uniter_model_generation(const uniter_model_t* m) { return m ? m->generation : 0; }
 
 extern "C" int uniter_model_set_ready_events(uniter_model_t* m, void* const* events, int n) {
-  UCHECK_ARG(m && (n == 0 || (events && n == m->cfg.num_hidden_layers + 1)),
-             "set_ready_events: need num_hidden_layers + 1 events (embeddings, layer 0 ..) or n = 0");
+  UCHECK_ARG(m && (n == 0 || (events && (n == m->cfg.num_hidden_layers + 1 || n == m->cfg.num_hidden_layers + 2))),
+             "set_ready_events: need num_hidden_layers + 1 events (embeddings, layer 0 ..), one more (the word table, last) or n = 0");
   m->ready.clear();
   for (int i = 0; i < n; ++i) {
     UCHECK_ARG(events[i], "set_ready_events: event %d is NULL", i);

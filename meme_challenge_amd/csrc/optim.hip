@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 2 * stride) {
     const size_t j = i + stride;
-    const bool f0 = flags[(i * 4) / CHUNK] != 0, f1 = j < n4 && flags[(j * 4) / CHUNK] != 0;
+    const bool f0 = !flags || flags[(i * 4) / CHUNK] != 0, f1 = j < n4 && (!flags || flags[(j * 4) / CHUNK] != 0);
     f32x4 v = {0.f, 0.f, 0.f, 0.f}, w = v;
     if (f0) v = g16 ? widen4(g16, i) : reinterpret_cast<const f32x4*>(g)[i];
     if (f1) w = g16 ? widen4(g16, j) : reinterpret_cast<const f32x4*>(g)[j];
@@ -87,7 +87,7 @@ __device__ __forceinline__ void adam_update4(const AdamArgs& a, float coef, floa
     p[e] = pp - a.step_size * (m[e] / denom);
   }
 }
-__device__ __forceinline__ void adam_store4(const AdamArgs& a, size_t i, const f32x4& p, const f32x4& m, const f32x4& v) {
+__device__ __forceinline__ void adam_store4(const AdamArgs& a, size_t i, const f32x4& p, const f32x4& m, const f32x4& v, bool clear) {
   // the update streams 34 bytes per parameter once: non-temporal accesses, so that it does not evict the operand panels of
   // the forward kernels that share the chip with it from the L2s
   __builtin_nontemporal_store(p, reinterpret_cast<f32x4*>(a.p) + i);
@@ -97,8 +97,11 @@ __device__ __forceinline__ void adam_store4(const AdamArgs& a, size_t i, const f
   }
   __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(a.m) + i);
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.v) + i);
-  if (a.zero_grads) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(a.g) + i);
+  // zero_grad: only where something was written -- four of five rows of the embeddings' block (the word table away from
+  // the batch's tokens) hold zeros already
+  if (clear) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(a.g) + i);
 }
+__device__ __forceinline__ bool any_nonzero(const f32x4& g) { return g[0] != 0.f || g[1] != 0.f || g[2] != 0.f || g[3] != 0.f; }
 
 // Two 16-byte elements per thread and iteration, all eight loads issued before the arithmetic: a grid of one or two
 // workgroups per CU (the launch that shares the chip with the next forward, see trainer.FusedAdam) still keeps
@@ -123,8 +126,15 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     if (f1) {
       p1 = NT_LOAD(a.p, j); g1 = a.g16 ? widen4(a.g16, j) : NT_LOAD(a.g, j); m1 = NT_LOAD(a.m, j); v1 = NT_LOAD(a.v, j);
     }
-    if (f0) { adam_update4(a, coef, f0 == 2 ? a.wd : 0.f, p0, g0, m0, v0); adam_store4(a, i, p0, m0, v0); }
-    if (f1) { adam_update4(a, coef, f1 == 2 ? a.wd : 0.f, p1, g1, m1, v1); adam_store4(a, j, p1, m1, v1); }
+    // (gradients read from the bf16 payload: the fp32 buffer holds this rank's own sums, cleared whatever the payload says)
+    if (f0) {
+      const bool c0 = a.zero_grads && (a.g16 != nullptr || any_nonzero(g0));
+      adam_update4(a, coef, f0 == 2 ? a.wd : 0.f, p0, g0, m0, v0); adam_store4(a, i, p0, m0, v0, c0);
+    }
+    if (f1) {
+      const bool c1 = a.zero_grads && (a.g16 != nullptr || any_nonzero(g1));
+      adam_update4(a, coef, f1 == 2 ? a.wd : 0.f, p1, g1, m1, v1); adam_store4(a, j, p1, m1, v1, c1);
+    }
   }
 }
 
@@ -162,6 +172,19 @@ extern "C" int uniter_grad_sumsq_bf16(const void* grads_bf16, const uint8_t* chu
                      (const unsigned short*)grads_bf16);
   UCHECK_LAUNCH();
   hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, sumsq);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+// One slice of the norm, unreduced: `nblocks` workgroups leave their partial sums in parts[0 .. nblocks); the caller joins
+// the slices' partials with uniter_sumsq_combine.  chunk_flags NULL = every chunk counts (a parameter without a gradient
+// this step holds zeros: the buffer is cleared by the optimizer step).
+extern "C" int uniter_grad_sumsq_part(const float* grads, const uint8_t* chunk_flags, size_t n, double* parts, int nblocks,
+                                      void* stream) {
+  UCHECK_ARG(grads && parts && nblocks >= 1 && nblocks <= 2048, "grad_sumsq_part: bad argument");
+  UCHECK_SHAPE(n % 4 == 0 && ((uintptr_t)grads & 15) == 0, "grad_sumsq_part: n must be a multiple of 4, 16-byte aligned");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, grads, chunk_flags, n / 4, parts,
+                     (const unsigned short*)nullptr);
   UCHECK_LAUNCH();
   return 0;
 }

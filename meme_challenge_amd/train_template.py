@@ -211,6 +211,9 @@ class TrainerTemplate(object):
             # the update of step i runs beside the forward of step i+1 (trainer.FusedAdam.step);
             # every other reader of the parameters joins first (ModelSaver.save)
             self.optimizer.overlap_encoder = enc
+        if enc is not None and self.grad_sync is None and hasattr(self.optimizer, 'attach_norm_hooks') and \
+                (self.config.get('max_grad_norm') or 0) > 0:
+            self.optimizer.attach_norm_hooks(enc)    # clip norm reduced bucket by bucket during the backward pass
 
     # --------------------------------------------------------------------- step
     def _loss_and_probs(self, preds, labels):

@@ -115,6 +115,10 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(st.flat_params)
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=st.device)
         self._parts = None          # per-slice partial sums of the clip norm (data parallel: one per collective)
+        # the clip norm taken during the backward pass (attach_norm_hooks): unreduced partial sums per bucket
+        self._np_buf = None
+        self._np_blocks = 0         # partial sums written by the backward that just ran (0 = not armed)
+        self._np_seen = None
         n_ws = _lib.lib().uniter_grad_sumsq_ws_bytes(st.numel)
         self._ws = torch.empty(n_ws, dtype=torch.uint8, device=st.device)
         self._ws_bytes = n_ws
@@ -140,8 +144,64 @@ class FusedAdam(torch.optim.Optimizer):
             covered = sorted(head + blocks)
             ok = ok and covered[0][0] == 0 and covered[-1][1] == st.numel and \
                 all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
-            self._plan_cache = (head, blocks) if ok else False
+            word = None
+            if ok:      # the word-embedding table, when it opens the embeddings' bucket: its update is a launch of its own
+                name = next((n for n in st.names if n.endswith('embeddings.word_embeddings.weight')), None)
+                if name is not None and st.offsets[name] == blocks[0][0]:
+                    end = st.offsets[name] + (st.params[name].numel() + CHUNK - 1) // CHUNK * CHUNK
+                    if end < blocks[0][1]:
+                        word = (st.offsets[name], end)
+            self._plan_cache = (head, blocks, word) if ok else False
         return self._plan_cache or None
+
+    NORM_BLOCKS = 256           # workgroups (= partial sums) per layer slice, on the side stream beside the input-gradient chain
+    NORM_BLOCKS_LAST = 2048     # the embeddings' slice runs alone behind the backward pass: the whole chip
+
+    def attach_norm_hooks(self, encoder):
+        """Take the clip norm (clip_grad_norm_, train_template.py:104) slice by slice DURING the backward pass: the
+        encoder's backward schedule announces every bucket of the flat gradient buffer the moment it is final (head,
+        layer nl-1 .. 0 on the weight-gradient stream, embeddings on the main stream) and this optimizer reduces the
+        bucket into partial sums right there -- on a stream that idles half of each layer anyway.  `step` then only
+        joins the partial sums (one 1-workgroup launch) instead of streaming all 440 MB of gradients once more
+        behind the backward pass.  Single process only: with a data-parallel exchange attached the norm is that of the
+        REDUCED gradients (dp.GradSync.pieces)."""
+        if getattr(encoder, '_grad_hook', None) is not None:
+            return False
+        st = self.store
+        nb = len(st.bucket_ranges)
+        self._np_buf = torch.zeros((nb - 1) * self.NORM_BLOCKS + self.NORM_BLOCKS_LAST, dtype=torch.float64, device=st.device)
+        self._np_blocks, self._np_seen = 0, set()
+        nl = encoder.config.num_hidden_layers
+        if nb not in (nl + 1, nl + 2):
+            return False
+        first_layer = nb - nl - 1            # index of layer nl-1's bucket (0 when there is no head bucket)
+        lib = _lib.lib()
+
+        def reduce_bucket(k, stream):
+            lo, hi = st.bucket_ranges[k]
+            sp = stream.cuda_stream if stream is not None else _lib.cur_stream()
+            check(lib.uniter_grad_sumsq_part(st.flat_grads.data_ptr() + 4 * lo, None, hi - lo,
+                                             self._np_buf.data_ptr() + 8 * k * self.NORM_BLOCKS,
+                                             self.NORM_BLOCKS_LAST if k == nb - 1 else self.NORM_BLOCKS, sp),
+                  'uniter_grad_sumsq_part')
+            self._np_seen.add(k)
+
+        def hook(kind, index, stream):
+            if kind == 'begin':
+                self._np_seen = set()
+                self._np_blocks = 0
+                if first_layer == 1:
+                    reduce_bucket(0, stream)                 # head / pooler: final before the encoder's backward starts
+            elif kind == 'layer':
+                reduce_bucket(first_layer + (nl - 1 - index), stream)
+            elif kind == 'embed':
+                reduce_bucket(nb - 1, stream)
+                if len(self._np_seen) == nb:
+                    self._np_blocks = self._np_buf.numel()   # armed: every bucket of THIS backward is in
+
+        encoder._grad_hook = hook
+        self._norm_hook = hook
+        return True
 
     def join(self):
         """Make the current stream wait for an overlapped update still running on the side stream."""
@@ -208,11 +268,16 @@ class FusedAdam(torch.optim.Optimizer):
                                                 out_ptr, ptr(self._ws), self._ws_bytes, _lib.cur_stream()),
                           'uniter_grad_sumsq')
 
+            armed, self._np_blocks = self._np_blocks, 0
             pieces = sorted(grad_pieces) if (grad_ready is not None and grad_pieces) else None
             if pieces is not None and not (pieces[0][0] == 0 and pieces[-1][1] == st.numel and
                                            all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))):
                 pieces = None                     # the slices do not tile the buffer: one pass over all of it
-            if pieces is None or len(pieces) == 1:
+            if armed and grad_ready is None and grad_bf16 is None:
+                # the backward pass left the norm as partial sums (attach_norm_hooks): join them
+                check(lib.uniter_sumsq_combine(ptr(self._np_buf), armed, ptr(self._sumsq), _lib.cur_stream()),
+                      'uniter_sumsq_combine')
+            elif pieces is None or len(pieces) == 1:
                 if grad_ready is not None:
                     grad_ready(0, st.numel)
                 sumsq(0, st.numel, self._sumsq.data_ptr())
@@ -225,6 +290,8 @@ class FusedAdam(torch.optim.Optimizer):
                 check(lib.uniter_sumsq_combine(ptr(self._parts), len(pieces), ptr(self._sumsq), _lib.cur_stream()),
                       'uniter_sumsq_combine')
             grad_ready = None
+        else:
+            self._np_blocks = 0
         self.step_count += 1
         b1, b2 = g0['betas']
 
@@ -254,7 +321,9 @@ class FusedAdam(torch.optim.Optimizer):
             # The update is HBM-bound, the next forward MFMA-bound: run the encoder's blocks on the
             # side stream in the order the forward needs them (embeddings, layer 0, 1, ..), one event
             # per block; the next uniter_model_forward waits block by block instead of for all of it.
-            head, blocks = plan
+            head, blocks, word = plan
+            if os.environ.get('UNITER_ADAM_WORD_SPLIT') == '0':
+                word = None
             main = torch.cuda.current_stream()
             for lo, hi in head:                                  # pooler / heads: tiny, stay on this stream
                 if grad_ready is not None:
@@ -266,18 +335,32 @@ class FusedAdam(torch.optim.Optimizer):
             side.wait_stream(main)
             events = []
             import ctypes as C
-            for k, (lo, hi) in enumerate(blocks):
+
+            def block(lo, hi, max_wgs):
                 if grad_ready is not None:
                     with torch.cuda.stream(side):
                         grad_ready(lo, hi)
-                # the embeddings' block has the chip to itself (the forward waits for it); the layers' blocks share it
-                # with the forward of the layers before them: a grid that leaves the forward its wave slots
-                launch(lo, hi, C.c_void_p(side.cuda_stream), 0 if k == 0 else self.overlap_workgroups)
+                launch(lo, hi, C.c_void_p(side.cuda_stream), max_wgs)
                 ev = torch.cuda.Event()
                 ev.record(side)
-                events.append(ev)
+                return ev
+
+            word_ev = None
+            for k, (lo, hi) in enumerate(blocks):
+                # the embeddings' block has the chip to itself (the forward waits for it); the layers' blocks share it
+                # with the forward of the layers before them: a grid that leaves the forward its wave slots
+                if k == 0 and word is not None:
+                    # everything but the word table first (2 M parameters): the next forward's image branch reads no word
+                    # embedding and starts behind this launch, beside the table's 0.13 ms of streaming (capped grid)
+                    events.append(block(word[1], hi, 0))
+                    word_ev = block(word[0], word[1], self.overlap_workgroups * 2)
+                else:
+                    events.append(block(lo, hi, 0 if k == 0 else self.overlap_workgroups))
+            last = events[-1]                    # the side stream's last launch: what join() waits for
+            if word_ev is not None:
+                events.append(word_ev)
             enc._set_ready_events(events)
-            self._pending = events[-1]
+            self._pending = last
         if zero_grads:
             st.touched.clear()      # flags stay cached: the same set is touched again next step
 
@@ -425,6 +508,9 @@ class TrainStep(object):
         self.grad_sync = grad_sync          # DP: object with .finish() called before the optimizer step
         if config.get('loss_func', 'bce_logits') != 'bce_logits':
             raise UniterHipError("only loss_func='bce_logits' is built on the HIP path")
+        enc = getattr(model, 'uniter_model', None)
+        if grad_sync is None and enc is not None and isinstance(optimizer, FusedAdam) and (config.get('max_grad_norm') or 0) > 0:
+            optimizer.attach_norm_hooks(enc)        # the clip norm is reduced bucket by bucket during the backward pass
         self.iters = 0
         self.last_loss = None
         self.last_probs = None

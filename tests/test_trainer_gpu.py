@@ -108,3 +108,39 @@ def test_overlapped_optimizer_step_matches_single_launch():
     # (Adam turns an atomics-order difference of a near-zero gradient into a visible step: the bound is the larger of a
     # multiple of what two identical runs show and a few 1e-6 -- five steps at lr 1e-3 move the parameters by ~5e-3)
     assert diff <= max(4 * noise, 5e-6), (diff, noise)
+
+
+def test_clip_norm_taken_during_backward_equals_the_full_pass():
+    """FusedAdam.attach_norm_hooks: the clip norm reduced bucket by bucket while the backward pass runs (partial sums
+    joined by uniter_sumsq_combine) is the norm of the full pass over the gradient buffer -- same double-precision sum up
+    to its order -- with gradient accumulation (the partial sums of the STEPPING backward see the accumulated buffer) and
+    with the weight gradients on the side stream."""
+    from meme_challenge_amd.model import UniterConfig, UniterModel
+    from meme_challenge_amd.meme_uniter import MemeUniter
+    from meme_challenge_amd.trainer import FusedAdam, TrainStep, get_scheduler
+    from meme_challenge_amd.utils import make_synthetic_batch
+    cfg = UniterConfig.from_dict(TINY)
+    config = dict(optimizer='adam', lr=1e-3, beta1=0.9, beta2=0.999, weight_decay=1e-3, gradient_accumulation=2,
+                  max_grad_norm=0.05, pos_wt=1.8, loss_func='bce_logits', scheduler='warmup_cosine', warmup_steps=2,
+                  max_epoch=2)
+    bs = [make_synthetic_batch(4, 16, 6, seed=3 + k, vocab=TINY['vocab_size'], img_dim=TINY_IMG_DIM, device='cuda')
+          for k in range(2)]
+    finals, norms = {}, {}
+    for hooked in (False, True):
+        torch.manual_seed(0)
+        m = MemeUniter(UniterModel(cfg, img_dim=TINY_IMG_DIM), cfg.hidden_size, 1).cuda().train()
+        m.uniter_model.set_dropout_seed(5, 0)
+        opt = FusedAdam(m, lr=config['lr'], weight_decay=config['weight_decay'])
+        step = TrainStep(m, opt, get_scheduler(opt, config, steps_per_epoch=10), config)
+        assert m.uniter_model._grad_hook is not None          # TrainStep attached the hooks (clipping on, no exchange)
+        if not hooked:
+            m.uniter_model._grad_hook = None
+        seen = []
+        for it in range(5):
+            step.train_iter(bs[it % 2], iters=it)
+            seen.append(opt._sumsq.clone())
+        torch.cuda.synchronize()
+        finals[hooked], norms[hooked] = m.param_store().flat_params.clone(), torch.cat(seen)
+    assert float(norms[True].min()) > 0 and float(norms[True].sqrt().min()) > config['max_grad_norm']     # the clip was active
+    assert torch.allclose(norms[True], norms[False], rtol=1e-5, atol=0), (norms[True], norms[False])
+    assert (finals[True] - finals[False]).abs().max().item() <= 5e-6
