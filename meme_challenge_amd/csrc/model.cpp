@@ -900,8 +900,9 @@ extern "C" int uniter_model_set_weight_mirror(uniter_model_t* m, const float* fl
 extern "C" int uniter_model_set_precision(uniter_model_t* m, int precision) {
   UCHECK_ARG(m && precision >= 0 && precision <= 2, "set_precision: 0 (fp32), 1 (bf16 MFMA, fp32 operands) or 2 (bf16-resident operands)");
   UCHECK_ARG(precision != 2 || m->mirror, "set_precision: precision 2 needs uniter_model_set_weight_mirror first");
-  UCHECK_SHAPE(precision != 2 || m->cfg.intermediate_size % 64 == 0,
-               "set_precision: the bf16-resident mode needs intermediate_size %% 64 == 0 (got %d)", m->cfg.intermediate_size);
+  UCHECK_SHAPE(precision != 2 || (m->cfg.intermediate_size % 64 == 0 && m->cfg.hidden_size % 64 == 0),
+               "set_precision: the bf16-resident mode needs hidden_size and intermediate_size %% 64 == 0 (got %d, %d): every "
+               "forward and input-gradient product runs on 64-deep k-tiles", m->cfg.hidden_size, m->cfg.intermediate_size);
   m->precision = precision;
   return 0;
 }

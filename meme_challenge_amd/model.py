@@ -549,8 +549,8 @@ class _UniterFn(torch.autograd.Function):
         model = ctx.model
         if _lib.lib().uniter_model_generation(model._handle) != ctx.generation:
             raise UniterHipError('backward of a forward that is no longer the latest one on this UniterModel: the library '
-                                 'keeps the activations of ONE forward per model (run backward before the next forward, '
-                                 'or use torch.no_grad() for forwards that need no gradient)')
+                                 'keeps the activations of ONE forward per model: run backward before ANY further forward of '
+                                 'this model (forwards under torch.no_grad() reuse the same plan and count as well)')
         d_hidden = d_hidden.contiguous()
         model._run_backward(ctx.batch, d_hidden, ctx.all_layers, ctx.seed, ctx.offset, ctx.ws,
                             ctx.nbytes)
@@ -680,6 +680,9 @@ class UniterModel(UniterPreTrainedModel):
             self._applied_precision = None
         if self.precision not in ('fp32', 'bf16', 'bf16_hybrid'):
             raise ValueError("precision must be 'fp32', 'bf16' or 'bf16_hybrid'")
+        if self.precision == 'bf16' and (self.config.hidden_size % 64 or self.config.intermediate_size % 64):
+            raise ValueError("precision='bf16' needs hidden_size and intermediate_size to be multiples of 64 (the "
+                             "LDS-DMA GEMM stages 64-deep k-tiles); use 'bf16_hybrid' or 'fp32' for this config")
         if self.precision == 'bf16':
             mirror = st.ensure_mirror()            # refreshed here whenever the parameters changed behind its back
             if self._applied_precision != (self.precision, mirror.data_ptr()):
@@ -779,6 +782,12 @@ class UniterModel(UniterPreTrainedModel):
         check(_lib.lib().uniter_model_set_ready_events(self._handle, arr, len(events)),
               'uniter_model_set_ready_events')
 
+    @staticmethod
+    def lengths_from_mask(attention_mask):
+        """Per-sample lengths of a right-padded attention mask as a host list (ONE device -> host synchronisation, in the
+        caller's hands): what `seq_lens` wants when the batch does not carry it."""
+        return [int(n) for n in attention_mask.sum(dim=1).to(torch.int64).cpu().tolist()]
+
     def _pack(self, b, keep, attention_mask, gather_index, seq_lens):
         """Token packing: hand the library the valid positions only.  The
         attention mask must be right-padded (1..1 0..0 per row, what get_attention_mask builds):
@@ -786,13 +795,12 @@ class UniterModel(UniterPreTrainedModel):
         downstream, so dropping those rows changes no valid output and no gradient."""
         B, L = b.B, b.L
         if seq_lens is None:
-            if not getattr(self, '_warned_pack_sync', False):
-                logger.warning('pack_padded without seq_lens: the lengths are read back from attention_mask (one device->host '
-                               'synchronisation per forward); the collate of data.MemeDataset provides batch["seq_lens"]')
-                self._warned_pack_sync = True
-            lens = attention_mask.sum(dim=1).to(torch.int64).cpu().numpy()       # device -> host sync
-        else:
-            lens = np.asarray(torch.as_tensor(seq_lens).cpu().numpy(), dtype=np.int64).reshape(-1)
+            # the row count of the packed layout sizes the workspace on the host: it cannot come from a device tensor
+            # without a device -> host synchronisation in the middle of the step, so the lengths are an input
+            raise UniterHipError('pack_padded needs seq_lens (host list of tl + nbb per sample: batch["seq_lens"] of '
+                                 'data.MemeDataset\'s collate / utils.make_synthetic_batch; for a one-off call '
+                                 'UniterModel.lengths_from_mask(attention_mask) reads them back from the mask)')
+        lens = np.asarray(torch.as_tensor(seq_lens).cpu().numpy(), dtype=np.int64).reshape(-1)
         if lens.shape[0] != B or (lens < 1).any() or (lens > L).any():
             raise ValueError('seq_lens must hold B values in [1, L]')
         cu = np.zeros(B + 1, dtype=np.int32)
@@ -819,8 +827,8 @@ class UniterModel(UniterPreTrainedModel):
         """Same signature / return as model/model.py:336-367: list of per-layer
         hidden states, or the last layer's [B, L, H] tensor.
 
-        ``seq_lens`` (extension, host list of tl+nbb per sample) is only read when
-        ``self.pack_padded`` is set: it saves the device->host copy of ``attention_mask.sum(1)``."""
+        ``seq_lens`` (extension, host list of tl+nbb per sample) is read (and required) only when
+        ``self.pack_padded`` is set: the packed layout's row count sizes the workspace on the host."""
         self._ensure_handle()
         dev = self.embeddings.LayerNorm.weight.device
         keep = []

@@ -409,6 +409,7 @@ class UniterForPretraining(UniterPreTrainedModel):
         batch = defaultdict(lambda: None, batch)
         common = (batch['input_ids'], batch['position_ids'], batch['img_feat'], batch['img_pos_feat'],
                   batch['attn_masks'], batch['gather_index'])
+        self._seq_lens = batch['seq_lens']        # host lengths for token packing (UniterModel.pack_padded), when the batch has them
         if task == 'mlm':
             return self.forward_mlm(*common, batch['txt_labels'], compute_loss)
         elif task == 'mrfr':
@@ -434,7 +435,7 @@ class UniterForPretraining(UniterPreTrainedModel):
     def forward_mlm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                     txt_labels, compute_loss=True):
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
-                          output_all_encoded_layers=False)
+                          output_all_encoded_layers=False, seq_lens=getattr(self, '_seq_lens', None))
         T = input_ids.size(1)
         if seq.shape[1] < T:
             raise ValueError('sequence output shorter than the text length (model/pretrain.py:116)')
@@ -447,7 +448,7 @@ class UniterForPretraining(UniterPreTrainedModel):
     def forward_mrfr(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                      img_masks, img_mask_tgt, feat_targets, compute_loss=True):
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
-                          output_all_encoded_layers=False, img_masks=img_masks)
+                          output_all_encoded_layers=False, img_masks=img_masks, seq_lens=getattr(self, '_seq_lens', None))
         masked = self._masked_rows(seq, img_mask_tgt)
         pred = self.feat_regress(masked)
         if not compute_loss:
@@ -459,7 +460,7 @@ class UniterForPretraining(UniterPreTrainedModel):
         """model/pretrain.py:205-233: region classification on the masked regions; 'mrc' trains against the most
         likely non-background detector class, 'mrc-kl' against the detector's soft labels."""
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
-                          output_all_encoded_layers=False, img_masks=img_masks)
+                          output_all_encoded_layers=False, img_masks=img_masks, seq_lens=getattr(self, '_seq_lens', None))
         masked = self._masked_rows(seq, img_mask_tgt)
         scores = self.region_classifier(masked)
         if not compute_loss:
@@ -478,7 +479,7 @@ class UniterForPretraining(UniterPreTrainedModel):
             logger.info('forward_itm: ot_inputs given -- the reference discards the OT distance it computes from them; skipped')
             self._warned_ot = True
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
-                          output_all_encoded_layers=False)
+                          output_all_encoded_layers=False, seq_lens=getattr(self, '_seq_lens', None))
         pooled = self.uniter.pooler(seq)
         scores = self.itm_output(pooled)
         if not compute_loss:

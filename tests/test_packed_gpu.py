@@ -78,6 +78,7 @@ def test_packed_tiny_model_equals_padded_everywhere_valid(tiny):
         m.uniter_model.pack_padded = packed
         kw = model_kwargs(b)
         kw['output_all_encoded_layers'] = True
+        kw['seq_lens'] = lens
         layers = m.uniter_model(**kw)                      # one forward: the module keeps one set of activations
         logits = m.linear(m.uniter_model.pooler(layers[-1]))
         loss = bce_with_logits_loss(logits, b['labels'], 1.8)
@@ -111,6 +112,7 @@ def test_packed_all_layer_gradients_flow(tiny):
         m.uniter_model.pack_padded = packed
         kw = model_kwargs(b)
         kw['output_all_encoded_layers'] = True
+        kw['seq_lens'] = m.uniter_model.lengths_from_mask(b['attn_mask'])
         layers = m.uniter_model(**kw)
         loss = sum(((l * valid) ** 2).sum() * (0.1 + i) for i, l in enumerate(layers))
         loss.backward()
@@ -201,7 +203,7 @@ def test_single_modality_and_mask_inputs_in_every_layout(tiny, precision, mode):
         m = build(TINY, TINY_IMG_DIM, sd).eval()
         m.uniter_model.precision = precision
         m.uniter_model.pack_padded = packed
-        h = m.uniter_model(output_all_encoded_layers=False, **kw)
+        h = m.uniter_model(output_all_encoded_layers=False, seq_lens=m.uniter_model.lengths_from_mask(kw['attention_mask']), **kw)
         (h * h).sum().backward()
         torch.cuda.synchronize()
         outs[packed] = (h.detach().clone(), _grads(m))
@@ -215,10 +217,26 @@ def test_single_modality_and_mask_inputs_in_every_layout(tiny, precision, mode):
         m = build(TINY, TINY_IMG_DIM, sd).eval()
         m.uniter_model.precision = precision
         m.uniter_model.pack_padded = packed
-        h = m.uniter_model(output_all_encoded_layers=False, **kw)
+        h = m.uniter_model(output_all_encoded_layers=False, seq_lens=m.uniter_model.lengths_from_mask(kw['attention_mask']), **kw)
         ((h * valid.unsqueeze(-1)) ** 2).sum().backward()
         torch.cuda.synchronize()
         outs[packed] = _grads(m)
     gtol = 3e-4 if precision == 'fp32' else 6e-2
     for n, gp in outs[False].items():
         assert maxdiff(outs[True][n], gp) <= 1e-5 + gtol * max(gp.abs().max().item(), 1e-3), (n, maxdiff(outs[True][n], gp))
+
+
+def test_packing_needs_host_lengths(tiny):
+    """No hidden device -> host synchronisation: the packed layout's row count sizes the workspace on the host, so the
+    lengths are an input (batch['seq_lens']); asking for packing without them raises instead of reading the mask back."""
+    from meme_challenge_amd._lib import UniterHipError
+    sd = sd_from_npz(tiny)
+    b = to_dev(batch_from_npz(tiny))
+    m = build(TINY, TINY_IMG_DIM, sd).eval()
+    m.uniter_model.pack_padded = True
+    kw = model_kwargs(b)
+    with pytest.raises(UniterHipError, match='seq_lens'):
+        m(**kw)
+    lens = m.uniter_model.lengths_from_mask(b['attn_mask'])
+    assert lens == b['attn_mask'].sum(1).long().tolist()
+    assert maxdiff(m(seq_lens=lens, **kw), tiny['out/logits']) < 1e-5
