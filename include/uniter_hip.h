@@ -361,7 +361,8 @@ int uniter_dgelu_mul(const float* dy, const float* u, float* out, size_t n, void
  * clip_grad_norm_ + torch.optim.Adam/AdamW.step + zero_grad:
  * train_template.py:89-92,103-107; utils/optim_utils.py:9-46).
  *   chunk_flags[i] for elements [64*i, 64*i+64): 0 = skip (no gradient this step),
- *   1 = no weight decay, 2 = weight decay.
+ *   1 = no weight decay, 2 = weight decay; + 4 = zero_grads leaves this chunk's gradient alone (the next backward pass
+ *   overwrites it: uniter_model_set_wgrad_overwrite) -- 28 instead of 32 bytes per parameter.
  * ------------------------------------------------------------------------- */
 /* sumsq[0] = sum g^2 over flagged chunks (device scalar, double) */
 int uniter_grad_sumsq(const float* grads, const uint8_t* chunk_flags, size_t n,
@@ -485,6 +486,13 @@ size_t uniter_model_ws_bytes(const uniter_model_t* m, int B, int T, int R, int L
 int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* batch, float* hidden_out,
                          int all_layers, int train, uint64_t seed, uint32_t offset,
                          void* ws, size_t ws_bytes, void* stream);
+/* Gradient accumulation semantics without the clearing pass (optimizer.zero_grad, train_template.py:107): after an optimizer
+ * step that did NOT clear the encoder layers' weight gradients (uniter_adam_step*: chunk flag + 4), announce it here and the
+ * NEXT backward pass writes query|key|value / attention-output / intermediate / output weight gradients with `=` instead of
+ * `+=` (whole-K tiles: a plain store; kernels that add partial tiles clear their output first), then the flag resets:
+ * further backward passes (gradient_accumulation > 1) accumulate as before.  Everything else (biases, LayerNorm, embeddings,
+ * pooler) always accumulates into buffers the optimizer step cleared. */
+int uniter_model_set_wgrad_overwrite(uniter_model_t* m, int on);
 /* d_hidden: same layout as hidden_out.  Accumulates into the bound gradient buffers.
  * Stages let the caller interleave gradient all-reduce with backward:
  *   uniter_model_backward_begin, then layer nl-1 .. 0, then uniter_model_backward_embed. */

@@ -120,6 +120,7 @@ _SIGS = {
     'uniter_model_set_ready_events': (_I, [_P, _P, _I]),
     'uniter_model_set_weight_mirror': (_I, [_P, _P, _P, _SZ]),
     'uniter_model_set_precision': (_I, [_P, _I]),
+    'uniter_model_set_wgrad_overwrite': (_I, [_P, _I]),
     'uniter_model_ws_bytes': (_SZ, [_P, _I, _I, _I, _I, _I]),
     'uniter_model_forward': (_I, [_P, C.POINTER(UniterBatchC), _P, _I, _I, _U64, _U32, _P, _SZ, _P]),
     'uniter_model_backward_begin': (_I, [_P, C.POINTER(UniterBatchC), _P, _I, _U64, _U32, _P, _SZ, _P, _P]),

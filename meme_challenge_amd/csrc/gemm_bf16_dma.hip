@@ -526,7 +526,7 @@ struct GGroupD {
   int start[5];     // first work item of product p; start[n..4] = total
 };
 
-template <int ST>
+template <int ST, bool ACC>
 __global__ __launch_bounds__(256, (ST == 2 ? 2 : 1)) void gemm_dma_wgrad_group_kernel(const GGroupD G) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * 256 * 128];
   // a grid smaller than the tile count (G.max_wgs): the workgroup walks its XCD's chunk in strides of the grid -- fewer
@@ -539,7 +539,9 @@ __global__ __launch_bounds__(256, (ST == 2 ? 2 : 1)) void gemm_dma_wgrad_group_k
     else __syncthreads();                 // the slowest wave has left the previous tile's last LDS stage
     any = true;
     const int p = (w >= G.start[1]) + (w >= G.start[2]) + (w >= G.start[3]);
-    gemm_dma_tile<128, 128, true, true, true, ST, UNITER_EPI_ADD>(G.p[p], w - G.start[p], smem);
+    // ACC: dW += (the output is its own aux operand); !ACC: dW = (the first backward pass after an optimizer step that left
+    // the gradient uncleared: no read of dW, and the optimizer wrote no zeros -- uniter_model_set_wgrad_overwrite)
+    gemm_dma_tile<128, 128, true, true, true, ST, ACC ? UNITER_EPI_ADD : UNITER_EPI_NONE>(G.p[p], w - G.start[p], smem);
   }
   if (any) stamp_end(G.p[0].stamp);
 }
@@ -646,7 +648,7 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
 // dW_p[M_p, N_p] += A_p^T B_p for up to four products of one reduction length K (A_p [K, M_p], B_p [K, N_p] bf16,
 // dW_p fp32 with leading dimension N_p), one launch; cfg 1 = two LDS stages (two workgroups per CU), 4 = three.
 int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A,
-                            const void* const* B, float* const* dW, void* stream) {
+                            const void* const* B, float* const* dW, void* stream, int overwrite) {
   UCHECK_ARG(n >= 1 && n <= 4 && K > 0 && Mo && No && A && B && dW, "wgrad_group: bad argument");
   GGroupD G;
   unsigned long long* stamp = take_stamp_slot();
@@ -661,8 +663,8 @@ int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K,
                  "wgrad_group: M, N %% 8, 16-byte aligned buffers, 31-bit offsets (product %d: %d x %d, K=%d)", p, Mo[p], No[p], K);
     GArgsD& g = G.p[p];
     g.M = Mo[p]; g.N = No[p]; g.K = K; g.A = A[p]; g.lda = Mo[p]; g.B = B[p]; g.ldb = No[p]; g.C = dW[p]; g.ldc = No[p];
-    g.c_split_stride = 0; g.Cb = nullptr; g.ldcb = 0; g.epi = UNITER_EPI_ADD; g.bias = nullptr;
-    g.aux_in = dW[p]; g.aux_in_bf16 = 0; g.aux_out = nullptr; g.aux_out_bf16 = 0; g.ld_aux = No[p];
+    g.c_split_stride = 0; g.Cb = nullptr; g.ldcb = 0; g.epi = overwrite ? UNITER_EPI_NONE : UNITER_EPI_ADD; g.bias = nullptr;
+    g.aux_in = overwrite ? nullptr : dW[p]; g.aux_in_bf16 = 0; g.aux_out = nullptr; g.aux_out_bf16 = 0; g.ld_aux = No[p];
     g.nsplit = 1; g.stamp = stamp; g.dbg = 0;
     plan_tiles<128>(g, 128);
     total += g.tiles_m * g.tiles_n;
@@ -676,15 +678,20 @@ int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K,
   static const int cap = [] { const char* e = getenv("UNITER_WGRAD_GROUP_WGS"); return e ? atoi(e) / 8 * 8 : 0; }();
   if (cap >= 8 && grid > cap) grid = cap;
   hipStream_t st = (hipStream_t)stream;
-  if (cfg == 4) hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<3>), dim3(grid), dim3(256), 0, st, G);
-  else hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<2>), dim3(grid), dim3(256), 0, st, G);
+  if (cfg == 4) {
+    if (overwrite) hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<3, false>), dim3(grid), dim3(256), 0, st, G);
+    else hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<3, true>), dim3(grid), dim3(256), 0, st, G);
+  } else {
+    if (overwrite) hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<2, false>), dim3(grid), dim3(256), 0, st, G);
+    else hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<2, true>), dim3(grid), dim3(256), 0, st, G);
+  }
   UCHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int uniter_wgrad_bf16_group(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
                                        const void* const* B, float* const* dW, void* stream) {
-  return gemm_bf16v2_wgrad_group(cfg, n, M, N, K, A, B, dW, stream);
+  return gemm_bf16v2_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, 0);
 }
 
 // Split-K choice for the GEMMs whose N is the hidden size (measured on MI355X, tests/tools/gemm_v2_lab.py,

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
 }
 
 template <int BM, int BN, bool AKM, bool BKM, int TAG>
-int launch_v3(GemmArgs g, hipStream_t st, int slots) {
+int launch_v3(GemmArgs g, hipStream_t st, int slots, bool allow_sk = true) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   const int tiles = g.tiles_m * g.tiles_n;
@@ -582,7 +582,7 @@ int launch_v3(GemmArgs g, hipStream_t st, int slots) {
   int grid = tiles < slots ? (tiles + 7) / 8 * 8 : slots;
   // stream-K when the tiles fill the slots unevenly (only legal for a plain accumulating GEMM)
   static const int sk_mode = env_int("UNITER_GEMM_SK", 1);     // 0 never, 1 heuristic, 2 whenever legal
-  if constexpr (TAG == 0) if (sk_mode && g.beta == 1 && g.epi == UNITER_EPI_NONE && !g.colsum_part && tiles >= 8) {
+  if constexpr (TAG == 0) if (allow_sk && sk_mode && g.beta == 1 && g.epi == UNITER_EPI_NONE && !g.colsum_part && tiles >= 8) {
     const int rounds = (tiles + slots - 1) / slots;
     const bool uneven = (long)tiles * 100 < (long)rounds * slots * 88;
     const long units = (long)tiles * ((g.K + BK - 1) / BK);
@@ -611,14 +611,14 @@ int dispatch_cfg(int cfg, const GemmArgs& g, hipStream_t st) {
     case 2: return launch<64, 128, AKM, BKM, TAG>(g, st);
     case 3: return launch<128, 64, AKM, BKM, TAG>(g, st);
     case 4: return launch<64, 64, AKM, BKM, TAG>(g, st);
-    case 21: case 24: {
+    case 21: case 24: case 25: {      // 25 = 24 without the stream-K form (whole-K tiles: operand panels shared k-synchronously)
       const bool fast = (g.K % BK == 0 || (AKM && BKM)) && (size_t)(AKM ? g.K : g.M) * g.lda * 4 < (1ull << 31) &&
                         (size_t)(BKM ? g.K : g.N) * g.ldb * 4 < (1ull << 31) &&
                         ((size_t)g.M + 128) * g.ldc * 4 < (1ull << 31) &&
                         ((size_t)g.M + 128) * (g.ld_aux > 0 ? g.ld_aux : 1) * 4 < (1ull << 31);
-      if (!fast) return dispatch_cfg<AKM, BKM, TAG>(cfg - 20, g, st);      // one-tile-per-workgroup kernel
+      if (!fast) return dispatch_cfg<AKM, BKM, TAG>(cfg == 21 ? 1 : 4, g, st);      // one-tile-per-workgroup kernel
       if (cfg == 21) return launch_v3<128, 128, AKM, BKM, TAG>(g, st, 512);
-      return launch_v3<64, 64, AKM, BKM, TAG>(g, st, 1024);
+      return launch_v3<64, 64, AKM, BKM, TAG>(g, st, 1024, cfg != 25);
     }
     default: uniter_set_error("gemm: bad cfg %d", cfg); return UNITER_E_ARG;
   }
@@ -663,7 +663,7 @@ int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int
   if (colsum_part) {
     const bool fast = (K % BK == 0 || (a_kmajor && b_kmajor)) && (size_t)(a_kmajor ? K : M) * lda * 4 < (1ull << 31) &&
                       (size_t)(b_kmajor ? K : N) * ldb * 4 < (1ull << 31);
-    UCHECK_SHAPE(fast && (cfg == 21 || cfg == 24) && beta == 0, "gemm: fused column sums need the v3 kernel (K %% 32 == 0)");
+    UCHECK_SHAPE(fast && (cfg == 21 || cfg == 24 || cfg == 25) && beta == 0, "gemm: fused column sums need the v3 kernel (K %% 32 == 0)");
   }
   hipStream_t st = (hipStream_t)stream;
   if (!a_kmajor && !b_kmajor)

@@ -35,7 +35,7 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
 int gemm_bf16v2_pick_split(int M, int N, int K);
 int gemm_bf16v2_wgrad_pieces(int M, int N, int K);
 int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A,
-                            const void* const* B, float* const* dW, void* stream);
+                            const void* const* B, float* const* dW, void* stream, int overwrite);
 int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta, hipStream_t st);
 int finalize_partials_jobs(int njobs, const float* const* part, const int* nparts, const size_t* stride,
                            float* const (*outs)[3], const int* nout, const int* seg, hipStream_t st);
@@ -135,6 +135,7 @@ struct uniter_model {
   uint32_t offset = 0;
   hipStream_t st = nullptr, side = nullptr;
   bool bwd_open = false;
+  bool wg_overwrite = false; // the next backward pass overwrites the encoder's weight gradients (uniter_model_set_wgrad_overwrite)
   uint64_t generation = 0;   // bumped by every forward: a backward must belong to the LATEST forward (one plan / workspace per model)
 
   float* P(int i) const { return p[i]; }
@@ -267,12 +268,31 @@ int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int
          int lda, const float* B, int ldb, float* C, int ldc, int epi, const float* bias, const float* aux_in,
          float* aux_out, int ld_aux, int beta, float* colsum_part = nullptr) {
   ProfScope ps(m, kind, st);
+  // weight gradients: UNITER_WGRAD_CFG = 21 selects 128 x 128 stream-K tiles (measured slower: DESIGN.md section 9), 24 the 64 x 64 ones
+  static const int wg_cfg = [] { const char* e = getenv("UNITER_WGRAD_CFG"); return e ? atoi(e) : 0; }();
+  // UNITER_WGRAD_WHOLE: bit mask over a layer's weight gradients by output shape (1: [H, I] output.dense, 2: [I, H]
+  // intermediate.dense, 4: [H, H] attention output, 8: [3H, H] query|key|value): whole-K tiles (cfg 25) instead of stream-K.
+  // Default 15: measured 13.95 against 14.06 ms per step with every shape on whole tiles -- the k-synchronous tiles of a
+  // tile row share their operand panel in L2 (the LayerNorm backward beside them runs at 17 instead of 26 us) -- and
+  // without float atomics the fp32 weight gradients are bit-reproducible and a first backward pass may overwrite them.
+  static const int wg_whole = [] { const char* e = getenv("UNITER_WGRAD_WHOLE"); return e ? atoi(e) : 15; }();
+  int cfg = 0;
+  const bool wgrad = kind == UNITER_K_GEMM_WGRAD && akm && bkm && (beta == 1 || beta == -1);
+  if (wgrad && m->precision == 0) {
+    cfg = wg_cfg;
+    const int H_ = m->cfg.hidden_size, I_ = m->cfg.intermediate_size;
+    const int bit = (M == H_ && N == I_) ? 1 : (M == I_ && N == H_) ? 2 : (M == H_ && N == H_) ? 4 : (M == 3 * H_ && N == H_) ? 8 : 0;
+    if (wg_whole & bit) cfg = 25;
+  }
+  if (beta == -1) {
+    // overwrite requested (uniter_model_set_wgrad_overwrite): whole-K tiles store their result; every form that adds
+    // partial tiles with float atomics gets a cleared output first
+    if (cfg == 25) beta = 0;
+    else { UCHECK_HIP(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(float), st)); beta = 1; }
+  }
   if (m->precision >= 1)      // embeddings' projections (fp32 inputs) also run on the bf16 pipe in mode 2
     return gemm_bf16_run(0, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux_in, aux_out, ld_aux, beta,
                          colsum_part, st);
-  // weight gradients (stream-K): UNITER_WGRAD_CFG = 21 selects 128 x 128 tiles (half the operand bytes per FLOP), 24 the 64 x 64 ones
-  static const int wg_cfg = [] { const char* e = getenv("UNITER_WGRAD_CFG"); return e ? atoi(e) : 0; }();
-  const int cfg = (kind == UNITER_K_GEMM_WGRAD && akm && bkm && beta == 1) ? wg_cfg : 0;
   return gemm_f32_run(cfg, kind == UNITER_K_GEMM_FFN_UP_FWD, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias,
                       aux_in, aux_out, ld_aux, beta, colsum_part, st);
 }
@@ -296,6 +316,7 @@ int gemm_r(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, i
 }
 // dW[Mo, No] += A^T B with A [K, Mo], B [K, No] bf16: split-K slabs + one reduce pass where that beats stream-K atomics
 int wgrad_b16(uniter_model* m, const Plan& pl, hipStream_t st, int Mo, int No, int K, const void* A, const void* B, float* dW) {
+  if (m->wg_overwrite) UCHECK_HIP(hipMemsetAsync(dW, 0, (size_t)Mo * No * sizeof(float), st));      // these forms accumulate
   const int pieces = gemm_bf16v2_wgrad_pieces(Mo, No, K);
   if (pieces == 0 || !pl.wg_slabs)
     return gemm_r(m, UNITER_K_GEMM_WGRAD, st, 1, 1, Mo, No, K, A, Mo, B, No, dW, No, nullptr, 0, UNITER_EPI_NONE, nullptr,
@@ -707,7 +728,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     float* const dWs[3] = {m->LG(l, L_W1), m->LG(l, L_W2), m->LG(l, L_OW)};
     {
       ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-      UCHECK_RC(gemm_bf16v2_wgrad_group(1, 3, Mo, No, M, As, Bs, dWs, sd));
+      UCHECK_RC(gemm_bf16v2_wgrad_group(1, 3, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0));
     }
     UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
   }
@@ -773,7 +794,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
       const void* const Bs[1] = {xb};
       float* const dWs[1] = {m->LG(l, L_QW)};
       ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-      UCHECK_RC(gemm_bf16v2_wgrad_group(1, 1, Mo, No, M, As, Bs, dWs, sd));
+      UCHECK_RC(gemm_bf16v2_wgrad_group(1, 1, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0));
     } else if (pl.wg_group) {
       // all four weight gradients of the layer as one launch: 432 whole-K tiles for 512 workgroup slots (UNITER-base)
       const int Mo[4] = {I, H, 3 * H, H}, No[4] = {H, I, H, H};
@@ -782,7 +803,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
       float* const dWs[4] = {m->LG(l, L_W1), m->LG(l, L_W2), m->LG(l, L_QW), m->LG(l, L_OW)};
       {
         ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-        UCHECK_RC(gemm_bf16v2_wgrad_group(pl.wg_group == 4 ? 4 : 1, 4, Mo, No, M, As, Bs, dWs, sd));
+        UCHECK_RC(gemm_bf16v2_wgrad_group(pl.wg_group == 4 ? 4 : 1, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0));
       }
       UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
     } else {
@@ -793,15 +814,16 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
       UCHECK_RC(wgrad_b16(m, pl, sd, 3 * H, H, M, lb.dqkvb, xb, m->LG(l, L_QW)));
     }
   } else {
+    const int wb = m->wg_overwrite ? -1 : 1;      // -1: overwrite (or clear, then accumulate) -- see gemm()
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, g2, H, lb.hact, I, m->LG(l, L_W2), I, UNITER_EPI_NONE,
-                   nullptr, nullptr, nullptr, 0, 1));
+                   nullptr, nullptr, nullptr, 0, wb));
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, I, H, M, lb.du, I, lb.y1, H, m->LG(l, L_W1), H, UNITER_EPI_NONE,
-                   nullptr, nullptr, nullptr, 0, 1));
+                   nullptr, nullptr, nullptr, 0, wb));
     if (!fuse_db1) UCHECK_RC(uniter_colsum_f32(lb.du, M, I, I, m->LG(l, L_B1), 1, pl.col_ws, pl.col_ws_bytes, sd));
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, H, M, g1, H, lb.ctx, H, m->LG(l, L_OW), H, UNITER_EPI_NONE,
-                   nullptr, nullptr, nullptr, 0, 1));
+                   nullptr, nullptr, nullptr, 0, wb));
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkv, 3 * H, x, H, m->LG(l, L_QW), H,
-                   UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
+                   UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, wb));
   }
   if (!fused_qb) UCHECK_RC(uniter_colsum_f32(lb.dqkv, M, 3 * H, 3 * H, m->LG(l, L_QB), 1, pl.col_ws, pl.col_ws_bytes, sd));
   if (sd != st) UCHECK_HIP(hipEventRecord(m->ev_side[l], sd));
@@ -856,6 +878,13 @@ extern "C" int uniter_model_backward_embed(uniter_model_t* m) {
     UCHECK_HIP(hipStreamWaitEvent(st, m->ev_side[c.num_hidden_layers], 0));
   }
   m->bwd_open = false;
+  m->wg_overwrite = false;       // one backward pass: the next one accumulates again
+  return 0;
+}
+
+extern "C" int uniter_model_set_wgrad_overwrite(uniter_model_t* m, int on) {
+  UCHECK_ARG(m, "set_wgrad_overwrite: null model");
+  m->wg_overwrite = on != 0;
   return 0;
 }
 

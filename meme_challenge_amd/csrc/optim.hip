@@ -11,7 +11,9 @@
 // by the step kernel from device memory: no host synchronisation.
 // Per-64-element chunk flags carry the parameter-group split:
 //   0 = parameter received no gradient this step (torch skips grad=None params),
-//   1 = no weight decay ('bias' / 'LayerNorm.*' names), 2 = weight decay.
+//   1 = no weight decay ('bias' / 'LayerNorm.*' names), 2 = weight decay;
+//   + 4 = leave the gradient as it is (zero_grads notwithstanding): the next backward pass OVERWRITES this chunk
+//         (the encoder's weight gradients, uniter_model_set_wgrad_overwrite) -- 28 instead of 32 bytes per parameter.
 #include "common.h"
 
 namespace {
@@ -128,12 +130,12 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     }
     // (gradients read from the bf16 payload: the fp32 buffer holds this rank's own sums, cleared whatever the payload says)
     if (f0) {
-      const bool c0 = a.zero_grads && (a.g16 != nullptr || any_nonzero(g0));
-      adam_update4(a, coef, f0 == 2 ? a.wd : 0.f, p0, g0, m0, v0); adam_store4(a, i, p0, m0, v0, c0);
+      const bool c0 = a.zero_grads && !(f0 & 4) && (a.g16 != nullptr || any_nonzero(g0));
+      adam_update4(a, coef, (f0 & 3) == 2 ? a.wd : 0.f, p0, g0, m0, v0); adam_store4(a, i, p0, m0, v0, c0);
     }
     if (f1) {
-      const bool c1 = a.zero_grads && (a.g16 != nullptr || any_nonzero(g1));
-      adam_update4(a, coef, f1 == 2 ? a.wd : 0.f, p1, g1, m1, v1); adam_store4(a, j, p1, m1, v1, c1);
+      const bool c1 = a.zero_grads && !(f1 & 4) && (a.g16 != nullptr || any_nonzero(g1));
+      adam_update4(a, coef, (f1 & 3) == 2 ? a.wd : 0.f, p1, g1, m1, v1); adam_store4(a, j, p1, m1, v1, c1);
     }
   }
 }

@@ -175,6 +175,9 @@ class ParamStore(object):
             e = max(offs[n] + _round_up(self.params[n].numel(), CHUNK) for n in names)
             self.bucket_ranges.append((s, e))
         self.touched = set()
+        # True between an optimizer step that did not clear the encoder layers' weight gradients (FusedAdam.lazy_zero) and the
+        # backward pass that overwrites them: p.grad of those tensors holds LAST step's values meanwhile
+        self.wgrad_stale = False
 
     @staticmethod
     def _order(named):
@@ -269,6 +272,7 @@ class ParamStore(object):
 
     def zero_grads(self):
         self.flat_grads.zero_()
+        self.wgrad_stale = False
         self.touched.clear()
         self.reattach_grads(full=True)
 
@@ -758,6 +762,11 @@ class UniterModel(UniterPreTrainedModel):
             side = self._side_stream
             side.wait_stream(main)
         side_ptr = C.c_void_p(side.cuda_stream) if side is not None else None
+        if getattr(st, 'wgrad_stale', False):
+            # the optimizer step left the encoder's weight gradients uncleared (trainer.FusedAdam, lazy_zero): this backward
+            # pass overwrites them; the flag holds for one pass, later micro-batches accumulate
+            check(lib.uniter_model_set_wgrad_overwrite(self._handle, 1), 'uniter_model_set_wgrad_overwrite')
+            st.wgrad_stale = False
         check(lib.uniter_model_backward_begin(self._handle, C.byref(batch), ptr(d_hidden),
                                               int(all_layers), seed, offset, ptr(ws), nbytes,
                                               _lib.cur_stream(), side_ptr), 'uniter_model_backward_begin')

@@ -214,6 +214,8 @@ class TrainerTemplate(object):
         if enc is not None and self.grad_sync is None and hasattr(self.optimizer, 'attach_norm_hooks') and \
                 (self.config.get('max_grad_norm') or 0) > 0:
             self.optimizer.attach_norm_hooks(enc)    # clip norm reduced bucket by bucket during the backward pass
+        if enc is not None and hasattr(self.optimizer, 'lazy_zero_encoder'):
+            self.optimizer.lazy_zero_encoder = enc   # zero_grad skips the weight gradients the next backward pass overwrites
 
     # --------------------------------------------------------------------- step
     def _loss_and_probs(self, preds, labels):

@@ -128,6 +128,12 @@ class FusedAdam(torch.optim.Optimizer):
         # set to the UniterModel to overlap the update with the next forward (see step()); anything
         # else that reads parameters on the current stream must call join() first
         self.overlap_encoder = None
+        # set to the UniterModel: zero_grad (fused into step) skips the encoder layers' weight gradients -- four fifths of all
+        # parameters -- and the next backward pass writes them with `=` instead of `+=` (uniter_model_set_wgrad_overwrite):
+        # 28 instead of 32 bytes per parameter, no read-modify-write in the weight-gradient epilogues.  Until that backward
+        # pass those .grad tensors hold the previous step's values (ParamStore.wgrad_stale); the trainers of this package
+        # never read them in between (the reference calls zero_grad right after step, train_template.py:105-107)
+        self.lazy_zero_encoder = None
         self.overlap_workgroups = int(os.environ.get('UNITER_ADAM_OVERLAP_WGS', '256'))
         self._pending = None
         self._plan_cache = None
@@ -209,9 +215,12 @@ class FusedAdam(torch.optim.Optimizer):
             torch.cuda.current_stream().wait_event(self._pending)
             self._pending = None
 
-    def _chunk_flags(self):
+    LAZY_SUFFIXES = ('attention.self.query.weight', 'attention.self.key.weight', 'attention.self.value.weight',
+                     'attention.output.dense.weight', 'intermediate.dense.weight', 'output.dense.weight')
+
+    def _chunk_flags(self, lazy=False):
         st = self.store
-        key = frozenset(st.touched)
+        key = (frozenset(st.touched), bool(lazy))
         if key != self._flags_key:
             flags = self._flags_cache.get(key)
             if flags is None:
@@ -219,7 +228,8 @@ class FusedAdam(torch.optim.Optimizer):
                 for n in st.touched:
                     o = st.offsets[n] // CHUNK
                     k = (st.params[n].numel() + CHUNK - 1) // CHUNK
-                    host[o:o + k] = 1 if no_decay(n) else 2
+                    keep = 4 if (lazy and '.encoder.layer.' in '.' + n and n.endswith(self.LAZY_SUFFIXES)) else 0
+                    host[o:o + k] = (1 if no_decay(n) else 2) + keep
                 flags = host.to(st.device)
                 if len(self._flags_cache) < 16:
                     self._flags_cache[key] = flags
@@ -255,7 +265,8 @@ class FusedAdam(torch.optim.Optimizer):
         lr = float(g0['lr'])
         if float(g1['lr']) != lr:
             raise UniterHipError('FusedAdam needs one learning rate for both parameter groups')
-        flags = self._chunk_flags()
+        lazy = bool(zero_grads) and self.lazy_zero_encoder is not None and os.environ.get('UNITER_LAZY_ZERO') != '0'
+        flags = self._chunk_flags(lazy)
         lib = _lib.lib()
         if max_grad_norm and max_grad_norm > 0:
             def sumsq(lo, hi, out_ptr):
@@ -363,6 +374,8 @@ class FusedAdam(torch.optim.Optimizer):
             self._pending = last
         if zero_grads:
             st.touched.clear()      # flags stay cached: the same set is touched again next step
+            if lazy:
+                st.wgrad_stale = True
 
     def zero_grad(self, set_to_none=False):
         self.store.zero_grads()
@@ -511,6 +524,8 @@ class TrainStep(object):
         enc = getattr(model, 'uniter_model', None)
         if grad_sync is None and enc is not None and isinstance(optimizer, FusedAdam) and (config.get('max_grad_norm') or 0) > 0:
             optimizer.attach_norm_hooks(enc)        # the clip norm is reduced bucket by bucket during the backward pass
+        if enc is not None and isinstance(optimizer, FusedAdam):
+            optimizer.lazy_zero_encoder = enc       # zero_grad skips what the next backward pass overwrites anyway
         self.iters = 0
         self.last_loss = None
         self.last_probs = None
