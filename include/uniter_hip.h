@@ -226,6 +226,15 @@ size_t uniter_attn_keep_bits_bytes(int B, int L, int nh);
 int uniter_attn_fwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
                        void* ctx_bf16, float* lse, void* keep_bits, int B, int L, int nh, float p_drop,
                        uint64_t seed, uint32_t offset, uint32_t site, void* stream);
+/* The keep flags drawn AHEAD of the forward pass, for `nlayers` layers in one launch (layer l at keep_bits +
+ * l * layer_stride_bytes, dropout site site0 + l * site_step): ten dependent Philox rounds per four keys stall an attention
+ * kernel's three waves per SIMD, a full-occupancy elementwise pass hides them.  The _pre forms of the forward pass with
+ * keep_bits_ready = 1 READ keep_bits instead of drawing (and storing) them: identical masks, identical results. */
+int uniter_attn_keep_bits_gen(void* keep_bits, size_t layer_stride_bytes, int nlayers, int B, int L, int nh, float p_drop,
+                              uint64_t seed, uint32_t offset, uint32_t site0, uint32_t site_step, void* stream);
+int uniter_attn_fwd_pre(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx, void* ctx_bf16,
+                        float* lse, void* keep_bits, int keep_bits_ready, int B, int L, int nh, float p_drop, uint64_t seed,
+                        uint32_t offset, uint32_t site, void* stream);
 int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
                        const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16,
                        float* bias_part, const void* keep_bits, float* delta, int B, int L, int nh, float p_drop,
@@ -240,6 +249,9 @@ size_t uniter_attn_bf16_bwd_ws_bytes(int B, int L, int nh);
 int uniter_attn_bf16_fwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens,
                          float* ctx, void* ctx_bf16, float* lse, void* keep_bits, int B, int L, int nh, float p_drop,
                          uint64_t seed, uint32_t offset, uint32_t site, void* stream);
+int uniter_attn_bf16_fwd_pre(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens,
+                             float* ctx, void* ctx_bf16, float* lse, void* keep_bits, int keep_bits_ready, int B, int L,
+                             int nh, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream);
 int uniter_attn_bf16_bwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens,
                          const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16,
                          float* bias_part, const void* keep_bits, float* delta, int B, int L, int nh, float p_drop,

@@ -46,6 +46,7 @@ struct Args {
   const float* dctx;
   float* dqkv; u16* dqkv_b16;
   u16* keep_bits;          // optional [B*nh, L, Lr/32, 2] dropout keep flags written by the forward pass, read by dQ
+  int keep_ready;          // the forward pass reads keep_bits (uniter_attn_keep_bits_gen drew them ahead) instead of drawing them
   float* bias_part;        // optional [B, 3H] per-sample column sums of dqkv (QKV bias gradient partials)
   float* delta;            // [B, nh, L]
   u16* pd_ws; u16* ds_ws;  // [B*nh][Lr][Lr] bf16, indexed [key][query]
@@ -291,16 +292,18 @@ __global__ __launch_bounds__(768) void attn_b16_fwd_kernel(const Args a, int Lr)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
     if (a.drop.active && vq) {
-      const uint64_t grow = ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2);
       unsigned bits = 0;
+      const size_t kidx = (((size_t)bh * a.L + q) * nblk + (k0 >> 5)) * 2 + h;
+      if (a.keep_ready) {
+        bits = a.keep_bits[kidx];
+      } else {
+        const uint64_t grow = ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const unsigned b4 = drop_bits4(a.drop, grow + 2 * g + h);
-        bits |= b4 << (4 * g);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) s[4 * g + t] *= ((b4 >> t) & 1u) ? a.drop.scale : 0.f;
+        for (int g = 0; g < 4; ++g) bits |= drop_bits4(a.drop, grow + 2 * g + h) << (4 * g);
+        if (a.keep_bits) a.keep_bits[kidx] = (u16)bits;
       }
-      if (a.keep_bits) a.keep_bits[(((size_t)bh * a.L + q) * nblk + (k0 >> 5)) * 2 + h] = (u16)bits;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] *= ((bits >> r) & 1u) ? a.drop.scale : 0.f;
     }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {                                   // O^T[d][query] += V^T . Pd^T
@@ -573,12 +576,21 @@ extern "C" size_t uniter_attn_bf16_bwd_ws_bytes(int B, int L, int nh) {
 extern "C" int uniter_attn_bf16_fwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
                                     void* ctx_bf16, float* lse, void* keep_bits, int B, int L, int nh, float p_drop,
                                     uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
+  return uniter_attn_bf16_fwd_pre(qkv, qkv_is_bf16, attn_mask, cu_seqlens, ctx, ctx_bf16, lse, keep_bits, 0, B, L, nh, p_drop,
+                                  seed, offset, site, stream);
+}
+
+extern "C" int uniter_attn_bf16_fwd_pre(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens,
+                                        float* ctx, void* ctx_bf16, float* lse, void* keep_bits, int keep_bits_ready, int B,
+                                        int L, int nh, float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
+                                        void* stream) {
   UCHECK_ARG(qkv && ctx && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_bf16_fwd: need attn_mask or cu_seqlens (not both)");
+  UCHECK_ARG(!keep_bits_ready || keep_bits, "attn_bf16_fwd_pre: keep_bits_ready without keep_bits");
   Args a = {};
   UCHECK_RC(fill(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.qb16 = qkv_is_bf16; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_b16 = (u16*)ctx_bf16; a.lse = lse;
-  a.keep_bits = (u16*)keep_bits;
+  a.keep_bits = (u16*)keep_bits; a.keep_ready = keep_bits_ready;
   const int Lr = (L + 31) / 32 * 32, nblk = Lr / 32;
   const size_t lds = max3((size_t)(Lr * KLD + D * TLD) * 2 + Lr * 4, (size_t)nblk * XROW * 64 * 4, 0);
   UCHECK_RC(set_lds(attn_b16_fwd_kernel, lds));

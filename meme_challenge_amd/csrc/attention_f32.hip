@@ -45,6 +45,7 @@ struct AttnArgs {
   unsigned short* dqkv_b16;
   unsigned short* keep_bits; // optional [B*nh, L, Lr/32, 2]: dropout keep flags of a (query, key block, lane half), written by the
                              // forward pass and read by dQ instead of a second Philox evaluation
+  int keep_ready;            // the forward pass READS keep_bits (uniter_attn_keep_bits_gen filled them) instead of drawing them
   float* bias_part;          // optional [B, 3H]: per-sample column sums of dqkv (the QKV bias gradient, reduced over B later)
   const int* cu;        // [B+1] prefix sums of per-sample lengths (packed rows), or NULL: sample b owns rows b*L .. b*L+L-1
   int B, L, nh, H, Lp4; // Lp4 = roundup(L,4)/4
@@ -671,16 +672,19 @@ __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, i
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
     if (a.drop.active && vq) {
-      const uint64_t grow = ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2);
       unsigned bits = 0;
+      const size_t kidx = (((size_t)bh * a.L + q) * nblk + (k0 >> 5)) * 2 + h;
+      if (a.keep_ready) {
+        bits = a.keep_bits[kidx];       // drawn ahead by attn_keep_bits_kernel: ten dependent Philox rounds per 4 keys cost a
+                                        // 3-waves-per-SIMD attention kernel far more than a full-occupancy elementwise pass
+      } else {
+        const uint64_t grow = ((uint64_t)bh * a.L + q) * a.Lp4 + (k0 >> 2);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const unsigned b4 = drop_bits4(a.drop, grow + 2 * g + h);
-        bits |= b4 << (4 * g);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) s[4 * g + t] *= ((b4 >> t) & 1u) ? a.drop.scale : 0.f;
+        for (int g = 0; g < 4; ++g) bits |= drop_bits4(a.drop, grow + 2 * g + h) << (4 * g);
+        if (a.keep_bits) a.keep_bits[kidx] = (unsigned short)bits;
       }
-      if (a.keep_bits) a.keep_bits[(((size_t)bh * a.L + q) * nblk + (k0 >> 5)) * 2 + h] = (unsigned short)bits;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] *= ((bits >> r) & 1u) ? a.drop.scale : 0.f;
     }
     tileT_times_acc(Vs + k0 * LDT, s, o0, o1, i, h);
   }
@@ -916,6 +920,26 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs 
   }
 }
 
+// Dropout keep flags of the attention probabilities for `nlayers` layers at once, in the layout the L <= 192 kernels store
+// and read ([B*nh, L, Lr/32, 2] 16-bit words: bit 4g + t of word (bh, q, key block kb, half h) = key 32 kb + 8g + 4h + t kept).
+// One thread per word (four Philox4x32-10 calls): a full-occupancy elementwise pass hides the ten dependent rounds that
+// stall the attention kernels' three waves per SIMD (forward with dropout 17.4 vs 11.5 us per layer in the bf16 mode).
+__global__ __launch_bounds__(256) void attn_keep_bits_kernel(unsigned short* __restrict__ out, size_t layer_stride,
+                                                             size_t words, int L, int nblk, int Lp4, DropCfg d,
+                                                             uint32_t site_step) {
+  const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= words) return;
+  d.site += site_step * blockIdx.y;
+  const int h = (int)(w & 1);
+  const size_t r = w >> 1;                    // (bh * L + q) * nblk + kb
+  const int kb = (int)(r % nblk);
+  const uint64_t grow = (uint64_t)(r / nblk) * Lp4 + (uint64_t)kb * 8;
+  unsigned bits = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bits |= drop_bits4(d, grow + 2 * g + h) << (4 * g);
+  out[(size_t)blockIdx.y * layer_stride + w] = (unsigned short)bits;
+}
+
 constexpr int RES_MAX_LR = 256;      // 8 waves (2 per SIMD: 256 VGPRs each); 2*256*68*4 B = 139 KB LDS
 
 inline size_t res_lds_bytes(int Lr) { return (size_t)(2 * Lr * LDT + 2 * Lr + 192) * sizeof(float); }
@@ -1018,14 +1042,39 @@ extern "C" size_t uniter_attn_keep_bits_bytes(int B, int L, int nh) {
   return (size_t)B * nh * L * (Lr / 32) * 2 * sizeof(unsigned short);
 }
 
+extern "C" int uniter_attn_keep_bits_gen(void* keep_bits, size_t layer_stride_bytes, int nlayers, int B, int L, int nh,
+                                         float p_drop, uint64_t seed, uint32_t offset, uint32_t site0, uint32_t site_step,
+                                         void* stream) {
+  UCHECK_ARG(keep_bits && nlayers >= 1 && nlayers <= 65535 && B > 0 && L > 0 && nh > 0 && layer_stride_bytes % 2 == 0,
+             "attn_keep_bits_gen: bad argument");
+  UCHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "attn_keep_bits_gen: bad dropout p");
+  const int Lr = (L + 31) / 32 * 32, nblk = Lr / 32;
+  UCHECK_SHAPE(Lr <= SPLIT_MAX_LR, "attn_keep_bits_gen: L %d > %d", L, SPLIT_MAX_LR);
+  const size_t words = (size_t)B * nh * L * nblk * 2;
+  UCHECK_ARG(nlayers == 1 || layer_stride_bytes >= words * 2, "attn_keep_bits_gen: layers overlap");
+  const DropCfg d = make_drop(p_drop, seed, offset, site0);
+  hipLaunchKernelGGL(attn_keep_bits_kernel, dim3((unsigned)((words + 255) / 256), nlayers), dim3(256), 0, (hipStream_t)stream,
+                     (unsigned short*)keep_bits, layer_stride_bytes / 2, words, L, nblk, (L + 3) / 4, d, site_step);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int uniter_attn_fwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
                                   void* ctx_bf16, float* lse, void* keep_bits, int B, int L, int nh, float p_drop,
                                   uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
+  return uniter_attn_fwd_pre(qkv, attn_mask, cu_seqlens, ctx, ctx_bf16, lse, keep_bits, 0, B, L, nh, p_drop, seed, offset, site,
+                             stream);
+}
+
+extern "C" int uniter_attn_fwd_pre(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+                                   void* ctx_bf16, float* lse, void* keep_bits, int keep_bits_ready, int B, int L, int nh,
+                                   float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
   UCHECK_ARG(qkv && ctx && ((attn_mask != nullptr) != (cu_seqlens != nullptr)), "attn_fwd_ex: need attn_mask or cu_seqlens (not both)");
+  UCHECK_ARG(!keep_bits_ready || keep_bits, "attn_fwd_pre: keep_bits_ready without keep_bits");
   AttnArgs a = {};
   UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_b16 = (unsigned short*)ctx_bf16; a.lse = lse;
-  a.keep_bits = (unsigned short*)keep_bits;
+  a.keep_bits = (unsigned short*)keep_bits; a.keep_ready = keep_bits_ready;
   const int Lr = (L + 31) / 32 * 32;
   UCHECK_SHAPE(Lr <= uniter_attn_varlen_max_len(), "attn_fwd_ex: L %d > %d", L, uniter_attn_varlen_max_len());
   const size_t lds = res_lds_bytes(Lr);

@@ -545,6 +545,19 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   // L <= 192: attention on the bf16 pipe (attention_bf16.hip), which also writes the bf16 copies of its outputs
   const bool attn_b16 = res && L <= uniter_attn_varlen_max_len();
 
+  // dropout keep flags of the attention probabilities of ALL layers, drawn in one elementwise launch ahead of the layers
+  // (the L <= 192 kernels then read them; the backward pass reads the same words)
+  static const bool pregen_env = [] { const char* e = getenv("UNITER_KEEP_PREGEN"); return !e || e[0] != '0'; }();
+  bool keep_pre = pregen_env && save && pa > 0.f && L <= uniter_attn_varlen_max_len() && (attn_b16 || packed || save);
+  if (keep_pre) {
+    const size_t stride = nl > 1 ? (size_t)((char*)pl.layers[1].keepb - (char*)pl.layers[0].keepb) : 0;
+    for (int l = 1; l < nl && keep_pre; ++l)
+      keep_pre = (size_t)((char*)pl.layers[l].keepb - (char*)pl.layers[0].keepb) == stride * l;
+    if (keep_pre)
+      UCHECK_RC(uniter_attn_keep_bits_gen(pl.layers[0].keepb, stride, nl, B, L, nh, pa, seed, offset, SITE_ATTN_PROBS(0),
+                                          SITE_ATTN_PROBS(1) - SITE_ATTN_PROBS(0), st));
+  }
+
   // ---- encoder (model/model.py:282-292; model/layer.py:166-170) ----
   const float* x = pl.emb;
   for (int l = 0; l < nl; ++l) {
@@ -563,13 +576,13 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     {
       ProfScope ps(m, UNITER_K_ATTN_FWD, st);
       if (attn_b16)      // precision 2: the attention products run on the bf16 pipe as well
-        UCHECK_RC(uniter_attn_bf16_fwd(lb.qkv, 1, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
-                                       lb.ctx, lb.ctxb, lb.lse, save ? lb.keepb : nullptr, B, L, nh, pa, seed, offset,
-                                       SITE_ATTN_PROBS(l), st));
+        UCHECK_RC(uniter_attn_bf16_fwd_pre(lb.qkv, 1, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
+                                           lb.ctx, lb.ctxb, lb.lse, save ? lb.keepb : nullptr, keep_pre ? 1 : 0, B, L, nh, pa,
+                                           seed, offset, SITE_ATTN_PROBS(l), st));
       else if (packed || (save && L <= uniter_attn_varlen_max_len()))
-        UCHECK_RC(uniter_attn_fwd_ex(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
-                                     lb.ctx, nullptr, lb.lse, save ? lb.keepb : nullptr, B, L, nh, pa, seed, offset,
-                                     SITE_ATTN_PROBS(l), st));
+        UCHECK_RC(uniter_attn_fwd_pre(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
+                                      lb.ctx, nullptr, lb.lse, save ? lb.keepb : nullptr, keep_pre ? 1 : 0, B, L, nh, pa,
+                                      seed, offset, SITE_ATTN_PROBS(l), st));
       else
         UCHECK_RC(uniter_attn_fwd(lb.qkv, b->attention_mask, lb.ctx, lb.lse, B, L, nh, pa, seed, offset,
                                   SITE_ATTN_PROBS(l), st));

@@ -120,3 +120,48 @@ def test_attention_bwd_ex_emits_qkv_bias_partials(B, L, nh, p):
     ref = dqkv.view(B, L, 3 * H).double().sum(1)
     assert (part.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
     assert torch.equal(ctxb, ctx.bfloat16()) and torch.equal(dqkvb, dqkv.bfloat16())
+
+
+@pytest.mark.parametrize('B,L,nh,p', [(2, 164, 3, 0.1), (3, 37, 2, 0.25), (1, 192, 1, 0.1)])
+def test_keep_bits_drawn_ahead_are_the_kernels_own(B, L, nh, p):
+    """uniter_attn_keep_bits_gen (all layers' dropout keep flags in one elementwise launch) writes, for every layer, exactly
+    the words the forward kernels draw and store themselves, and a forward pass that READS them (the _pre forms,
+    keep_bits_ready = 1) returns bit-identical context rows and log-sum-exps -- fp32 and bf16 kernels."""
+    from meme_challenge_amd import _lib as Lb
+    lib = Lb.lib()
+    H = nh * 64
+    g = torch.Generator().manual_seed(L)
+    qkv = torch.randn(B * L, 3 * H, generator=g).cuda()
+    mask = torch.ones(B, L)
+    mask[B - 1, L - 5:] = 0
+    mask = mask.cuda()
+    seed, offset, nlayers, site0, step = 0x1234ABCD5678, 9, 3, 2, 4          # SITE_ATTN_PROBS(l) = 2 + 4 l
+    nbytes = lib.uniter_attn_keep_bits_bytes(B, L, nh)
+    stride = nbytes + 256                                                     # layers need not be adjacent
+    ahead = torch.zeros(nlayers * stride // 2, dtype=torch.int16, device='cuda')
+    Lb.check(lib.uniter_attn_keep_bits_gen(Lb.ptr(ahead), stride, nlayers, B, L, nh, p, seed, offset, site0, step,
+                                           Lb.cur_stream()))
+    for layer in range(nlayers):
+        site = site0 + step * layer
+        mine = ahead[layer * stride // 2: layer * stride // 2 + nbytes // 2]
+        for kind in ('f32', 'b16'):
+            outs = []
+            for ready in (0, 1):
+                ctx = torch.empty(B * L, H, device='cuda')
+                lse = torch.empty(B, nh, L, device='cuda')
+                kb = mine.clone() if ready else torch.zeros(nbytes // 2, dtype=torch.int16, device='cuda')
+                if kind == 'f32':
+                    Lb.check(lib.uniter_attn_fwd_pre(Lb.ptr(qkv), Lb.ptr(mask), None, Lb.ptr(ctx), None, Lb.ptr(lse), Lb.ptr(kb),
+                                                     ready, B, L, nh, p, seed, offset, site, Lb.cur_stream()))
+                else:
+                    Lb.check(lib.uniter_attn_bf16_fwd_pre(Lb.ptr(qkv), 0, Lb.ptr(mask), None, Lb.ptr(ctx), None, Lb.ptr(lse),
+                                                          Lb.ptr(kb), ready, B, L, nh, p, seed, offset, site, Lb.cur_stream()))
+                torch.cuda.synchronize()
+                outs.append((ctx, lse, kb))
+            assert torch.equal(outs[0][2], mine), (kind, layer)           # the kernel's own draw == the words drawn ahead
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (kind, layer)
+    # different layers draw different masks; a kept fraction of about 1 - p
+    assert not torch.equal(ahead[:nbytes // 2], ahead[stride // 2: stride // 2 + nbytes // 2])
+    bits = ahead[:nbytes // 2].to(torch.int32) & 0xffff
+    frac = sum(((bits >> k) & 1).float().mean().item() for k in range(16)) / 16
+    assert abs(frac - (1 - p)) < 0.02
