@@ -107,7 +107,7 @@ def pmc_traffic(args, M, cfgd, build_info):
     FETCH_SIZE / WRITE_SIZE runs of this command, tests/tools/run_profile.sh -> tests/tools/pmc_to_traffic.py;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside a timed
     run, so this is a PROFILE ARTEFACT, reported only for the shape AND the library build it was taken on."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_traffic.json')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_pmc_traffic.json')
     try:
         allrec = json.load(open(path))
         rec = allrec['ffn_up_fwd']
@@ -120,10 +120,11 @@ def pmc_traffic(args, M, cfgd, build_info):
     if rec.get('build') and rec['build'] != build_info:
         return None
     out = {'gemm_ffn_up_fwd': {'bytes_per_launch': int(rec['traffic_bytes']), 'algorithmic_bytes': int(rec['algorithmic_bytes'])}}
-    wg = allrec.get('wgrad_stream_k')
+    wg = allrec.get('wgrad') or allrec.get('wgrad_stream_k')
     if wg and wg.get('build') == rec.get('build'):
-        # the time-dominant family of the fp32 step (average over its four shapes)
+        # the weight-gradient family of the fp32 step (average over its four shapes)
         out['gemm_wgrad'] = {'bytes_per_launch': int(wg['traffic_bytes']), 'algorithmic_bytes': int(wg['algorithmic_bytes_avg']),
+                             'kernel': wg.get('kernel'),
                              'note': 'reads served by L2 misses: the operand set stays in the Infinity Cache (FETCH_SIZE counts L2 fills)'}
     return out
 
@@ -387,7 +388,7 @@ def run_rank(args):
                7: ('gemm_wgrad', 'mfma', nl * (g_qkv + g_o + 2 * g_ffn)), 8: ('attention_bwd', 'mfma', nl * 2 * att),
                9: ('layernorm_fwd', 'hbm', nl * 2 * 16.0 * M_eff * H), 10: ('layernorm_bwd', 'hbm', nl * 2 * 16.0 * M_eff * H)}
         kernel_of = {'f32': {1: 'gemm_f32_v3_kernel<64,64,false,false,TAG=1>', 6: 'gemm_f32_v3_kernel<64,64,false,true,...>',
-                             7: 'gemm_f32_v3_kernel<64,64,true,true,0,SK> (stream-K)'},
+                             7: 'gemm_f32_v3_kernel<64,64,true,true,0,false> (whole-K 64x64 tiles; UNITER_WGRAD_WHOLE=0: the stream-K form)'},
                      'bf16': {1: 'gemm_dma_kernel<128,128,false,false,SWAP,2,EPI=5> (bias + GELU + gelu\' bf16)',
                               6: 'gemm_dma_kernel<128,128,false,true,SWAP,2,EPI>', 7: 'gemm_dma_wgrad_group_kernel<2> (the four weight gradients of a layer in one launch of whole-K 128x128 tiles)'}}
         families = []
@@ -457,7 +458,7 @@ def run_rank(args):
                                                   'measured': 'union of the stamped launch intervals of gemm_dgrad and gemm_wgrad inside the timed region'}
             tr = pmc_traffic(args, M_eff, cfgd, build_info)
             if tr is not None:
-                out['traffic_from_profile'] = dict(tr, source='profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this '
+                out['traffic_from_profile'] = dict(tr, source='profiles/r03_pmc_traffic.json (rocprofv3 --pmc passes of this '
                                                               'command on this library build; FETCH_SIZE doubled per the gfx950 '
                                                               'correction, WRITE_SIZE exact)')
         # the optimizer step alone (HBM-bound: 32 B / parameter), measured after the timed region.  This and the CPU leg

@@ -19,3 +19,4 @@ extern "C" const char* uniter_build_info(void) {
 }
 
 unsigned long long* g_uniter_stamp_slot = nullptr;
+int g_uniter_launch_prio = 0;

@@ -20,6 +20,7 @@
 //     transposed in LDS (one ds_read_b128 per MFMA) against Pd / dS read from the bf16 scratch the dQ
 //     kernel wrote ([B*nh][key][query], half the bytes of the fp32 kernels' scratch).
 #include <type_traits>
+#include <stdlib.h>
 #include "common.h"
 #include "philox.h"
 
@@ -46,6 +47,7 @@ struct Args {
   const float* dctx;
   float* dqkv; u16* dqkv_b16;
   u16* keep_bits;          // optional [B*nh, L, Lr/32, 2] dropout keep flags written by the forward pass, read by dQ
+  int prio;                // wave priority (UNITER_ATTN_PRIO, default 2)
   int keep_ready;          // the forward pass reads keep_bits (uniter_attn_keep_bits_gen drew them ahead) instead of drawing them
   float* bias_part;        // optional [B, 3H] per-sample column sums of dqkv (QKV bias gradient partials)
   float* delta;            // [B, nh, L]
@@ -228,6 +230,7 @@ __device__ __forceinline__ void stage_mask(float* mb, const Args& a, int b, int 
 // ---------------------------------------------------------------- forward ---
 // LDS: K row-major | V transposed | mask bias; afterwards the (O, m, l) exchange aliases it
 __global__ __launch_bounds__(768) void attn_b16_fwd_kernel(const Args a, int Lr) {
+  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
   u16* Kb = reinterpret_cast<u16*>(smem_raw);
   u16* Vt = Kb + Lr * KLD;
   float* mb = reinterpret_cast<float*>(Vt + D * TLD);
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(768) void attn_b16_fwd_kernel(const Args a, int Lr)
 // LDS: K row-major | V row-major | K transposed | mask bias
 template <bool QB16>
 __global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr, int red_off) {
+  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
   u16* Kb = reinterpret_cast<u16*>(smem_raw);
   u16* Vb = Kb + Lr * KLD;
   u16* Kt = Vb + Lr * KLD;
@@ -471,6 +475,7 @@ __global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr, 
 // ------------------------------------------------------------ backward: dK, dV ---
 // LDS: Q transposed | dO transposed.  dV^T[d][key] = sum_q dO[q][d] Pd[q][key], dK^T = sum_q Q[q][d] dS[q][key]
 __global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr, int red_off) {
+  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
   u16* Qt = reinterpret_cast<u16*>(smem_raw);
   u16* dOt = Qt + D * TLD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
@@ -562,6 +567,8 @@ int fill(Args& a, int B, int L, int nh, float p_drop, uint64_t seed, uint32_t of
   a.B = B; a.L = L; a.nh = nh; a.H = nh * D; a.Lp4 = (L + 3) / 4;
   a.scale = 0.125f;        // 1/sqrt(64), model/layer.py:86
   a.drop = make_drop(p_drop, seed, offset, site);
+  static const int prio = [] { const char* e = getenv("UNITER_ATTN_PRIO"); return e ? atoi(e) : 2; }();
+  a.prio = prio;
   return 0;
 }
 

@@ -23,6 +23,7 @@
 //
 // Layouts: qkv [B*L, 3H] (columns [Q|K|V], head h at h*64), ctx/dctx [B*L, H],
 // lse/delta [B, nh, L].  head_dim == 64.
+#include <stdlib.h>
 #include "common.h"
 #include "philox.h"
 
@@ -45,6 +46,7 @@ struct AttnArgs {
   unsigned short* dqkv_b16;
   unsigned short* keep_bits; // optional [B*nh, L, Lr/32, 2]: dropout keep flags of a (query, key block, lane half), written by the
                              // forward pass and read by dQ instead of a second Philox evaluation
+  int prio;                  // wave priority of the L <= 192 kernels (UNITER_ATTN_PRIO, default 2)
   int keep_ready;            // the forward pass READS keep_bits (uniter_attn_keep_bits_gen filled them) instead of drawing them
   float* bias_part;          // optional [B, 3H]: per-sample column sums of dqkv (the QKV bias gradient, reduced over B later)
   const int* cu;        // [B+1] prefix sums of per-sample lengths (packed rows), or NULL: sample b owns rows b*L .. b*L+L-1
@@ -621,6 +623,7 @@ __device__ __forceinline__ void stage_mask(float* mb, const AttnArgs& a, int b, 
 }
 
 __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, int Lr) {
+  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
   float* Ks = dyn_smem;
   float* Vs = Ks + Lr * LDT;
   float* mb = Vs + Lr * LDT;
@@ -722,6 +725,7 @@ __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, i
 
 __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a, int Lr, float* __restrict__ pd_ws,
                                                                 float* __restrict__ ds_ws) {
+  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
   float* Ks = dyn_smem;
   float* Vs = Ks + Lr * LDT;
   float* mb = Vs + Lr * LDT;
@@ -831,6 +835,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
 __global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs a, int Lr,
                                                                  const float* __restrict__ pd_ws,
                                                                  const float* __restrict__ ds_ws) {
+  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
   float* Qs = dyn_smem;
   float* dOs = Qs + Lr * LDT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
@@ -964,6 +969,8 @@ int make_args(AttnArgs& a, int B, int L, int nh, float p_drop, uint64_t seed, ui
   a.B = B; a.L = L; a.nh = nh; a.H = nh * D; a.Lp4 = (L + 3) / 4;
   a.scale = 0.125f;   // 1/sqrt(64), model/layer.py:86
   a.drop = make_drop(p_drop, seed, offset, site);
+  static const int prio = [] { const char* e = getenv("UNITER_ATTN_PRIO"); return e ? atoi(e) : 2; }();
+  a.prio = prio;
   return 0;
 }
 

@@ -41,7 +41,25 @@ static inline unsigned long long* take_stamp_slot() {
   return s;
 }
 
+// Wave priority of the NEXT matrix-kernel launch (0 = default, 1..3 = s_setprio level at kernel entry; the launch that reads
+// it resets it).  fp32 matrix and vector instructions share one issue pipe per SIMD and two kernels that share a CU are
+// arbitrated wave by wave by priority, then age: the model's schedule gives the kernels of its critical path (forward,
+// input-gradient chain, attention, row passes) a higher level than the weight-gradient launches of the side stream, which have
+// slack (HIP stream priorities do not reach this arbitration: measured no effect).  One host thread per model.
+extern int g_uniter_launch_prio;
+static inline int take_launch_prio() {
+  const int p = g_uniter_launch_prio;
+  g_uniter_launch_prio = 0;
+  return p;
+}
+
 #ifdef __HIPCC__
+// uniform branch around the immediate-operand instruction
+__device__ __forceinline__ void set_wave_prio(int level) {
+  if (level >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (level == 2) __builtin_amdgcn_s_setprio(2);
+  else if (level == 1) __builtin_amdgcn_s_setprio(1);
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

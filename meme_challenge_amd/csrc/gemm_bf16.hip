@@ -577,6 +577,7 @@ int gemm_bf16res_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, c
   g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux; g.beta = beta;
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
   g.stamp = take_stamp_slot();
+  (void)take_launch_prio();
   if (cfg == 0) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     // measured (tests/tools/gemm_lab.py at M = 1424 / 2624 / 5248, profiles/r01_gemm_bf16_resident_tiles.txt): a
@@ -643,6 +644,7 @@ int gemm_bf16_run(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, cons
   g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux; g.beta = beta;
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
   g.stamp = take_stamp_slot();
+  (void)take_launch_prio();
   if (cfg == 0) {
     // operand delivery bound: the biggest tile that still fills the chip
     // measured on MI355X (tests/tools/gemm_bf16_exp.py): 128x128 only pays once it fills the chip

@@ -47,6 +47,7 @@ struct GArgsD {
   int ld_aux;
   int tiles_m, tiles_n, band_h, nsplit;
   unsigned long long* stamp;    // optional {first start, last end} slot (common.h)
+  int prio;      // wave priority (common.h: g_uniter_launch_prio)
   int dbg;       // measurement builds only (tests/tools/gemm_v2_lab.py): 1 = drop every output store, 2 = skip the k-loop
 };
 
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), (ST * (BM + BN) * 128 <
   // work item -> (tile, k-piece), banded tile order inside an XCD's chunk
   const int w = xcd_work_item(g.tiles_m * g.tiles_n * g.nsplit);
   if (w < 0) return;
+  set_wave_prio(g.prio);
   stamp_begin(g.stamp);
   gemm_dma_tile<BM, BN, AKM, BKM, SWAP, ST, EPI>(g, w, smem);
   stamp_end(g.stamp);
@@ -633,6 +635,7 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.nsplit = nsplit;
   g.dbg = cfg >> 8; cfg &= 0xff;
   g.stamp = take_stamp_slot();
+  g.prio = take_launch_prio();
   if (cfg == 0) {
     // few tiles and one k-piece (the attention-output products: 126 tiles of 128 x 128 for 256 CUs): 64 x 128 tiles,
     // twice the workgroups (12.0 -> 10.6 us forward, 11.7 -> 10.0 us input gradient; profiles/r02_gemm_bf16_v2.txt)
@@ -665,7 +668,7 @@ int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K,
     g.M = Mo[p]; g.N = No[p]; g.K = K; g.A = A[p]; g.lda = Mo[p]; g.B = B[p]; g.ldb = No[p]; g.C = dW[p]; g.ldc = No[p];
     g.c_split_stride = 0; g.Cb = nullptr; g.ldcb = 0; g.epi = overwrite ? UNITER_EPI_NONE : UNITER_EPI_ADD; g.bias = nullptr;
     g.aux_in = overwrite ? nullptr : dW[p]; g.aux_in_bf16 = 0; g.aux_out = nullptr; g.aux_out_bf16 = 0; g.ld_aux = No[p];
-    g.nsplit = 1; g.stamp = stamp; g.dbg = 0;
+    g.nsplit = 1; g.stamp = stamp; g.dbg = 0; g.prio = 0;
     plan_tiles<128>(g, 128);
     total += g.tiles_m * g.tiles_n;
   }

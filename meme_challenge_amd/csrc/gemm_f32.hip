@@ -46,6 +46,7 @@ struct GemmArgs {
   int band_h;
   float* colsum_part;   // optional [ceil(M/32)][N]: per-32-row-block column sums of the stored C (v3 only)
   unsigned long long* stamp;    // optional {first start, last end} slot (common.h)
+  int prio;                     // wave priority (common.h: g_uniter_launch_prio)
 };
 
 __device__ __forceinline__ float buf_ld_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int aux) {
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
     t_first = idx; k_first = 0;
   }
   if (total_units == 0) return;
+  set_wave_prio(g.prio);
   stamp_begin(g.stamp);
   const int t_step = SK ? 1 : per_xcd;
 
@@ -659,6 +661,7 @@ int gemm_f32_run(int cfg, int tag, int a_kmajor, int b_kmajor, int M, int N, int
   g.epi = epilogue; g.bias = bias; g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux;
   g.beta = beta; g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.colsum_part = colsum_part;
   g.stamp = take_stamp_slot();
+  g.prio = take_launch_prio();
   if (cfg == 0) cfg = choose_cfg(M, N);
   if (colsum_part) {
     const bool fast = (K % BK == 0 || (a_kmajor && b_kmajor)) && (size_t)(a_kmajor ? K : M) * lda * 4 < (1ull << 31) &&

@@ -15,6 +15,16 @@
 
 namespace {
 
+// The row passes are HBM-bound streams with a few hundred vector instructions per row.  Inside the training step they run
+// beside the other stream's fp32 GEMMs, whose v_mfma_f32_32x32x2_f32 occupy the SIMD's vector pipe for 64 cycles each (fp32
+// matrix and vector instructions share one pipe on gfx950: tests/tools/mfma_valu_coissue.hip): at equal priority every
+// vector instruction of a row pass queues behind them (the pass took 45-65 us beside a weight-gradient GEMM against 13 alone
+// and 23 beside a full-rate HBM copy, tests/tools/ln_beside_lab.py).  Raised wave priority lets its few instructions go first.
+#ifndef UNITER_LN_PRIO
+#define UNITER_LN_PRIO 3
+#endif
+#define LN_SETPRIO() __builtin_amdgcn_s_setprio(UNITER_LN_PRIO)
+
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x,
                                                      const float* __restrict__ res,
@@ -25,6 +35,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ rstd_out, int M, int H,
                                                      DropCfg drop, unsigned short* __restrict__ y_b16,
                                                      int nslab, size_t slab_stride) {
+  LN_SETPRIO();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -68,6 +79,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
                                                      unsigned short* __restrict__ dx_b16, int nslab,
                                                      size_t slab_stride) {
   __shared__ __attribute__((aligned(16))) float red[LNB_WAVES * NV * 256];
+  LN_SETPRIO();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H4 = H >> 2;
   f32x4 g[NV], dg[NV], db[NV], dbx[NV];     // dbx: column sum of dx = bias gradient of the producing Linear

@@ -290,6 +290,12 @@ int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int
     if (cfg == 25) beta = 0;
     else { UCHECK_HIP(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(float), st)); beta = 1; }
   }
+  // wave priority of the critical path's GEMMs over the side stream's weight gradients (common.h).  fp32: measured WORSE
+  // (14.09 against 13.73 ms per step with level 2: the input-gradient GEMM then starves the weight-gradient launch it
+  // shares the matrix pipe with, and the chain waits for that launch at the layer's end), so the default is 0 here; the
+  // bf16-resident GEMMs below gain 0.6 % from level 2 (their bound is operand staging, not the pipe)
+  static const int main_prio = [] { const char* e = getenv("UNITER_MAIN_PRIO"); return e ? atoi(e) : 0; }();
+  g_uniter_launch_prio = kind == UNITER_K_GEMM_WGRAD ? 0 : main_prio;
   if (m->precision >= 1)      // embeddings' projections (fp32 inputs) also run on the bf16 pipe in mode 2
     return gemm_bf16_run(0, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux_in, aux_out, ld_aux, beta,
                          colsum_part, st);
@@ -303,6 +309,8 @@ int gemm_v2(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, in
             const void* B, int ldb, float* C, int ldc, int nsplit, unsigned short* Cb, int ldcb, int epi,
             const float* bias, const void* aux_in, int aux_in_b16, void* aux_out, int aux_out_b16, int ld_aux) {
   ProfScope ps(m, kind, st);
+  static const int main_prio = [] { const char* e = getenv("UNITER_MAIN_PRIO_BF16"); return e ? atoi(e) : 2; }();
+  g_uniter_launch_prio = main_prio;
   return gemm_bf16v2_run(0, nsplit, 0, bkm, M, N, K, A, lda, B, ldb, C, ldc, (long)M * ldc, Cb, ldcb, epi, bias, aux_in,
                          aux_in_b16, aux_out, aux_out_b16, ld_aux, 0, st);
 }
