@@ -66,6 +66,12 @@ int uniter_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
                     float* C, int ldc, int epilogue, const float* bias,
                     const float* aux_in, float* aux_out, int ld_aux,
                     int beta, void* stream);
+/* dW_p[M_p, N_p] (+)= A_p^T B_p for up to four products of ONE reduction length K (A_p [K, M_p], B_p [K, N_p], dW_p with
+ * leading dimension N_p; overwrite != 0: `=`), one persistent launch of whole-K 64 x 64 tiles: the four weight gradients of an
+ * encoder layer (autograd of the nn.Linear of model/layer.py:76-78,112,140,153), no partial tiles, no float atomics between
+ * workgroups.  UNITER_E_SHAPE: a product outside the kernel's range (M, N % 4, 31-bit offsets) -- launch them one by one. */
+int uniter_wgrad_f32_group(int n, const int* M, const int* N, int K, const float* const* A, const float* const* B,
+                           float* const* dW, int overwrite, void* stream);
 /* tile-configuration override for tuning (0 = heuristic). */
 int uniter_gemm_f32_cfg(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K,
                     const float* A, int lda, const float* B, int ldb,

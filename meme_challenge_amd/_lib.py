@@ -58,6 +58,7 @@ _SIGS = {
     'uniter_slab_reduce_add': (_I, [_P, _I, _SZ, _P, _SZ, _P]),
     'uniter_colsum_bf16_add': (_I, [_P, _I, _I, _I, _P, _P]),
     'uniter_wgrad_bf16_group': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    'uniter_wgrad_f32_group': (_I, [_I, _P, _P, _I, _P, _P, _P, _I, _P]),
     'uniter_ln_bwd_b16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_ln_bwd_rows': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_ln_bwd_finalize': (_I, [_P, _SZ, _I, _I, _P, _P, _P, _P]),

@@ -570,6 +570,173 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(const GemmArgs g) {
   stamp_end(g.stamp);
 }
 
+
+// ---------------------------------------------------------------------------
+// Grouped weight gradients: up to four products dW_p[M_p, N_p] (+)= A_p^T B_p of ONE reduction length K (A_p [K, M_p], B_p [K, N_p],
+// both k-major: the four weight gradients of an encoder layer, K = rows of the batch) as ONE persistent launch of whole-K
+// 64 x 64 tiles.  Their tiles are numbered through (1728 for UNITER-base) and walked by 1024 workgroup slots like the tiles of
+// one product in gemm_f32_v3_kernel -- same k-loop, same prefetch distance -- so a layer's weight gradients cost one
+// prologue / last round instead of four, and 1728 tiles balance over the slots better than 576 + 576 + 144 + 432 do launch by
+// launch.  No partial tiles: no float atomics (overwrite = a plain store, accumulate = one atomic add per element, one adder).
+// ---------------------------------------------------------------------------
+struct GemmGroup {
+  const float* A[4]; const float* B[4]; float* C[4];
+  int M[4], N[4];              // output shape of product p (lda = M, ldb = ldc = N)
+  int tiles_m[4], tiles_n[4], band_h[4];
+  int start[5];                // first tile of product p; start[n .. 4] = total
+  int K, overwrite, prio;
+  unsigned long long* stamp;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_wgrad_group_kernel(const GemmGroup G) {
+  constexpr int BM = 64, BN = 64;
+  constexpr bool AKM = true, BKM = true;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = 1, TN = 1;
+  constexpr int SA = TileSize<BM, AKM>::value, SB = TileSize<BN, BKM>::value;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (SA + SB)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = G.start[4];
+  const int nk = (G.K + BK - 1) / BK;      // rows >= K of a k-major operand read as 0 (buffer range check)
+
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int chunk_n = q + (xcd < r ? 1 : 0);
+  const int my_tiles = idx < chunk_n ? (chunk_n - idx + per_xcd - 1) / per_xcd : 0;
+  const int total_units = my_tiles * nk;
+  if (total_units == 0) return;
+  set_wave_prio(G.prio);
+  stamp_begin(G.stamp);
+
+  // (product, tile row, tile column) of global tile T
+#define LOCATE(T, P_, M0_, N0_)                                                          \
+  do {                                                                                   \
+    const int T_ = (T);                                                                  \
+    P_ = (T_ >= G.start[1]) + (T_ >= G.start[2]) + (T_ >= G.start[3]);                   \
+    int tm_, tn_;                                                                        \
+    tile_coords(T_ - G.start[P_], G.tiles_m[P_], G.tiles_n[P_], G.band_h[P_], tm_, tn_); \
+    M0_ = tm_ * BM; N0_ = tn_ * BN;                                                      \
+  } while (0)
+
+  // load cursor
+  int lt = idx, lk = 0, lp, lm0, ln0;
+  int voA[BM / 32], voB[BN / 32];
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  int kstepA, kstepB;
+#define BIND_LOAD()                                                                      \
+  do {                                                                                   \
+    LOCATE(chunk0 + lt, lp, lm0, ln0);                                                   \
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.A[lp]), 0, G.K * G.M[lp] * 4, 0x00020000); \
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.B[lp]), 0, G.K * G.N[lp] * 4, 0x00020000); \
+    kstepA = BK * G.M[lp] * 4; kstepB = BK * G.N[lp] * 4;                                \
+    tile_offsets<BM, AKM>(voA, G.M[lp], lm0, tid);                                       \
+    tile_offsets<BN, BKM>(voB, G.N[lp], ln0, tid);                                       \
+  } while (0)
+  BIND_LOAD();
+  int loaded = 0;
+#define LOAD_UNIT(RA, RB)                                                                \
+  do {                                                                                   \
+    if (loaded < total_units) {                                                          \
+      tile_load_buf<BM>(RA, rsA, voA, lk * kstepA);                                      \
+      tile_load_buf<BN>(RB, rsB, voB, lk * kstepB);                                      \
+      ++loaded;                                                                          \
+      if (++lk == nk) {                                                                  \
+        lk = 0; lt += per_xcd;                                                           \
+        if (loaded < total_units) BIND_LOAD();                                           \
+      }                                                                                  \
+    }                                                                                    \
+  } while (0)
+
+  f32x4 ra0[BM / 32], rb0[BN / 32], ra1[BM / 32], rb1[BN / 32];
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  LOAD_UNIT(ra0, rb0);
+  tile_store<BM, AKM>(ra0, smem, tid);
+  tile_store<BN, BKM>(rb0, smem + SA, tid);
+  LOAD_UNIT(ra1, rb1);
+  __syncthreads();
+  fa0[0] = frag_read<BM, AKM>(smem, wm * WM, 0, i, h);
+  fb0[0] = frag_read<BN, BKM>(smem + SA, wn * WN, 0, i, h);
+
+  // compute cursor
+  int ct = idx, ck = 0, cp, m0, n0;
+  LOCATE(chunk0 + ct, cp, m0, n0);
+  f32x16 acc;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) acc[rr] = 0.f;
+
+#define MFMA4(FA, FB)                                                                    \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0][t], FB[0][t], acc, 0, 0, 0);
+#define RDF(FA, FB, SAp, SBp, KB)                                                        \
+  FA[0] = frag_read<BM, AKM>(SAp, wm * WM, KB, i, h);                                    \
+  FB[0] = frag_read<BN, BKM>(SBp, wn * WN, KB, i, h);
+#define GROUP_EPILOGUE()                                                                 \
+  {                                                                                      \
+    constexpr int OOB = 0x7ffffff0;                                                      \
+    const int Mp = G.M[cp], Np = G.N[cp];                                                \
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(G.C[cp], 0, Mp * Np * 4, 0x00020000); \
+    const int col = n0 + wn * WN + i;                                                    \
+    const int r0 = m0 + wm * WM + 4 * h;                                                 \
+    const int voC = col < Np ? (r0 * Np + col) * 4 : OOB;                                \
+    _Pragma("unroll") for (int rr = 0; rr < 16; ++rr) {                                  \
+      const int kr = (rr & 3) + 8 * (rr >> 2);                                           \
+      if (G.overwrite) buf_st_f32(acc[rr], rsC, voC, kr * Np * 4, 0);                    \
+      else __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[rr], rsC, voC, kr * Np * 4, 0); \
+      acc[rr] = 0.f;                                                                     \
+    }                                                                                    \
+  }
+#define K_ITER(U, STAGE)                                                                 \
+  {                                                                                      \
+    const float* sA = smem + (STAGE) * (SA + SB);                                        \
+    const float* sB = sA + SA;                                                           \
+    float* dA = smem + (1 - (STAGE)) * (SA + SB);                                        \
+    const bool more = (U) + 1 < total_units;                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    RDF(fa1, fb1, sA, sB, 1)                                                             \
+    MFMA4(fa0, fb0)                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    RDF(fa0, fb0, sA, sB, 2)                                                             \
+    MFMA4(fa1, fb1)                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    if (more) {                                                                          \
+      tile_store<BM, AKM>(ra1, dA, tid);                                                 \
+      tile_store<BN, BKM>(rb1, dA + SA, tid);                                            \
+    }                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    LOAD_UNIT(ra1, rb1);                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    RDF(fa1, fb1, sA, sB, 3)                                                             \
+    MFMA4(fa0, fb0)                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    __syncthreads();                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    if (more) { RDF(fa0, fb0, dA, (dA + SA), 0) }                                        \
+    MFMA4(fa1, fb1)                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    if (++ck == nk) {                                                                    \
+      GROUP_EPILOGUE();                                                                  \
+      ck = 0; ct += per_xcd;                                                             \
+      if (more) LOCATE(chunk0 + ct, cp, m0, n0);                                         \
+    }                                                                                    \
+  }
+  int u = 0;
+  for (; u + 1 < total_units; u += 2) {
+    K_ITER(u, 0)
+    K_ITER(u + 1, 1)
+  }
+  if (u < total_units) K_ITER(u, 0)
+#undef K_ITER
+#undef GROUP_EPILOGUE
+#undef RDF
+#undef MFMA4
+#undef LOAD_UNIT
+#undef BIND_LOAD
+#undef LOCATE
+  stamp_end(G.stamp);
+}
+
 template <int BM, int BN, bool AKM, bool BKM, int TAG>
 int launch_v3(GemmArgs g, hipStream_t st, int slots, bool allow_sk = true) {
   g.tiles_m = (g.M + BM - 1) / BM;
@@ -636,6 +803,46 @@ int choose_cfg(int M, int N) {
 }
 
 }  // namespace
+
+// dW_p[Mo_p, No_p] (+)= A_p^T B_p, p < n <= 4, A_p [K, Mo_p], B_p [K, No_p] fp32 (gemm_f32_wgrad_group_kernel); returns
+// UNITER_E_SHAPE for shapes the grouped kernel does not take (the caller then launches the products one by one)
+int gemm_f32_wgrad_group(int n, const int* Mo, const int* No, int K, const float* const* A, const float* const* B,
+                         float* const* dW, int overwrite, void* stream) {
+  UCHECK_ARG(n >= 1 && n <= 4 && K > 0 && Mo && No && A && B && dW, "wgrad_group_f32: bad argument");
+  GemmGroup G = {};
+  int total = 0;
+  for (int p = 0; p < 4; ++p) {
+    G.start[p] = total;
+    if (p >= n) { G.A[p] = G.A[0]; G.B[p] = G.B[0]; G.C[p] = G.C[0]; G.M[p] = G.M[0]; G.N[p] = G.N[0];
+                  G.tiles_m[p] = G.tiles_m[0]; G.tiles_n[p] = G.tiles_n[0]; G.band_h[p] = G.band_h[0]; continue; }
+    UCHECK_ARG(Mo[p] > 0 && No[p] > 0 && A[p] && B[p] && dW[p], "wgrad_group_f32: bad product %d", p);
+    const bool ok = Mo[p] % 4 == 0 && No[p] % 4 == 0 && ((uintptr_t)A[p] & 15) == 0 && ((uintptr_t)B[p] & 15) == 0 &&
+                    (size_t)K * Mo[p] * 4 < (1ull << 31) && (size_t)K * No[p] * 4 < (1ull << 31) &&
+                    ((size_t)Mo[p] + 128) * No[p] * 4 < (1ull << 31);
+    if (!ok) { uniter_set_error("wgrad_group_f32: product %d (%d x %d, K = %d) outside the grouped kernel's range", p, Mo[p], No[p], K); return UNITER_E_SHAPE; }
+    G.A[p] = A[p]; G.B[p] = B[p]; G.C[p] = dW[p]; G.M[p] = Mo[p]; G.N[p] = No[p];
+    G.tiles_m[p] = (Mo[p] + 63) / 64; G.tiles_n[p] = (No[p] + 63) / 64;
+    const long panel = 64l * K * 4;
+    long bh = (3l << 19) / (panel > 0 ? panel : 1);
+    G.band_h[p] = (int)(bh < 1 ? 1 : (bh > 16 ? 16 : bh));
+    if (G.band_h[p] > G.tiles_m[p]) G.band_h[p] = G.tiles_m[p];
+    total += G.tiles_m[p] * G.tiles_n[p];
+  }
+  G.start[4] = total;
+  for (int p = n; p < 4; ++p) G.start[p] = total;
+  G.K = K; G.overwrite = overwrite; G.prio = take_launch_prio(); G.stamp = take_stamp_slot();
+  static const int slots_env = env_int("UNITER_WGRAD_GROUP_F32_SLOTS", 1024);
+  const int slots = slots_env >= 8 ? slots_env / 8 * 8 : 1024;
+  const int grid = total < slots ? (total + 7) / 8 * 8 : slots;
+  hipLaunchKernelGGL(gemm_f32_wgrad_group_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, G);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_wgrad_f32_group(int n, const int* M, const int* N, int K, const float* const* A, const float* const* B,
+                                      float* const* dW, int overwrite, void* stream) {
+  return gemm_f32_wgrad_group(n, M, N, K, A, B, dW, overwrite, stream);
+}
 
 // tag != 0 selects a separately named instantiation of the x @ W^T kernel (TAG template
 // argument) so that one call site (the FFN-up forward GEMM) is its own row in rocprofv3 --stats.

@@ -32,6 +32,8 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
                     const void* B, int ldb, float* C, int ldc, long c_split_stride, void* Cb, int ldcb, int epilogue,
                     const float* bias, const void* aux_in, int aux_in_bf16, void* aux_out, int aux_out_bf16,
                     int ld_aux, int beta, void* stream);
+int gemm_f32_wgrad_group(int n, const int* Mo, const int* No, int K, const float* const* A, const float* const* B,
+                         float* const* dW, int overwrite, void* stream);
 int gemm_bf16v2_pick_split(int M, int N, int K);
 int gemm_bf16v2_wgrad_pieces(int M, int N, int K);
 int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A,
@@ -836,6 +838,27 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     }
   } else {
     const int wb = m->wg_overwrite ? -1 : 1;      // -1: overwrite (or clear, then accumulate) -- see gemm()
+    // UNITER_WGRAD_GROUP_F32=1: the layer's four weight gradients as ONE persistent launch of whole-K tiles (1728 tiles for
+    // 1024 slots, uniter_wgrad_f32_group).  Measured (three same-box pairs): the launch itself runs at 0.47-0.49 of the fp32 peak
+    // in situ (four launches: 0.39), both gradient families together at 0.78 (0.67), the attention backward beside it at 97
+    // instead of 151 us -- and the STEP is 0.7-1.1 % slower (13.87-13.90 vs 13.72-13.75 ms): its 1024 resident workgroups
+    // hold every CU's LDS for 370 us, and each kernel of the input-gradient chain queues for slots before its first
+    // workgroup starts (a wait no per-launch figure shows).  So the default stays four launches.
+    static const bool group_env = [] { const char* e = getenv("UNITER_WGRAD_GROUP_F32"); return e && e[0] == '1'; }();
+    static const bool whole_all = [] { const char* e = getenv("UNITER_WGRAD_WHOLE"); return !e || atoi(e) == 15; }();
+    static const bool cfg_default = [] { const char* e = getenv("UNITER_WGRAD_CFG"); return !e || atoi(e) == 0; }();
+    bool grouped = false;
+    if (group_env && whole_all && cfg_default && m->precision == 0 && fuse_db1) {
+      const int Mo[4] = {H, I, H, 3 * H}, No[4] = {I, H, H, H};
+      const float* const As[4] = {g2, lb.du, g1, lb.dqkv};
+      const float* const Bs[4] = {lb.hact, lb.y1, lb.ctx, x};
+      float* const dWs[4] = {m->LG(l, L_W2), m->LG(l, L_W1), m->LG(l, L_OW), m->LG(l, L_QW)};
+      ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
+      const int rc = gemm_f32_wgrad_group(4, Mo, No, M, As, Bs, dWs, m->wg_overwrite ? 1 : 0, sd);
+      if (rc == 0) grouped = true;
+      else if (rc != UNITER_E_SHAPE) return rc;
+    }
+    if (!grouped) {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, H, I, M, g2, H, lb.hact, I, m->LG(l, L_W2), I, UNITER_EPI_NONE,
                    nullptr, nullptr, nullptr, 0, wb));
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, I, H, M, lb.du, I, lb.y1, H, m->LG(l, L_W1), H, UNITER_EPI_NONE,
@@ -845,6 +868,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                    nullptr, nullptr, nullptr, 0, wb));
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, sd, 1, 1, 3 * H, H, M, lb.dqkv, 3 * H, x, H, m->LG(l, L_QW), H,
                    UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, wb));
+    }
   }
   if (!fused_qb) UCHECK_RC(uniter_colsum_f32(lb.dqkv, M, 3 * H, 3 * H, m->LG(l, L_QB), 1, pl.col_ws, pl.col_ws_bytes, sd));
   if (sd != st) UCHECK_HIP(hipEventRecord(m->ev_side[l], sd));

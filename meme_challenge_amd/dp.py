@@ -217,7 +217,8 @@ class GradSync(object):
             n = srt.numel()
             all_ids = torch.empty(self.world * n, dtype=srt.dtype, device=srt.device)
             all_rows = torch.empty(self.world * n, H, dtype=rows.dtype, device=rows.device)
-            if self.world > 1:
+            if self.world > 1 or (dist.is_initialized() and os.environ.get('UNITER_DP_FORCE') == '1'):
+                # (UNITER_DP_FORCE: the collectives themselves also on a single rank -- tests on one GPU)
                 w_ids = dist.all_gather_into_tensor(all_ids, srt, group=self.group, async_op=True)
                 w_rows = dist.all_gather_into_tensor(all_rows, rows, group=self.group, async_op=True)
                 w_ids.wait()

@@ -44,6 +44,12 @@ def test_single_rank_rccl_path_matches_plain_step():
     # bf16 payload: gradients rounded once (2^-9 relative) before Adam; after two steps at lr 1e-3 the parameters move by
     # at most a few lr relative to the run without the collective
     assert out['bf16_payload_maxdiff'] < 5e-3, out
+    # the sparse word-embedding exchange through RCCL's all-gather (one rank: the gathered rows are the rank's own): the table
+    # leaves the dense collectives (one more range: table | rest of the embeddings), same parameters as the plain steps
+    sp = out['sparse_info']
+    assert sp['sparse_steps'] == 2 and len(sp['sync_ranges']) == len(sp['ranges']) + 1, sp
+    assert out['fp32_sparse_maxdiff'] <= 4 * noise, out
+    assert out['bf16_sparse_steps'] == 2 and out['bf16_sparse_maxdiff'] < 5e-3, out
 
 
 def test_two_ranks_share_the_batch():

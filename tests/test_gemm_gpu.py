@@ -114,3 +114,30 @@ def test_gemm_rejects_bad_args():
     rc = lib.uniter_gemm_f32(0, 0, 64, 64, 62, L.ptr(x), 64, L.ptr(x), 64, L.ptr(x), 64, 0,
                              None, None, None, 0, 0, L.cur_stream())
     assert rc == -2 and b'multiples of 4' in lib.uniter_last_error()
+
+
+@pytest.mark.parametrize('K,shapes', [(2624, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),
+                                      (100, [(64, 128), (132, 68)]), (37, [(256, 4)])])
+def test_grouped_weight_gradients(K, shapes):
+    """uniter_wgrad_f32_group: up to four dW_p (+)= A_p^T B_p of one reduction length as ONE launch of whole-K tiles --
+    the encoder layer's shapes, ragged shapes (tile tails in both dimensions, a reduction length that is no multiple of the
+    32-deep k-tile), overwrite and accumulate; every product against float64."""
+    import ctypes as C
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(K)
+    n = len(shapes)
+    As = [torch.randn(K, m, generator=g).cuda() for m, _ in shapes]
+    Bs = [torch.randn(K, nn, generator=g).cuda() for _, nn in shapes]
+    init = [torch.randn(m, nn, generator=g).cuda() for m, nn in shapes]
+    Ms = (C.c_int * n)(*[m for m, _ in shapes]); Ns = (C.c_int * n)(*[nn for _, nn in shapes])
+    pa = (C.c_void_p * n)(*[a.data_ptr() for a in As]); pb = (C.c_void_p * n)(*[b.data_ptr() for b in Bs])
+    for overwrite in (1, 0):
+        outs = [t.clone() for t in init]
+        pc = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        L.check(lib.uniter_wgrad_f32_group(n, Ms, Ns, K, pa, pb, pc, overwrite, L.cur_stream()), 'uniter_wgrad_f32_group')
+        torch.cuda.synchronize()
+        for a, b, o, i0 in zip(As, Bs, outs, init):
+            ref = a.double().t() @ b.double() + (0 if overwrite else i0.double())
+            err = (o.double() - ref).abs().max().item()
+            assert err <= 2e-6 * K ** 0.5 * max(1.0, ref.abs().max().item()) / 10 + 1e-5, (overwrite, tuple(o.shape), err)

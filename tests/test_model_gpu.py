@@ -265,3 +265,22 @@ def test_backward_of_a_stale_forward_fails_loudly(tiny, train):
         m(**model_kwargs(b))               # no-grad forwards in between do count (they overwrite the plan) ...
     third = bce_with_logits_loss(m(**model_kwargs(b)), b['labels'], 1.8)
     third.backward()                       # ... and a fresh forward works again
+
+
+@pytest.mark.parametrize('env', [{'UNITER_WGRAD_GROUP_F32': '1'}, {'UNITER_WGRAD_WHOLE': '0', 'UNITER_LAZY_ZERO': '0'},
+                                 {'UNITER_KEEP_PREGEN': '0', 'UNITER_ADAM_WORD_SPLIT': '0'}])
+def test_alternative_schedules_keep_the_golden_gradients(env):
+    """The switches that select another form of the same arithmetic (the layer's weight gradients as one grouped whole-K
+    launch; the stream-K form with a clearing zero_grad; dropout flags drawn inside the attention kernels and the embeddings'
+    optimizer block in one launch) are read once per process: the reference-golden gradient, dropout-replay and trainer-step
+    tests run again in a child process with the switch set."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-p', 'no:cacheprovider',
+                        'tests/test_model_gpu.py::test_tiny_loss_and_all_grads_match_reference_golden',
+                        'tests/test_model_gpu.py::test_base_logits_and_grads_match_reference_golden',
+                        'tests/test_model_gpu.py::test_train_mode_dropout_replay_matches_oracle',
+                        'tests/test_trainer_gpu.py::test_trainer_steps_match_reference'],
+                       cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]

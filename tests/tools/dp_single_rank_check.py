@@ -14,7 +14,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'tests'))
 
 
-def run(payload, precision, cfgd, B, T, R, max_grad_norm):
+def run(payload, precision, cfgd, B, T, R, max_grad_norm, sparse=False):
     from meme_challenge_amd.model import UniterConfig, UniterModel
     from meme_challenge_amd.meme_uniter import MemeUniter
     from meme_challenge_amd.trainer import FusedAdam, TrainStep, get_scheduler
@@ -32,7 +32,7 @@ def run(payload, precision, cfgd, B, T, R, max_grad_norm):
     opt = FusedAdam(model, lr=config['lr'], weight_decay=config['weight_decay'])
     opt.overlap_encoder = enc
     sched = get_scheduler(opt, config, steps_per_epoch=10)
-    sync = dp.attach(model, payload=payload) if payload else None
+    sync = dp.attach(model, payload=payload, sparse_embeddings=sparse) if payload else None
     step = TrainStep(model, opt, sched, config, grad_sync=sync)
     batch = make_synthetic_batch(B, T, R, seed=5, device='cuda')
     info = {}
@@ -48,7 +48,8 @@ def run(payload, precision, cfgd, B, T, R, max_grad_norm):
         side = enc._side_stream.cuda_stream
         info.update(launched=sync.launched, n_buckets=len(store.bucket_ranges),
                     ranges=[list(r) for r in store.bucket_ranges],
-                    on_side_stream=[s == side for s in sync.launch_streams], payload=sync.payload)
+                    on_side_stream=[s == side for s in sync.launch_streams], payload=sync.payload,
+                    sparse_steps=sync.sparse_steps, sync_ranges=[list(r) for r in sync.ranges])
     return store.flat_params.detach().clone(), float(step.last_loss.item()), info
 
 
@@ -79,6 +80,13 @@ def main():
     out['bf16_payload_maxdiff'] = float(d)
     out['bf16_payload_scale'] = float((ref_b16 - ref_clip).abs().max().item())
     out['bf16_info'] = info3
+    # sparse word-embedding exchange: RCCL all-gather of (ids, rows), summed in rank order over cleared rows
+    got, _, info4 = run('fp32', 'fp32', cfgd, *shape, max_grad_norm=5, sparse=True)
+    out['fp32_sparse_maxdiff'] = float((got - ref_clip).abs().max().item())
+    out['sparse_info'] = info4
+    got, _, info5 = run('bf16', 'bf16', cfgd, *shape, max_grad_norm=5, sparse=True)
+    out['bf16_sparse_maxdiff'] = float((got - ref_b16).abs().max().item())
+    out['bf16_sparse_steps'] = info5['sparse_steps']
     dist.destroy_process_group()
     print('DPCHECK ' + json.dumps(out), flush=True)
 
