@@ -838,13 +838,17 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     }
   } else {
     const int wb = m->wg_overwrite ? -1 : 1;      // -1: overwrite (or clear, then accumulate) -- see gemm()
-    // UNITER_WGRAD_GROUP_F32=1: the layer's four weight gradients as ONE persistent launch of whole-K tiles (1728 tiles for
+    // UNITER_WGRAD_GROUP_F32=1: EVERY layer's four weight gradients as ONE persistent launch of whole-K tiles (1728 tiles for
     // 1024 slots, uniter_wgrad_f32_group).  Measured (three same-box pairs): the launch itself runs at 0.47-0.49 of the fp32 peak
     // in situ (four launches: 0.39), both gradient families together at 0.78 (0.67), the attention backward beside it at 97
     // instead of 151 us -- and the STEP is 0.7-1.1 % slower (13.87-13.90 vs 13.72-13.75 ms): its 1024 resident workgroups
     // hold every CU's LDS for 370 us, and each kernel of the input-gradient chain queues for slots before its first
-    // workgroup starts (a wait no per-launch figure shows).  So the default stays four launches.
-    static const bool group_env = [] { const char* e = getenv("UNITER_WGRAD_GROUP_F32"); return e && e[0] == '1'; }();
+    // workgroup starts (a wait no per-launch figure shows).  So layers nl-1 .. 1 keep four launches.
+    // Layer 0 is the exception (UNITER_WGRAD_GROUP_F32 = 2, the default; 0 = never, 1 = every layer): its weight gradients run
+    // BEHIND the input-gradient chain, alone on the chip, where four launches of 576 / 576 / 144 / 432 tiles leave a quarter
+    // of the 1024 slots idle and one balanced launch does not: 13.69 -> 13.55 ms per step (three same-box pairs).
+    static const int group_mode = [] { const char* e = getenv("UNITER_WGRAD_GROUP_F32"); return e ? atoi(e) : 2; }();
+    const bool group_env = group_mode == 1 || (group_mode == 2 && l == 0);
     static const bool whole_all = [] { const char* e = getenv("UNITER_WGRAD_WHOLE"); return !e || atoi(e) == 15; }();
     static const bool cfg_default = [] { const char* e = getenv("UNITER_WGRAD_CFG"); return !e || atoi(e) == 0; }();
     bool grouped = false;

@@ -268,7 +268,7 @@ def test_backward_of_a_stale_forward_fails_loudly(tiny, train):
 
 
 @pytest.mark.parametrize('env', [{'UNITER_WGRAD_GROUP_F32': '1'}, {'UNITER_WGRAD_WHOLE': '0', 'UNITER_LAZY_ZERO': '0'},
-                                 {'UNITER_KEEP_PREGEN': '0', 'UNITER_ADAM_WORD_SPLIT': '0'}])
+                                 {'UNITER_KEEP_PREGEN': '0', 'UNITER_ADAM_WORD_SPLIT': '0', 'UNITER_WGRAD_GROUP_F32': '0'}])
 def test_alternative_schedules_keep_the_golden_gradients(env):
     """The switches that select another form of the same arithmetic (the layer's weight gradients as one grouped whole-K
     launch; the stream-K form with a clearing zero_grad; dropout flags drawn inside the attention kernels and the embeddings'
