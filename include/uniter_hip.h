@@ -545,6 +545,9 @@ int uniter_prof_collect_stamps(uniter_model_t* m, int* n_launches, double* total
  * union of the launches' intervals, e.g. what the input- and weight-gradient GEMMs, which share the chip on two streams,
  * took together.  Call before uniter_prof_enable_stamps(m, 0, ..) discards the stamps. */
 int uniter_prof_stamps_union(uniter_model_t* m, unsigned kind_mask, double* union_ms);
+/* Every stamped launch in launch order: its UNITER_K_* kind and [first workgroup's start, last workgroup's end] in
+ * microseconds since the first stamped launch's start -- where on the step's time axis each GEMM ran (synchronises). */
+int uniter_prof_stamp_spans(uniter_model_t* m, int* kinds, double* start_us, double* end_us, int cap, int* n);
 
 #ifdef __cplusplus
 }

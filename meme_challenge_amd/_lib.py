@@ -135,6 +135,7 @@ _SIGS = {
     'uniter_prof_enable_stamps': (_I, [_P, _I, _P]),
     'uniter_prof_collect_stamps': (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), _I]),
     'uniter_prof_stamps_union': (_I, [_P, C.c_uint, C.POINTER(C.c_double)]),
+    'uniter_prof_stamp_spans': (_I, [_P, _P, _P, _P, _I, _P]),
     'uniter_prof_collect_kinds': (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double), _I]),
     'uniter_prof_collect': (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }

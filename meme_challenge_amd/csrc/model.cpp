@@ -502,6 +502,24 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   m->bwd_open = false;
   ++m->generation;
 
+  const bool res = pl.res;
+  // L <= 192: attention on the bf16 pipe (attention_bf16.hip), which also writes the bf16 copies of its outputs
+  const bool attn_b16 = res && L <= uniter_attn_varlen_max_len();
+
+  // dropout keep flags of the attention probabilities of ALL layers, drawn in one elementwise launch ahead of everything --
+  // a function of (seed, offset) alone, so it runs while the optimizer still streams the word table the text branch waits for
+  // (the L <= 192 kernels then read them; the backward pass reads the same words)
+  static const bool pregen_env = [] { const char* e = getenv("UNITER_KEEP_PREGEN"); return !e || e[0] != '0'; }();
+  bool keep_pre = pregen_env && save && pa > 0.f && L <= uniter_attn_varlen_max_len() && (attn_b16 || packed || save);
+  if (keep_pre) {
+    const size_t stride = nl > 1 ? (size_t)((char*)pl.layers[1].keepb - (char*)pl.layers[0].keepb) : 0;
+    for (int l = 1; l < nl && keep_pre; ++l)
+      keep_pre = (size_t)((char*)pl.layers[l].keepb - (char*)pl.layers[0].keepb) == stride * l;
+    if (keep_pre)
+      UCHECK_RC(uniter_attn_keep_bits_gen(pl.layers[0].keepb, stride, nl, B, L, nh, pa, seed, offset, SITE_ATTN_PROBS(0),
+                                          SITE_ATTN_PROBS(1) - SITE_ATTN_PROBS(0), st));
+  }
+
   // parameters still being written by an optimizer step on another stream (uniter_model_set_ready_events)
   // ready = [embeddings, layer 0 .. nl-1] or, with one more event, [embeddings WITHOUT the word table, layers.., word table]:
   // the image branch (region projection, 3 LayerNorms) then runs while the optimizer still streams the 89-MB word table
@@ -546,28 +564,11 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   if (packed) UCHECK_RC(uniter_row_gather(pl.cat, b->pack_src, pl.emb, M, H, B * S, st));
   else UCHECK_RC(uniter_gather_rows(pl.cat, joint ? b->gather_index : nullptr, pl.emb, B, S, L, H, st));
   const size_t PH = (size_t)B * L * H;          // one layer of the padded output
-  const bool res = pl.res;
   if (res) {
     UCHECK_ARG(m->mirror != nullptr, "model_forward: precision 2 needs uniter_model_set_weight_mirror");
     UCHECK_RC(cast_b(pl.emb, pl.embb, (size_t)M * H, st));
   }
   const unsigned short* xb = pl.embb;
-  // L <= 192: attention on the bf16 pipe (attention_bf16.hip), which also writes the bf16 copies of its outputs
-  const bool attn_b16 = res && L <= uniter_attn_varlen_max_len();
-
-  // dropout keep flags of the attention probabilities of ALL layers, drawn in one elementwise launch ahead of the layers
-  // (the L <= 192 kernels then read them; the backward pass reads the same words)
-  static const bool pregen_env = [] { const char* e = getenv("UNITER_KEEP_PREGEN"); return !e || e[0] != '0'; }();
-  bool keep_pre = pregen_env && save && pa > 0.f && L <= uniter_attn_varlen_max_len() && (attn_b16 || packed || save);
-  if (keep_pre) {
-    const size_t stride = nl > 1 ? (size_t)((char*)pl.layers[1].keepb - (char*)pl.layers[0].keepb) : 0;
-    for (int l = 1; l < nl && keep_pre; ++l)
-      keep_pre = (size_t)((char*)pl.layers[l].keepb - (char*)pl.layers[0].keepb) == stride * l;
-    if (keep_pre)
-      UCHECK_RC(uniter_attn_keep_bits_gen(pl.layers[0].keepb, stride, nl, B, L, nh, pa, seed, offset, SITE_ATTN_PROBS(0),
-                                          SITE_ATTN_PROBS(1) - SITE_ATTN_PROBS(0), st));
-  }
-
   // ---- encoder (model/model.py:282-292; model/layer.py:166-170) ----
   const float* x = pl.emb;
   for (int l = 0; l < nl; ++l) {
@@ -1038,6 +1039,35 @@ extern "C" int uniter_prof_collect_stamps(uniter_model_t* m, int* n_launches, do
     if (t0 == ~0ull || t1 < t0) continue;                  // the scope launched no stamped kernel
     n_launches[m->stamp_tag[i]] += 1;
     total_ms[m->stamp_tag[i]] += (double)(t1 - t0) * 1e-5;  // 100 MHz ticks -> ms
+  }
+  return 0;
+}
+
+// every stamped launch in launch order: kind and [first workgroup's start, last workgroup's end] in microseconds since the
+// first stamped launch's start (the GPU's 100-MHz clock): where on the step's time axis each GEMM sits, with nothing added to
+// the streams -- e.g. how long the chip takes from the last backward GEMM of a step to the first forward GEMM of the next
+extern "C" int uniter_prof_stamp_spans(uniter_model_t* m, int* kinds, double* start_us, double* end_us, int cap, int* n) {
+  UCHECK_ARG(m && kinds && start_us && end_us && n && cap >= 0, "prof_stamp_spans: null pointer");
+  *n = 0;
+  if (!m->stamp_buf || m->stamp_used == 0) return 0;
+  UCHECK_HIP(hipDeviceSynchronize());
+  const size_t per = (size_t)2 * STAMP_WGS;
+  std::vector<unsigned long long> h(m->stamp_used * per);
+  UCHECK_HIP(hipMemcpy(h.data(), m->stamp_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  unsigned long long base = 0;
+  for (size_t i = 0; i < m->stamp_used && *n < cap; ++i) {
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int w = 0; w < STAMP_WGS; ++w) {
+      const unsigned long long a = h[i * per + w], b = h[i * per + STAMP_WGS + w];
+      if (a && a < t0) t0 = a;
+      if (b > t1) t1 = b;
+    }
+    if (t0 == ~0ull || t1 < t0) continue;
+    if (*n == 0) base = t0;
+    kinds[*n] = m->stamp_tag[i];
+    start_us[*n] = ((double)t0 - (double)base) * 1e-2;
+    end_us[*n] = ((double)t1 - (double)base) * 1e-2;
+    ++*n;
   }
   return 0;
 }
