@@ -388,7 +388,8 @@ def run_rank(args):
                7: ('gemm_wgrad', 'mfma', nl * (g_qkv + g_o + 2 * g_ffn)), 8: ('attention_bwd', 'mfma', nl * 2 * att),
                9: ('layernorm_fwd', 'hbm', nl * 2 * 16.0 * M_eff * H), 10: ('layernorm_bwd', 'hbm', nl * 2 * 16.0 * M_eff * H)}
         kernel_of = {'f32': {1: 'gemm_f32_v3_kernel<64,64,false,false,TAG=1>', 6: 'gemm_f32_v3_kernel<64,64,false,true,...>',
-                             7: 'gemm_f32_v3_kernel<64,64,true,true,0,false> (whole-K 64x64 tiles; UNITER_WGRAD_WHOLE=0: the stream-K form)'},
+                             7: 'gemm_f32_v3_kernel<64,64,true,true,0,false> (whole-K 64x64 tiles; UNITER_WGRAD_WHOLE=0: the stream-K form); layer 0: '
+                                'gemm_f32_wgrad_group_kernel (its four products as one launch)'},
                      'bf16': {1: 'gemm_dma_kernel<128,128,false,false,SWAP,2,EPI=5> (bias + GELU + gelu\' bf16)',
                               6: 'gemm_dma_kernel<128,128,false,true,SWAP,2,EPI>', 7: 'gemm_dma_wgrad_group_kernel<2> (the four weight gradients of a layer in one launch of whole-K 128x128 tiles)'}}
         families = []

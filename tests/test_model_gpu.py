@@ -284,3 +284,31 @@ def test_alternative_schedules_keep_the_golden_gradients(env):
                        cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
+
+
+def test_launch_stamps_put_the_gemms_on_one_clock(tiny):
+    """uniter_prof_enable_stamps + uniter_prof_stamp_spans (measurement only): with stamps on, a forward + backward leaves
+    one [start, end] interval per GEMM launch, in launch order, on the GPU's own clock -- forward kinds first, each interval
+    non-empty, forward GEMMs strictly one after the other (they share a stream), everything inside a sane span."""
+    import ctypes as C
+    from meme_challenge_amd import _lib
+    from meme_challenge_amd.trainer import bce_with_logits_loss
+    m = build(TINY, TINY_IMG_DIM, sd_from_npz(tiny)).train()
+    b = to_dev(batch_from_npz(tiny))
+    enc = m.uniter_model
+    bce_with_logits_loss(m(**model_kwargs(b)), b['labels'], 1.8).backward()      # builds the handle
+    lib = _lib.lib()
+    _lib.check(lib.uniter_prof_enable_stamps(enc._handle, 1, None))
+    bce_with_logits_loss(m(**model_kwargs(b)), b['labels'], 1.8).backward()
+    cap = 512
+    kinds, t0, t1, n = (C.c_int * cap)(), (C.c_double * cap)(), (C.c_double * cap)(), C.c_int(0)
+    _lib.check(lib.uniter_prof_stamp_spans(enc._handle, kinds, t0, t1, cap, C.byref(n)))
+    _lib.check(lib.uniter_prof_enable_stamps(enc._handle, 0, None))
+    spans = [(kinds[i], t0[i], t1[i]) for i in range(n.value)]
+    nl = TINY['num_hidden_layers']
+    fwd = [s for s in spans if s[0] in (1, 2, 3, 4)]
+    assert len(fwd) == 4 * nl and spans[:len(fwd)] == fwd                        # QKV, attention output, FFN up, FFN down per layer
+    assert sum(1 for s in spans if s[0] == 6) == 4 * nl                          # input gradients
+    assert sum(1 for s in spans if s[0] == 7) >= 1                               # weight gradients (grouped or one by one)
+    assert spans[0][1] == 0.0 and all(0.0 <= a < e < 1e6 for _, a, e in spans)
+    assert all(x[2] <= y[1] for x, y in zip(fwd, fwd[1:]))
