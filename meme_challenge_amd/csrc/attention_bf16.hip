@@ -348,8 +348,7 @@ __global__ __launch_bounds__(768) void attn_b16_fwd_kernel(const Args a, int Lr)
 // ------------------------------------------------- backward: dQ, delta, Pd / dS scratch ---
 // LDS: K row-major | V row-major | K transposed | mask bias
 template <bool QB16>
-__global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr, int red_off) {
-  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
+__device__ __forceinline__ void b16_dq_body(const Args& a, int Lr, int red_off) {
   u16* Kb = reinterpret_cast<u16*>(smem_raw);
   u16* Vb = Kb + Lr * KLD;
   u16* Kt = Vb + Lr * KLD;
@@ -472,10 +471,15 @@ __global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr, 
   }
 }
 
+template <bool QB16>
+__global__ __launch_bounds__(768) void attn_b16_dq_kernel(const Args a, int Lr, int red_off) {
+  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
+  b16_dq_body<QB16>(a, Lr, red_off);
+}
+
 // ------------------------------------------------------------ backward: dK, dV ---
 // LDS: Q transposed | dO transposed.  dV^T[d][key] = sum_q dO[q][d] Pd[q][key], dK^T = sum_q Q[q][d] dS[q][key]
-__global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr, int red_off) {
-  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
+__device__ __forceinline__ void b16_dkv_body(const Args& a, int Lr, int red_off) {
   u16* Qt = reinterpret_cast<u16*>(smem_raw);
   u16* dOt = Qt + D * TLD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
@@ -552,6 +556,21 @@ __global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr,
   }
 }
 
+__global__ __launch_bounds__(768) void attn_b16_dkv_kernel(const Args a, int Lr, int red_off) {
+  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
+  b16_dkv_body(a, Lr, red_off);
+}
+
+// Both passes in one launch (attention_f32.hip, attn_bwd_fused_split_kernel): a workgroup's dK / dV pass reads only the Pd / dS
+// blocks its own dQ pass wrote, so it follows behind a workgroup barrier instead of behind a second launch.
+template <bool QB16>
+__global__ __launch_bounds__(768) void attn_b16_bwd_fused_kernel(const Args a, int Lr, int red_dq, int red_dkv) {
+  set_wave_prio(a.prio);
+  b16_dq_body<QB16>(a, Lr, red_dq);
+  __syncthreads();
+  b16_dkv_body(a, Lr, red_dkv);
+}
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   UCHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -625,6 +644,21 @@ extern "C" int uniter_attn_bf16_bwd(const void* qkv, int qkv_is_bf16, const floa
   const size_t red_dq = max3((size_t)(2 * Lr * KLD + D * TLD) * 2 + Lr * 4, (size_t)nblk * XROW * 64 * 4, 0);
   const size_t red_dkv = max3((size_t)(2 * D * TLD) * 2, (size_t)nblk * 64 * 64 * 4, 0);
   const size_t lds_dq = red_dq + 192 * 4, lds_dkv = red_dkv + 192 * 4;
+  static const bool fused = [] { const char* e = getenv("UNITER_ATTN_BWD_FUSED"); return !(e && e[0] == '0'); }();
+  if (fused) {
+    const size_t lds = lds_dq > lds_dkv ? lds_dq : lds_dkv;
+    if (a.qb16) {
+      UCHECK_RC(set_lds(attn_b16_bwd_fused_kernel<true>, lds));
+      hipLaunchKernelGGL(attn_b16_bwd_fused_kernel<true>, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr, (int)red_dq,
+                         (int)red_dkv);
+    } else {
+      UCHECK_RC(set_lds(attn_b16_bwd_fused_kernel<false>, lds));
+      hipLaunchKernelGGL(attn_b16_bwd_fused_kernel<false>, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr, (int)red_dq,
+                         (int)red_dkv);
+    }
+    UCHECK_LAUNCH();
+    return 0;
+  }
   UCHECK_RC(set_lds(attn_b16_dkv_kernel, lds_dkv));
   if (a.qb16) {
     UCHECK_RC(set_lds(attn_b16_dq_kernel<true>, lds_dq));

@@ -723,9 +723,8 @@ __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, i
   }
 }
 
-__global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a, int Lr, float* __restrict__ pd_ws,
-                                                                float* __restrict__ ds_ws) {
-  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
+// (no __restrict__ on the scratch pointers of the two bodies: the fused kernel runs both on the same memory)
+__device__ __forceinline__ void bwd_dq_split_body(const AttnArgs& a, int Lr, float* pd_ws, float* ds_ws) {
   float* Ks = dyn_smem;
   float* Vs = Ks + Lr * LDT;
   float* mb = Vs + Lr * LDT;
@@ -831,11 +830,14 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a
   ASTAMP(1, 6);
 }
 
-// dV^T[d][key] = sum_q dO[q][d] Pd[q][key],  dK^T[d][key] = sum_q Q[q][d] dS[q][key]
-__global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs a, int Lr,
-                                                                 const float* __restrict__ pd_ws,
-                                                                 const float* __restrict__ ds_ws) {
+__global__ __launch_bounds__(768) void attn_bwd_dq_split_kernel(const AttnArgs a, int Lr, float* __restrict__ pd_ws,
+                                                                float* __restrict__ ds_ws) {
   set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
+  bwd_dq_split_body(a, Lr, pd_ws, ds_ws);
+}
+
+// dV^T[d][key] = sum_q dO[q][d] Pd[q][key],  dK^T[d][key] = sum_q Q[q][d] dS[q][key]
+__device__ __forceinline__ void bwd_dkv_split_body(const AttnArgs& a, int Lr, const float* pd_ws, const float* ds_ws) {
   float* Qs = dyn_smem;
   float* dOs = Qs + Lr * LDT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
@@ -925,6 +927,26 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs 
   }
 }
 
+__global__ __launch_bounds__(768) void attn_bwd_dkv_split_kernel(const AttnArgs a, int Lr,
+                                                                 const float* __restrict__ pd_ws,
+                                                                 const float* __restrict__ ds_ws) {
+  set_wave_prio(a.prio);      // critical path of the step: ahead of the side stream's weight gradients (common.h)
+  bwd_dkv_split_body(a, Lr, pd_ws, ds_ws);
+}
+
+// Both passes in ONE launch: a workgroup's dK / dV pass reads only what its own dQ pass left in the scratch (the Pd / dS blocks
+// of its (batch, head)), so it can follow at once -- behind a workgroup-wide barrier and a fence that makes the scratch stores
+// visible inside the workgroup -- instead of behind the slowest workgroup of a first launch.  In the training step the pair then takes a CU ONCE: a
+// 12-wave, 107-KB workgroup needs an empty CU, and between two launches the other stream's GEMM workgroups move in.
+__global__ __launch_bounds__(768) void attn_bwd_fused_split_kernel(const AttnArgs a, int Lr, float* pd_ws, float* ds_ws) {
+  set_wave_prio(a.prio);
+  bwd_dq_split_body(a, Lr, pd_ws, ds_ws);
+  // workgroup scope is enough (and an agent-scope fence is a write-back of the L2): the waves of a workgroup share a CU, the
+  // vector L1 writes through, and no wave has read these scratch lines in this launch
+  __syncthreads();
+  bwd_dkv_split_body(a, Lr, pd_ws, ds_ws);
+}
+
 // Dropout keep flags of the attention probabilities for `nlayers` layers at once, in the layout the L <= 192 kernels store
 // and read ([B*nh, L, Lr/32, 2] 16-bit words: bit 4g + t of word (bh, q, key block kb, half h) = key 32 kb + 8g + 4h + t kept).
 // One thread per word (four Philox4x32-10 calls): a full-occupancy elementwise pass hides the ten dependent rounds that
@@ -962,6 +984,12 @@ bool split_enabled() {
   return on;
 }
 
+// UNITER_ATTN_BWD_FUSED=0: the two passes of the L <= 192 backward as two launches (A/B measurements)
+bool bwd_fused() {
+  static const bool on = [] { const char* e = getenv("UNITER_ATTN_BWD_FUSED"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 int make_args(AttnArgs& a, int B, int L, int nh, float p_drop, uint64_t seed, uint32_t offset,
               uint32_t site) {
   UCHECK_ARG(B > 0 && L > 0 && nh > 0, "attention: bad dims B=%d L=%d nh=%d", B, L, nh);
@@ -971,6 +999,23 @@ int make_args(AttnArgs& a, int B, int L, int nh, float p_drop, uint64_t seed, ui
   a.drop = make_drop(p_drop, seed, offset, site);
   static const int prio = [] { const char* e = getenv("UNITER_ATTN_PRIO"); return e ? atoi(e) : 2; }();
   a.prio = prio;
+  return 0;
+}
+
+int launch_bwd_split(const AttnArgs& a, int Lr, float* pd_ws, float* ds_ws, hipStream_t st) {
+  const size_t lds = res_lds_bytes(Lr);
+  if (bwd_fused()) {
+    UCHECK_RC(set_dyn_lds(attn_bwd_fused_split_kernel, lds));
+    hipLaunchKernelGGL(attn_bwd_fused_split_kernel, dim3(a.B * a.nh), dim3(Lr * 4), lds, st, a, Lr, pd_ws, ds_ws);
+    UCHECK_LAUNCH();
+    return 0;
+  }
+  UCHECK_RC(set_dyn_lds(attn_bwd_dq_split_kernel, lds));
+  UCHECK_RC(set_dyn_lds(attn_bwd_dkv_split_kernel, lds));
+  hipLaunchKernelGGL(attn_bwd_dq_split_kernel, dim3(a.B * a.nh), dim3(Lr * 4), lds, st, a, Lr, pd_ws, ds_ws);
+  UCHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, dim3(a.B * a.nh), dim3(Lr * 4), lds, st, a, Lr, pd_ws, ds_ws);
+  UCHECK_LAUNCH();
   return 0;
 }
 
@@ -1031,16 +1076,9 @@ extern "C" int uniter_attn_bwd_varlen(const float* qkv, const int32_t* cu_seqlen
   UCHECK_RC(make_args(a, B, Lmax, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = nullptr; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
   a.dctx = dctx; a.dqkv = dqkv; a.delta = delta;
-  const size_t lds = res_lds_bytes(Lr);
   float* pd_ws = (float*)ws;
   float* ds_ws = pd_ws + (size_t)B * nh * Lr * Lr;
-  UCHECK_RC(set_dyn_lds(attn_bwd_dq_split_kernel, lds));
-  UCHECK_RC(set_dyn_lds(attn_bwd_dkv_split_kernel, lds));
-  hipLaunchKernelGGL(attn_bwd_dq_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr, pd_ws, ds_ws);
-  UCHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr, pd_ws, ds_ws);
-  UCHECK_LAUNCH();
-  return 0;
+  return launch_bwd_split(a, Lr, pd_ws, ds_ws, (hipStream_t)stream);
 }
 
 // General forms: mask XOR cu_seqlens, optional bf16 copies of the outputs (split kernels only: L <= 192).
@@ -1105,16 +1143,9 @@ extern "C" int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, cons
   UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
   a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (unsigned short*)dqkv_bf16; a.bias_part = bias_part; a.keep_bits = (unsigned short*)keep_bits; a.delta = delta;
-  const size_t lds = res_lds_bytes(Lr);
   float* pd_ws = (float*)ws;
   float* ds_ws = pd_ws + (size_t)B * nh * Lr * Lr;
-  UCHECK_RC(set_dyn_lds(attn_bwd_dq_split_kernel, lds));
-  UCHECK_RC(set_dyn_lds(attn_bwd_dkv_split_kernel, lds));
-  hipLaunchKernelGGL(attn_bwd_dq_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr, pd_ws, ds_ws);
-  UCHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr, pd_ws, ds_ws);
-  UCHECK_LAUNCH();
-  return 0;
+  return launch_bwd_split(a, Lr, pd_ws, ds_ws, (hipStream_t)stream);
 }
 
 extern "C" size_t uniter_attn_bwd_ws_bytes(int B, int L, int nh) {
@@ -1136,18 +1167,9 @@ extern "C" int uniter_attn_bwd(const float* qkv, const float* attn_mask, const f
   a.dctx = dctx; a.dqkv = dqkv; a.delta = delta;
   const int Lr = (L + 31) / 32 * 32;
   if (Lr <= SPLIT_MAX_LR && split_enabled()) {
-    const size_t lds = res_lds_bytes(Lr);
     float* pd_ws = (float*)ws;
     float* ds_ws = pd_ws + (size_t)B * nh * Lr * Lr;
-    UCHECK_RC(set_dyn_lds(attn_bwd_dq_split_kernel, lds));
-    UCHECK_RC(set_dyn_lds(attn_bwd_dkv_split_kernel, lds));
-    hipLaunchKernelGGL(attn_bwd_dq_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr,
-                       pd_ws, ds_ws);
-    UCHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_bwd_dkv_split_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr,
-                       pd_ws, ds_ws);
-    UCHECK_LAUNCH();
-    return 0;
+    return launch_bwd_split(a, Lr, pd_ws, ds_ws, (hipStream_t)stream);
   }
   if (Lr <= RES_MAX_LR) {
     const size_t lds = res_lds_bytes(Lr);

@@ -268,11 +268,12 @@ def test_backward_of_a_stale_forward_fails_loudly(tiny, train):
 
 
 @pytest.mark.parametrize('env', [{'UNITER_WGRAD_GROUP_F32': '1'}, {'UNITER_WGRAD_WHOLE': '0', 'UNITER_LAZY_ZERO': '0'},
-                                 {'UNITER_KEEP_PREGEN': '0', 'UNITER_ADAM_WORD_SPLIT': '0', 'UNITER_WGRAD_GROUP_F32': '0'}])
+                                 {'UNITER_KEEP_PREGEN': '0', 'UNITER_ADAM_WORD_SPLIT': '0', 'UNITER_WGRAD_GROUP_F32': '0', 'UNITER_ATTN_BWD_FUSED': '0',
+                                  'UNITER_ADAM_EMB_MAIN': '0'}])
 def test_alternative_schedules_keep_the_golden_gradients(env):
     """The switches that select another form of the same arithmetic (the layer's weight gradients as one grouped whole-K
-    launch; the stream-K form with a clearing zero_grad; dropout flags drawn inside the attention kernels and the embeddings'
-    optimizer block in one launch) are read once per process: the reference-golden gradient, dropout-replay and trainer-step
+    launch; the stream-K form with a clearing zero_grad; dropout flags drawn inside the attention kernels, the embeddings'
+    optimizer block in one launch on the side stream, the attention backward as two launches) are read once per process: the reference-golden gradient, dropout-replay and trainer-step
     tests run again in a child process with the switch set."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
