@@ -51,6 +51,13 @@ __global__ __launch_bounds__(256, WPC) void probe(const unsigned short* __restri
   for (int k = tid; k < ST * STAGE / 4; k += 256) reinterpret_cast<unsigned*>(smem)[k] = 0x3c003c00u + k % 5;
   __syncthreads();
 #define ISSUE(KT, STG)                                                                                       \
+  if (!(FLAGS & 1) && !(FLAGS & 4)) {                                                                                        \
+    _Pragma("unroll") for (int t = 0; t < NIA; ++t)                                                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + (STG) * STAGE + (wave + 4 * t) * 1024), 16, voA[t], ((KT) & 31) * 128, 0, 0); \
+    _Pragma("unroll") for (int t = 0; t < NIB; ++t)                                                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + (STG) * STAGE + IMG_A + (wave + 4 * t) * 1024), 16, voB[t], ((KT) & 31) * 128, 0, 0); \
+  }
+#define ISSUE0(KT, STG)                                                                                      \
   if (!(FLAGS & 1)) {                                                                                        \
     _Pragma("unroll") for (int t = 0; t < NIA; ++t)                                                          \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + (STG) * STAGE + (wave + 4 * t) * 1024), 16, voA[t], ((KT) & 31) * 128, 0, 0); \
@@ -73,30 +80,38 @@ __global__ __launch_bounds__(256, WPC) void probe(const unsigned short* __restri
   _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                             \
   _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                             \
     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[BUF][b], xa[BUF][a], acc[a][b], 0, 0, 0);
-#define COMPUTE(STG)                                                                                         \
+// quarter Q of the next k-tile's fills (FLAGS & 4: the fills are issued between the steps instead of in front of them)
+#define ISSUE_Q(KT, STG, Q)                                                                                  \
+  if ((FLAGS & 4) && !(FLAGS & 1)) {                                                                         \
+    _Pragma("unroll") for (int t = 0; t < NIA; ++t) if ((t & 3) == (Q))                                      \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + (STG) * STAGE + (wave + 4 * t) * 1024), 16, voA[t], ((KT) & 31) * 128, 0, 0); \
+    _Pragma("unroll") for (int t = 0; t < NIB; ++t) if ((t & 3) == (Q))                                      \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + (STG) * STAGE + IMG_A + (wave + 4 * t) * 1024), 16, voB[t], ((KT) & 31) * 128, 0, 0); \
+  }
+#define COMPUTE(STG, KTN, STGN)                                                                              \
   {                                                                                                          \
     const unsigned char* sA = smem + (STG) * STAGE;                                                          \
     const unsigned char* sB = sA + IMG_A;                                                                    \
     RD(0, 0, sA, sB)                                                                                         \
-    RD(1, 1, sA, sB) MM(0)                                                                                   \
-    RD(2, 0, sA, sB) MM(1)                                                                                   \
-    RD(3, 1, sA, sB) MM(0)                                                                                   \
-    MM(1)                                                                                                    \
+    RD(1, 1, sA, sB) MM(0) ISSUE_Q(KTN, STGN, 0)                                                             \
+    RD(2, 0, sA, sB) MM(1) ISSUE_Q(KTN, STGN, 1)                                                             \
+    RD(3, 1, sA, sB) MM(0) ISSUE_Q(KTN, STGN, 2)                                                             \
+    MM(1) ISSUE_Q(KTN, STGN, 3)                                                                              \
   }
   if (ST == 3) {
-    ISSUE(0, 0); ISSUE(1, 1);
+    ISSUE0(0, 0); ISSUE0(1, 1);
     for (int kt = 0; kt < nk; kt += 3) {
 #define STEP3(O, STG)                                                            \
       wait_vm<NDMA>(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); \
-      ISSUE(kt + (O) + 2, ((STG) + 2) % 3) COMPUTE(STG) __builtin_amdgcn_sched_barrier(0);
+      ISSUE(kt + (O) + 2, ((STG) + 2) % 3) COMPUTE(STG, kt + (O) + 2, ((STG) + 2) % 3) __builtin_amdgcn_sched_barrier(0);
       STEP3(0, 0) STEP3(1, 1) STEP3(2, 2)
     }
   } else {
-    ISSUE(0, 0);
+    ISSUE0(0, 0);
     for (int kt = 0; kt < nk; kt += 2) {
 #define STEP2(O, STG)                                                            \
       wait_vm<0>(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); \
-      ISSUE(kt + (O) + 1, 1 - (STG)) COMPUTE(STG) __builtin_amdgcn_sched_barrier(0);
+      ISSUE(kt + (O) + 1, 1 - (STG)) COMPUTE(STG, kt + (O) + 1, 1 - (STG)) __builtin_amdgcn_sched_barrier(0);
       STEP2(0, 0) STEP2(1, 1)
     }
   }
@@ -139,6 +154,7 @@ int main() {
   run<128, 128, 2, 2, 2, 2, 1>("  the same without the DMA fills", src, out);
   run<128, 128, 2, 2, 2, 2, 2>("  the same without the fragment reads", src, out);
   run<128, 128, 2, 2, 2, 2, 3>("  the same with neither (MFMA chain + barrier)", src, out);
+  run<128, 128, 2, 2, 2, 2, 4>("  the kernel with the fills issued between the four steps", src, out);
   run<128, 128, 2, 2, 3, 1, 0>("128x128, 2x2 per wave, 3 stages, 1 workgroup per CU", src, out);
   run<128, 256, 4, 2, 3, 1, 0>("128x256, 4x2 per wave, 3 stages, 1 workgroup per CU", src, out);
   run<128, 256, 4, 2, 3, 1, 1>("  the same without the DMA fills", src, out);
