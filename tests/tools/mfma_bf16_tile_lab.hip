@@ -155,6 +155,8 @@ int main() {
   run<128, 128, 2, 2, 2, 2, 2>("  the same without the fragment reads", src, out);
   run<128, 128, 2, 2, 2, 2, 3>("  the same with neither (MFMA chain + barrier)", src, out);
   run<128, 128, 2, 2, 2, 2, 4>("  the kernel with the fills issued between the four steps", src, out);
+  run<128, 64, 2, 1, 2, 3, 0>("128x64, 2x1 per wave, 2 stages, 3 workgroups per CU", src, out);
+  run<64, 128, 1, 2, 2, 3, 0>("64x128, 1x2 per wave, 2 stages, 3 workgroups per CU", src, out);
   run<128, 128, 2, 2, 3, 1, 0>("128x128, 2x2 per wave, 3 stages, 1 workgroup per CU", src, out);
   run<128, 256, 4, 2, 3, 1, 0>("128x256, 4x2 per wave, 3 stages, 1 workgroup per CU", src, out);
   run<128, 256, 4, 2, 3, 1, 1>("  the same without the DMA fills", src, out);
