@@ -675,10 +675,12 @@ int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K,
   G.start[4] = total;
   for (int p = n; p < 4; ++p) G.start[p] = total;
   int grid = (total + 7) / 8 * 8;
-  // UNITER_WGRAD_GROUP_WGS: cap of the grid (a multiple of 8; 0 = one workgroup per tile).  256 = one workgroup of this
-  // launch per CU: the launch alone takes what two co-resident workgroups take (a lone 4-wave tile runs its k-loop at
-  // 0.57 us per k-tile against 0.93 for two), and every CU keeps a slot for the other stream's kernels
-  static const int cap = [] { const char* e = getenv("UNITER_WGRAD_GROUP_WGS"); return e ? atoi(e) / 8 * 8 : 0; }();
+  // UNITER_WGRAD_GROUP_WGS: cap of the grid (a multiple of 8; 0 = one workgroup per tile).  Default 256 = one workgroup of this
+  // launch per CU, walking its tiles: the launch alone takes what two co-resident workgroups take (a lone 4-wave tile runs
+  // its k-loop at 0.57 us per k-tile against 0.93 for two), and every CU keeps a slot for the other stream's kernels.
+  // Measured again once the attention backward took its CU in one launch (four same-box rounds): UNITER-base 4.75 -> 4.71 ms,
+  // UNITER-large 9.65 -> 9.49, config 5 at B = 32 8.19 -> 8.00 ms per step; 192 / 320 / 384 workgroups 4.77-4.80, 128 5.13
+  static const int cap = [] { const char* e = getenv("UNITER_WGRAD_GROUP_WGS"); return e ? atoi(e) / 8 * 8 : 256; }();
   if (cap >= 8 && grid > cap) grid = cap;
   hipStream_t st = (hipStream_t)stream;
   if (cfg == 4) {
