@@ -287,6 +287,21 @@ def test_alternative_schedules_keep_the_golden_gradients(env):
     assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
 
 
+def test_alternative_bf16_schedules_keep_parity():
+    """The bf16 mode's switches (the grouped weight-gradient launch with one workgroup per tile instead of 256 walking
+    workgroups, the attention backward as two launches, stream-K weight gradients instead of the grouped launch): the bf16
+    parity and lazy-zero tests run again in a child process with each set."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env in ({'UNITER_WGRAD_GROUP_WGS': '0', 'UNITER_ATTN_BWD_FUSED': '0'}, {'UNITER_WGRAD_GROUP': '0'}):
+        r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-p', 'no:cacheprovider',
+                            'tests/test_model_gpu.py::test_bf16_mfma_mode_tracks_fp32_reference',
+                            'tests/test_trainer_gpu.py::test_lazy_zero_grad_overwrite_equals_clearing'],
+                           cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (env, r.stdout[-3000:] + r.stderr[-2000:])
+        assert ' passed' in r.stdout and 'failed' not in r.stdout, (env, r.stdout[-500:])
+
+
 def test_launch_stamps_put_the_gemms_on_one_clock(tiny):
     """uniter_prof_enable_stamps + uniter_prof_stamp_spans (measurement only): with stamps on, a forward + backward leaves
     one [start, end] interval per GEMM launch, in launch order, on the GPU's own clock -- forward kinds first, each interval
