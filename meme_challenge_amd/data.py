@@ -284,9 +284,10 @@ def hash_str(s):
     return h
 
 
-def write_synthetic_dataset(root, n=64, num_bb=(10, 36), img_dim=2048, seed=0, splits=('train', 'dev_seen')):
+def write_synthetic_dataset(root, n=64, num_bb=(10, 36), img_dim=2048, seed=0, splits=('train', 'dev_seen'), text_words=(3, 8)):
     """Create a dataset in the reference's ON-DISK FORMAT (jsonl + per-image .npy feature files) with
-    a learnable signal: label 1 memes have a shifted feature mean and contain a marker word."""
+    a learnable signal: label 1 memes have a shifted feature mean and contain a marker word.  text_words / num_bb: (min, max)
+    words per caption and regions per image (BASELINE configs[1] shapes: text_words=(126, 126), num_bb=(36, 36))."""
     rng = np.random.default_rng(seed)
     feat_dir = os.path.join(root, 'img_feats')
     os.makedirs(feat_dir, exist_ok=True)
@@ -306,7 +307,7 @@ def write_synthetic_dataset(root, n=64, num_bb=(10, 36), img_dim=2048, seed=0, s
                         'objects': rng.integers(0, 1600, nbb), 'objects_conf': rng.random(nbb).astype(np.float32)}
                 np.save(os.path.join(feat_dir, expand_id(idx) + '.npy'), feat)
                 np.save(os.path.join(feat_dir, expand_id(idx) + '_info.npy'), info, allow_pickle=True)
-                text = ' '.join(rng.choice(words, int(rng.integers(3, 9)))) + (' hateful' if label else ' nice')
+                text = ' '.join(rng.choice(words, int(rng.integers(text_words[0], text_words[1] + 1)))) + (' hateful' if label else ' nice')
                 f.write(json.dumps({'id': idx, 'img': 'img/%s.png' % expand_id(idx), 'label': label, 'text': text}) + '\n')
                 idx += 1
     return feat_dir

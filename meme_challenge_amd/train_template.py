@@ -312,9 +312,11 @@ class TrainerTemplate(object):
         self.log.reset()
         self._ids = None
         every = self.config['log_every']
+        t0, seen = time.time(), 0
         for self.iters, self.batch in enumerate(self.config['train_loader']):
             self.model.train()
             self.batch = self.batch_to_device(self.batch)
+            seen += int(self.batch['labels'].shape[0]) if torch.is_tensor(self.batch.get('labels')) else 0
             self.train_iter_step()
             done = self.total_iters + self.iters + 1
             if done % every == 0:
@@ -322,7 +324,9 @@ class TrainerTemplate(object):
                 w.add_scalar('Train/Loss', self.log.recent_loss(), done)
                 w.add_scalar('Stats/learning_rate', self.scheduler.get_last_lr()[0], done)
         self.total_iters += self.iters + 1
-        probs, labels, self.train_loss = self.log.collect()
+        probs, labels, self.train_loss = self.log.collect()        # (the epoch's one device -> host flush)
+        self.train_rate = seen / max(time.time() - t0, 1e-9)       # samples per second of this rank, input pipeline included
+        self.config['writer'].add_scalar('Stats/train_samples_per_s', self.train_rate, self.total_iters)
         self.train_metrics = standard_metrics(probs, labels, add_optimal_acc=True)
 
     def _after_epoch(self):
@@ -338,10 +342,11 @@ class TrainerTemplate(object):
         self._log_metrics('Validation', self.val_metrics, self.epoch)
         if _is_main():
             print("\nEpoch: {}/{},  train_loss = {:.4f}, train_acc = {:.4f}, train_aucroc = {:.4f}  |  "
-                  "eval_loss = {:.4f}, eval_acc = {:.4f}, eval_aucroc = {:.4f}  |  lr = {:.8f}  elapsed {:.1f}s"
+                  "eval_loss = {:.4f}, eval_acc = {:.4f}, eval_aucroc = {:.4f}  |  lr = {:.8f}  elapsed {:.1f}s  "
+                  "({:.0f} train samples/s)"
                   .format(self.epoch, self.config['max_epoch'], self.train_loss, self.train_metrics['accuracy'],
                           self.train_metrics['aucroc'], self.val_loss, self.val_metrics['accuracy'],
-                          self.val_metrics['aucroc'], lr, time.time() - self.start))
+                          self.val_metrics['aucroc'], lr, time.time() - self.start, getattr(self, 'train_rate', 0.0)))
         key = self.config['optimize_for']
         improved, stop = self.plateau.update(self.val_loss if key == 'loss' else self.val_metrics[key])
         if _distributed() and dist.get_world_size() > 1:

@@ -107,6 +107,8 @@ def build_parser():
     parser.add_argument('--dropout', type=float, default=0.2)
     # additive
     parser.add_argument('--synthetic', type=int, default=0, help='write + use a synthetic dataset of N samples per split')
+    parser.add_argument('--synthetic_full_length', action='store_true',
+                        help='synthetic captions that fill --max_txt_len and images with --num_bb regions (BASELINE configs[1] shapes)')
     parser.add_argument('--hash_tokenizer', action='store_true', help='offline tokenizer instead of bert-base-cased')
     parser.add_argument('--feature_shards', action='store_true',
                         help='pack the per-sample region-feature files of every split into one memory-mapped shard '
@@ -154,8 +156,11 @@ def _main(argv=None):
         if rank == 0:                    # one writer; the other ranks wait below before they open any file
             os.makedirs(config['data_path'], exist_ok=True)
             if not os.path.isfile(os.path.join(config['data_path'], 'train.jsonl')):
+                full = config.get('synthetic_full_length')
                 write_synthetic_dataset(config['data_path'], n=config['synthetic'],
-                                        splits=('train', 'dev_seen', 'test_seen'))
+                                        splits=('train', 'dev_seen', 'test_seen'),
+                                        text_words=(config['max_txt_len'], config['max_txt_len']) if full else (3, 8),
+                                        num_bb=(config['num_bb'], config['num_bb']) if full else (10, 36))
         if ddp:
             torch.distributed.barrier()
         config['feature_path'] = os.path.join(config['data_path'], 'img_feats')
