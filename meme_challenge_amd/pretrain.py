@@ -426,30 +426,42 @@ class UniterForPretraining(UniterPreTrainedModel):
     def _masked_rows(hidden, mask):
         """_compute_masked_hidden (model/pretrain.py:129-133): rows of `hidden` [B,L,H] where
         `mask` [B,L'] (L' <= L) is set, in row-major order."""
-        B, L, _ = hidden.shape
-        mask = mask.bool()
-        nz = torch.nonzero(mask, as_tuple=False)                 # (host sync, as the reference's boolean indexing)
-        idx = (nz[:, 0] * L + nz[:, 1]).contiguous()
-        return _GatherRowsFn.apply(hidden, idx)
+        return UniterForPretraining._rows_at(hidden, UniterForPretraining._mask_positions(mask))
+
+    @staticmethod
+    def _mask_positions(mask):
+        """[n, 2] (sample, position) of the set entries of `mask`, row-major: the ONE host synchronisation of a masked task's
+        step (the count sizes everything behind it; the reference's boolean indexing synchronises the same way).  It depends
+        on the batch only, so the forward_* methods take it BEFORE the encoder is enqueued -- the host then waits for the
+        previous step's tail instead of for this step's forward -- and reuse it for the labels (a second boolean indexing
+        would be a second synchronisation)."""
+        return torch.nonzero(mask.bool(), as_tuple=False)
+
+    @staticmethod
+    def _rows_at(hidden, nz):
+        L = hidden.shape[1]
+        return _GatherRowsFn.apply(hidden, (nz[:, 0] * L + nz[:, 1]).contiguous())
 
     def forward_mlm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                     txt_labels, compute_loss=True):
+        nz = self._mask_positions(txt_labels != -1)
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                           output_all_encoded_layers=False, seq_lens=getattr(self, '_seq_lens', None))
         T = input_ids.size(1)
         if seq.shape[1] < T:
             raise ValueError('sequence output shorter than the text length (model/pretrain.py:116)')
-        masked = self._masked_rows(seq, txt_labels != -1)       # == seq[:, :T][mask]
+        masked = self._rows_at(seq, nz)                         # == seq[:, :T][mask]
         scores = self.cls(masked)
         if not compute_loss:
             return scores
-        return _CrossEntropyFn.apply(scores, txt_labels[txt_labels != -1])
+        return _CrossEntropyFn.apply(scores, txt_labels[nz[:, 0], nz[:, 1]])      # == txt_labels[txt_labels != -1]
 
     def forward_mrfr(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                      img_masks, img_mask_tgt, feat_targets, compute_loss=True):
+        nz = self._mask_positions(img_mask_tgt)
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                           output_all_encoded_layers=False, img_masks=img_masks, seq_lens=getattr(self, '_seq_lens', None))
-        masked = self._masked_rows(seq, img_mask_tgt)
+        masked = self._rows_at(seq, nz)
         pred = self.feat_regress(masked)
         if not compute_loss:
             return pred
@@ -459,9 +471,10 @@ class UniterForPretraining(UniterPreTrainedModel):
                     img_masks, img_mask_tgt, label_targets, task, compute_loss=True):
         """model/pretrain.py:205-233: region classification on the masked regions; 'mrc' trains against the most
         likely non-background detector class, 'mrc-kl' against the detector's soft labels."""
+        nz = self._mask_positions(img_mask_tgt)
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                           output_all_encoded_layers=False, img_masks=img_masks, seq_lens=getattr(self, '_seq_lens', None))
-        masked = self._masked_rows(seq, img_mask_tgt)
+        masked = self._rows_at(seq, nz)
         scores = self.region_classifier(masked)
         if not compute_loss:
             return scores
