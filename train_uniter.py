@@ -188,6 +188,10 @@ def _main(argv=None):
                          ragged_regions=config['ragged_regions'])
         kw = dict(batch_size=config['batch_size'], num_workers=config['num_workers'], collate_fn=ds.get_collate_fn(),
                   pin_memory=True)
+        if config['num_workers'] > 0:
+            # worker processes live across epochs: re-spawning them costs seconds per epoch and loader (an epoch of this trainer
+            # is a fraction of a second of GPU time)
+            kw.update(persistent_workers=True, prefetch_factor=4)
         if train:
             sampler = ConfounderSampler(ds, config['confounder_repeat'])
             if ddp:                      # the reference's nn.DataParallel split every batch over the GPUs; here every rank draws its own batches
