@@ -194,6 +194,61 @@ def cur_stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# --------------------------------------------------------------------------- #
+# streams shared by everything this package builds in a process
+# --------------------------------------------------------------------------- #
+# HIP maps every stream that has been USED onto one of GPU_MAX_HW_QUEUES hardware queues, round-robin.  A side stream per
+# model and a copy stream per DataLoader (six loaders and a model per cross-validation fold) walk through those queues, and
+# the stream that lands on the main stream's queue runs BEHIND it instead of beside it: the fp32 step 16.0 instead of 13.5 ms
+# with seven other streams in use (tests/tools/stream_queue_probe.py).  So: ONE side stream and ONE copy stream per device
+# and process, and the side stream is chosen by measurement -- the first candidate whose spin kernel overlaps the current
+# stream's.
+_SHARED_STREAMS = {}
+
+
+def _overlaps(stream, device, cycles=400000):
+    """True when a spin on `stream` runs BESIDE a spin on the current stream (different hardware queues)."""
+    main = torch.cuda.current_stream(device)
+    for attempt in range(2):                 # the first pass pays the stream's first use (its hardware queue is created then)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        torch.cuda.synchronize(device)
+        ev[0].record(main)
+        torch.cuda._sleep(cycles)
+        ev[1].record(main)                   # one spin alone
+        torch.cuda.synchronize(device)
+        ev[2].record(main)
+        stream.wait_event(ev[2])
+        torch.cuda._sleep(cycles)
+        with torch.cuda.stream(stream):
+            torch.cuda._sleep(cycles)
+        main.wait_stream(stream)
+        ev[3].record(main)                   # two spins, one per stream: 1.15 x one spin beside each other, 2.1 x in a row
+        torch.cuda.synchronize(device)
+    return ev[2].elapsed_time(ev[3]) < 1.6 * ev[0].elapsed_time(ev[1])
+
+
+def shared_stream(device, kind='side'):
+    """The process-wide stream of `kind` ('side': weight gradients / optimizer blocks / collectives; 'copy': host -> device
+    prefetch) on `device`."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), kind)
+    s = _SHARED_STREAMS.get(key)
+    if s is None:
+        if kind == 'side' and hasattr(torch.cuda, '_sleep') and os.environ.get('UNITER_STREAM_PROBE') != '0':
+            tried = []
+            for _ in range(8):
+                s = torch.cuda.Stream(device=dev)
+                if _overlaps(s, dev):
+                    break
+                tried.append(s)               # (kept alive: the next candidate is another stream)
+            else:
+                s = tried[0]
+        else:
+            s = torch.cuda.Stream(device=dev)
+        _SHARED_STREAMS[key] = s
+    return s
+
+
 def require_gpu_tensor(t, dtype=None, name='tensor'):
     if t is None:
         return

@@ -105,7 +105,8 @@ class DevicePrefetcher(object):
 
     def __init__(self, loader, device):
         self.loader, self.device = loader, torch.device(device)
-        self.stream = torch.cuda.Stream(device=self.device)
+        from . import _lib
+        self.stream = _lib.shared_stream(self.device, 'copy')      # one copy stream per device, whatever the number of loaders
 
     def __len__(self):
         return len(self.loader)

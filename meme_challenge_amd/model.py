@@ -758,7 +758,7 @@ class UniterModel(UniterPreTrainedModel):
         side = None
         if self.use_side_stream:
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=d_hidden.device)
+                self._side_stream = _lib.shared_stream(d_hidden.device, 'side')
             side = self._side_stream
             side.wait_stream(main)
         side_ptr = C.c_void_p(side.cuda_stream) if side is not None else None

@@ -342,7 +342,7 @@ class FusedAdam(torch.optim.Optimizer):
                 launch(lo, hi, _lib.cur_stream())
             side = enc._side_stream
             if side is None:
-                side = enc._side_stream = torch.cuda.Stream(device=st.device)
+                side = enc._side_stream = _lib.shared_stream(st.device, 'side')
             side.wait_stream(main)
             events = []
             import ctypes as C

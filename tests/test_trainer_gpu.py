@@ -190,3 +190,18 @@ def test_lazy_zero_grad_overwrite_equals_clearing(precision):
         torch.cuda.synchronize()
         finals[lazy] = st.flat_params.clone()
     assert (finals[True] - finals[False]).abs().max().item() <= 5e-6
+
+
+@pytest.mark.parametrize('n_other', [0, 7, 15])
+def test_side_stream_runs_beside_the_main_stream_whatever_else_is_in_use(n_other):
+    """_lib.shared_stream: HIP hands out its hardware queues round-robin to the streams in use, and a side stream that lands on
+    the main stream's queue serialises the two halves of the backward pass (16.0 instead of 13.5 ms per fp32 step with seven
+    other streams in use).  The package's ONE side stream per device is chosen by measurement: whatever number of other
+    streams a process has put to use, a spin kernel on it overlaps one on the current stream (child process: the choice is
+    made once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, 'tests/tools/stream_queue_probe.py', str(n_other)], cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'overlaps the current stream: True' in r.stdout, r.stdout
