@@ -31,6 +31,8 @@ python tests/tools/gemm_exactfit.py > $O/gemm_f32_exactfit.txt 2>&1
 ./tests/tools/mfma_peak.bin > $O/mfma_peak_clock.txt 2>&1
 python tests/tools/ln_bench.py > $O/ln_isolated.txt 2>&1
 (python tests/tools/step_boundary.py bf16; python tests/tools/step_boundary.py fp32) 2>&1 | grep -v amdgpu.ids > $O/step_boundary.txt
+(for n in 0 7; do python tests/tools/stream_queue_probe.py $n --step; done) 2>&1 | grep -v amdgpu.ids > $O/stream_queue_probe.txt
+(python tests/tools/cli_throughput.py fp32; python tests/tools/cli_throughput.py bf16; python tests/tools/cli_throughput.py bf16 --feature_shards) 2>&1 | grep 'samples/s' > $O/cli_throughput_raw.txt
 fi
 if [ "$part" = "2" ]; then
 pm() { name=$1; shift; ctr=$1; shift; timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$name -o p -- python3 bench.py --no_cpu_baseline --steps 3 --warmup 1 --prof_kind 0 "$@" > /dev/null 2>$O/pmc_$name.err; python tests/tools/pmc_summary.py $O/pmc_$name $O/pmc_$name.csv; }
