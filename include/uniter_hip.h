@@ -176,6 +176,49 @@ int uniter_ln_bwd_rows_slabs(const float* dy, int nslab, size_t slab_stride, con
  * M[p] % 8 == 0, N[p] % 8 == 0, 16-byte aligned buffers; the dW[p] must not overlap. */
 int uniter_wgrad_bf16_group(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
                             const void* const* B, float* const* dW, void* stream);
+/* ---- fp32-accurate products on the bf16 matrix pipe: "x3" operands (csrc/gemm_split3.hip) -----------------------
+ * An fp32 value is exactly the sum of three bf16 pieces (round-to-nearest residuals).  The x3 form of a [rows][cols]
+ * fp32 tensor holds piece p of element (r, c) at  base + r * row_stride + p * piece_stride + c  (bf16 elements):
+ * activations as [rows][3][ld] (row_stride 3 ld, piece_stride ld), weights piece-major (row_stride ld, piece_stride =
+ * the flat buffer's length).  A product of two x3 operands runs as SIX bf16 MFMA products per block (a1 b1, a1 b2,
+ * a2 b1, a1 b3, a2 b2, a3 b1; fp32 accumulate; the dropped terms are <= 2^-24 |a b|): fp32 accuracy at 6/16 of the fp32
+ * matrix pipe's time.  Replaces cuBLAS behind nn.Linear of model/layer.py:76-78,112,140,153 (forward, input gradient,
+ * weight gradient) in the fp32 mode `fp32x3` (uniter_model_set_precision 3).
+ *
+ * uniter_split3: fp32 [rows][ld] -> x3;  uniter_join3: the exact sum of the pieces back to fp32.
+ * cols % 8 == 0, ld % 4 == 0, strides % 8 == 0, 16-byte aligned buffers. */
+int uniter_split3(const float* x, int rows, int cols, int ld, void* x3, size_t row_stride, size_t piece_stride,
+                  void* stream);
+int uniter_join3(const void* x3, int rows, int cols, size_t row_stride, size_t piece_stride, float* x, int ld,
+                 void* stream);
+/* C [M, N] (fp32, optional; slab s of a split-K launch at C + s * c_split_stride) and / or C_x3 (optional; row stride
+ * ldcx, piece stride pscx) = epilogue(A . B^T):  A x3 of M rows (a_kmajor: K rows), row stride lda, piece stride psa;
+ * B x3 of N rows (b_kmajor: K rows).  Layouts and epilogues: forward (a_kmajor = b_kmajor = 0): NONE, BIAS, BIAS_GELU_D
+ * (aux_out = gelu'(u) fp32, outputs = gelu(u)); input gradient (b_kmajor = 1): NONE, ADD, MUL (aux_in fp32 [M, ld_aux]);
+ * weight gradient (both 1, any K; operands [K][3][.]): NONE, ADD.  K % 32 == 0 unless both operands are k-major;
+ * N % 8 == 0.  Rows beyond an operand's row count read as zeros only in the [rows][3][ld] form (what a k-major
+ * operand with a ragged K needs).  cfg: 0 = choose, 1..3 = wave geometry (gemm_split3.hip).  nsplit > 1: fp32 slabs only;
+ * piece 0 applies the epilogue, the consumer adds the slabs. */
+int uniter_gemm_x3_cfg(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda,
+                       int psa, const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* C_x3,
+                       int ldcx, int pscx, int epilogue, const float* bias, const float* aux_in, float* aux_out,
+                       int ld_aux, void* stream);
+/* The weight gradients of one encoder layer in one launch on x3 operands (as uniter_wgrad_bf16_group): for p < n <= 4
+ * dW[p] [M[p], N[p]] (fp32) (+)= A[p]^T B[p], A[p] x3 [K][3][M[p]], B[p] x3 [K][3][N[p]]; whole-K 128 x 128 tiles, no
+ * atomics, bit-reproducible.  overwrite = 1 stores instead of adding; max_wgs > 0 caps the grid (the persistent
+ * workgroups walk the tiles; default one per CU); cfg as uniter_gemm_x3_cfg. */
+int uniter_wgrad_x3_group(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
+                          const void* const* B, float* const* dW, int overwrite, int max_wgs, void* stream);
+/* out[c] += sum_r X[r, c] for an x3 tensor X [rows][3][ldx] (bias gradient of intermediate.dense from dU). */
+int uniter_colsum_x3_add(const void* x3, int rows, int cols, int ldx, float* out, void* stream);
+/* uniter_ln_fwd_slabs / uniter_ln_bwd_rows_slabs whose operand copy for the next GEMM is x3 [M][3][H] instead of bf16 */
+int uniter_ln_fwd_slabs_x3(const float* x, int nslab, size_t slab_stride, const float* res, const float* gamma,
+                           const float* beta, float* z_out, float* y, void* y_x3, float* mean, float* rstd,
+                           int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream);
+int uniter_ln_bwd_rows_slabs_x3(const float* dy, int nslab, size_t slab_stride, const float* z, const float* mean,
+                                const float* rstd, const float* gamma, float* dz, float* dx, void* dx_x3,
+                                int want_dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
+                                uint32_t site, void* ws, size_t ws_bytes, void* stream);
 /* out[n] += sum_m X[m, n] for a bf16 matrix X [M, ld] (bias gradient of a dense layer from the bf16 gradient of its
  * output; replaces the autograd sum of model/layer.py:140 in the bf16 mode).  N % 8 == 0, ld % 8 == 0. */
 int uniter_colsum_bf16_add(const void* X, int M, int N, int ld, float* out, void* stream);
@@ -428,6 +471,14 @@ int uniter_adam_step_g16(float* params, float* grads, const void* grads_bf16, fl
                          const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale,
                          float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                          int step, int adamw, int zero_grads, void* mirror_bf16, int max_workgroups, void* stream);
+/* uniter_adam_step_g16 whose mirror holds the three bf16 pieces of every updated parameter (x = x1 + x2 + x3 exactly), piece p
+ * at mirror + p * mirror_piece_stride elements: the piece-major x3 weights of the fp32x3 mode (uniter_gemm_x3_cfg), written
+ * by the update itself.  mirror_piece_stride = 0: one bf16 copy, as uniter_adam_step_g16.
+ * Replaces the optimizer step of train_template.py:95-109 + utils/optim_utils.py:9-46. */
+int uniter_adam_step_x3(float* params, float* grads, const void* grads_bf16, float* exp_avg, float* exp_avg_sq,
+                        const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale, float max_norm,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, int adamw,
+                        int zero_grads, void* mirror, size_t mirror_piece_stride, int max_workgroups, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Whole-model schedule: the library owns the kernel sequence of
@@ -481,7 +532,12 @@ typedef struct {
  * 2: as 1 with bf16-RESIDENT GEMM operands: the encoder weights are read from a bf16 mirror of the
  * flat parameter buffer (uniter_model_set_weight_mirror; the caller refreshes it after every update
  * with uniter_cast_bf16) and activations are handed from kernel to kernel as bf16 copies; the FFN
- * activation and its gradient exist only in bf16. */
+ * activation and its gradient exist only in bf16.
+ * 3 (`fp32x3`): fp32 results from the bf16 matrix pipe -- every dense product of the encoder layers (forward, input
+ * gradient, weight gradient: model/layer.py:76-78,112,140,153) runs on x3 operands (three bf16 pieces per value, six
+ * MFMA products, fp32 accumulate: uniter_gemm_x3_cfg), no less accurate than the fp32 MFMA kernels of mode 0; attention,
+ * LayerNorm, embeddings, loss and optimizer are those of mode 0.  The weight mirror then holds the three pieces of every
+ * parameter, piece p at mirror + p * numel (3 * numel bf16 elements; uniter_adam_step_x3 / uniter_split3 write it). */
 int  uniter_model_set_weight_mirror(uniter_model_t* m, const float* flat_base, const void* mirror_bf16, size_t numel);
 int  uniter_model_set_precision(uniter_model_t* m, int precision);
 /* Number of uniter_model_forward calls on this handle so far.  The handle keeps ONE plan (activations of the latest

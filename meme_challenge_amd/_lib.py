@@ -67,6 +67,13 @@ _SIGS = {
     'uniter_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P]),
     'uniter_gemm_bf16res_cfg': (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     'uniter_gemm_bf16v2_cfg': (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, C.c_long, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
+    'uniter_split3': (_I, [_P, _I, _I, _I, _P, _SZ, _SZ, _P]),
+    'uniter_join3': (_I, [_P, _I, _I, _SZ, _SZ, _P, _I, _P]),
+    'uniter_gemm_x3_cfg': (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, C.c_long, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
+    'uniter_ln_fwd_slabs_x3': (_I, [_P, _I, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P]),
+    'uniter_ln_bwd_rows_slabs_x3': (_I, [_P, _I, _SZ, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
+    'uniter_wgrad_x3_group': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
+    'uniter_colsum_x3_add': (_I, [_P, _I, _I, _I, _P, _P]),
     'uniter_cast_bf16': (_I, [_P, _P, _SZ, _P]),
     'uniter_attn_bwd_ws_bytes': (_SZ, [_I, _I, _I]),
     'uniter_attn_varlen_max_len': (_I, []),
@@ -112,6 +119,7 @@ _SIGS = {
     'uniter_adam_step_mirror': (_I, [_P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _P]),
     'uniter_adam_step_ex': (_I, [_P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _I, _P]),
     'uniter_adam_step_g16': (_I, [_P, _P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _I, _P]),
+    'uniter_adam_step_x3': (_I, [_P, _P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _SZ, _I, _P]),
     'uniter_grad_sumsq_bf16': (_I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
     'uniter_sumsq_combine': (_I, [_P, _I, _P, _P]),
     'uniter_grad_sumsq_part': (_I, [_P, _P, _SZ, _P, _I, _P]),

@@ -1,0 +1,829 @@
+// fp32-accurate dense products on the bf16 matrix pipe of gfx950: "x3" operands.
+//
+// gfx950's fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VECTOR rate, 1/16 of v_mfma_f32_32x32x16_bf16.  An fp32
+// value is EXACTLY the sum of three bf16 pieces x = x1 + x2 + x3 (round-to-nearest residuals: 8 + 8 + 8 significant bits
+// and a sign each), so a product a*b is the six bf16 x bf16 products
+//     a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1)          (dropped: a2 b3, a3 b2, a3 b3 <= 2^-24 |a b|)
+// accumulated in fp32 by the MFMA: six bf16 MFMAs per 32x32x16 block are 6/16 of the fp32 pipe's time for the same block
+// (416.7 TFLOP/s of fp32-equivalent work at the bf16 pipe's 2.5 PFLOP/s).  Every bf16 x bf16 product is exact in fp32, so
+// the result differs from an fp32 FMA chain only by the dropped 2^-24 terms and the accumulation order; measured against
+// float64 on the model's shapes the error is 0.75-0.93 x the native fp32 kernel's (profiles/r04_gemm_x3_lab.txt).
+//
+// Replaces cuBLAS behind nn.Linear forward, input-gradient and weight-gradient products of model/layer.py:76-78 (query /
+// key / value), :112 (attention output), :140 (intermediate) and :153 (output) in the fp32 mode `fp32x3` (precision 3).
+//
+// x3 form of a [rows][cols] tensor: three bf16 pieces addressed as  piece p of (r, c) = base + r * row_stride + p *
+// piece_stride + c  (elements).  Activations are written [rows][3][ld] (row_stride 3 ld, piece_stride ld): ONE buffer
+// descriptor covers the tensor and its range check zero-fills whole rows beyond `rows` in all three pieces.  Weights are
+// written piece-major [3][rows][ld] by the optimizer (row_stride ld, piece_stride rows * ld: a flat mirror per piece).
+//
+// Kernel: LDS-DMA ring as gemm_bf16_dma.hip (buffer_load_dwordx4 ... lds, no staging registers), 32-deep k-tiles of 3 + 3
+// piece images per stage, transposed accumulator (lane = output row), ALL LDS reads as inline assembly with explicit
+// lgkmcnt(0) waits (hipcc drains vmcnt before compiler-visible LDS reads while an LDS-DMA is in flight).
+// LDS images per piece and stage:
+//   k-contiguous operand ([rows][K]): [R][32] bf16, 64-B rows, 16-B chunk c of row r at c ^ ((r >> 2) & 3): the 16 lanes
+//     of a ds_read_b128 group cover all 64 banks.
+//   k-major operand ([K][cols]): the image of gemm_bf16_dma.hip cut to 32 k-rows: 256-B segments, chunk c of k-row k at
+//     c ^ (((k & 3) << 2) | ((k >> 2) & 3)), gathered by ds_read_b64_tr_b16.
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct S3Args {
+  int M, N, K;
+  const void* A; int lda, psa;   // x3: row stride, piece stride (elements); k-contiguous: rows = M, k-major: rows = K
+  const void* B; int ldb, psb;   // x3; k-contiguous: rows = N, k-major: rows = K
+  float* C; int ldc;             // fp32 output (optional); slab s of a split-K launch at C + s * c_split_stride
+  long c_split_stride;
+  unsigned short* Cx; int ldcx, pscx;  // x3 output (optional): row stride, piece stride
+  const float* bias;
+  const float* aux_in;
+  float* aux_out;
+  int ld_aux;
+  int tiles_m, tiles_n, band_h, nsplit;
+  unsigned long long* stamp;
+  int prio;
+  int dbg;
+};
+
+#define OOB 0x7ffffff0        /* buffer offset beyond every descriptor: load returns 0, store is dropped */
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ void tile_coords3(int t, int tiles_m, int tiles_n, int band_h, int& tm, int& tn) {
+  const int full = band_h * tiles_n;
+  const int band = t / full;
+  const int rem = t - band * full;
+  const int bh = min(band_h, tiles_m - band * band_h);
+  tn = rem / bh;
+  tm = band * band_h + (rem - tn * bh);
+}
+
+__device__ __forceinline__ unsigned pack2r(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};      // v_cvt_pk_bf16_f32: round to nearest even
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bflo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bfhi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// the three bf16 pieces of two fp32 values (exact: every residual is representable)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& w1, unsigned& w2, unsigned& w3) {
+  w1 = pack2r(x0, x1);
+  float r0 = x0 - bflo(w1), r1 = x1 - bfhi(w1);
+  w2 = pack2r(r0, r1);
+  r0 -= bflo(w2); r1 -= bfhi(w2);
+  w3 = pack2r(r0, r1);
+}
+
+// work item of this workgroup, XCD-chunked (blocks b and b + 8 share an XCD's L2)
+__device__ __forceinline__ int xcd_work_item3(int nwork, int round = 0) {
+  const int xcd = blockIdx.x & 7, idx = (blockIdx.x >> 3) + round * (int)(gridDim.x >> 3);
+  const int q8 = nwork >> 3, r8 = nwork & 7;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+  return idx < chunk_n ? chunk0 + idx : -1;
+}
+
+// ---- LDS-DMA fill of the three piece images of one operand ---------------------------------------------------------
+template <int R, bool KM, int NW, int KT>
+struct Dma3 {
+  static constexpr int NP = R * KT / 512;          // 1-KiB wave-instructions per piece image and k-tile
+  static_assert(KT == 32, "32-deep k-tiles");
+  static_assert(NP >= NW && NP % NW == 0, "piece image must split evenly over the loader waves");
+  static_assert(!KM || R == 128 || R == 256, "k-major tiles are 128 or 256 wide");
+  static constexpr int NI = NP / NW;
+  static constexpr int IMG = R * KT * 2;
+  int voff[NI];
+  // rs: row stride of the operand (elements)
+  static __device__ __forceinline__ int kstep(int rs) { return (KM ? KT * rs : KT) * 2; }
+  __device__ __forceinline__ void offsets(int rs, int rc0, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+      const int j = wave + NW * t;
+      if constexpr (!KM) {
+        const int row = 16 * j + (lane >> 2), c = (lane & 3) ^ ((lane >> 4) & 3);
+        voff[t] = (rc0 + row) * rs * 2 + c * 16;
+      } else if constexpr (R == 128) {
+        const int k = 4 * j + (lane >> 4);
+        const int c = (lane & 15) ^ (((lane >> 4) << 2) | (j & 3));
+        voff[t] = (k * rs + rc0) * 2 + c * 16;
+      } else {
+        const int k = 2 * j + (lane >> 5);
+        const int sw = (((2 * (j & 1) + (lane >> 5)) & 3) << 2) | ((j >> 1) & 3);
+        const int c = (lane & 15) ^ sw;
+        voff[t] = (k * rs + rc0) * 2 + ((lane >> 4) & 1) * 256 + c * 16;
+      }
+    }
+  }
+  // piece image P, wave-instruction T of this wave
+  template <int P, int T>
+  __device__ __forceinline__ void issue1(__amdgpu_buffer_rsrc_t rs, unsigned char* img, int soff, int pstep, int wave) const {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(img + P * IMG + (wave + NW * T) * 1024), 16, voff[T], soff + P * pstep, 0, 0);
+  }
+};
+
+// ---- MFMA operand fragments: per-lane LDS byte offsets inside one piece image -------------------------------------------
+template <int R, bool KM, int NB, int KT>
+struct Frag3 {
+  unsigned ka[KT / 16];     // k-contiguous: offset of k16-step ks in the wave's first block (block t: + t * 32 rows)
+  unsigned tr[NB][2];       // k-major: offsets of the two transposed reads of block t (k16-step ks: + ks * 16 k-rows)
+  static constexpr int ROWB = KT * 2;
+  __device__ __forceinline__ void init(int i5, int h, int blk0) {
+    if constexpr (!KM) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) ka[ks] = (blk0 * 32 + i5) * 64 + ((((2 * ks + h) ^ ((i5 >> 2) & 3))) << 4);
+    } else {
+      const int l16 = i5 & 15, q = l16 >> 2, p = l16 & 3;
+      const int s1 = (q << 2) | (2 * h), s2 = s1 | 1;
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const int r0 = (blk0 + t) * 32;
+        const int seg = r0 >> 7;
+        const int c = ((r0 & 127) >> 3) + 2 * (i5 >> 4) + (p >> 1);
+        const int base = (8 * h + q) * (R * 2) + 8 * (p & 1) + seg * 256;
+        tr[t][0] = base + ((c ^ s1) << 4);
+        tr[t][1] = base + 4 * (R * 2) + ((c ^ s2) << 4);
+      }
+    }
+  }
+};
+
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128_o(u32x4_t& out, unsigned addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(out) : "v"(addr), "n"(OFF) : "memory");
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr_o(u32x2_t& out, unsigned addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(out) : "v"(addr), "n"(OFF) : "memory");
+#endif
+}
+__device__ __forceinline__ void lgkm_wait0() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+// ties a fragment's first use to the statements above it (the wait): an empty volatile asm that "rewrites" the register
+__device__ __forceinline__ void tie(u32x4_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v)::"memory");
+#endif
+}
+template <int N> __device__ __forceinline__ void wait_vm3() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One k-contiguous operand's fragments of one k16-step: [piece][block], 8 consecutive k of row (block, i5) per lane half
+template <int R, int NB, int KT>
+struct FragRegs {
+  u32x4_t v[3][NB];
+  template <int KS>
+  __device__ __forceinline__ void read(const Frag3<R, false, NB, KT>& f, unsigned img_addr) {
+    constexpr int IMG = R * KT * 2;
+    static_for<0, 3>([&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      static_for<0, NB>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        lds_read_b128_o<P * IMG + T * 32 * KT * 2>(v[P][T], img_addr + f.ka[KS]);
+      });
+    });
+  }
+};
+
+// k-major fragments: the two halves must stay separate registers until the wait (an asm output cannot be half a vector)
+template <int R, int NB, int KT>
+struct FragRegsKM {
+  u32x2_t lo[3][NB], hi[3][NB];
+  template <int KS>
+  __device__ __forceinline__ void read(const Frag3<R, true, NB, KT>& f, unsigned img_addr) {
+    constexpr int IMG = R * KT * 2;
+    static_for<0, 3>([&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      static_for<0, NB>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        lds_read_tr_o<P * IMG + KS * 16 * R * 2>(lo[P][T], img_addr + f.tr[T][0]);
+        lds_read_tr_o<P * IMG + KS * 16 * R * 2>(hi[P][T], img_addr + f.tr[T][1]);
+      });
+    });
+  }
+};
+
+__device__ __forceinline__ void tie2(u32x2_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v)::"memory");
+#endif
+}
+
+// epilogue kinds of this kernel
+enum { S3_NONE = 0, S3_BIAS = 1, S3_ADD = 4, S3_BIAS_GELU_D = 5, S3_MUL = 6 };
+
+// epilogue of one output tile: lane = output row m, register group gq of block (a, b) = columns nb + 8 gq + 4 h .. + 3
+template <int WM, int WN, int EPI>
+__device__ __forceinline__ void s3_epilogue(const S3Args& g, int piece, int m0, int n0, int wm, int wn, int i5, int h,
+                                            f32x16 (&acc)[WM / 32][WN / 32]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int AB = WM / 32, BB = WN / 32;
+  float* Cp = g.C ? g.C + (size_t)piece * g.c_split_stride : nullptr;
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(Cp, 0, Cp ? g.M * g.ldc * 4 : 0, 0x00020000);
+  const bool first = piece == 0;          // the other k-pieces store plain partial sums
+  const __amdgpu_buffer_rsrc_t rsCx = __builtin_amdgcn_make_buffer_rsrc(g.Cx, 0, g.Cx ? ((g.M - 1) * g.ldcx + 2 * g.pscx + g.N) * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.aux_in), 0, g.aux_in ? g.M * g.ld_aux * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(g.aux_out, 0, g.aux_out ? g.M * g.ld_aux * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.bias), 0, g.bias ? g.N * 4 : 0, 0x00020000);
+  constexpr bool HAS_BIAS = EPI == S3_BIAS || EPI == S3_BIAS_GELU_D;
+  constexpr bool HAS_AUX = EPI == S3_ADD || EPI == S3_MUL;
+  constexpr bool TWO = EPI == S3_BIAS_GELU_D;
+  f32x4 bv[HAS_BIAS ? BB : 1][4], ax[HAS_AUX ? AB : 1][HAS_AUX ? BB : 1][4];
+  if (HAS_BIAS && first) {
+#pragma unroll
+    for (int b = 0; b < BB; ++b)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n = n0 + wn * WN + b * 32 + 8 * gq + 4 * h;
+        bv[b][gq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsBias, n < g.N ? n * 4 : OOB, 0, 0));
+      }
+  }
+  if (HAS_AUX && first) {
+#pragma unroll
+    for (int a = 0; a < AB; ++a)
+#pragma unroll
+      for (int b = 0; b < BB; ++b)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int m = m0 + wm * WM + a * 32 + i5;
+          const int n = n0 + wn * WN + b * 32 + 8 * gq + 4 * h;
+          ax[a][b][gq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsI, n < g.N ? (m * g.ld_aux + n) * 4 : OOB, 0, 0));
+        }
+  }
+#pragma unroll
+  for (int a = 0; a < AB; ++a) {
+    const int m = m0 + wm * WM + a * 32 + i5;                 // this lane's output row
+#pragma unroll
+    for (int b = 0; b < BB; ++b) {
+      const int nb = n0 + wn * WN + b * 32;                   // first column of the block
+      f32x16& v = acc[a][b];
+      f32x16 x2;     // second output (gelu')
+      if (first) {
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) v[rr] += bv[b][rr >> 2][rr & 3];
+        }
+        if constexpr (EPI == S3_BIAS_GELU_D) {
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) { float y_, d_; gelu_pair_fast(v[rr], y_, d_); v[rr] = y_; x2[rr] = d_; }
+        } else if constexpr (EPI == S3_MUL) {
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) v[rr] *= ax[a][b][rr >> 2][rr & 3];
+        } else if constexpr (EPI == S3_ADD) {
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) v[rr] += ax[a][b][rr >> 2][rr & 3];
+        }
+      }
+      if (Cp) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int n = nb + 8 * gq + 4 * h;
+          const f32x4 o = {v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsC, n < g.N ? (m * g.ldc + n) * 4 : OOB, 0, 0);
+        }
+      }
+      if (TWO) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int n = nb + 8 * gq + 4 * h;
+          const f32x4 o = {x2[4 * gq], x2[4 * gq + 1], x2[4 * gq + 2], x2[4 * gq + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsX, n < g.N ? (m * g.ld_aux + n) * 4 : OOB, 0, 0);
+        }
+      }
+      // x3 output: groups (gq, gq + 1) exchanged between the lane halves -> 8 consecutive columns per lane, one 16-byte
+      // store per piece
+      if (g.Cx) {
+#pragma unroll
+        for (int gp = 0; gp < 4; gp += 2) {
+          const int n8 = nb + 8 * (gp + h);
+          const bool ok = n8 < g.N;
+          unsigned wa[3][2], wb[3][2];
+          split3_pair(v[4 * gp], v[4 * gp + 1], wa[0][0], wa[1][0], wa[2][0]);
+          split3_pair(v[4 * gp + 2], v[4 * gp + 3], wa[0][1], wa[1][1], wa[2][1]);
+          split3_pair(v[4 * gp + 4], v[4 * gp + 5], wb[0][0], wb[1][0], wb[2][0]);
+          split3_pair(v[4 * gp + 6], v[4 * gp + 7], wb[0][1], wb[1][1], wb[2][1]);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(wa[p][0], wb[p][0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(wa[p][1], wb[p][1], false, false);
+            const u32x4_t o = {r0[0], r1[0], r0[1], r1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(o, rsCx, ok ? (m * g.ldcx + p * g.pscx + n8) * 2 : OOB, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#endif
+}
+
+// up to four products of one launch (the weight gradients of an encoder layer; a single product otherwise): the tiles of all
+// products are numbered through, start[p] = first work item of product p, start[4] = total
+struct S3Group {
+  S3Args p[4];
+  int start[5];
+};
+
+// ---- persistent form with loader waves ------------------------------------------------------------------------------------
+// An LDS-DMA instruction holds its wave's issue until the CU's texture-address unit takes it (35-45 cycles per 1-KiB instruction
+// when all of a CU's waves load: ~30 B/clk/CU, the L2 -> LDS ceiling), and a 128 x 128 x3 tile needs 48 such instructions per
+// 32-deep k-tile against 1536 cycles of MFMAs per SIMD: waves that both load and multiply spend as long blocked in front of the
+// address unit as in the matrix pipe, and the two do not overlap (measured: MFMAs alone 0.84 us per k-tile, LDS-DMA + fragment
+// reads alone 0.96, together 1.33).  So the roles are split: NWC compute waves (fragment reads + MFMAs + epilogue, never a vector
+// memory instruction inside the k-loop) and NWL loader waves (LDS-DMA only), one s_barrier per k-tile between them.  The workgroup
+// is persistent over its work items (XCD-chunked, banded tile order) and the k-tiles of all its items form ONE sequence: the
+// loaders run ST - 1 k-tiles ahead across item boundaries, so the next tile's first stages land while the compute waves are in
+// the epilogue of the previous one, and that epilogue's stores drain under the next tile's k-loop.
+//   loader:   [issue k-tiles 0 .. ST-2]  for u: { vmcnt: k-tile u landed;  barrier B_u;  issue k-tile u + ST - 1 -> stage (u - 1) % ST }
+//   compute:                            for u: { barrier B_u;  read stage u % ST, MFMAs;  (last k-tile of an item: epilogue) }
+// B_u orders k-tile u's LDS-DMA before its reads (every loader waited for its own instructions) and the reads of k-tile u - 1
+// (each compute wave waits lgkmcnt(0) before its last MFMAs) before the LDS-DMA that overwrites their stage.
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, int EPI>
+__global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NWL), ((BM / WM) * (BN / WN) + NWL + 3) / 4)
+void gemm_s3p_kernel(const S3Group G) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int AB = WM / 32, BB = WN / 32, WGN = BN / WN, NWC = (BM / WM) * WGN;
+  constexpr int IMG_A = BM * KT * 2, IMG_B = BN * KT * 2, STAGE = 3 * (IMG_A + IMG_B);
+  constexpr int KS = KT / 16;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * STAGE];
+  const int nwork = G.start[4];
+  if (xcd_work_item3(nwork, 0) < 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  stamp_begin(G.p[0].stamp);
+#ifdef UNITER_X3_LAB
+  if ((G.p[0].dbg & 16) && G.p[0].bias && tid == 0) {      // shader clock and real time of this workgroup's lifetime
+    unsigned long long* o = (unsigned long long*)G.p[0].bias + (size_t)blockIdx.x * 4;
+    o[0] = __builtin_amdgcn_s_memtime(); o[2] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+
+  // work item number `round` of this workgroup: product, tile origin, k-tile range
+  struct Item { int p, piece, m0, n0, kb, ke; bool valid; };
+  auto item = [&](int round) -> Item {
+    Item it;
+    const int w = xcd_work_item3(nwork, round);
+    it.valid = w >= 0;
+    if (!it.valid) { it.p = 0; it.piece = it.m0 = it.n0 = it.kb = it.ke = 0; return it; }
+    it.p = (w >= G.start[1]) + (w >= G.start[2]) + (w >= G.start[3]);
+    const S3Args& g = G.p[it.p];
+    const int local = w - G.start[it.p];
+    const int tile = local / g.nsplit;
+    it.piece = local - tile * g.nsplit;
+    int tmi, tni;
+    tile_coords3(tile, g.tiles_m, g.tiles_n, g.band_h, tmi, tni);
+    it.m0 = tmi * BM; it.n0 = tni * BN;
+    const int nk = (g.K + KT - 1) / KT;
+    it.kb = (int)((long)nk * it.piece / g.nsplit);
+    it.ke = (int)((long)nk * (it.piece + 1) / g.nsplit);
+    return it;
+  };
+#ifdef UNITER_X3_LAB
+  const int dbg = G.p[0].dbg;       // measurement builds (tests/tools/gemm_x3_lab.py): 1 = no LDS-DMA, 2 = no LDS reads, 4 = no MFMAs
+#else
+  constexpr int dbg = 0;
+#endif
+
+  if (wave >= NWC) {
+    // ------------------------------------------------------------------ loader waves ----
+    set_wave_prio(2);
+    typedef Dma3<BM, AKM, NWL, KT> DA;
+    typedef Dma3<BN, BKM, NWL, KT> DB;
+    constexpr int NDL = 3 * (DA::NI + DB::NI);        // LDS-DMA instructions per loader wave and k-tile
+    static_assert((ST - 2) * NDL <= 63, "vmcnt is six bits");
+    const int lw = wave - NWC;
+    DA da;
+    DB db;
+    int ir = 0;                   // issue cursor: item, k-tile
+    Item it = item(0);
+    int ikt = it.kb;
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    int kstepA = 0, kstepB = 0, pstepA = 0, pstepB = 0;
+    auto bind = [&]() {
+      const S3Args& g = G.p[it.p];
+      // records: the last row's third piece ends the operand -- whole rows beyond `rows` read as zeros where the pieces of a
+      // row lie behind each other (activations); piece-major weights have no rows beyond theirs in a k-loop
+      rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0,
+                                              (((AKM ? g.K : g.M) - 1) * g.lda + 2 * g.psa + (AKM ? g.M : g.K)) * 2, 0x00020000);
+      rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0,
+                                              (((BKM ? g.K : g.N) - 1) * g.ldb + 2 * g.psb + (BKM ? g.N : g.K)) * 2, 0x00020000);
+      da.offsets(g.lda, it.m0, lw, lane);
+      db.offsets(g.ldb, it.n0, lw, lane);
+      kstepA = DA::kstep(g.lda); kstepB = DB::kstep(g.ldb);
+      pstepA = g.psa * 2; pstepB = g.psb * 2;
+    };
+    bind();
+    int istage = 0, issued = 0, consumed = 0;
+    auto issue_next = [&]() {
+      while (it.valid && ikt >= it.ke) {
+        it = item(++ir);
+        ikt = it.kb;
+        if (it.valid) bind();
+      }
+      if (!it.valid) return;
+      if (!(dbg & 1)) {
+        unsigned char* sbase = smem + istage * STAGE;
+        static_for<0, 3 * DA::NI>([&](auto ic) {
+          constexpr int I = decltype(ic)::value;
+          da.template issue1<I / DA::NI, I % DA::NI>(rsA, sbase, ikt * kstepA, pstepA, lw);
+        });
+        static_for<0, 3 * DB::NI>([&](auto ic) {
+          constexpr int I = decltype(ic)::value;
+          db.template issue1<I / DB::NI, I % DB::NI>(rsB, sbase + 3 * IMG_A, ikt * kstepB, pstepB, lw);
+        });
+      }
+      ++ikt; ++issued;
+      istage = istage == ST - 1 ? 0 : istage + 1;
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < ST - 1; ++s_) issue_next();
+    for (int r = 0;; ++r) {
+      const Item c = item(r);
+      if (!c.valid) break;
+      for (int kt = c.kb; kt < c.ke; ++kt) {
+        // k-tile `consumed` has landed once at most the k-tiles issued after it are outstanding
+        if (issued - consumed - 1 >= ST - 2) wait_vm3<(ST - 2) * NDL>(); else wait_vm3<0>();
+        __builtin_amdgcn_s_barrier();
+        issue_next();
+        ++consumed;
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ compute waves ----
+    const int i5 = lane & 31, h = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+    Frag3<BM, AKM, AB, KT> fa;
+    Frag3<BN, BKM, BB, KT> fb;
+    fa.init(i5, h, wm * AB);
+    fb.init(i5, h, wn * BB);
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+    struct Frs {
+      typename std::conditional<AKM, FragRegsKM<BM, AB, KT>, FragRegs<BM, AB, KT>>::type a;
+      typename std::conditional<BKM, FragRegsKM<BN, BB, KT>, FragRegs<BN, BB, KT>>::type b;
+    };
+    f32x16 acc[AB][BB];
+    auto get_a = [&](Frs& f, auto pc, auto tc) -> bf16x8 {
+      constexpr int P = decltype(pc)::value, T = decltype(tc)::value;
+      if constexpr (AKM) return __builtin_bit_cast(bf16x8, u32x4_t{f.a.lo[P][T][0], f.a.lo[P][T][1], f.a.hi[P][T][0], f.a.hi[P][T][1]});
+      else return __builtin_bit_cast(bf16x8, f.a.v[P][T]);
+    };
+    auto get_b = [&](Frs& f, auto pc, auto tc) -> bf16x8 {
+      constexpr int P = decltype(pc)::value, T = decltype(tc)::value;
+      if constexpr (BKM) return __builtin_bit_cast(bf16x8, u32x4_t{f.b.lo[P][T][0], f.b.lo[P][T][1], f.b.hi[P][T][0], f.b.hi[P][T][1]});
+      else return __builtin_bit_cast(bf16x8, f.b.v[P][T]);
+    };
+    auto tie_frs = [&](Frs& f) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int t = 0; t < AB; ++t) {
+          if constexpr (AKM) { tie2(f.a.lo[p][t]); tie2(f.a.hi[p][t]); } else tie(f.a.v[p][t]);
+        }
+#pragma unroll
+        for (int t = 0; t < BB; ++t) {
+          if constexpr (BKM) { tie2(f.b.lo[p][t]); tie2(f.b.hi[p][t]); } else tie(f.b.v[p][t]);
+        }
+      }
+    };
+    // the six products of one k16-step on every accumulator block, smallest terms first
+    auto mma_step = [&](Frs& f) {
+      static_for<0, 6>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        constexpr int PA = Q == 0 ? 0 : Q == 1 ? 2 : Q == 2 ? 1 : Q == 3 ? 0 : Q == 4 ? 1 : 0;
+        constexpr int PB = Q == 0 ? 2 : Q == 1 ? 0 : Q == 2 ? 1 : Q == 3 ? 1 : Q == 4 ? 0 : 0;
+        static_for<0, AB>([&](auto ac) {
+          constexpr int A_ = decltype(ac)::value;
+          static_for<0, BB>([&](auto bc) {
+            constexpr int B_ = decltype(bc)::value;
+            acc[A_][B_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                get_b(f, std::integral_constant<int, PB>{}, bc), get_a(f, std::integral_constant<int, PA>{}, ac), acc[A_][B_], 0, 0, 0);
+          });
+        });
+      });
+    };
+    int stg = 0;
+    for (int r = 0;; ++r) {
+      const Item c = item(r);
+      if (!c.valid) break;
+#pragma unroll
+      for (int a = 0; a < AB; ++a)
+#pragma unroll
+        for (int b = 0; b < BB; ++b)
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) acc[a][b][rr] = 0.f;
+      for (int kt = c.kb; kt < c.ke; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned sA = lds0 + stg * STAGE, sB = sA + 3 * IMG_A;
+        Frs f0;
+        if (!(dbg & 2)) {
+          f0.a.template read<0>(fa, sA);
+          f0.b.template read<0>(fb, sB);
+        }
+        lgkm_wait0();
+        tie_frs(f0);
+        if constexpr (KS == 2) {
+          Frs f1;
+          if (!(dbg & 2)) {
+            f1.a.template read<1>(fa, sA);
+            f1.b.template read<1>(fb, sB);
+          }
+          if (!(dbg & 4)) mma_step(f0);
+          lgkm_wait0();
+          tie_frs(f1);
+          if (!(dbg & 4)) mma_step(f1);
+        } else {
+          if (!(dbg & 4)) mma_step(f0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stg = stg == ST - 1 ? 0 : stg + 1;
+      }
+      s3_epilogue<WM, WN, EPI>(G.p[c.p], c.piece, c.m0, c.n0, wm, wn, i5, h, acc);
+    }
+  }
+#ifdef UNITER_X3_LAB
+  if ((dbg & 16) && G.p[0].bias && tid == 0) {
+    unsigned long long* o = (unsigned long long*)G.p[0].bias + (size_t)blockIdx.x * 4;
+    o[1] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+  stamp_end(G.p[0].stamp);
+#endif
+}
+
+template <int BM>
+void plan_tiles3(S3Args& g, int BN) {
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  const long panel = (long)BM * g.K * 6;
+  long bh = (3l << 19) / (panel > 0 ? panel : 1);
+  g.band_h = (int)(bh < 1 ? 1 : (bh > 16 ? 16 : bh));
+  if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
+}
+
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, int EPI>
+int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
+  const int nwork = G.start[4];
+  int grid = (nwork + 7) / 8 * 8;
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 8 ? n / 8 * 8 : 256;
+  }();
+  const int cap = max_wgs >= 8 ? max_wgs / 8 * 8 : cus;       // one workgroup per CU: it owns the CU's LDS
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL((gemm_s3p_kernel<BM, BN, WM, WN, AKM, BKM, ST, KT, NWL, EPI>), dim3(grid),
+                     dim3(64 * ((BM / WM) * (BN / WN) + NWL)), 0, st, G);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+// cfg: tile geometry (all: 128 x 128 tiles, three 32-deep stages = 144 KB of LDS, one persistent workgroup per CU)
+//   1: 8 compute waves of 64 x 32 + 4 loader waves
+//   2: 4 compute waves of 64 x 64 + 4 loader waves
+//   3: 8 compute waves of 64 x 32 + 2 loader waves
+template <bool AKM, bool BKM, int EPI>
+int dispatch_cfg3p(int cfg, const S3Group& G, int max_wgs, hipStream_t st) {
+  switch (cfg) {
+    case 1: return launch_s3p<128, 128, 64, 32, AKM, BKM, 3, 32, 4, EPI>(G, max_wgs, st);
+    case 2: return launch_s3p<128, 128, 64, 64, AKM, BKM, 3, 32, 4, EPI>(G, max_wgs, st);
+    case 3: return launch_s3p<128, 128, 64, 32, AKM, BKM, 3, 32, 2, EPI>(G, max_wgs, st);
+    default: uniter_set_error("gemm_x3: bad cfg %d (1..3)", cfg); return UNITER_E_ARG;
+  }
+}
+
+template <bool AKM, bool BKM, int EPI>
+int dispatch_cfg3(int cfg, const S3Args& g, hipStream_t st) {
+  S3Group G;
+  for (int p = 0; p < 4; ++p) G.p[p] = g;
+  plan_tiles3<128>(G.p[0], 128);
+  const int total = G.p[0].tiles_m * G.p[0].tiles_n * g.nsplit;
+  G.start[0] = 0;
+  for (int p = 1; p <= 4; ++p) G.start[p] = total;
+  return dispatch_cfg3p<AKM, BKM, EPI>(cfg, G, 0, st);
+}
+
+template <bool AKM, bool BKM>
+int dispatch_epi3(int cfg, const S3Args& g, int epi, hipStream_t st) {
+  // forward products (weights k-contiguous): none / bias / bias + GELU; input gradients (weights k-major): none / add / mul;
+  // weight gradients (both k-major): none / add
+  if (epi == UNITER_EPI_NONE) return dispatch_cfg3<AKM, BKM, S3_NONE>(cfg, g, st);
+  if constexpr (!AKM && !BKM) {
+    if (epi == UNITER_EPI_BIAS) return dispatch_cfg3<AKM, BKM, S3_BIAS>(cfg, g, st);
+    if (epi == UNITER_EPI_BIAS_GELU_D) return dispatch_cfg3<AKM, BKM, S3_BIAS_GELU_D>(cfg, g, st);
+  } else {
+    if (epi == UNITER_EPI_ADD) return dispatch_cfg3<AKM, BKM, S3_ADD>(cfg, g, st);
+    if constexpr (!AKM) {
+      if (epi == UNITER_EPI_MUL) return dispatch_cfg3<AKM, BKM, S3_MUL>(cfg, g, st);
+    }
+  }
+  uniter_set_error("gemm_x3: epilogue %d is not built for this operand layout", epi);
+  return UNITER_E_ARG;
+}
+
+// ---- fp32 -> x3 (every tensor no producer kernel writes in pieces) ------------------------------------------------------
+// piece p of x[r][c] -> x3[r * rs + p * ps + c]
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int rows, int cols, int ld,
+                                                     unsigned short* __restrict__ x3, size_t rs, size_t ps) {
+  const int c8 = blockIdx.x * 32 + (threadIdx.x & 31);       // 8 consecutive columns per thread
+  const int r = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (r >= rows || c8 * 8 >= cols) return;
+  const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + (size_t)r * ld + c8 * 8);
+  const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + (size_t)r * ld + c8 * 8 + 4);
+  unsigned w[3][4];
+  split3_pair(v0[0], v0[1], w[0][0], w[1][0], w[2][0]);
+  split3_pair(v0[2], v0[3], w[0][1], w[1][1], w[2][1]);
+  split3_pair(v1[0], v1[1], w[0][2], w[1][2], w[2][2]);
+  split3_pair(v1[2], v1[3], w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+    *reinterpret_cast<u32x4_t*>(x3 + (size_t)r * rs + p * ps + c8 * 8) = u32x4_t{w[p][0], w[p][1], w[p][2], w[p][3]};
+}
+
+// x3 -> fp32 (tests, and consumers that want the plain tensor back): the exact sum of the three pieces
+__global__ __launch_bounds__(256) void join3_kernel(const unsigned short* __restrict__ x3, int rows, int cols, size_t rs, size_t ps,
+                                                    float* __restrict__ x, int ld) {
+  const int c8 = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int r = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (r >= rows || c8 * 8 >= cols) return;
+  u32x4_t w[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) w[p] = *reinterpret_cast<const u32x4_t*>(x3 + (size_t)r * rs + p * ps + c8 * 8);
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[2 * e] = (bflo(w[2][e]) + bflo(w[1][e])) + bflo(w[0][e]);
+    o[2 * e + 1] = (bfhi(w[2][e]) + bfhi(w[1][e])) + bfhi(w[0][e]);
+  }
+  *reinterpret_cast<f32x4*>(x + (size_t)r * ld + c8 * 8) = f32x4{o[0], o[1], o[2], o[3]};
+  *reinterpret_cast<f32x4*>(x + (size_t)r * ld + c8 * 8 + 4) = f32x4{o[4], o[5], o[6], o[7]};
+}
+
+// column sums of an x3 tensor [rows][3][ldx] added to out[cols] (the bias gradient of intermediate.dense from dU, which exists
+// only as x3): one workgroup per 64 columns and row slab, one float atomic per column and workgroup
+__global__ __launch_bounds__(256) void colsum3_kernel(const unsigned short* __restrict__ x3, int rows, int cols, int ldx,
+                                                      float* __restrict__ out, int rows_per_wg) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rq = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+  float s = 0.f;
+  if (c < cols) {
+    for (int r = r0 + rq; r < r1; r += 4) {
+      const unsigned short* p = x3 + (size_t)r * 3 * ldx + c;
+      const float a = __builtin_bit_cast(float, (unsigned)p[0] << 16), b = __builtin_bit_cast(float, (unsigned)p[ldx] << 16),
+                  d = __builtin_bit_cast(float, (unsigned)p[2 * ldx] << 16);
+      s += (d + b) + a;
+    }
+  }
+  part[rq][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rq == 0 && c < cols) atomicAdd(out + c, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+// 31-bit buffer offsets: the largest byte offset an x3 operand of `rows` rows is addressed with (tile overhang included)
+bool x3_fits(size_t rows, int rs, int ps, int ext) { return ((rows + 256) * (size_t)rs + 2 * (size_t)ps + ext) * 2 < (1ull << 31); }
+
+}  // namespace
+
+// C / Cx = epi(A . B^T) on x3 operands (fp32-accurate, six bf16 MFMA products per block, fp32 accumulate).
+int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, int psa,
+                const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* Cx, int ldcx, int pscx,
+                int epilogue, const float* bias, const float* aux_in, float* aux_out, int ld_aux, void* stream) {
+  UCHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && (C || Cx), "gemm_x3: bad argument");
+  UCHECK_ARG(!a_kmajor || (b_kmajor && !Cx && (epilogue == UNITER_EPI_NONE || epilogue == UNITER_EPI_ADD)),
+             "gemm_x3: A k-major only as the weight-gradient layout (both operands k-major, fp32 output, none / add)");
+  UCHECK_ARG(nsplit >= 1 && nsplit <= 8 && (nsplit == 1 || (C && !Cx && c_split_stride >= (long)M * ldc)),
+             "gemm_x3: split-K needs fp32 slabs (no x3 output)");
+  UCHECK_ARG(!(epilogue == UNITER_EPI_BIAS || epilogue == UNITER_EPI_BIAS_GELU_D) || bias, "gemm_x3: epilogue needs bias");
+  UCHECK_ARG(!(epilogue == UNITER_EPI_ADD || epilogue == UNITER_EPI_MUL) || aux_in, "gemm_x3: epilogue needs aux_in");
+  UCHECK_ARG(epilogue != UNITER_EPI_BIAS_GELU_D || aux_out, "gemm_x3: epilogue needs aux_out");
+  UCHECK_SHAPE(((a_kmajor && b_kmajor) || K % 32 == 0) && lda % 8 == 0 && ldb % 8 == 0 && psa % 8 == 0 && psb % 8 == 0 && N % 8 == 0 &&
+               (!a_kmajor || M % 8 == 0) && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && (ldc % 4 == 0) &&
+               (ldcx % 8 == 0) && (pscx % 8 == 0) && (ld_aux % 4 == 0) && ((uintptr_t)C & 15) == 0 && ((uintptr_t)Cx & 15) == 0 &&
+               ((uintptr_t)aux_in & 15) == 0 && ((uintptr_t)aux_out & 15) == 0 && ((uintptr_t)bias & 15) == 0,
+               "gemm_x3: K %% 32, N %% 8, strides %% 8 (x3) / %% 4 (fp32) and 16-byte aligned buffers required "
+               "(M=%d N=%d K=%d)", M, N, K);
+  UCHECK_SHAPE(lda > 0 && ldb > 0 && psa >= 0 && psb >= 0 && x3_fits(a_kmajor ? K : M, lda, psa, a_kmajor ? M : K) &&
+               x3_fits(b_kmajor ? K : N, ldb, psb, b_kmajor ? N : K) && (!Cx || (ldcx > 0 && pscx >= 0 && x3_fits(M, ldcx, pscx, N))) &&
+               ((size_t)M + 256) * (ldc > 0 ? ldc : 1) * 4 < (1ull << 31) &&
+               ((size_t)M + 256) * (ld_aux > 0 ? ld_aux : 1) * 4 < (1ull << 31), "gemm_x3: operand beyond 31-bit offsets");
+  S3Args g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.psa = psa; g.B = B; g.ldb = ldb; g.psb = psb; g.C = C; g.ldc = ldc;
+  g.c_split_stride = c_split_stride; g.Cx = (unsigned short*)Cx; g.ldcx = ldcx; g.pscx = pscx; g.bias = bias;
+  g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux;
+  g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.nsplit = nsplit;
+  g.dbg = cfg >> 8; cfg &= 0xff;
+  g.stamp = take_stamp_slot();
+  g.prio = take_launch_prio();
+  if (cfg == 0) cfg = 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (a_kmajor) return dispatch_epi3<true, true>(cfg, g, epilogue, st);
+  return b_kmajor ? dispatch_epi3<false, true>(cfg, g, epilogue, st) : dispatch_epi3<false, false>(cfg, g, epilogue, st);
+}
+
+// Pieces for the split-K slab form of the products whose N is the hidden size (126 tiles of 128 x 128 for 256 persistent
+// workgroups at M = 2624): two pieces fill the chip (K = 3072: 107 -> 68 us, K = 768: 32 -> 24 us; four pieces lose again:
+// profiles/r04_gemm_x3_lab.txt); the consumer's row pass adds the slabs (uniter_ln_fwd_slabs / uniter_ln_bwd_rows_slabs).
+int gemm_x3_pick_split(int M, int N, int K) {
+  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  return (tiles <= 160 && K >= 512) ? 2 : 1;
+}
+
+extern "C" int uniter_gemm_x3_cfg(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A,
+                                  int lda, int psa, const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride,
+                                  void* C_x3, int ldcx, int pscx, int epilogue, const float* bias, const float* aux_in,
+                                  float* aux_out, int ld_aux, void* stream) {
+  return gemm_x3_run(cfg, nsplit, a_kmajor, b_kmajor, M, N, K, A, lda, psa, B, ldb, psb, C, ldc, c_split_stride, C_x3, ldcx,
+                     pscx, epilogue, bias, aux_in, aux_out, ld_aux, stream);
+}
+
+extern "C" int uniter_split3(const float* x, int rows, int cols, int ld, void* x3, size_t row_stride, size_t piece_stride,
+                             void* stream) {
+  UCHECK_ARG(x && x3 && rows > 0 && cols > 0, "split3: bad argument");
+  UCHECK_SHAPE(cols % 8 == 0 && ld % 4 == 0 && row_stride % 8 == 0 && piece_stride % 8 == 0 && ((uintptr_t)x & 15) == 0 &&
+               ((uintptr_t)x3 & 15) == 0, "split3: cols %% 8, ld %% 4, strides %% 8 and 16-byte aligned buffers required");
+  hipLaunchKernelGGL(split3_kernel, dim3((cols / 8 + 31) / 32, (rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld,
+                     (unsigned short*)x3, row_stride, piece_stride);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_join3(const void* x3, int rows, int cols, size_t row_stride, size_t piece_stride, float* x, int ld,
+                            void* stream) {
+  UCHECK_ARG(x && x3 && rows > 0 && cols > 0, "join3: bad argument");
+  UCHECK_SHAPE(cols % 8 == 0 && ld % 4 == 0 && row_stride % 8 == 0 && piece_stride % 8 == 0 && ((uintptr_t)x & 15) == 0 &&
+               ((uintptr_t)x3 & 15) == 0, "join3: cols %% 8, ld %% 4, strides %% 8 and 16-byte aligned buffers required");
+  hipLaunchKernelGGL(join3_kernel, dim3((cols / 8 + 31) / 32, (rows + 7) / 8), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x3, rows, cols, row_stride, piece_stride, x, ld);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_colsum_x3_add(const void* x3, int rows, int cols, int ldx, float* out, void* stream) {
+  UCHECK_ARG(x3 && out && rows > 0 && cols > 0 && ldx >= cols, "colsum_x3_add: bad argument");
+  const int slabs = rows >= 4096 ? 32 : rows >= 512 ? 16 : 1;
+  const int rpw = (rows + slabs - 1) / slabs;
+  hipLaunchKernelGGL(colsum3_kernel, dim3((cols + 63) / 64, (rows + rpw - 1) / rpw), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x3, rows, cols, ldx, out, rpw);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+// dW_p[M_p, N_p] (+)= A_p^T B_p for up to four products of one reduction length K (A_p [K][3][M_p], B_p [K][3][N_p] x3,
+// dW_p fp32 with leading dimension N_p), one launch of whole-K tiles.
+int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A, const void* const* B,
+                        float* const* dW, void* stream, int overwrite, int max_wgs) {
+  UCHECK_ARG(n >= 1 && n <= 4 && K > 0 && Mo && No && A && B && dW, "wgrad_x3_group: bad argument");
+  S3Group G;
+  unsigned long long* stamp = take_stamp_slot();
+  int total = 0;
+  for (int p = 0; p < 4; ++p) {
+    G.start[p] = total;
+    if (p >= n) { G.p[p] = G.p[0]; continue; }
+    UCHECK_ARG(Mo[p] > 0 && No[p] > 0 && A[p] && B[p] && dW[p], "wgrad_x3_group: bad product %d", p);
+    UCHECK_SHAPE(Mo[p] % 8 == 0 && No[p] % 8 == 0 && ((uintptr_t)A[p] & 15) == 0 && ((uintptr_t)B[p] & 15) == 0 &&
+                 ((uintptr_t)dW[p] & 15) == 0 && x3_fits(K, 3 * Mo[p], Mo[p], Mo[p]) && x3_fits(K, 3 * No[p], No[p], No[p]) &&
+                 ((size_t)Mo[p] + 256) * No[p] * 4 < (1ull << 31),
+                 "wgrad_x3_group: M, N %% 8, 16-byte aligned buffers, 31-bit offsets (product %d: %d x %d, K=%d)", p, Mo[p], No[p], K);
+    S3Args& g = G.p[p];
+    g.M = Mo[p]; g.N = No[p]; g.K = K; g.A = A[p]; g.lda = 3 * Mo[p]; g.psa = Mo[p]; g.B = B[p]; g.ldb = 3 * No[p]; g.psb = No[p];
+    g.C = dW[p]; g.ldc = No[p];
+    g.c_split_stride = 0; g.Cx = nullptr; g.ldcx = 0; g.pscx = 0; g.bias = nullptr;
+    g.aux_in = overwrite ? nullptr : dW[p]; g.aux_out = nullptr; g.ld_aux = No[p];
+    g.nsplit = 1; g.stamp = stamp; g.prio = 0; g.dbg = 0;
+    plan_tiles3<128>(g, 128);
+    total += g.tiles_m * g.tiles_n;
+  }
+  G.start[4] = total;
+  for (int p = n; p < 4; ++p) G.start[p] = total;
+  if (cfg == 0) cfg = 1;
+  hipStream_t st = (hipStream_t)stream;
+  return overwrite ? dispatch_cfg3p<true, true, S3_NONE>(cfg, G, max_wgs, st) : dispatch_cfg3p<true, true, S3_ADD>(cfg, G, max_wgs, st);
+}
+
+extern "C" int uniter_wgrad_x3_group(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
+                                     const void* const* B, float* const* dW, int overwrite, int max_wgs, void* stream) {
+  return gemm_x3_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, overwrite, max_wgs);
+}

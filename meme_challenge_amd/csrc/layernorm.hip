@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int M, int H,
                                                      DropCfg drop, unsigned short* __restrict__ y_b16,
-                                                     int nslab, size_t slab_stride) {
+                                                     int nslab, size_t slab_stride, int pieces) {
   LN_SETPRIO();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if (mean_out && lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
   row_affine<NV>(v, gamma, beta, mean, rstd, H4, lane);
   row_store<NV>(v, y + (size_t)row * H, H4, lane);
-  if (y_b16) row_store_bf16<NV>(v, y_b16 + (size_t)row * H, H4, lane);     // operand copy for a bf16-resident GEMM
+  if (y_b16) {      // operand copy for the next GEMM: bf16, or the three bf16 pieces [M][3][H] of the fp32-accurate products
+    if (pieces == 3) row_store_x3<NV>(v, y_b16 + (size_t)row * 3 * H, H, H4, lane);
+    else row_store_bf16<NV>(v, y_b16 + (size_t)row * H, H4, lane);
+  }
 }
 
 // grid: nblk workgroups of LNB_WAVES waves; wave w of block b walks rows b*W+w, +W*nblk, ...  Eight waves and (up to
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
                                                      float* __restrict__ part, int M, int H,
                                                      DropCfg drop, int want_dbias,
                                                      unsigned short* __restrict__ dx_b16, int nslab,
-                                                     size_t slab_stride) {
+                                                     size_t slab_stride, int pieces) {
   __shared__ __attribute__((aligned(16))) float red[LNB_WAVES * NV * 256];
   LN_SETPRIO();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -100,7 +103,10 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const float* __r
     if (dz) row_store<NV>(d, dz + (size_t)row * H, H4, lane);
     if (drop.active) row_dropout<NV>(d, drop, (uint64_t)row * H4, H4, lane);
     if (dx && (dx != dz || drop.active)) row_store<NV>(d, dx + (size_t)row * H, H4, lane);
-    if (dx_b16) row_store_bf16<NV>(d, dx_b16 + (size_t)row * H, H4, lane);
+    if (dx_b16) {
+      if (pieces == 3) row_store_x3<NV>(d, dx_b16 + (size_t)row * 3 * H, H, H4, lane);
+      else row_store_bf16<NV>(d, dx_b16 + (size_t)row * H, H4, lane);
+    }
     if (want_dbias) {
 #pragma unroll
       for (int k = 0; k < NV; ++k) if (lane + 64 * k < H4) dbx[k] += d[k];
@@ -406,10 +412,9 @@ extern "C" int uniter_ln_fwd_b16(const float* x, const float* res, const float* 
   return uniter_ln_fwd_slabs(x, 1, 0, res, gamma, beta, z_out, y, y_bf16, mean, rstd, M, H, p_drop, seed, offset, site, stream);
 }
 
-extern "C" int uniter_ln_fwd_slabs(const float* x, int nslab, size_t slab_stride, const float* res, const float* gamma,
-                                   const float* beta, float* z_out, float* y, void* y_bf16, float* mean, float* rstd,
-                                   int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
-                                   void* stream) {
+static int ln_fwd_run(const float* x, int nslab, size_t slab_stride, const float* res, const float* gamma,
+                      const float* beta, float* z_out, float* y, void* y_bf16, int pieces, float* mean, float* rstd,
+                      int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
   UCHECK_ARG(x && gamma && beta && y, "ln_fwd: null pointer");
   UCHECK_ARG(nslab >= 1 && (nslab == 1 || slab_stride >= (size_t)M * H), "ln_fwd: bad slab count / stride");
   UCHECK_ARG((mean == nullptr) == (rstd == nullptr), "ln_fwd: mean/rstd must both be given or NULL");
@@ -420,9 +425,24 @@ extern "C" int uniter_ln_fwd_slabs(const float* x, int nslab, size_t slab_stride
   const DropCfg drop = make_drop(p_drop, seed, offset, site);
   const int nv = (H / 4 + 63) / 64;
   LN_DISPATCH(nv, ln_fwd_kernel, dim3((M + 3) / 4), x, res, gamma, beta, z_out, y, mean, rstd, M, H, drop,
-              (unsigned short*)y_bf16, nslab, slab_stride);
+              (unsigned short*)y_bf16, nslab, slab_stride, pieces);
   UCHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int uniter_ln_fwd_slabs(const float* x, int nslab, size_t slab_stride, const float* res, const float* gamma,
+                                   const float* beta, float* z_out, float* y, void* y_bf16, float* mean, float* rstd,
+                                   int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
+                                   void* stream) {
+  return ln_fwd_run(x, nslab, slab_stride, res, gamma, beta, z_out, y, y_bf16, 1, mean, rstd, M, H, p_drop, seed, offset, site, stream);
+}
+
+extern "C" int uniter_ln_fwd_slabs_x3(const float* x, int nslab, size_t slab_stride, const float* res, const float* gamma,
+                                      const float* beta, float* z_out, float* y, void* y_x3, float* mean, float* rstd,
+                                      int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site,
+                                      void* stream) {
+  UCHECK_SHAPE(H % 8 == 0 && ((uintptr_t)y_x3 & 15) == 0, "ln_fwd: the x3 copy needs H %% 8 == 0 and a 16-byte aligned buffer");
+  return ln_fwd_run(x, nslab, slab_stride, res, gamma, beta, z_out, y, y_x3, 3, mean, rstd, M, H, p_drop, seed, offset, site, stream);
 }
 
 extern "C" size_t uniter_ln_bwd_ws_bytes(int M, int H) {
@@ -458,13 +478,13 @@ extern "C" int uniter_ln_bwd_rows(const float* dy, const float* z, const float* 
                                   site, ws, ws_bytes, stream);
 }
 
-extern "C" int uniter_ln_bwd_rows_slabs(const float* dy, int nslab, size_t slab_stride, const float* z, const float* mean,
-                                        const float* rstd, const float* gamma, float* dz, float* dx, void* dx_bf16,
-                                        int want_dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
-                                        uint32_t site, void* ws, size_t ws_bytes, void* stream) {
+static int ln_bwd_rows_run(const float* dy, int nslab, size_t slab_stride, const float* z, const float* mean,
+                           const float* rstd, const float* gamma, float* dz, float* dx, void* dx_bf16, int pieces,
+                           int want_dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
+                           uint32_t site, void* ws, size_t ws_bytes, void* stream) {
   UCHECK_ARG(dy && z && mean && rstd && gamma && ws, "ln_bwd: null pointer");
   UCHECK_ARG(nslab >= 1 && (nslab == 1 || slab_stride >= (size_t)M * H), "ln_bwd: bad slab count / stride");
-  UCHECK_ARG(dz || dx, "ln_bwd: need dz or dx");
+  UCHECK_ARG(dz || dx || dx_bf16, "ln_bwd: need dz or dx");
   UCHECK_SHAPE(H % 4 == 0 && H >= 4, "ln_bwd: H must be a multiple of 4");
   UCHECK_ARG(ws_bytes >= uniter_ln_bwd_ws_bytes(M, H), "ln_bwd: workspace too small");
   if (M <= 0) return 0;
@@ -473,7 +493,7 @@ extern "C" int uniter_ln_bwd_rows_slabs(const float* dy, int nslab, size_t slab_
   const int nv = (H / 4 + 63) / 64;
   const int nblk = ln_bwd_blocks(M);
   float* part = (float*)ws;
-#define LNB_ARGS dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop, want_dbias != 0, (unsigned short*)dx_bf16, nslab, slab_stride
+#define LNB_ARGS dy, z, mean, rstd, gamma, dz, dx, part, M, H, drop, want_dbias != 0, (unsigned short*)dx_bf16, nslab, slab_stride, pieces
   if (lnb_waves() == 8) {
     switch (nv) {
       case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, 8>), dim3(nblk), dim3(512), 0, st, LNB_ARGS); break;
@@ -494,6 +514,23 @@ extern "C" int uniter_ln_bwd_rows_slabs(const float* dy, int nslab, size_t slab_
 #undef LNB_ARGS
   UCHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int uniter_ln_bwd_rows_slabs(const float* dy, int nslab, size_t slab_stride, const float* z, const float* mean,
+                                        const float* rstd, const float* gamma, float* dz, float* dx, void* dx_bf16,
+                                        int want_dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
+                                        uint32_t site, void* ws, size_t ws_bytes, void* stream) {
+  return ln_bwd_rows_run(dy, nslab, slab_stride, z, mean, rstd, gamma, dz, dx, dx_bf16, 1, want_dbias, M, H, p_drop, seed,
+                         offset, site, ws, ws_bytes, stream);
+}
+
+extern "C" int uniter_ln_bwd_rows_slabs_x3(const float* dy, int nslab, size_t slab_stride, const float* z, const float* mean,
+                                           const float* rstd, const float* gamma, float* dz, float* dx, void* dx_x3,
+                                           int want_dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
+                                           uint32_t site, void* ws, size_t ws_bytes, void* stream) {
+  UCHECK_SHAPE(H % 8 == 0 && ((uintptr_t)dx_x3 & 15) == 0, "ln_bwd: the x3 copy needs H %% 8 == 0 and a 16-byte aligned buffer");
+  return ln_bwd_rows_run(dy, nslab, slab_stride, z, mean, rstd, gamma, dz, dx, dx_x3, 3, want_dbias, M, H, p_drop, seed,
+                         offset, site, ws, ws_bytes, stream);
 }
 
 // internal: the partial-row count / row stride of a row pass over M rows (for finalize_partials_jobs)

@@ -34,6 +34,12 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
                     int ld_aux, int beta, void* stream);
 int gemm_f32_wgrad_group(int n, const int* Mo, const int* No, int K, const float* const* A, const float* const* B,
                          float* const* dW, int overwrite, void* stream);
+int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, int psa,
+                const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* Cx, int ldcx, int pscx,
+                int epilogue, const float* bias, const float* aux_in, float* aux_out, int ld_aux, void* stream);
+int gemm_x3_pick_split(int M, int N, int K);
+int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A, const void* const* B,
+                        float* const* dW, void* stream, int overwrite, int max_wgs);
 int gemm_bf16v2_pick_split(int M, int N, int K);
 int gemm_bf16v2_wgrad_pieces(int M, int N, int K);
 int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A,
@@ -81,6 +87,7 @@ struct LayerBufs {   // saved activations + backward scratch of one layer
   float* qb_part;             // [B, 3H] per-sample column sums of dqkv from the attention backward kernels
   void *ln_ws1, *ln_ws2;      // column partials of the two LayerNorm backward passes (finalized on the side stream)
   // precision 2: bf16 copies that feed the bf16-resident GEMMs (hact and du exist only in bf16 there)
+  // precision 3: the same tensors as x3 pieces [rows][3][cols] (three times the elements) for the fp32-accurate products
   unsigned short *ctxb, *y1b, *hactb, *y2b, *g2b, *dub, *g1b, *dqkvb;
 };
 
@@ -93,6 +100,8 @@ struct Plan {
   float *dcat, *d_imgfc, *d_posfc, *d_feat, *dsum, *dpk;
   unsigned short* embb;   // precision 2: bf16 copy of the embedding output
   bool res;               // this plan was carved for precision 2
+  bool x3;                // this plan was carved for precision 3: the *b buffers hold x3 pieces [rows][3][cols], embb likewise
+  int ns_kh;              // precision 3: k-pieces of the attention-output forward product (N = K = hidden)
   // precision 2: k-pieces of the GEMMs whose N is the hidden size (their fp32 outputs are that many slabs, summed by
   // the LayerNorm row pass that consumes them): K = intermediate (FFN-down forward, FFN-up dgrad), K = 3 hidden (QKV dgrad)
   int ns_ki, ns_k3h;
@@ -180,18 +189,21 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
   pl.cat = cv.f((size_t)B * pl.S * H);
   pl.emb = cv.f(M * H);
   pl.res = m->precision == 2;
-  pl.embb = pl.res ? cv.h(M * H) : nullptr;
-  pl.ns_ki = pl.res ? gemm_bf16v2_pick_split(pl.M, H, I) : 1;
-  pl.ns_k3h = pl.res ? gemm_bf16v2_pick_split(pl.M, H, 3 * H) : 1;
-  const size_t s_ki = (size_t)pl.ns_ki, s_k3h = (size_t)pl.ns_k3h;
+  pl.x3 = m->precision == 3;
+  const size_t pc = pl.x3 ? 3 : 1;       // bf16 elements per value in the operand copies
+  pl.embb = (pl.res || pl.x3) ? cv.h(pc * M * H) : nullptr;
+  pl.ns_ki = pl.res ? gemm_bf16v2_pick_split(pl.M, H, I) : pl.x3 ? gemm_x3_pick_split(pl.M, H, I) : 1;
+  pl.ns_k3h = pl.res ? gemm_bf16v2_pick_split(pl.M, H, 3 * H) : pl.x3 ? gemm_x3_pick_split(pl.M, H, 3 * H) : 1;
+  pl.ns_kh = pl.x3 ? gemm_x3_pick_split(pl.M, H, H) : 1;
+  const size_t s_ki = (size_t)pl.ns_ki, s_k3h = (size_t)pl.ns_k3h, s_kh = (size_t)pl.ns_kh;
   pl.layers.resize(nl);
   const bool save = mode != 0;
   auto alloc_fwd = [&](LayerBufs& b) {
-    b.qkv = cv.f(M * 3 * H); b.lse = cv.f((size_t)B * nh * L); b.ctx = cv.f(M * H); b.t1 = cv.f(M * H);
+    b.qkv = cv.f(M * 3 * H); b.lse = cv.f((size_t)B * nh * L); b.ctx = cv.f(M * H); b.t1 = cv.f(s_kh * M * H);
     b.z1 = save ? cv.f(M * H) : nullptr; b.mean1 = cv.f(M); b.rstd1 = cv.f(M); b.y1 = cv.f(M * H);
     b.u = save ? cv.f(M * I) : nullptr; b.hact = cv.f(M * I); b.t2 = cv.f(s_ki * M * H);
     b.z2 = save ? cv.f(M * H) : nullptr; b.mean2 = cv.f(M); b.rstd2 = cv.f(M); b.y2 = cv.f(M * H);
-    if (pl.res) { b.ctxb = cv.h(M * H); b.y1b = cv.h(M * H); b.hactb = cv.h(M * I); b.y2b = cv.h(M * H); }
+    if (pl.res || pl.x3) { b.ctxb = cv.h(pc * M * H); b.y1b = cv.h(pc * M * H); b.hactb = cv.h(pc * M * I); b.y2b = cv.h(pc * M * H); }
   };
   if (save) {
     for (int l = 0; l < nl; ++l) {
@@ -206,7 +218,7 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
       b.keepb = (unsigned short*)cv.raw(uniter_attn_keep_bits_bytes(B, L, nh));
       b.ln_ws1 = cv.raw(uniter_ln_bwd_ws_bytes(pl.M, H));
       b.ln_ws2 = cv.raw(uniter_ln_bwd_ws_bytes(pl.M, H));
-      if (pl.res) { b.g2b = cv.h(M * H); b.dub = cv.h(M * I); b.g1b = cv.h(M * H); b.dqkvb = cv.h(M * 3 * H); }
+      if (pl.res || pl.x3) { b.g2b = cv.h(pc * M * H); b.dub = cv.h(pc * M * I); b.g1b = cv.h(pc * M * H); b.dqkvb = cv.h(pc * M * 3 * H); }
     }
   } else {
     // inference: every layer reuses one set of buffers; the layer output ping-pongs
@@ -280,7 +292,7 @@ int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int
   static const int wg_whole = [] { const char* e = getenv("UNITER_WGRAD_WHOLE"); return e ? atoi(e) : 15; }();
   int cfg = 0;
   const bool wgrad = kind == UNITER_K_GEMM_WGRAD && akm && bkm && (beta == 1 || beta == -1);
-  if (wgrad && m->precision == 0) {
+  if (wgrad && (m->precision == 0 || m->precision == 3)) {
     cfg = wg_cfg;
     const int H_ = m->cfg.hidden_size, I_ = m->cfg.intermediate_size;
     const int bit = (M == H_ && N == I_) ? 1 : (M == I_ && N == H_) ? 2 : (M == H_ && N == H_) ? 4 : (M == 3 * H_ && N == H_) ? 8 : 0;
@@ -298,7 +310,7 @@ int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int
   // bf16-resident GEMMs below gain 0.6 % from level 2 (their bound is operand staging, not the pipe)
   static const int main_prio = [] { const char* e = getenv("UNITER_MAIN_PRIO"); return e ? atoi(e) : 0; }();
   g_uniter_launch_prio = kind == UNITER_K_GEMM_WGRAD ? 0 : main_prio;
-  if (m->precision >= 1)      // embeddings' projections (fp32 inputs) also run on the bf16 pipe in mode 2
+  if (m->precision == 1 || m->precision == 2)      // embeddings' projections (fp32 inputs) also run on the bf16 pipe in mode 2
     return gemm_bf16_run(0, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias, aux_in, aux_out, ld_aux, beta,
                          colsum_part, st);
   return gemm_f32_run(cfg, kind == UNITER_K_GEMM_FFN_UP_FWD, akm, bkm, M, N, K, A, lda, B, ldb, C, ldc, epi, bias,
@@ -315,6 +327,20 @@ int gemm_v2(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, in
   g_uniter_launch_prio = main_prio;
   return gemm_bf16v2_run(0, nsplit, 0, bkm, M, N, K, A, lda, B, ldb, C, ldc, (long)M * ldc, Cb, ldcb, epi, bias, aux_in,
                          aux_in_b16, aux_out, aux_out_b16, ld_aux, 0, st);
+}
+// precision 3: A = x3 activations [M][3][K]; W = the piece-major x3 mirror of an encoder weight (row stride ldw, piece stride =
+// the flat parameter buffer's length); outputs fp32 (nsplit slabs) or x3 [M][3][N]; aux operands fp32 (csrc/gemm_split3.hip)
+int gemm_x3(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, int K, const void* A, const unsigned short* W,
+            int ldw, float* C, int nsplit, unsigned short* Cx, int epi, const float* bias, const float* aux_in, float* aux_out) {
+  ProfScope ps(m, kind, st);
+  static const int cfg = [] { const char* e = getenv("UNITER_X3_CFG"); return e ? atoi(e) : 0; }();
+  static const int main_prio = [] { const char* e = getenv("UNITER_MAIN_PRIO_X3"); return e ? atoi(e) : 0; }();
+  g_uniter_launch_prio = main_prio;
+  return gemm_x3_run(cfg, nsplit, 0, bkm, M, N, K, A, 3 * K, K, W, ldw, (int)m->mirror_numel, C, N, (long)M * N, Cx, 3 * N, N, epi,
+                     bias, aux_in, aux_out, N, st);
+}
+int split_x3(const float* src, unsigned short* dst, int rows, int cols, hipStream_t st) {
+  return uniter_split3(src, rows, cols, cols, dst, (size_t)3 * cols, (size_t)cols, st);
 }
 // weight gradients (both operands k-major, stream-K, fp32 atomics into the gradient buffer): gemm_bf16.hip
 int gemm_r(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int N, int K, const void* A, int lda,
@@ -496,13 +522,13 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   const int B = b->B, T = b->T, R = b->R, L = b->L, S = pl.S, M = pl.M;
   const bool save = train != 0;
   static const bool gelu_d_env = [] { const char* e = getenv("UNITER_GELU_D"); return !(e && e[0] == '0'); }();
-  const bool gelu_d = gelu_d_env;      // UNITER_GELU_D=0: A/B switch (store the pre-activation, libm erf twice)
+  const bool gelu_d = gelu_d_env || m->precision == 3;      // UNITER_GELU_D=0: A/B switch (store the pre-activation, libm erf twice)
   pl.gelu_d = gelu_d;
   m->batch = *b; m->hidden_out = hidden_out; m->all_layers = all_layers; m->seed = seed; m->offset = offset;
   m->bwd_open = false;
   ++m->generation;
 
-  const bool res = pl.res;
+  const bool res = pl.res, x3 = pl.x3;
   // L <= 192: attention on the bf16 pipe (attention_bf16.hip), which also writes the bf16 copies of its outputs
   const bool attn_b16 = res && L <= uniter_attn_varlen_max_len();
 
@@ -564,9 +590,10 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   if (packed) UCHECK_RC(uniter_row_gather(pl.cat, b->pack_src, pl.emb, M, H, B * S, st));
   else UCHECK_RC(uniter_gather_rows(pl.cat, joint ? b->gather_index : nullptr, pl.emb, B, S, L, H, st));
   const size_t PH = (size_t)B * L * H;          // one layer of the padded output
-  if (res) {
-    UCHECK_ARG(m->mirror != nullptr, "model_forward: precision 2 needs uniter_model_set_weight_mirror");
-    UCHECK_RC(cast_b(pl.emb, pl.embb, (size_t)M * H, st));
+  if (res || x3) {
+    UCHECK_ARG(m->mirror != nullptr, "model_forward: precision 2 / 3 needs uniter_model_set_weight_mirror");
+    if (res) UCHECK_RC(cast_b(pl.emb, pl.embb, (size_t)M * H, st));
+    else UCHECK_RC(split_x3(pl.emb, pl.embb, M, H, st));
   }
   const unsigned short* xb = pl.embb;
   // ---- encoder (model/model.py:282-292; model/layer.py:166-170) ----
@@ -581,6 +608,9 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     else if (res)
       UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_QKV_FWD, st, 0, M, 3 * H, H, xb, H, m->WB(l, L_QW), H, lb.qkv, 3 * H, 1,
                         nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, 0, nullptr, 0, 0));
+    else if (x3)
+      UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_QKV_FWD, st, 0, M, 3 * H, H, xb, m->WB(l, L_QW), H, lb.qkv, 1, nullptr,
+                        UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr));
     else
       UCHECK_RC(gemm(m, UNITER_K_GEMM_QKV_FWD, st, 0, 0, M, 3 * H, H, x, H, m->LP(l, L_QW), H, lb.qkv, 3 * H,
                      UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
@@ -602,12 +632,22 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
       if (!attn_b16) UCHECK_RC(cast_b(lb.ctx, lb.ctxb, (size_t)M * H, st));
       UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, M, H, H, lb.ctxb, H, m->WB(l, L_OW), H, lb.t1, H, 1,
                         nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, 0, nullptr, 0, 0));
+    } else if (x3) {
+      // the context as x3 pieces: operand of the projection below and of its weight gradient
+      UCHECK_RC(split_x3(lb.ctx, lb.ctxb, M, H, st));
+      UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, M, H, H, lb.ctxb, m->WB(l, L_OW), H, lb.t1, pl.ns_kh, nullptr,
+                        UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, nullptr));
     } else {
       UCHECK_RC(gemm(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, 0, M, H, H, lb.ctx, H, m->LP(l, L_OW), H, lb.t1, H,
                      UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, nullptr, 0, 0));
     }
     {
       ProfScope ps(m, UNITER_K_LN, st);
+      if (x3)
+        UCHECK_RC(uniter_ln_fwd_slabs_x3(lb.t1, pl.ns_kh, (size_t)M * H, x, m->LP(l, L_LN1_G), m->LP(l, L_LN1_B), lb.z1, lb.y1,
+                                         lb.y1b, save ? lb.mean1 : nullptr, save ? lb.rstd1 : nullptr, M, H, ph, seed, offset,
+                                         SITE_ATTN_OUT(l), st));
+      else
       UCHECK_RC(uniter_ln_fwd_b16(lb.t1, x, m->LP(l, L_LN1_G), m->LP(l, L_LN1_B), lb.z1, lb.y1, res ? lb.y1b : nullptr,
                                   save ? lb.mean1 : nullptr, save ? lb.rstd1 : nullptr, M, H, ph, seed, offset,
                                   SITE_ATTN_OUT(l), st));
@@ -619,6 +659,12 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
                         save ? (void*)lb.u : (void*)lb.hact, 1, I));
       UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_FFN_DOWN_FWD, st, 0, M, H, I, lb.hactb, I, m->WB(l, L_W2), I, lb.t2, H, pl.ns_ki,
                         nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_B2), nullptr, 0, nullptr, 0, 0));
+    } else if (x3) {
+      // the activation exists only as x3 pieces (operand of FFN-down and of its weight gradient); gelu'(u) stays fp32
+      UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_FFN_UP_FWD, st, 0, M, I, H, lb.y1b, m->WB(l, L_W1), H, nullptr, 1, lb.hactb,
+                        UNITER_EPI_BIAS_GELU_D, m->LP(l, L_B1), nullptr, save ? lb.u : lb.hact));
+      UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_FFN_DOWN_FWD, st, 0, M, H, I, lb.hactb, m->WB(l, L_W2), I, lb.t2, pl.ns_ki, nullptr,
+                        UNITER_EPI_BIAS, m->LP(l, L_B2), nullptr, nullptr));
     } else {
       UCHECK_RC(gemm(m, UNITER_K_GEMM_FFN_UP_FWD, st, 0, 0, M, I, H, lb.y1, H, m->LP(l, L_W1), H, lb.hact, I,
                      gelu_d ? UNITER_EPI_BIAS_GELU_D : UNITER_EPI_BIAS_GELU, m->LP(l, L_B1), nullptr, lb.u, I, 0));
@@ -627,13 +673,18 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     }
     {
       ProfScope ps(m, UNITER_K_LN, st);
+      if (x3)
+        UCHECK_RC(uniter_ln_fwd_slabs_x3(lb.t2, pl.ns_ki, (size_t)M * H, lb.y1, m->LP(l, L_LN2_G), m->LP(l, L_LN2_B), lb.z2, y2,
+                                         lb.y2b, save ? lb.mean2 : nullptr, save ? lb.rstd2 : nullptr, M, H, ph, seed, offset,
+                                         SITE_FFN_OUT(l), st));
+      else
       UCHECK_RC(uniter_ln_fwd_slabs(lb.t2, pl.ns_ki, (size_t)M * H, lb.y1, m->LP(l, L_LN2_G), m->LP(l, L_LN2_B), lb.z2, y2,
                                     res ? lb.y2b : nullptr, save ? lb.mean2 : nullptr, save ? lb.rstd2 : nullptr, M, H,
                                     ph, seed, offset, SITE_FFN_OUT(l), st));
     }
     lb.y2 = y2;
     x = y2;
-    if (res) xb = lb.y2b;
+    if (res || x3) xb = lb.y2b;
     if (packed && (all_layers || l == nl - 1)) {
       // padded [B, L, H] view for the caller: valid rows scattered, padded positions zero
       float* dst = all_layers ? hidden_out + l * PH : hidden_out;
@@ -701,14 +752,19 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   // the dropped gradient in fp32: the operand of the fp32 GEMMs; the bf16-resident GEMMs read its bf16 copy only, so
   // the fp32 store (8 MB per pass) is skipped there
-  float* g2 = ph > 0.f ? (pl.res ? nullptr : lb.g2) : lb.dz2;
-  float* g1 = ph > 0.f ? (pl.res ? nullptr : lb.g1) : lb.dz1;
+  const bool x3 = pl.x3;
+  float* g2 = ph > 0.f ? ((pl.res || x3) ? nullptr : lb.g2) : lb.dz2;
+  float* g1 = ph > 0.f ? ((pl.res || x3) ? nullptr : lb.g1) : lb.dz1;
   // precision 2: the next layer's dx may be split-K slabs (summed here); never for the last layer (dy is the caller's
   // gradient), with all_layers (dy is dsum) or in layer 0 (the embedding backward reads a plain dx)
   const int ns_dy = (l == nl - 1 || m->all_layers) ? 1 : pl.ns_k3h;
   const int ns_dx = (l == 0 || m->all_layers) ? 1 : pl.ns_k3h;
   {
     ProfScope ps(m, UNITER_K_LN_BWD, st);
+    if (x3)
+      UCHECK_RC(uniter_ln_bwd_rows_slabs_x3(dy, ns_dy, MH, lb.z2, lb.mean2, lb.rstd2, m->LP(l, L_LN2_G), lb.dz2, g2, lb.g2b, 1, M, H,
+                                            ph, m->seed, m->offset, SITE_FFN_OUT(l), lb.ln_ws2, pl.ln_ws_bytes, st));
+    else
     UCHECK_RC(uniter_ln_bwd_rows_slabs(dy, ns_dy, MH, lb.z2, lb.mean2, lb.rstd2, m->LP(l, L_LN2_G), lb.dz2, g2,
                                        pl.res ? lb.g2b : nullptr, 1, M, H, ph, m->seed, m->offset, SITE_FFN_OUT(l),
                                        lb.ln_ws2, pl.ln_ws_bytes, st));
@@ -728,6 +784,12 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                       epi_du, nullptr, lb.u, 1, nullptr, 0, I));
     UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, I, lb.dub, I, m->WB(l, L_W1), H, lb.dy1, H, pl.ns_ki, nullptr, 0,
                       UNITER_EPI_ADD, nullptr, lb.dz2, 0, nullptr, 0, H));
+  } else if (x3) {
+    // dU = (g2 . W2) * gelu'(u) exists only as x3 pieces: operand of the next product and of intermediate.dense's weight gradient
+    UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, I, H, lb.g2b, m->WB(l, L_W2), I, nullptr, 1, lb.dub, UNITER_EPI_MUL,
+                      nullptr, lb.u, nullptr));
+    UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, I, lb.dub, m->WB(l, L_W1), H, lb.dy1, pl.ns_ki, nullptr, UNITER_EPI_ADD,
+                      nullptr, lb.dz2, nullptr));
   } else {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, g2, H, m->LP(l, L_W2), I, lb.du, I, epi_du,
                    nullptr, lb.u, nullptr, I, 0, fuse_db1 ? lb.du_csum : nullptr));
@@ -736,6 +798,10 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   {
     ProfScope ps(m, UNITER_K_LN_BWD, st);
+    if (x3)
+      UCHECK_RC(uniter_ln_bwd_rows_slabs_x3(lb.dy1, pl.ns_ki, MH, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1, g1, lb.g1b,
+                                            1, M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l), lb.ln_ws1, pl.ln_ws_bytes, st));
+    else
     UCHECK_RC(uniter_ln_bwd_rows_slabs(lb.dy1, res ? pl.ns_ki : 1, MH, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1,
                                        g1, res ? lb.g1b : nullptr, 1, M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l),
                                        lb.ln_ws1, pl.ln_ws_bytes, st));
@@ -759,6 +825,9 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   if (res) {
     UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, H, lb.g1b, H, m->WB(l, L_OW), H, lb.dctx, H, 1, nullptr, 0,
                       UNITER_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0));
+  } else if (x3) {
+    UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, H, lb.g1b, m->WB(l, L_OW), H, lb.dctx, 1, nullptr, UNITER_EPI_NONE,
+                      nullptr, nullptr, nullptr));
   } else {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, H, g1, H, m->LP(l, L_OW), H, lb.dctx, H, UNITER_EPI_NONE,
                    nullptr, nullptr, nullptr, 0, 0));
@@ -784,6 +853,10 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     if (!attn_b16) UCHECK_RC(cast_b(lb.dqkv, lb.dqkvb, (size_t)M * 3 * H, st));
     UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, 3 * H, lb.dqkvb, 3 * H, m->WB(l, L_QW), H, lb.dx, H, ns_dx,
                       nullptr, 0, UNITER_EPI_ADD, nullptr, lb.dz1, 0, nullptr, 0, H));
+  } else if (x3) {
+    UCHECK_RC(split_x3(lb.dqkv, lb.dqkvb, M, 3 * H, st));
+    UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, 3 * H, lb.dqkvb, m->WB(l, L_QW), H, lb.dx, ns_dx, nullptr, UNITER_EPI_ADD,
+                      nullptr, lb.dz1, nullptr));
   } else {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, 3 * H, lb.dqkv, 3 * H, m->LP(l, L_QW), H, lb.dx, H,
                    UNITER_EPI_ADD, nullptr, lb.dz1, nullptr, H, 0));
@@ -799,7 +872,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   {
     const int lnp = ln_bwd_partial_rows(M);
     const float* parts[4] = {(const float*)lb.ln_ws2, (const float*)lb.ln_ws1, fused_qb ? lb.qb_part : nullptr,
-                             (!res && fuse_db1) ? lb.du_csum : nullptr};
+                             (!res && !x3 && fuse_db1) ? lb.du_csum : nullptr};
     const int nparts[4] = {lnp, lnp, B, (M + 31) / 32};
     const size_t strides[4] = {(size_t)3 * H, (size_t)3 * H, (size_t)3 * H, (size_t)I};
     float* const outs[4][3] = {{m->LG(l, L_LN2_G), m->LG(l, L_LN2_B), m->LG(l, L_B2)},
@@ -837,6 +910,21 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
       UCHECK_RC(wgrad_b16(m, pl, sd, H, H, M, lb.g1b, lb.ctxb, m->LG(l, L_OW)));
       UCHECK_RC(wgrad_b16(m, pl, sd, 3 * H, H, M, lb.dqkvb, xb, m->LG(l, L_QW)));
     }
+  } else if (x3) {
+    // the layer's four weight gradients as ONE persistent launch of whole-K 128 x 128 tiles on x3 operands (432 tiles for
+    // UNITER-base), no atomics; UNITER_WGRAD_X3_WGS caps its grid (0 = one workgroup per CU)
+    const unsigned short* xb = l == 0 ? pl.embb : pl.layers[l - 1].y2b;
+    const int Mo[4] = {I, H, 3 * H, H}, No[4] = {H, I, H, H};
+    const void* const As[4] = {lb.dub, lb.g2b, lb.dqkvb, lb.g1b};
+    const void* const Bs[4] = {lb.y1b, lb.hactb, xb, lb.ctxb};
+    float* const dWs[4] = {m->LG(l, L_W1), m->LG(l, L_W2), m->LG(l, L_QW), m->LG(l, L_OW)};
+    static const int x3_cfg = [] { const char* e = getenv("UNITER_X3_CFG"); return e ? atoi(e) : 0; }();
+    static const int x3_wgs = [] { const char* e = getenv("UNITER_WGRAD_X3_WGS"); return e ? atoi(e) : 0; }();
+    {
+      ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
+      UCHECK_RC(gemm_x3_wgrad_group(x3_cfg, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, x3_wgs));
+    }
+    UCHECK_RC(uniter_colsum_x3_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
   } else {
     const int wb = m->wg_overwrite ? -1 : 1;      // -1: overwrite (or clear, then accumulate) -- see gemm()
     // UNITER_WGRAD_GROUP_F32=1: EVERY layer's four weight gradients as ONE persistent launch of whole-K tiles (1728 tiles for
@@ -853,7 +941,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     static const bool whole_all = [] { const char* e = getenv("UNITER_WGRAD_WHOLE"); return !e || atoi(e) == 15; }();
     static const bool cfg_default = [] { const char* e = getenv("UNITER_WGRAD_CFG"); return !e || atoi(e) == 0; }();
     bool grouped = false;
-    if (group_env && whole_all && cfg_default && m->precision == 0 && fuse_db1) {
+    if (group_env && whole_all && cfg_default && (m->precision == 0) && fuse_db1) {
       const int Mo[4] = {H, I, H, 3 * H}, No[4] = {I, H, H, H};
       const float* const As[4] = {g2, lb.du, g1, lb.dqkv};
       const float* const Bs[4] = {lb.hact, lb.y1, lb.ctx, x};
@@ -977,8 +1065,14 @@ extern "C" int uniter_model_set_weight_mirror(uniter_model_t* m, const float* fl
 }
 
 extern "C" int uniter_model_set_precision(uniter_model_t* m, int precision) {
-  UCHECK_ARG(m && precision >= 0 && precision <= 2, "set_precision: 0 (fp32), 1 (bf16 MFMA, fp32 operands) or 2 (bf16-resident operands)");
-  UCHECK_ARG(precision != 2 || m->mirror, "set_precision: precision 2 needs uniter_model_set_weight_mirror first");
+  UCHECK_ARG(m && precision >= 0 && precision <= 3, "set_precision: 0 (fp32), 1 (bf16 MFMA, fp32 operands), 2 (bf16-resident operands) "
+             "or 3 (fp32 from three bf16 pieces)");
+  UCHECK_ARG(precision < 2 || m->mirror, "set_precision: precision 2 / 3 needs uniter_model_set_weight_mirror first");
+  UCHECK_SHAPE(precision != 3 || (m->cfg.intermediate_size % 32 == 0 && m->cfg.hidden_size % 32 == 0),
+               "set_precision: the fp32x3 mode needs hidden_size and intermediate_size %% 32 == 0 (got %d, %d): every forward and "
+               "input-gradient product runs on 32-deep k-tiles", m->cfg.hidden_size, m->cfg.intermediate_size);
+  UCHECK_SHAPE(precision != 3 || 2 * m->mirror_numel * 2 + (size_t)4096 * m->cfg.intermediate_size * 2 < (1ull << 31),
+               "set_precision: the fp32x3 mode addresses the weight pieces with 31-bit offsets (%zu parameters are too many)", m->mirror_numel);
   UCHECK_SHAPE(precision != 2 || (m->cfg.intermediate_size % 64 == 0 && m->cfg.hidden_size % 64 == 0),
                "set_precision: the bf16-resident mode needs hidden_size and intermediate_size %% 64 == 0 (got %d, %d): every "
                "forward and input-gradient product runs on 64-deep k-tiles", m->cfg.hidden_size, m->cfg.intermediate_size);

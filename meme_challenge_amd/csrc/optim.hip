@@ -72,6 +72,7 @@ struct AdamArgs {
   float gscale, max_norm, lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2;
   int adamw, zero_grads;
   unsigned short* mirror;     // optional bf16 copy of the updated parameters (precision 'bf16' weight mirror)
+  size_t mirror_ps;           // > 0: the mirror holds the THREE bf16 pieces of every parameter, piece p at mirror + p * mirror_ps (precision 'fp32x3')
   const unsigned short* g16;  // optional: read the gradient from this bf16 buffer (reduced data-parallel payload); g is still zeroed
 };
 
@@ -95,7 +96,15 @@ __device__ __forceinline__ void adam_store4(const AdamArgs& a, size_t i, const f
   __builtin_nontemporal_store(p, reinterpret_cast<f32x4*>(a.p) + i);
   if (a.mirror) {
     typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-    reinterpret_cast<bf16x4_t*>(a.mirror)[i] = bf16x4_t{(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
+    const bf16x4_t o = {(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
+    reinterpret_cast<bf16x4_t*>(a.mirror)[i] = o;
+    if (a.mirror_ps) {      // x = x1 + x2 + x3 exactly (round-to-nearest residuals): the operands of csrc/gemm_split3.hip
+      f32x4 r = {p[0] - (float)o[0], p[1] - (float)o[1], p[2] - (float)o[2], p[3] - (float)o[3]};
+      const bf16x4_t o2 = {(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
+      reinterpret_cast<bf16x4_t*>(a.mirror + a.mirror_ps)[i] = o2;
+      r = f32x4{r[0] - (float)o2[0], r[1] - (float)o2[1], r[2] - (float)o2[2], r[3] - (float)o2[3]};
+      reinterpret_cast<bf16x4_t*>(a.mirror + 2 * a.mirror_ps)[i] = bf16x4_t{(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
+    }
   }
   __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(a.m) + i);
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.v) + i);
@@ -229,6 +238,16 @@ extern "C" int uniter_adam_step_g16(float* params, float* grads, const void* gra
                                     float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                                     float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
                                     int max_workgroups, void* stream) {
+  return uniter_adam_step_x3(params, grads, grads_bf16, exp_avg, exp_avg_sq, chunk_flags, n, sumsq, grad_scale, max_norm, lr,
+                             beta1, beta2, eps, weight_decay, step, adamw, zero_grads, mirror_bf16, 0, max_workgroups, stream);
+}
+
+extern "C" int uniter_adam_step_x3(float* params, float* grads, const void* grads_bf16, float* exp_avg,
+                                   float* exp_avg_sq, const uint8_t* chunk_flags, size_t n, const double* sumsq,
+                                   float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
+                                   size_t mirror_piece_stride, int max_workgroups, void* stream) {
+  UCHECK_SHAPE(mirror_piece_stride % 4 == 0 && (mirror_piece_stride == 0 || mirror_bf16), "adam_step: bad mirror piece stride");
   UCHECK_ARG(params && grads && exp_avg && exp_avg_sq && chunk_flags, "adam_step: null pointer");
   UCHECK_SHAPE(((uintptr_t)grads_bf16 & 7) == 0, "adam_step: bf16 gradients must be 8-byte aligned");
   UCHECK_SHAPE(n % CHUNK == 0, "adam_step: n must be a multiple of 64");
@@ -239,6 +258,7 @@ extern "C" int uniter_adam_step_g16(float* params, float* grads, const void* gra
   a.sumsq = sumsq; a.gscale = grad_scale; a.max_norm = max_norm; a.lr = lr; a.b1 = beta1; a.b2 = beta2;
   a.eps = eps; a.wd = weight_decay; a.adamw = adamw; a.zero_grads = zero_grads;
   a.mirror = (unsigned short*)mirror_bf16;
+  a.mirror_ps = mirror_piece_stride;
   a.g16 = (const unsigned short*)grads_bf16;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);

@@ -36,6 +36,26 @@ __device__ __forceinline__ void row_store_bf16(const f32x4 (&v)[NV], unsigned sh
     }
   }
 }
+// the three bf16 pieces of the row (x = x1 + x2 + x3 exactly, round-to-nearest residuals: csrc/gemm_split3.hip) at
+// p, p + H, p + 2 H: the operand copy of an fp32-accurate product on the bf16 matrix pipe
+template <int NV>
+__device__ __forceinline__ void row_store_x3(const f32x4 (&v)[NV], unsigned short* __restrict__ p, int H, int H4, int lane) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = lane + 64 * k;
+    if (c < H4) {
+      f32x4 r = v[k];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        const bf16x4_t o = {(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
+        reinterpret_cast<bf16x4_t*>(p + (size_t)pc * H)[c] = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] -= (float)o[e];
+      }
+    }
+  }
+}
 // multiply by the dropout keep-mask * 1/(1-p); group0 = index of the row's first 4-element group
 template <int NV>
 __device__ __forceinline__ void row_dropout(f32x4 (&v)[NV], const DropCfg& d, uint64_t group0, int H4, int lane) {

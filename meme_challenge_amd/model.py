@@ -248,13 +248,16 @@ class ParamStore(object):
         self.touched.update(names)
 
     # -- bf16 mirror of the parameters (precision 'bf16': GEMM weight operands are read from it) ----
-    def ensure_mirror(self):
-        """Allocate / refresh the bf16 copy of the flat parameter buffer.  Stale when a torch op wrote
-        a parameter in place (load_state_dict, p.add_(..): every Parameter's version counter is summed,
+    # precision 'fp32x3': the mirror holds the THREE bf16 pieces of every parameter, piece p at mirror[p * numel:]
+    def ensure_mirror(self, pieces=1):
+        """Allocate / refresh the bf16 copy (or the three bf16 pieces) of the flat parameter buffer.  Stale when a torch
+        op wrote a parameter in place (load_state_dict, p.add_(..): every Parameter's version counter is summed,
         ~20 us for 212 tensors) or a raw-pointer kernel did and said so (mirror_dirty; trainer.FusedAdam
         refreshes the mirror itself, block by block)."""
-        if getattr(self, 'mirror', None) is None or self.mirror.device != self.flat_params.device:
-            self.mirror = torch.empty(self.numel, dtype=torch.bfloat16, device=self.flat_params.device)
+        if (getattr(self, 'mirror', None) is None or self.mirror.device != self.flat_params.device
+                or getattr(self, 'mirror_pieces', 1) != pieces):
+            self.mirror = torch.empty(pieces * self.numel, dtype=torch.bfloat16, device=self.flat_params.device)
+            self.mirror_pieces = pieces
             self.mirror_dirty = True
             self._mirror_version = -1
         version = self.flat_params._version
@@ -267,8 +270,12 @@ class ParamStore(object):
         return self.mirror
 
     def refresh_mirror(self, lo, hi, stream_ptr):
-        check(_lib.lib().uniter_cast_bf16(self.flat_params.data_ptr() + 4 * lo, self.mirror.data_ptr() + 2 * lo,
-                                          hi - lo, stream_ptr), 'uniter_cast_bf16')
+        if getattr(self, 'mirror_pieces', 1) == 3:
+            check(_lib.lib().uniter_split3(self.flat_params.data_ptr() + 4 * lo, 1, hi - lo, hi - lo,
+                                           self.mirror.data_ptr() + 2 * lo, 0, self.numel, stream_ptr), 'uniter_split3')
+        else:
+            check(_lib.lib().uniter_cast_bf16(self.flat_params.data_ptr() + 4 * lo, self.mirror.data_ptr() + 2 * lo,
+                                              hi - lo, stream_ptr), 'uniter_cast_bf16')
 
     def zero_grads(self):
         self.flat_grads.zero_()
@@ -682,17 +689,22 @@ class UniterModel(UniterPreTrainedModel):
             self._handle = h
             self._prefix_names = None
             self._applied_precision = None
-        if self.precision not in ('fp32', 'bf16', 'bf16_hybrid'):
-            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16_hybrid'")
+        if self.precision not in ('fp32', 'fp32x3', 'bf16', 'bf16_hybrid'):
+            raise ValueError("precision must be 'fp32', 'fp32x3', 'bf16' or 'bf16_hybrid'")
         if self.precision == 'bf16' and (self.config.hidden_size % 64 or self.config.intermediate_size % 64):
             raise ValueError("precision='bf16' needs hidden_size and intermediate_size to be multiples of 64 (the "
-                             "LDS-DMA GEMM stages 64-deep k-tiles); use 'bf16_hybrid' or 'fp32' for this config")
-        if self.precision == 'bf16':
-            mirror = st.ensure_mirror()            # refreshed here whenever the parameters changed behind its back
+                             "bf16-resident GEMMs run on 64-deep k-tiles); use 'bf16_hybrid' or 'fp32' for this model")
+        if self.precision == 'fp32x3' and (self.config.hidden_size % 32 or self.config.intermediate_size % 32):
+            raise ValueError("precision='fp32x3' needs hidden_size and intermediate_size to be multiples of 32 (its products "
+                             "run on 32-deep k-tiles); use 'fp32' for this model")
+        if self.precision in ('bf16', 'fp32x3'):
+            # refreshed here whenever the parameters changed behind its back
+            mirror = st.ensure_mirror(3 if self.precision == 'fp32x3' else 1)
             if self._applied_precision != (self.precision, mirror.data_ptr()):
                 check(_lib.lib().uniter_model_set_weight_mirror(self._handle, ptr(st.flat_params), ptr(mirror),
                                                                 st.numel), 'uniter_model_set_weight_mirror')
-                check(_lib.lib().uniter_model_set_precision(self._handle, 2), 'uniter_model_set_precision')
+                check(_lib.lib().uniter_model_set_precision(self._handle, 3 if self.precision == 'fp32x3' else 2),
+                      'uniter_model_set_precision')
                 self._applied_precision = (self.precision, mirror.data_ptr())
         elif self._applied_precision != self.precision:
             check(_lib.lib().uniter_model_set_precision(self._handle, 1 if self.precision == 'bf16_hybrid' else 0),
