@@ -138,7 +138,7 @@ def parse_args(argv=None):
     ap.add_argument('--txt_len', type=int, default=128)
     ap.add_argument('--num_bb', type=int, default=36)
     ap.add_argument('--model', choices=['base', 'large'], default='base')
-    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
+    ap.add_argument('--precision', choices=['fp32', 'fp32x3', 'bf16'], default='fp32',
                     help="fp32 (BASELINE configs[1], default) or bf16: bf16 MFMA for the dense GEMMs, fp32 elsewhere (configs[2])")
     ap.add_argument('--workload', choices=['finetune', 'multitask'], default='finetune',
                     help='finetune = MemeUniter step (BASELINE configs[1-3], default); multitask = UNITER + ITM/MLM/MRFR '
@@ -374,7 +374,7 @@ def run_rank(args):
         cur = batch if args.workload == 'finetune' else batches['itm']
         total, ffn, ffn_up = flops_per_step(cfgd, B, T, R, L_eff, cur['seq_lens'] if args.packed else None)
         M_eff = sum(cur['seq_lens']) if args.packed else B * L_eff
-        dt_name = 'f32' if args.precision == 'fp32' else 'bf16'
+        dt_name = 'f32' if args.precision in ('fp32', 'fp32x3') else 'bf16'
         peak = PEAK_TFLOPS[dt_name]
         H, I, nl = cfgd['hidden_size'], cfgd['intermediate_size'], cfgd['num_hidden_layers']
         sq = sum(n * n for n in cur['seq_lens']) if args.packed else B * L_eff * L_eff

@@ -288,6 +288,16 @@ int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, const int32_t* 
                        const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16,
                        float* bias_part, const void* keep_bits, float* delta, int B, int L, int nh, float p_drop,
                        uint64_t seed, uint32_t offset, uint32_t site, void* ws, size_t ws_bytes, void* stream);
+/* uniter_attn_fwd_pre / uniter_attn_bwd_ex whose operand copies are x3 pieces (csrc/gemm_split3.hip) instead of bf16:
+ * ctx_x3 [B*L][3][H], dqkv_x3 [B*L][3][3H]; with dqkv_x3 given the fp32 dqkv may be NULL (nothing else reads it in the
+ * fp32x3 mode: the bias partials come from the kernel).  model/layer.py:85-100. */
+int uniter_attn_fwd_pre_x3(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+                           void* ctx_x3, float* lse, void* keep_bits, int keep_bits_ready, int B, int L, int nh,
+                           float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream);
+int uniter_attn_bwd_ex_x3(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, const float* ctx,
+                          const float* lse, const float* dctx, float* dqkv, void* dqkv_x3, float* bias_part,
+                          const void* keep_bits, float* delta, int B, int L, int nh, float p_drop, uint64_t seed,
+                          uint32_t offset, uint32_t site, void* ws, size_t ws_bytes, void* stream);
 /* The same two operations on the bf16 matrix pipe (precision mode 2): Q, K, V rounded to bf16 while
  * staged, fp32 scores / softmax / dropout / LSE, probabilities and score gradients rounded to bf16 as
  * MFMA operands.  Same arguments and Philox element indices as the _ex forms; L <= 192;

@@ -44,6 +44,7 @@ struct AttnArgs {
   float* delta;         // [B, nh, L]
   unsigned short* ctx_b16;   // optional bf16 copies of ctx / dqkv (operands of bf16-resident GEMMs)
   unsigned short* dqkv_b16;
+  int b16_pieces;            // 3: the copies are x3 pieces [rows][3][ld] (operands of the fp32-accurate products, csrc/gemm_split3.hip)
   unsigned short* keep_bits; // optional [B*nh, L, Lr/32, 2]: dropout keep flags of a (query, key block, lane half), written by the
                              // forward pass and read by dQ instead of a second Philox evaluation
   int prio;                  // wave priority of the L <= 192 kernels (UNITER_ATTN_PRIO, default 2)
@@ -126,6 +127,32 @@ __device__ __forceinline__ void store_rowT_bf16(unsigned short* __restrict__ row
     *reinterpret_cast<bf16x4_t*>(row + 8 * g + 4 * h) = v0;
     *reinterpret_cast<bf16x4_t*>(row + 32 + 8 * g + 4 * h) = v1;
   }
+}
+
+// the three bf16 pieces of the row (x = x1 + x2 + x3 exactly, round-to-nearest residuals) at row, row + ps, row + 2 ps
+__device__ __forceinline__ void store_rowT_x3(unsigned short* __restrict__ row, int ps, const f32x16& a0, const f32x16& a1,
+                                              float mul, int h) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 r0 = {a0[4 * g] * mul, a0[4 * g + 1] * mul, a0[4 * g + 2] * mul, a0[4 * g + 3] * mul};
+    f32x4 r1 = {a1[4 * g] * mul, a1[4 * g + 1] * mul, a1[4 * g + 2] * mul, a1[4 * g + 3] * mul};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const bf16x4_t v0 = {(__bf16)r0[0], (__bf16)r0[1], (__bf16)r0[2], (__bf16)r0[3]};
+      const bf16x4_t v1 = {(__bf16)r1[0], (__bf16)r1[1], (__bf16)r1[2], (__bf16)r1[3]};
+      *reinterpret_cast<bf16x4_t*>(row + p * ps + 8 * g + 4 * h) = v0;
+      *reinterpret_cast<bf16x4_t*>(row + p * ps + 32 + 8 * g + 4 * h) = v1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { r0[e] -= (float)v0[e]; r1[e] -= (float)v1[e]; }
+    }
+  }
+}
+// bf16 copy or x3 pieces of one 64-wide head slice of row `r` of a [rows][ld] tensor
+__device__ __forceinline__ void store_rowT_copy(unsigned short* __restrict__ base, int pieces, size_t r, int ld, int col,
+                                                const f32x16& a0, const f32x16& a1, float mul, int h) {
+  if (pieces == 3) store_rowT_x3(base + r * 3 * ld + col, ld, a0, a1, mul, h);
+  else store_rowT_bf16(base + r * ld + col, a0, a1, mul, h);
 }
 
 __device__ __forceinline__ void stage_mask_bias(float* mb, const float* __restrict__ mask_row, int k0, int L, int tid) {
@@ -718,7 +745,7 @@ __global__ __launch_bounds__(768) void attn_fwd_split_kernel(const AttnArgs a, i
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (vq) {
     store_rowT(a.ctx + ((size_t)sp.row0 + q) * a.H + head * D, o0, o1, 1.0f / l_tot, h);
-    if (a.ctx_b16) store_rowT_bf16(a.ctx_b16 + ((size_t)sp.row0 + q) * a.H + head * D, o0, o1, 1.0f / l_tot, h);
+    if (a.ctx_b16) store_rowT_copy(a.ctx_b16, a.b16_pieces, (size_t)sp.row0 + q, a.H, head * D, o0, o1, 1.0f / l_tot, h);
     if (h == 0 && a.lse) a.lse[(size_t)bh * a.L + q] = m_run + __logf(l_tot);
   }
 }
@@ -818,8 +845,8 @@ __device__ __forceinline__ void bwd_dq_split_body(const AttnArgs& a, int Lr, flo
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq0[r] += xb[r * 64 + lane]; dq1[r] += xb[(16 + r) * 64 + lane]; }
     if (vq) {
-      store_rowT(a.dqkv + ((size_t)sp.row0 + q) * ld + head * D, dq0, dq1, 1.0f, h);
-      if (a.dqkv_b16) store_rowT_bf16(a.dqkv_b16 + ((size_t)sp.row0 + q) * ld + head * D, dq0, dq1, 1.0f, h);
+      if (a.dqkv) store_rowT(a.dqkv + ((size_t)sp.row0 + q) * ld + head * D, dq0, dq1, 1.0f, h);
+      if (a.dqkv_b16) store_rowT_copy(a.dqkv_b16, a.b16_pieces, (size_t)sp.row0 + q, ld, head * D, dq0, dq1, 1.0f, h);
     }
     if (a.bias_part) acc_colsum(red, dq0, dq1, vq, i, h);
   }
@@ -909,13 +936,14 @@ __device__ __forceinline__ void bwd_dkv_split_body(const AttnArgs& a, int Lr, co
       dv0[r] += xb[(32 + r) * 64 + lane]; dv1[r] += xb[(48 + r) * 64 + lane];
     }
     if (vk) {
-      float* row = a.dqkv + ((size_t)sp.row0 + key) * ld + head * D;
-      store_rowT(row + a.H, dk0, dk1, 1.0f, h);
-      store_rowT(row + 2 * a.H, dv0, dv1, 1.0f, h);
+      if (a.dqkv) {
+        float* row = a.dqkv + ((size_t)sp.row0 + key) * ld + head * D;
+        store_rowT(row + a.H, dk0, dk1, 1.0f, h);
+        store_rowT(row + 2 * a.H, dv0, dv1, 1.0f, h);
+      }
       if (a.dqkv_b16) {
-        unsigned short* rb = a.dqkv_b16 + ((size_t)sp.row0 + key) * ld + head * D;
-        store_rowT_bf16(rb + a.H, dk0, dk1, 1.0f, h);
-        store_rowT_bf16(rb + 2 * a.H, dv0, dv1, 1.0f, h);
+        store_rowT_copy(a.dqkv_b16, a.b16_pieces, (size_t)sp.row0 + key, ld, a.H + head * D, dk0, dk1, 1.0f, h);
+        store_rowT_copy(a.dqkv_b16, a.b16_pieces, (size_t)sp.row0 + key, ld, 2 * a.H + head * D, dv0, dv1, 1.0f, h);
       }
     }
     if (a.bias_part) { acc_colsum(red + 64, dk0, dk1, vk, i, h); acc_colsum(red + 128, dv0, dv1, vk, i, h); }
@@ -1111,14 +1139,33 @@ extern "C" int uniter_attn_fwd_ex(const float* qkv, const float* attn_mask, cons
                              stream);
 }
 
+static int attn_fwd_pre_run(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+                            void* ctx_bf16, int pieces, float* lse, void* keep_bits, int keep_bits_ready, int B, int L, int nh,
+                            float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream);
+
 extern "C" int uniter_attn_fwd_pre(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
                                    void* ctx_bf16, float* lse, void* keep_bits, int keep_bits_ready, int B, int L, int nh,
                                    float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
+  return attn_fwd_pre_run(qkv, attn_mask, cu_seqlens, ctx, ctx_bf16, 1, lse, keep_bits, keep_bits_ready, B, L, nh, p_drop, seed,
+                          offset, site, stream);
+}
+
+extern "C" int uniter_attn_fwd_pre_x3(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+                                      void* ctx_x3, float* lse, void* keep_bits, int keep_bits_ready, int B, int L, int nh,
+                                      float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
+  UCHECK_ARG(ctx_x3 && ((uintptr_t)ctx_x3 & 7) == 0, "attn_fwd_pre_x3: ctx_x3 is NULL or misaligned");
+  return attn_fwd_pre_run(qkv, attn_mask, cu_seqlens, ctx, ctx_x3, 3, lse, keep_bits, keep_bits_ready, B, L, nh, p_drop, seed,
+                          offset, site, stream);
+}
+
+static int attn_fwd_pre_run(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+                            void* ctx_bf16, int pieces, float* lse, void* keep_bits, int keep_bits_ready, int B, int L, int nh,
+                            float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
   UCHECK_ARG(qkv && ctx && ((attn_mask != nullptr) != (cu_seqlens != nullptr)), "attn_fwd_ex: need attn_mask or cu_seqlens (not both)");
   UCHECK_ARG(!keep_bits_ready || keep_bits, "attn_fwd_pre: keep_bits_ready without keep_bits");
   AttnArgs a = {};
   UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
-  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_b16 = (unsigned short*)ctx_bf16; a.lse = lse;
+  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_b16 = (unsigned short*)ctx_bf16; a.b16_pieces = pieces; a.lse = lse;
   a.keep_bits = (unsigned short*)keep_bits; a.keep_ready = keep_bits_ready;
   const int Lr = (L + 31) / 32 * 32;
   UCHECK_SHAPE(Lr <= uniter_attn_varlen_max_len(), "attn_fwd_ex: L %d > %d", L, uniter_attn_varlen_max_len());
@@ -1129,12 +1176,38 @@ extern "C" int uniter_attn_fwd_pre(const float* qkv, const float* attn_mask, con
   return 0;
 }
 
+static int attn_bwd_ex_run(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
+                           const float* ctx, const float* lse, const float* dctx, float* dqkv,
+                           void* dqkv_bf16, int pieces, float* bias_part, const void* keep_bits, float* delta, int B, int L,
+                           int nh, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws,
+                           size_t ws_bytes, void* stream);
+
 extern "C" int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
                                   const float* ctx, const float* lse, const float* dctx, float* dqkv,
                                   void* dqkv_bf16, float* bias_part, const void* keep_bits, float* delta, int B, int L,
                                   int nh, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws,
                                   size_t ws_bytes, void* stream) {
-  UCHECK_ARG(qkv && ctx && lse && dctx && dqkv && delta && ws && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
+  UCHECK_ARG(dqkv, "attn_bwd_ex: dqkv is NULL");
+  return attn_bwd_ex_run(qkv, attn_mask, cu_seqlens, ctx, lse, dctx, dqkv, dqkv_bf16, 1, bias_part, keep_bits, delta, B, L, nh,
+                         p_drop, seed, offset, site, ws, ws_bytes, stream);
+}
+
+extern "C" int uniter_attn_bwd_ex_x3(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
+                                     const float* ctx, const float* lse, const float* dctx, float* dqkv,
+                                     void* dqkv_x3, float* bias_part, const void* keep_bits, float* delta, int B, int L,
+                                     int nh, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  UCHECK_ARG(dqkv_x3 && ((uintptr_t)dqkv_x3 & 7) == 0, "attn_bwd_ex_x3: dqkv_x3 is NULL or misaligned");
+  return attn_bwd_ex_run(qkv, attn_mask, cu_seqlens, ctx, lse, dctx, dqkv, dqkv_x3, 3, bias_part, keep_bits, delta, B, L, nh,
+                         p_drop, seed, offset, site, ws, ws_bytes, stream);
+}
+
+static int attn_bwd_ex_run(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens,
+                           const float* ctx, const float* lse, const float* dctx, float* dqkv,
+                           void* dqkv_bf16, int pieces, float* bias_part, const void* keep_bits, float* delta, int B, int L,
+                           int nh, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* ws,
+                           size_t ws_bytes, void* stream) {
+  UCHECK_ARG(qkv && ctx && lse && dctx && (dqkv || dqkv_bf16) && delta && ws && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_bwd_ex: null pointer, or not exactly one of attn_mask / cu_seqlens");
   const int Lr = (L + 31) / 32 * 32;
   UCHECK_SHAPE(Lr <= uniter_attn_varlen_max_len(), "attn_bwd_ex: L %d > %d", L, uniter_attn_varlen_max_len());
@@ -1142,7 +1215,7 @@ extern "C" int uniter_attn_bwd_ex(const float* qkv, const float* attn_mask, cons
   AttnArgs a = {};
   UCHECK_RC(make_args(a, B, L, nh, p_drop, seed, offset, site));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
-  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (unsigned short*)dqkv_bf16; a.bias_part = bias_part; a.keep_bits = (unsigned short*)keep_bits; a.delta = delta;
+  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_b16 = (unsigned short*)dqkv_bf16; a.b16_pieces = pieces; a.bias_part = bias_part; a.keep_bits = (unsigned short*)keep_bits; a.delta = delta;
   float* pd_ws = (float*)ws;
   float* ds_ws = pd_ws + (size_t)B * nh * Lr * Lr;
   return launch_bwd_split(a, Lr, pd_ws, ds_ws, (hipStream_t)stream);

@@ -359,7 +359,7 @@ struct S3Group {
 //   compute:                            for u: { barrier B_u;  read stage u % ST, MFMAs;  (last k-tile of an item: epilogue) }
 // B_u orders k-tile u's LDS-DMA before its reads (every loader waited for its own instructions) and the reads of k-tile u - 1
 // (each compute wave waits lgkmcnt(0) before its last MFMAs) before the LDS-DMA that overwrites their stage.
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, int EPI>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, bool STAG, int EPI>
 __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NWL), ((BM / WM) * (BN / WN) + NWL + 3) / 4)
 void gemm_s3p_kernel(const S3Group G) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -400,7 +400,7 @@ void gemm_s3p_kernel(const S3Group G) {
     return it;
   };
 #ifdef UNITER_X3_LAB
-  const int dbg = G.p[0].dbg;       // measurement builds (tests/tools/gemm_x3_lab.py): 1 = no LDS-DMA, 2 = no LDS reads, 4 = no MFMAs
+  const int dbg = G.p[0].dbg;       // measurement builds (tests/tools/gemm_x3_lab.py): 1 = no LDS-DMA, 2 = no LDS reads, 4 = no MFMAs, 64 = no barriers
 #else
   constexpr int dbg = 0;
 #endif
@@ -464,7 +464,7 @@ void gemm_s3p_kernel(const S3Group G) {
       for (int kt = c.kb; kt < c.ke; ++kt) {
         // k-tile `consumed` has landed once at most the k-tiles issued after it are outstanding
         if (issued - consumed - 1 >= ST - 2) wait_vm3<(ST - 2) * NDL>(); else wait_vm3<0>();
-        __builtin_amdgcn_s_barrier();
+        if (!(dbg & 64)) __builtin_amdgcn_s_barrier();
         issue_next();
         ++consumed;
       }
@@ -522,6 +522,12 @@ void gemm_s3p_kernel(const S3Group G) {
         });
       });
     };
+    // STAG: the second half of the compute waves (the SIMD partners of the first half: a workgroup's waves go round the four SIMDs)
+    // runs the MFMAs of a k-tile's second k16-step BEHIND the next k-tile's barrier, on fragments it read in front of it: while the
+    // first half waits for its fragment reads after a barrier, the partner's deferred MFMAs keep the matrix pipe busy, and from
+    // then on the two halves alternate between reading and multiplying instead of doing both in lockstep
+    const bool late = STAG && wave >= NWC / 2;
+    static_assert(KS == 2, "two k16-steps per k-tile");
     int stg = 0;
     for (int r = 0;; ++r) {
       const Item c = item(r);
@@ -532,33 +538,37 @@ void gemm_s3p_kernel(const S3Group G) {
         for (int b = 0; b < BB; ++b)
 #pragma unroll
           for (int rr = 0; rr < 16; ++rr) acc[a][b][rr] = 0.f;
+      Frs f0, f1;
+      bool pending = false;       // f1 holds the fragments of a k16-step whose MFMAs have not run yet
       for (int kt = c.kb; kt < c.ke; ++kt) {
-        __builtin_amdgcn_s_barrier();
+        if (!(dbg & 64)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const unsigned sA = lds0 + stg * STAGE, sB = sA + 3 * IMG_A;
-        Frs f0;
         if (!(dbg & 2)) {
           f0.a.template read<0>(fa, sA);
           f0.b.template read<0>(fb, sB);
         }
+        if (pending && !(dbg & 4)) mma_step(f1);
+        // (sched_barrier: MFMAs are plain register operations to the compiler, free to sink below the volatile waits -- it did, and
+        // every wave then sat out its fragment reads with the matrix pipe idle)
+        __builtin_amdgcn_sched_barrier(0);
         lgkm_wait0();
         tie_frs(f0);
-        if constexpr (KS == 2) {
-          Frs f1;
-          if (!(dbg & 2)) {
-            f1.a.template read<1>(fa, sA);
-            f1.b.template read<1>(fb, sB);
-          }
-          if (!(dbg & 4)) mma_step(f0);
-          lgkm_wait0();
-          tie_frs(f1);
-          if (!(dbg & 4)) mma_step(f1);
-        } else {
-          if (!(dbg & 4)) mma_step(f0);
+        if (!(dbg & 2)) {
+          f1.a.template read<1>(fa, sA);
+          f1.b.template read<1>(fb, sB);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 4)) mma_step(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        lgkm_wait0();           // in front of the next barrier either way: the loaders overwrite this stage behind it
+        tie_frs(f1);
+        if (late) pending = true;
+        else if (!(dbg & 4)) mma_step(f1);
         __builtin_amdgcn_sched_barrier(0);
         stg = stg == ST - 1 ? 0 : stg + 1;
       }
+      if (pending && !(dbg & 4)) mma_step(f1);
       s3_epilogue<WM, WN, EPI>(G.p[c.p], c.piece, c.m0, c.n0, wm, wn, i5, h, acc);
     }
   }
@@ -582,7 +592,7 @@ void plan_tiles3(S3Args& g, int BN) {
   if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, int EPI>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, bool STAG, int EPI>
 int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
   const int nwork = G.start[4];
   int grid = (nwork + 7) / 8 * 8;
@@ -593,22 +603,22 @@ int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
   }();
   const int cap = max_wgs >= 8 ? max_wgs / 8 * 8 : cus;       // one workgroup per CU: it owns the CU's LDS
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((gemm_s3p_kernel<BM, BN, WM, WN, AKM, BKM, ST, KT, NWL, EPI>), dim3(grid),
+  hipLaunchKernelGGL((gemm_s3p_kernel<BM, BN, WM, WN, AKM, BKM, ST, KT, NWL, STAG, EPI>), dim3(grid),
                      dim3(64 * ((BM / WM) * (BN / WN) + NWL)), 0, st, G);
   UCHECK_LAUNCH();
   return 0;
 }
 
 // cfg: tile geometry (all: 128 x 128 tiles, three 32-deep stages = 144 KB of LDS, one persistent workgroup per CU)
-//   1: 8 compute waves of 64 x 32 + 4 loader waves
+//   1: 8 compute waves of 64 x 32 + 4 loader waves (default)
 //   2: 4 compute waves of 64 x 64 + 4 loader waves
-//   3: 8 compute waves of 64 x 32 + 2 loader waves
+//   3: as 1 with the second four compute waves half a k-tile behind the first (STAG; measured: no gain)
 template <bool AKM, bool BKM, int EPI>
 int dispatch_cfg3p(int cfg, const S3Group& G, int max_wgs, hipStream_t st) {
   switch (cfg) {
-    case 1: return launch_s3p<128, 128, 64, 32, AKM, BKM, 3, 32, 4, EPI>(G, max_wgs, st);
-    case 2: return launch_s3p<128, 128, 64, 64, AKM, BKM, 3, 32, 4, EPI>(G, max_wgs, st);
-    case 3: return launch_s3p<128, 128, 64, 32, AKM, BKM, 3, 32, 2, EPI>(G, max_wgs, st);
+    case 1: return launch_s3p<128, 128, 64, 32, AKM, BKM, 3, 32, 4, false, EPI>(G, max_wgs, st);
+    case 2: return launch_s3p<128, 128, 64, 64, AKM, BKM, 3, 32, 4, false, EPI>(G, max_wgs, st);
+    case 3: return launch_s3p<128, 128, 64, 32, AKM, BKM, 3, 32, 4, true, EPI>(G, max_wgs, st);
     default: uniter_set_error("gemm_x3: bad cfg %d (1..3)", cfg); return UNITER_E_ARG;
   }
 }
@@ -681,25 +691,34 @@ __global__ __launch_bounds__(256) void join3_kernel(const unsigned short* __rest
 }
 
 // column sums of an x3 tensor [rows][3][ldx] added to out[cols] (the bias gradient of intermediate.dense from dU, which exists
-// only as x3): one workgroup per 64 columns and row slab, one float atomic per column and workgroup
+// only as x3: 48 MB read once, on the weight-gradient stream): block (bx, by) covers 512 columns (64 lanes x 8, three 16-byte
+// loads per row and lane) and rows by * RPB .. + RPB; four row-lanes meet in LDS, then one fp32 atomic per column and block
 __global__ __launch_bounds__(256) void colsum3_kernel(const unsigned short* __restrict__ x3, int rows, int cols, int ldx,
-                                                      float* __restrict__ out, int rows_per_wg) {
-  __shared__ float part[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rq = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
-  float s = 0.f;
+                                                      float* __restrict__ out, int rows_per_block) {
+  __shared__ float red[4][64 * 8 + 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 512 + lane * 8;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < cols) {
-    for (int r = r0 + rq; r < r1; r += 4) {
+    const int r1 = min(rows, (int)(blockIdx.y + 1) * rows_per_block);
+    for (int r = blockIdx.y * rows_per_block + wave; r < r1; r += 4) {
       const unsigned short* p = x3 + (size_t)r * 3 * ldx + c;
-      const float a = __builtin_bit_cast(float, (unsigned)p[0] << 16), b = __builtin_bit_cast(float, (unsigned)p[ldx] << 16),
-                  d = __builtin_bit_cast(float, (unsigned)p[2 * ldx] << 16);
-      s += (d + b) + a;
+      const u32x4_t v0 = *reinterpret_cast<const u32x4_t*>(p), v1 = *reinterpret_cast<const u32x4_t*>(p + ldx),
+                    v2 = *reinterpret_cast<const u32x4_t*>(p + 2 * ldx);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s[2 * k] += (bflo(v2[k]) + bflo(v1[k])) + bflo(v0[k]);
+        s[2 * k + 1] += (bfhi(v2[k]) + bfhi(v1[k])) + bfhi(v0[k]);
+      }
     }
   }
-  part[rq][threadIdx.x & 63] = s;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = s[k];
   __syncthreads();
-  if (rq == 0 && c < cols) atomicAdd(out + c, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+  for (int k = threadIdx.x; k < 512; k += 256) {
+    const int cc = blockIdx.x * 512 + k;
+    if (cc < cols) atomicAdd(out + cc, (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]));
+  }
 }
 
 // 31-bit buffer offsets: the largest byte offset an x3 operand of `rows` rows is addressed with (tile overhang included)
@@ -783,10 +802,15 @@ extern "C" int uniter_join3(const void* x3, int rows, int cols, size_t row_strid
 
 extern "C" int uniter_colsum_x3_add(const void* x3, int rows, int cols, int ldx, float* out, void* stream) {
   UCHECK_ARG(x3 && out && rows > 0 && cols > 0 && ldx >= cols, "colsum_x3_add: bad argument");
-  const int slabs = rows >= 4096 ? 32 : rows >= 512 ? 16 : 1;
-  const int rpw = (rows + slabs - 1) / slabs;
-  hipLaunchKernelGGL(colsum3_kernel, dim3((cols + 63) / 64, (rows + rpw - 1) / rpw), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)x3, rows, cols, ldx, out, rpw);
+  UCHECK_SHAPE(cols % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x3 & 15) == 0, "colsum_x3_add: cols, ldx multiples of 8 and a 16-byte aligned operand required");
+  // ~2048 workgroups: enough loads in flight for the HBM stream, few enough atomics per column (as uniter_colsum_bf16_add)
+  const int cb = (cols + 511) / 512;
+  int rb = (2048 + cb - 1) / cb;
+  if (rb > (rows + 3) / 4) rb = (rows + 3) / 4;
+  if (rb < 1) rb = 1;
+  const int rpb = (rows + rb - 1) / rb;
+  hipLaunchKernelGGL(colsum3_kernel, dim3(cb, (rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x3, rows, cols, ldx, out, rpb);
   UCHECK_LAUNCH();
   return 0;
 }

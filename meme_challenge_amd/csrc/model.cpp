@@ -620,6 +620,10 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
         UCHECK_RC(uniter_attn_bf16_fwd_pre(lb.qkv, 1, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
                                            lb.ctx, lb.ctxb, lb.lse, save ? lb.keepb : nullptr, keep_pre ? 1 : 0, B, L, nh, pa,
                                            seed, offset, SITE_ATTN_PROBS(l), st));
+      else if (x3 && L <= uniter_attn_varlen_max_len())      // the context leaves the kernel as x3 pieces too
+        UCHECK_RC(uniter_attn_fwd_pre_x3(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
+                                         lb.ctx, lb.ctxb, lb.lse, save ? lb.keepb : nullptr, keep_pre ? 1 : 0, B, L, nh, pa,
+                                         seed, offset, SITE_ATTN_PROBS(l), st));
       else if (packed || (save && L <= uniter_attn_varlen_max_len()))
         UCHECK_RC(uniter_attn_fwd_pre(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
                                       lb.ctx, nullptr, lb.lse, save ? lb.keepb : nullptr, keep_pre ? 1 : 0, B, L, nh, pa,
@@ -633,8 +637,8 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
       UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, M, H, H, lb.ctxb, H, m->WB(l, L_OW), H, lb.t1, H, 1,
                         nullptr, 0, UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, 0, nullptr, 0, 0));
     } else if (x3) {
-      // the context as x3 pieces: operand of the projection below and of its weight gradient
-      UCHECK_RC(split_x3(lb.ctx, lb.ctxb, M, H, st));
+      // the context as x3 pieces: operand of the projection below and of its weight gradient (L <= 192: the attention kernel wrote them)
+      if (L > uniter_attn_varlen_max_len()) UCHECK_RC(split_x3(lb.ctx, lb.ctxb, M, H, st));
       UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_ATTN_OUT_FWD, st, 0, M, H, H, lb.ctxb, m->WB(l, L_OW), H, lb.t1, pl.ns_kh, nullptr,
                         UNITER_EPI_BIAS, m->LP(l, L_OB), nullptr, nullptr));
     } else {
@@ -840,6 +844,11 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                                      nullptr /* fp32 dqkv has no reader in this mode: bias partials are fused */,
                                      lb.dqkvb, lb.qb_part, lb.keepb, lb.delta, B, L, nh, pa, m->seed, m->offset,
                                      SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
+    else if (fused_qb && x3)      // dqkv leaves the kernel as x3 pieces only: nothing reads an fp32 copy in this mode
+      UCHECK_RC(uniter_attn_bwd_ex_x3(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
+                                      pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, nullptr, lb.dqkvb,
+                                      lb.qb_part, lb.keepb, lb.delta, B, L, nh, pa, m->seed, m->offset, SITE_ATTN_PROBS(l),
+                                      pl.attn_ws, pl.attn_ws_bytes, st));
     else if (fused_qb)
       UCHECK_RC(uniter_attn_bwd_ex(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
                                    pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, lb.dqkv, nullptr,
@@ -854,7 +863,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, 3 * H, lb.dqkvb, 3 * H, m->WB(l, L_QW), H, lb.dx, H, ns_dx,
                       nullptr, 0, UNITER_EPI_ADD, nullptr, lb.dz1, 0, nullptr, 0, H));
   } else if (x3) {
-    UCHECK_RC(split_x3(lb.dqkv, lb.dqkvb, M, 3 * H, st));
+    if (!fused_qb) UCHECK_RC(split_x3(lb.dqkv, lb.dqkvb, M, 3 * H, st));
     UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, 3 * H, lb.dqkvb, m->WB(l, L_QW), H, lb.dx, ns_dx, nullptr, UNITER_EPI_ADD,
                       nullptr, lb.dz1, nullptr));
   } else {

@@ -307,9 +307,17 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = g0['betas']
 
         mirror = getattr(st, 'mirror', None)
+        enc = self.overlap_encoder
+        plan = self._overlap_plan(enc) if enc is not None else None
+        # the mirror feeds the encoder LAYERS' dense products only: blocks outside them (the 24 M parameters of the embeddings,
+        # the heads) skip its 2 - 6 bytes per parameter
+        layers_rng = (min(b[0] for b in plan[1][1:]), max(b[1] for b in plan[1][1:])) if plan is not None and len(plan[1]) > 1 else None
 
         def launch(lo, hi, stream_ptr, max_wgs=0):
             off = lo * 4
+            mirror = getattr(st, 'mirror', None)
+            if mirror is not None and layers_rng is not None and not (lo >= layers_rng[0] and hi <= layers_rng[1]):
+                mirror = None
             # the bf16 weight mirror (precision 'bf16') is written by the same kernel, on the same stream
             # (precision 'fp32x3': its three bf16 pieces, piece p at mirror + p * numel)
             check(lib.uniter_adam_step_x3(st.flat_params.data_ptr() + off, st.flat_grads.data_ptr() + off,
@@ -324,8 +332,6 @@ class FusedAdam(torch.optim.Optimizer):
                                           max_wgs, stream_ptr),
                   'uniter_adam_step')
 
-        enc = self.overlap_encoder
-        plan = self._overlap_plan(enc) if enc is not None else None
         if plan is None:
             if grad_ready is not None:
                 grad_ready(0, st.numel)

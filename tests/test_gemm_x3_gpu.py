@@ -1,0 +1,275 @@
+"""GPU: fp32-accurate products on the bf16 matrix pipe (csrc/gemm_split3.hip: three bf16 pieces per value, six MFMA
+products per block, fp32 accumulate) -- the dense products of model/layer.py:76-78,112,140,153 in the `fp32x3` mode.
+
+Reference: the SAME fp32 operands multiplied in float64.  The bar is not a tolerance picked for this kernel: on every
+shape of the model the maximum and the rms error must be no more than 1.5 x those of the native fp32 MFMA kernel
+(uniter_gemm_f32_cfg) on the same operands -- the kernel it replaces (measured: 0.75-0.93 x)."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EPI_NONE, EPI_BIAS, EPI_ADD, EPI_BIAS_GELU_D, EPI_MUL = 0, 1, 4, 5, 6
+
+
+def _gelu(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def _dgelu(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+def split3(x, piece_major=False):
+    """fp32 [rows, cols] on the GPU -> x3 by the library's kernel: [rows][3][cols], or piece-major [3][rows][cols]"""
+    from meme_challenge_amd import _lib as L
+    rows, cols = x.shape
+    o = torch.empty((3, rows, cols) if piece_major else (rows, 3, cols), dtype=torch.bfloat16, device='cuda')
+    rs, ps = (cols, rows * cols) if piece_major else (3 * cols, cols)
+    L.check(L.lib().uniter_split3(L.ptr(x), rows, cols, cols, L.ptr(o), rs, ps, L.cur_stream()), 'split3')
+    return o
+
+
+def join3(x3, piece_major=False):
+    from meme_challenge_amd import _lib as L
+    rows, cols = (x3.shape[1], x3.shape[2]) if piece_major else (x3.shape[0], x3.shape[2])
+    o = torch.empty(rows, cols, device='cuda')
+    rs, ps = (cols, rows * cols) if piece_major else (3 * cols, cols)
+    L.check(L.lib().uniter_join3(L.ptr(x3), rows, cols, rs, ps, L.ptr(o), cols, L.cur_stream()), 'join3')
+    return o
+
+
+def x3_gemm(cfg, ns, akm, bkm, M, N, K, A3, B3, C, Cx, epi, bias, aux_in, aux_out, b_piece_major=False):
+    from meme_challenge_amd import _lib as L
+    a_cols = A3.shape[2]
+    if b_piece_major:
+        b_rows, b_cols = B3.shape[1], B3.shape[2]
+        ldb, psb = b_cols, b_rows * b_cols
+    else:
+        b_cols = B3.shape[2]
+        ldb, psb = 3 * b_cols, b_cols
+    return L.lib().uniter_gemm_x3_cfg(cfg, ns, akm, bkm, M, N, K, L.ptr(A3), 3 * a_cols, a_cols, L.ptr(B3), ldb, psb,
+                                      L.ptr(C), N, M * N, L.ptr(Cx), 3 * N, N, epi, L.ptr(bias), L.ptr(aux_in),
+                                      L.ptr(aux_out), N, L.cur_stream())
+
+
+def _operands(akm, bkm, M, N, K, seed):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    A = torch.randn((K, M) if akm else (M, K), device='cuda', generator=g)
+    B = torch.randn((K, N) if bkm else (N, K), device='cuda', generator=g) * 0.05
+    return A, B
+
+
+def _ref(akm, bkm, A, B):
+    a, b = A.double().cpu(), B.double().cpu()
+    return (a.t() if akm else a) @ (b if bkm else b.t())
+
+
+def _errs(got, ref):
+    d = (got.double().cpu() - ref).abs()
+    return d.max().item(), d.pow(2).mean().sqrt().item()
+
+
+def test_pieces_are_exact():
+    """x = x1 + x2 + x3 exactly, over 30 binades and with zeros, and the pieces are what round-to-nearest residuals give"""
+    g = torch.Generator(device='cuda').manual_seed(1)
+    x = torch.randn(257, 512, device='cuda', generator=g) * torch.exp(torch.randn(257, 512, device='cuda', generator=g) * 6)
+    x[0, :8] = 0.0
+    x[1, :4] = torch.tensor([1.0, -1.0, 2.0 ** -100, -(2.0 ** 100)], device='cuda')
+    for pm in (False, True):
+        p = split3(x, pm)
+        assert torch.equal(join3(p, pm), x)
+        pieces = p if pm else p.permute(1, 0, 2)
+        p1 = x.bfloat16()
+        r1 = x - p1.float()
+        p2 = r1.bfloat16()
+        p3 = (r1 - p2.float()).bfloat16()
+        assert torch.equal(pieces[0], p1) and torch.equal(pieces[1], p2) and torch.equal(pieces[2], p3)
+        assert torch.equal(pieces.double().sum(0), x.double())
+
+
+MODEL_SHAPES = [  # name, akm, bkm, M, N, K    (UNITER-base at BASELINE configs[1]: M = 16 x 164)
+    ('qkv_fwd', 0, 0, 2624, 2304, 768), ('attnout_fwd', 0, 0, 2624, 768, 768), ('ffnup_fwd', 0, 0, 2624, 3072, 768),
+    ('ffndown_fwd', 0, 0, 2624, 768, 3072), ('ffndown_dgrad', 0, 1, 2624, 3072, 768), ('ffnup_dgrad', 0, 1, 2624, 768, 3072),
+    ('attnout_dgrad', 0, 1, 2624, 768, 768), ('qkv_dgrad', 0, 1, 2624, 768, 2304), ('w2_wgrad', 1, 1, 768, 3072, 2624),
+    ('w1_wgrad', 1, 1, 3072, 768, 2624), ('wo_wgrad', 1, 1, 768, 768, 2624), ('wqkv_wgrad', 1, 1, 2304, 768, 2624),
+    ('large_ffnup_fwd', 0, 0, 1424, 4096, 1024), ('large_ffnup_dgrad', 0, 1, 1424, 1024, 4096)]
+
+
+@pytest.mark.parametrize('shape', MODEL_SHAPES, ids=[s[0] for s in MODEL_SHAPES])
+def test_every_model_shape_is_no_less_accurate_than_the_fp32_mfma_kernel(shape):
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    name, akm, bkm, M, N, K = shape
+    A, B = _operands(akm, bkm, M, N, K, seed=len(name))
+    ref = _ref(akm, bkm, A, B)
+    C32 = torch.empty(M, N, device='cuda')
+    L.check(lib.uniter_gemm_f32_cfg(0, akm, bkm, M, N, K, L.ptr(A), A.shape[1], L.ptr(B), B.shape[1], L.ptr(C32), N, 0, None,
+                                    None, None, N, 0, L.cur_stream()), 'gemm_f32')
+    e32 = _errs(C32, ref)
+    A3, B3 = split3(A), split3(B)
+    for cfg in (1, 2, 3):
+        C = torch.full((M, N), float('nan'), device='cuda')
+        L.check(x3_gemm(cfg, 1, akm, bkm, M, N, K, A3, B3, C, None, EPI_NONE, None, None, None), 'gemm_x3')
+        e = _errs(C, ref)
+        assert e[0] <= 1.5 * e32[0] and e[1] <= 1.5 * e32[1], (name, cfg, e, e32)
+    # bit-reproducible: no atomics, a fixed summation order
+    C2 = torch.empty(M, N, device='cuda')
+    L.check(x3_gemm(1, 1, akm, bkm, M, N, K, A3, B3, C2, None, EPI_NONE, None, None, None), 'gemm_x3')
+    C1 = torch.empty(M, N, device='cuda')
+    L.check(x3_gemm(1, 1, akm, bkm, M, N, K, A3, B3, C1, None, EPI_NONE, None, None, None), 'gemm_x3')
+    assert torch.equal(C1, C2)
+
+
+def _run(cfg, akm, bkm, M, N, K, epi, nsplit=1, out='f32', piece_major_b=False, seed=0):
+    from meme_challenge_amd import _lib as L
+    A, B = _operands(akm, bkm, M, N, K, seed)
+    g = torch.Generator(device='cuda').manual_seed(seed + 7)
+    bias = torch.randn(N, device='cuda', generator=g)
+    aux = torch.randn(M, N, device='cuda', generator=g)
+    ref = _ref(akm, bkm, A, B)
+    aux_ref = None
+    if epi in (EPI_BIAS, EPI_BIAS_GELU_D):
+        ref = ref + bias.double().cpu()
+    if epi == EPI_BIAS_GELU_D:
+        aux_ref, ref = _dgelu(ref), _gelu(ref)
+    if epi == EPI_ADD:
+        ref = ref + aux.double().cpu()
+    if epi == EPI_MUL:
+        ref = ref * aux.double().cpu()
+    A3, B3 = split3(A), split3(B, piece_major_b)
+    C = torch.full((nsplit, M, N), float('nan'), device='cuda') if out in ('f32', 'both') else None
+    Cx = torch.full((M, 3, N), float('nan'), dtype=torch.bfloat16, device='cuda') if out in ('x3', 'both') else None
+    auxo = torch.full((M, N), float('nan'), device='cuda')
+    L.check(x3_gemm(cfg, nsplit, akm, bkm, M, N, K, A3, B3, C, Cx, epi, bias, aux, auxo, piece_major_b), 'gemm_x3')
+    torch.cuda.synchronize()
+    tol = 3e-6 * math.sqrt(K) * (1.0 + ref.abs().max().item() * 0.05)
+    tag = (cfg, akm, bkm, M, N, K, epi, nsplit, out, piece_major_b)
+    if C is not None:
+        got = C.double().cpu().sum(0)
+        assert not torch.isnan(got).any(), tag
+        assert (got - ref).abs().max().item() < tol, tag + ((got - ref).abs().max().item(), tol)
+    if Cx is not None:
+        gx = join3(Cx).double().cpu()
+        assert not torch.isnan(gx).any(), tag
+        assert (gx - ref).abs().max().item() < tol, tag
+        if C is not None:       # the pieces are those of the fp32 output, exactly
+            assert torch.equal(join3(Cx), C[0]), tag
+    if epi == EPI_BIAS_GELU_D:
+        assert (auxo.double().cpu() - aux_ref).abs().max().item() < tol, tag
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 3])
+@pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 1)], ids=['forward', 'dgrad', 'wgrad'])
+def test_layouts_and_edges(cfg, layout):
+    akm, bkm = layout
+    _run(cfg, akm, bkm, M=168, N=192, K=128, epi=EPI_NONE)                      # ragged M, N not a tile multiple
+    _run(cfg, akm, bkm, M=320, N=264, K=192, epi=EPI_NONE)                      # N % 8 == 0 only
+    _run(cfg, akm, bkm, M=64, N=128, K=32, epi=EPI_NONE)                        # one k-tile
+    _run(cfg, akm, bkm, M=8, N=8, K=64, epi=EPI_NONE)                           # one 8 x 8 corner of a tile
+    _run(cfg, akm, bkm, M=520, N=776, K=320, epi=EPI_NONE)                      # several tiles per persistent workgroup
+    if akm:
+        _run(cfg, 1, 1, M=256, N=128, K=200, epi=EPI_NONE)                      # ragged K: rows beyond K must read as zeros
+        _run(cfg, 1, 1, M=128, N=256, K=1458, epi=EPI_ADD)                      # ragged K, dW += (aux = prior value)
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 3])
+def test_epilogues_and_outputs(cfg):
+    for epi in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_D):
+        for out in ('f32', 'x3', 'both'):
+            _run(cfg, 0, 0, M=200, N=256, K=128, epi=epi, out=out)
+    for epi in (EPI_NONE, EPI_ADD, EPI_MUL):
+        for out in ('f32', 'x3', 'both'):
+            _run(cfg, 0, 1, M=200, N=256, K=128, epi=epi, out=out)
+    _run(cfg, 1, 1, M=200, N=256, K=128, epi=EPI_ADD)
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 3])
+@pytest.mark.parametrize('nsplit', [2, 3, 4])
+def test_split_k_slabs(cfg, nsplit):
+    _run(cfg, 0, 0, M=300, N=256, K=640, epi=EPI_BIAS, nsplit=nsplit)
+    _run(cfg, 0, 1, M=300, N=256, K=640, epi=EPI_ADD, nsplit=nsplit)
+    _run(cfg, 0, 0, M=130, N=128, K=64, epi=EPI_BIAS, nsplit=nsplit)             # fewer k-tiles than pieces: empty pieces store zeros
+
+
+@pytest.mark.parametrize('bkm', [0, 1])
+def test_piece_major_weights(bkm):
+    """the weight operand as the optimizer writes it: three flat mirrors behind each other (piece stride = numel)"""
+    _run(1, 0, bkm, M=300, N=256, K=384, epi=EPI_NONE, piece_major_b=True)
+    _run(1, 0, bkm, M=2624, N=768, K=3072, epi=EPI_BIAS if not bkm else EPI_ADD, nsplit=2, piece_major_b=True)
+
+
+def test_model_shapes_with_their_epilogues():
+    _run(1, 0, 0, M=2624, N=3072, K=768, epi=EPI_BIAS_GELU_D, out='x3')           # FFN up: activation as pieces, gelu' fp32
+    _run(1, 0, 0, M=2624, N=2304, K=768, epi=EPI_BIAS)                            # QKV
+    _run(1, 0, 0, M=2624, N=768, K=3072, epi=EPI_BIAS, nsplit=2)                  # FFN down
+    _run(1, 0, 1, M=2624, N=3072, K=768, epi=EPI_MUL, out='x3')                   # FFN down dgrad (x gelu')
+    _run(1, 0, 1, M=2624, N=768, K=3072, epi=EPI_ADD, nsplit=2)                   # FFN up dgrad (+ residual gradient)
+
+
+def _group_call(cfg, Ms, Ns, K, As, Bs, Cs, overwrite, max_wgs=0):
+    from meme_challenge_amd import _lib as L
+    n = len(Ms)
+    IA, PA = ctypes.c_int * n, ctypes.c_void_p * n
+    return L.lib().uniter_wgrad_x3_group(cfg, n, IA(*Ms), IA(*Ns), K, PA(*[a.data_ptr() for a in As]), PA(*[b.data_ptr() for b in Bs]),
+                                         PA(*[c.data_ptr() for c in Cs]), overwrite, max_wgs, L.cur_stream())
+
+
+@pytest.mark.parametrize('cfg', [1, 2])
+@pytest.mark.parametrize('shapes,K', [([(128, 128)], 64), ([(136, 200), (256, 128), (8, 8)], 200),
+                                      ([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 2624),
+                                      ([(256, 64), (64, 256), (192, 64), (64, 64)], 1458)])
+def test_weight_gradient_group(cfg, shapes, K):
+    """Up to four dW (+)= dY^T X products of one reduction length in ONE persistent launch of whole-K tiles: against fp64,
+    accumulate and overwrite, on a capped grid too, bit-identical when repeated (no atomics)."""
+    from meme_challenge_amd import _lib as L
+    g = torch.Generator(device='cuda').manual_seed(len(shapes) * 1000 + K)
+    Af = [torch.randn(K, M, device='cuda', generator=g) for M, N in shapes]
+    Bf = [torch.randn(K, N, device='cuda', generator=g) * 0.05 for M, N in shapes]
+    C0 = [torch.randn(M, N, device='cuda', generator=g) for M, N in shapes]
+    As, Bs = [split3(a) for a in Af], [split3(b) for b in Bf]
+    Ms, Ns = [m for m, _ in shapes], [n for _, n in shapes]
+    for overwrite in (0, 1):
+        outs = []
+        for wgs in (0, 0, 64):
+            Cs = [c.clone() for c in C0]
+            L.check(_group_call(cfg, Ms, Ns, K, As, Bs, Cs, overwrite, wgs), 'wgrad_x3_group')
+            torch.cuda.synchronize()
+            outs.append([c.cpu() for c in Cs])
+        for (M, N), a, b, c0, c, c2, c3 in zip(shapes, Af, Bf, C0, outs[0], outs[1], outs[2]):
+            ref = a.double().cpu().t() @ b.double().cpu() + (0 if overwrite else c0.double().cpu())
+            assert (c.double() - ref).abs().max().item() < 3e-6 * math.sqrt(K) * (1 + 0.05 * ref.abs().max().item()), (M, N, K, overwrite)
+            assert torch.equal(c, c2) and torch.equal(c, c3)
+
+
+def test_colsum_of_pieces():
+    from meme_challenge_amd import _lib as L
+    g = torch.Generator(device='cuda').manual_seed(3)
+    for rows, cols in ((2624, 3072), (77, 72), (5000, 64)):
+        x = torch.randn(rows, cols, device='cuda', generator=g)
+        out = torch.randn(cols, device='cuda', generator=g)
+        ref = out.double().cpu() + x.double().cpu().sum(0)
+        L.check(L.lib().uniter_colsum_x3_add(L.ptr(split3(x)), rows, cols, cols, L.ptr(out), L.cur_stream()), 'colsum_x3')
+        assert (out.double().cpu() - ref).abs().max().item() < 2e-5 * math.sqrt(rows)
+
+
+def test_rejects():
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    x = torch.zeros(64, 3, 64, dtype=torch.bfloat16, device='cuda')
+    c = torch.zeros(64, 64, device='cuda')
+
+    def call(K=64, N=64, nsplit=1, cx=None, akm=0, bkm=0, epi=0, cfg=1):
+        return lib.uniter_gemm_x3_cfg(cfg, nsplit, akm, bkm, 64, N, K, L.ptr(x), 192, 64, L.ptr(x), 192, 64, L.ptr(c), 64, 64 * 64,
+                                      cx, 192, 64, epi, None, None, None, 64, L.cur_stream())
+    assert call() == 0
+    assert call(K=48) != 0 and b'gemm_x3' in lib.uniter_last_error()      # K % 32 unless both operands are k-major
+    assert call(N=60) != 0
+    assert call(nsplit=2, cx=L.ptr(x)) != 0                               # split-K has no x3 output
+    assert call(akm=1) != 0                                               # A k-major only with B k-major
+    assert call(epi=EPI_BIAS) != 0                                        # needs bias
+    assert call(bkm=1, epi=EPI_BIAS_GELU_D) != 0                          # no GELU on the input-gradient layout
+    assert call(cfg=9) != 0

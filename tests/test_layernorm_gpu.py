@@ -95,3 +95,46 @@ def test_colsum(M, N):
     assert (out.cpu().double() - 2.0 - X.double().sum(0)).abs().max() < 2e-4
     L.check(lib.uniter_colsum_f32(L.ptr(dX), M, N, N, L.ptr(out), 0, L.ptr(ws), n, L.cur_stream()))
     assert (out.cpu().double() - X.double().sum(0)).abs().max() < 2e-4
+
+
+@pytest.mark.parametrize('M,H,p,nslab', [(37, 768, 0.1, 1), (2624, 768, 0.1, 2), (9, 128, 0.0, 3), (50, 1024, 0.1, 1)])
+def test_ln_x3_copies_are_the_exact_pieces_of_the_fp32_outputs(M, H, p, nslab):
+    """fp32x3 mode: the operand copy the row passes hand to the next product is the three bf16 pieces [M][3][H] of the
+    fp32 output they also write -- their sum reproduces it bit for bit (forward y, backward dx after dropout), and the
+    fp32 outputs are those of the plain entry points (slabs summed in the pass)."""
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    gen = torch.Generator(device='cuda').manual_seed(M + H + nslab)
+    slabs = torch.randn(nslab, M, H, device='cuda', generator=gen)
+    res, dy = (torch.randn(M, H, device='cuda', generator=gen) for _ in range(2))
+    g = 1 + 0.1 * torch.randn(H, device='cuda', generator=gen)
+    b = 0.1 * torch.randn(H, device='cuda', generator=gen)
+    seed, offset, site = 0xABCDEF, 3, 5
+
+    def join(x3):
+        o = torch.empty(M, H, device='cuda')
+        L.check(lib.uniter_join3(L.ptr(x3), M, H, 3 * H, H, L.ptr(o), H, L.cur_stream()))
+        return o
+    z, y, z0, y0 = (torch.empty(M, H, device='cuda') for _ in range(4))
+    mu, rstd = torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
+    yx = torch.full((M, 3, H), float('nan'), dtype=torch.bfloat16, device='cuda')
+    L.check(lib.uniter_ln_fwd_slabs_x3(L.ptr(slabs), nslab, M * H, L.ptr(res), L.ptr(g), L.ptr(b), L.ptr(z), L.ptr(y), L.ptr(yx),
+                                       L.ptr(mu), L.ptr(rstd), M, H, p, seed, offset, site, L.cur_stream()))
+    L.check(lib.uniter_ln_fwd_slabs(L.ptr(slabs), nslab, M * H, L.ptr(res), L.ptr(g), L.ptr(b), L.ptr(z0), L.ptr(y0), None,
+                                    L.ptr(mu), L.ptr(rstd), M, H, p, seed, offset, site, L.cur_stream()))
+    assert torch.equal(y, y0) and torch.equal(z, z0) and torch.equal(join(yx), y)
+    ws_n = lib.uniter_ln_bwd_ws_bytes(M, H)
+    ws = torch.empty(ws_n, dtype=torch.uint8, device='cuda')
+    dys = torch.randn(nslab, M, H, device='cuda', generator=gen)
+    dz, dx, dz0, dx0 = (torch.empty(M, H, device='cuda') for _ in range(4))
+    dxx = torch.full((M, 3, H), float('nan'), dtype=torch.bfloat16, device='cuda')
+    L.check(lib.uniter_ln_bwd_rows_slabs_x3(L.ptr(dys), nslab, M * H, L.ptr(z), L.ptr(mu), L.ptr(rstd), L.ptr(g), L.ptr(dz), L.ptr(dx),
+                                            L.ptr(dxx), 1, M, H, p, seed, offset, site, L.ptr(ws), ws_n, L.cur_stream()))
+    L.check(lib.uniter_ln_bwd_rows_slabs(L.ptr(dys), nslab, M * H, L.ptr(z), L.ptr(mu), L.ptr(rstd), L.ptr(g), L.ptr(dz0), L.ptr(dx0),
+                                         None, 1, M, H, p, seed, offset, site, L.ptr(ws), ws_n, L.cur_stream()))
+    assert torch.equal(dz, dz0) and torch.equal(dx, dx0) and torch.equal(join(dxx), dx)
+    # the pieces alone (no fp32 dx: what the model's schedule asks for)
+    dxx2 = torch.full((M, 3, H), float('nan'), dtype=torch.bfloat16, device='cuda')
+    L.check(lib.uniter_ln_bwd_rows_slabs_x3(L.ptr(dys), nslab, M * H, L.ptr(z), L.ptr(mu), L.ptr(rstd), L.ptr(g), L.ptr(dz), None,
+                                            L.ptr(dxx2), 1, M, H, p, seed, offset, site, L.ptr(ws), ws_n, L.cur_stream()))
+    assert torch.equal(dxx2, dxx)

@@ -12,12 +12,18 @@ from common import (TINY, TINY_IMG_DIM, BASE, LARGE, sd_from_npz, batch_from_npz
 pytestmark = pytest.mark.gpu
 
 
-def build(cfg_dict, img_dim, sd):
+# the two forms of the fp32 path: native fp32 MFMA kernels, and the same products from three bf16 pieces per value on the bf16
+# matrix pipe (csrc/gemm_split3.hip) -- both are held to the SAME golden vectors at the SAME tolerances
+FP32_MODES = ['fp32', 'fp32x3']
+
+
+def build(cfg_dict, img_dim, sd, precision='fp32'):
     from meme_challenge_amd.model import UniterConfig, UniterModel
     from meme_challenge_amd.meme_uniter import MemeUniter
     cfg = UniterConfig.from_dict(cfg_dict)
     m = MemeUniter(UniterModel(cfg, img_dim=img_dim), cfg.hidden_size, 1)
     missing = m.load_state_dict(sd, strict=True)
+    m.uniter_model.precision = precision
     return m.cuda()
 
 
@@ -25,9 +31,10 @@ def to_dev(b):
     return {k: v.cuda() for k, v in b.items()}
 
 
-def test_tiny_forward_matches_reference_golden(tiny):
+@pytest.mark.parametrize('precision', FP32_MODES)
+def test_tiny_forward_matches_reference_golden(tiny, precision):
     sd = sd_from_npz(tiny)
-    m = build(TINY, TINY_IMG_DIM, sd).eval()
+    m = build(TINY, TINY_IMG_DIM, sd, precision).eval()
     b = to_dev(batch_from_npz(tiny))
     with torch.no_grad():
         kw = model_kwargs(b)
@@ -53,10 +60,11 @@ def test_tiny_forward_matches_reference_golden(tiny):
         assert maxdiff(mk, tiny['out/masked']) < 2e-5
 
 
-def test_tiny_loss_and_all_grads_match_reference_golden(tiny):
+@pytest.mark.parametrize('precision', FP32_MODES)
+def test_tiny_loss_and_all_grads_match_reference_golden(tiny, precision):
     from meme_challenge_amd.trainer import bce_with_logits_loss
     sd = sd_from_npz(tiny)
-    m = build(TINY, TINY_IMG_DIM, sd).eval()      # eval + grad enabled, as the golden was made
+    m = build(TINY, TINY_IMG_DIM, sd, precision).eval()      # eval + grad enabled, as the golden was made
     b = to_dev(batch_from_npz(tiny))
     logits = m(**model_kwargs(b))
     loss = bce_with_logits_loss(logits, b['labels'], 1.8)
@@ -69,13 +77,14 @@ def test_tiny_loss_and_all_grads_match_reference_golden(tiny):
         assert maxdiff(p.grad, ref) <= tol, (n, maxdiff(p.grad, ref), tol)
 
 
+@pytest.mark.parametrize('precision', FP32_MODES)
 @pytest.mark.parametrize('name', ['cfg1_full', 'cfg1_ragged', 'cfg2_full'])
-def test_base_logits_and_grads_match_reference_golden(shapes_base, name):
+def test_base_logits_and_grads_match_reference_golden(shapes_base, name, precision):
     from meme_challenge_amd.trainer import bce_with_logits_loss
     from meme_challenge_amd.utils import make_synthetic_batch
     z = shapes_base
     sd = O.synth_state_dict(BASE, seed=0, ln_jitter=0.02)
-    m = build(BASE, 2048, sd).eval()
+    m = build(BASE, 2048, sd, precision).eval()
     B, T, R, seed = z[name + '/shape'].tolist()
     tl = z[name + '/txt_lens'].tolist() if name + '/txt_lens' in z.files else None
     nbb = z[name + '/num_bbs'].tolist() if name + '/num_bbs' in z.files else None
@@ -105,11 +114,12 @@ def test_base_logits_and_grads_match_reference_golden(shapes_base, name):
     assert maxdiff(got, ref) <= 1e-7 + 1e-3 * ref.abs().max().item()
 
 
-def test_large_logits_match_reference_golden(shapes_large):
+@pytest.mark.parametrize('precision', FP32_MODES)
+def test_large_logits_match_reference_golden(shapes_large, precision):
     from meme_challenge_amd.utils import make_synthetic_batch
     z = shapes_large
     sd = O.synth_state_dict(LARGE, seed=0, ln_jitter=0.02)
-    m = build(LARGE, 2048, sd).eval()
+    m = build(LARGE, 2048, sd, precision).eval()
     B, T, R, seed = z['cfg4_full/shape'].tolist()
     b = make_synthetic_batch(B, T, R, seed=seed, device='cuda')
     with torch.no_grad():
@@ -117,12 +127,13 @@ def test_large_logits_match_reference_golden(shapes_large):
     assert maxdiff(logits, z['cfg4_full/logits']) < 1e-3
 
 
-def test_train_mode_dropout_replay_matches_oracle(tiny):
+@pytest.mark.parametrize('precision', FP32_MODES)
+def test_train_mode_dropout_replay_matches_oracle(tiny, precision):
     """Train mode: same Philox masks in the oracle and in the kernels -> forward
     and every parameter gradient agree to fp32 round-off."""
     from meme_challenge_amd.trainer import bce_with_logits_loss
     sd = sd_from_npz(tiny)
-    m = build(TINY, TINY_IMG_DIM, sd).train()
+    m = build(TINY, TINY_IMG_DIM, sd, precision).train()
     seed, offset = 0x5EED5EED1234, 9
     m.uniter_model.set_dropout_seed(seed, offset)
     b = batch_from_npz(tiny)

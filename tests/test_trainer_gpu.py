@@ -11,8 +11,9 @@ from common import TINY, TINY_IMG_DIM, sd_from_npz, batch_from_npz, maxdiff
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'fp32x3'])
 @pytest.mark.parametrize('optname', ['adam', 'adamw'])
-def test_trainer_steps_match_reference(trainer_steps, optname):
+def test_trainer_steps_match_reference(trainer_steps, optname, precision):
     from meme_challenge_amd.model import UniterConfig, UniterModel
     from meme_challenge_amd.meme_uniter import MemeUniter
     from meme_challenge_amd.trainer import get_optimizer, TrainStep, cosine_warmup_lambda
@@ -21,6 +22,7 @@ def test_trainer_steps_match_reference(trainer_steps, optname):
     m = MemeUniter(UniterModel(cfg, img_dim=TINY_IMG_DIM), cfg.hidden_size, 1)
     m.load_state_dict(sd_from_npz(z, 'sd0/'))
     m = m.cuda().eval()          # the golden run had dropout off
+    m.uniter_model.precision = precision     # fp32x3: the optimizer refreshes the three-piece weight mirror every step
     config = dict(optimizer=optname, lr=1e-3, beta1=0.9, beta2=0.999, weight_decay=1e-3,
                   gradient_accumulation=2, max_grad_norm=1, pos_wt=1.8, loss_func='bce_logits')
     opt = get_optimizer(m, config)
@@ -146,7 +148,7 @@ def test_clip_norm_taken_during_backward_equals_the_full_pass():
     assert (finals[True] - finals[False]).abs().max().item() <= 5e-6
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'fp32x3', 'bf16'])
 def test_lazy_zero_grad_overwrite_equals_clearing(precision):
     """FusedAdam.lazy_zero_encoder: zero_grad leaves the encoder layers' weight gradients alone (28 instead of 32 bytes per
     parameter in the optimizer step) and the next backward pass writes them with `=` (uniter_model_set_wgrad_overwrite);

@@ -3,7 +3,10 @@ next to the native fp32 MFMA kernel (uniter_gemm_f32_cfg), and time per launch p
 Interleaved rounds in one process; median over rounds; hipGraph replay of ITERS back-to-back launches.
 
     python tests/tools/gemm_x3_lab.py            # accuracy + timing
-    LAB_ACC=0 / LAB_TIME=0 skip a part; LAB_ONLY=name,name; LAB_CFGS=1,2,3
+    LAB_ACC=0 / LAB_TIME=0 skip a part; LAB_ONLY=name,name; LAB_CFGS=1,2,3; LAB_KSWEEP=32,768,1536 (fixed cost and slope)
+    measurement switches (cfg tokens 1d3 ..) need a variant build of the library:
+        UNITER_EXTRA_HIPCC_FLAGS=-DUNITER_X3_LAB python -c "from meme_challenge_amd import build; build.build(variant='x3lab')"
+        UNITER_LIB_VARIANT=x3lab LAB_CFGS=1,1d1,1d3,1d4 python tests/tools/gemm_x3_lab.py
 """
 import math, os, sys, statistics, ctypes
 import torch
@@ -15,7 +18,7 @@ ROUNDS = int(os.environ.get('LAB_ROUNDS', '5')); ITERS = int(os.environ.get('LAB
 def _cfg(tok):      # '1' or '1d3' = cfg 1 with measurement switches 3 (1 = no LDS-DMA, 2 = no LDS reads, 4 = no MFMAs)
     base, _, dbg = tok.partition('d')
     return int(base) | (int(dbg or 0) << 8)
-CFG_TOKS = os.environ.get('LAB_CFGS', '1,2,3,4,5,6').split(',')
+CFG_TOKS = os.environ.get('LAB_CFGS', '1,2,3').split(',')
 CFGS = [_cfg(t) for t in CFG_TOKS]
 NSPLITS = [int(c) for c in os.environ.get('LAB_NSPLIT', '1,2,4').split(',')]
 only = os.environ.get('LAB_ONLY')
@@ -25,13 +28,13 @@ def split3(x):
     """fp32 [rows, cols] cuda -> x3 [rows, 3, cols] bf16 by the library's kernel"""
     rows, cols = x.shape
     o = torch.empty(rows, 3, cols, dtype=torch.bfloat16, device='cuda')
-    L.check(lib.uniter_split3(L.ptr(x), rows, cols, cols, L.ptr(o), cols, L.cur_stream()), 'split3')
+    L.check(lib.uniter_split3(L.ptr(x), rows, cols, cols, L.ptr(o), 3 * cols, cols, L.cur_stream()), 'split3')
     return o
 
 
 def x3_gemm(cfg, ns, akm, bkm, M, N, K, A3, B3, C, Cx, epi, bias, aux_in, aux_out):
-    return lib.uniter_gemm_x3_cfg(cfg, ns, akm, bkm, M, N, K, L.ptr(A3), A3.shape[2], L.ptr(B3), B3.shape[2], L.ptr(C), N, M * N,
-                                  L.ptr(Cx), N, epi, L.ptr(bias), L.ptr(aux_in), L.ptr(aux_out), N, L.cur_stream())
+    return lib.uniter_gemm_x3_cfg(cfg, ns, akm, bkm, M, N, K, L.ptr(A3), 3 * A3.shape[2], A3.shape[2], L.ptr(B3), 3 * B3.shape[2], B3.shape[2],
+                                  L.ptr(C), N, M * N, L.ptr(Cx), 3 * N, N, epi, L.ptr(bias), L.ptr(aux_in), L.ptr(aux_out), N, L.cur_stream())
 
 
 def f32_gemm(akm, bkm, M, N, K, A, B, C, epi, bias, aux_in, aux_out, beta=0):
@@ -45,7 +48,7 @@ def errs(got, ref):
 
 
 # name, akm, bkm, M, N, K, epi
-shapes = [('qkv_fwd', 0, 0, MM, 3 * HH, HH, 1), ('attnout_fwd', 0, 0, MM, HH, HH, 1), ('ffnup_fwd', 0, 0, MM, II, HH, 5),
+shapes = [('plain_fwd', 0, 0, MM, II, HH, 0), ('qkv_fwd', 0, 0, MM, 3 * HH, HH, 1), ('attnout_fwd', 0, 0, MM, HH, HH, 1), ('ffnup_fwd', 0, 0, MM, II, HH, 5),
           ('ffndown_fwd', 0, 0, MM, HH, II, 1), ('ffndown_dgrad', 0, 1, MM, II, HH, 6), ('ffnup_dgrad', 0, 1, MM, HH, II, 4),
           ('attnout_dgrad', 0, 1, MM, HH, HH, 0), ('qkv_dgrad', 0, 1, MM, HH, 3 * HH, 4),
           ('w2_wgrad', 1, 1, HH, II, MM, 0), ('w1_wgrad', 1, 1, II, HH, MM, 0), ('wo_wgrad', 1, 1, HH, HH, MM, 0),
@@ -78,7 +81,7 @@ if os.environ.get('LAB_ACC', '1') == '1':
     x = torch.randn(300, 512, device='cuda') * torch.exp(torch.randn(300, 512, device='cuda') * 4)
     x3 = split3(x)
     back = torch.empty_like(x)
-    L.check(lib.uniter_join3(L.ptr(x3), 300, 512, 512, L.ptr(back), 512, L.cur_stream()), 'join3')
+    L.check(lib.uniter_join3(L.ptr(x3), 300, 512, 3 * 512, 512, L.ptr(back), 512, L.cur_stream()), 'join3')
     torch.cuda.synchronize()
     print('split3 -> join3 round trip: max |diff| / |x| = %.3g (0 = exact)' % ((back - x).abs() / x.abs()).max().item())
     p64 = x3.double().sum(1)
@@ -158,7 +161,7 @@ if os.environ.get('LAB_TIME', '1') == '1':
         Cs = [torch.zeros(m, n, device='cuda') for m, n in shp]
         IA = ctypes.c_int * 4; PA = ctypes.c_void_p * 4
         fl = sum(2.0 * m * n * MM for m, n in shp)
-        for cfg in [int(c) for c in os.environ.get('LAB_WG_CFGS', '1,2,11,12').split(',')]:
+        for cfg in [int(c) for c in os.environ.get('LAB_WG_CFGS', '1,2,3').split(',')]:
             for wgs in (0, 256):
                 run = lambda cfg=cfg, wgs=wgs: L.check(lib.uniter_wgrad_x3_group(cfg, 4, IA(*[m for m, n in shp]), IA(*[n for m, n in shp]), MM,
                                                        PA(*[a.data_ptr() for a in As]), PA(*[b.data_ptr() for b in Bs]),
