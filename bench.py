@@ -29,7 +29,10 @@ BASE = dict(attention_probs_dropout_prob=0.1, hidden_act='gelu', hidden_dropout_
             type_vocab_size=2, vocab_size=28996)       # == reference config/uniter-base.json
 LARGE = dict(BASE, hidden_size=1024, intermediate_size=4096, num_attention_heads=16, num_hidden_layers=24)
 
-PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}       # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32)
+# MI355X_MICROARCH.md: fp32 matrix pipe (v_mfma_f32_32x32x2_f32) 157.3; bf16 dense 2500.  'f32x3': the fp32 mode's dense
+# products as SIX bf16 MFMA products per block (three bf16 pieces per fp32 value, fp32 accumulate: csrc/gemm_split3.hip) --
+# 2500 / 6 = 416.7 TFLOP/s of fp32-equivalent work at the bf16 pipe's peak
+PEAK_TFLOPS = {'f32': 157.3, 'f32x3': 2500.0 / 6.0, 'bf16': 2500.0}
 
 
 def flops_per_step(cfg, B, T, R, L=None, lens=None):
@@ -59,10 +62,34 @@ def _lscpu_model():
     return 'unknown'
 
 
+def _physical_cores():
+    """Physical cores the process may run on: distinct (socket, core) pairs of the CPUs in its affinity mask (lscpu -p);
+    falls back to the affinity count."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    try:
+        import subprocess
+        out = subprocess.run(['lscpu', '-p=CPU,CORE,SOCKET'], capture_output=True, text=True, timeout=10).stdout
+        cores = set()
+        for line in out.splitlines():
+            if line.startswith('#') or not line.strip():
+                continue
+            cpu, core, sock = (int(x) if x else 0 for x in line.split(',')[:3])
+            if cpu in allowed:
+                cores.add((sock, core))
+        if cores:
+            return len(cores)
+    except Exception:
+        pass
+    return max(1, len(allowed))
+
+
 def cpu_baseline(seconds_budget=30.0):
     """Reported baseline only: the CPU oracle (port of the reference forward; autograd backward) on
-    BASELINE config 1 (B=4, T=64, R=36, UNITER-base, dropout on), timed on this box's host cores: N threads
-    (3 warm-up + up to 10 timed steps) and one thread (1 warm-up + up to 2 timed steps), both bounded by the budget."""
+    BASELINE config 1 (B=4, T=64, R=36, UNITER-base, dropout on), timed on this box's host cores: N = physical cores, 32
+    threads where that differs, and one thread (1 warm-up + up to 2 timed steps), all bounded by the budget."""
     import torch
     from oracle import uniter_oracle as O
     from oracle import step_oracle as S
@@ -89,17 +116,24 @@ def cpu_baseline(seconds_budget=30.0):
         return (time.perf_counter() - t0) / max(n, 1), n
 
     hw = os.cpu_count() or 1
-    nthreads = min(torch.get_num_threads(), 32)      # more threads than ~32 slow the small CPU ops down
-    dt, n = timed(nthreads, 3, 10, seconds_budget * 0.6)
-    dt1, n1 = timed(1, 1, 2, seconds_budget * 0.4)
-    torch.set_num_threads(nthreads)
-    return {'value': round(4.0 / dt, 3), 'unit': 'samples/s', 'cores': nthreads, 'kind': 'port',
-            'gflops': round(4.0 / dt * gf_per_sample, 1),
+    phys = _physical_cores()
+    legs = []
+    # N = the physical cores the process may use, and the 32-thread figure of earlier rounds (more threads
+    # than ~32 slow the oracle's small CPU ops down on a many-core host): `value` is the better of the two, `cores` says which
+    for nt in sorted({phys, min(phys, 32)}, reverse=True):
+        dt, n = timed(nt, 2, 8, seconds_budget * 0.3)
+        legs.append({'cores': nt, 'value': round(4.0 / dt, 3), 'gflops': round(4.0 / dt * gf_per_sample, 1), 'steps': n, 's_per_step': round(dt, 3)})
+    dt1, n1 = timed(1, 1, 2, seconds_budget * 0.3)
+    best = max(legs, key=lambda l: l['value'])
+    torch.set_num_threads(best['cores'])
+    return {'value': best['value'], 'unit': 'samples/s', 'cores': best['cores'], 'kind': 'port',
+            'gflops': best['gflops'], 'by_cores': legs, 'physical_cores': phys,
             'single_thread': {'value': round(4.0 / dt1, 3), 'gflops': round(4.0 / dt1 * gf_per_sample, 1), 'steps': n1},
             'cpu_model': _lscpu_model(), 'os_cpu_count': hw,
-            'sample': 'config 1: UNITER-base B=4 T=64 R=36 fwd+bwd, %d steps after 3 warm-ups on %d threads (%.3f s/step), '
-                      '%d steps after 1 warm-up on 1 thread (%.2f s/step); oracle/uniter_oracle.py (torch CPU fp32, dropout on)'
-                      % (n, nthreads, dt, n1, dt1)}
+            'sample': 'config 1: UNITER-base B=4 T=64 R=36 fwd+bwd after 2 warm-ups per leg: %s; %d steps after 1 warm-up on 1 '
+                      'thread (%.2f s/step); oracle/uniter_oracle.py (torch CPU fp32, dropout on)'
+                      % ('; '.join('%d steps on %d threads (%.3f s/step)' % (l['steps'], l['cores'], l['s_per_step']) for l in legs),
+                         n1, dt1)}
 
 
 def pmc_traffic(args, M, cfgd, build_info):
@@ -129,6 +163,63 @@ def pmc_traffic(args, M, cfgd, build_info):
     return out
 
 
+def parse_rccl_log(path):
+    """What RCCL says it built, from rank 0's NCCL_DEBUG=INFO log (INIT,GRAPH,TUNING): channel count, ring / tree graphs,
+    and the algorithm / protocol of the collectives where the TUNING lines name them.  Every field is None when the log has no
+    such line (the format is RCCL's, not a contract)."""
+    import re
+    out = {'channels': None, 'graphs': None, 'algorithm': None, 'protocol': None, 'log_lines': 0}
+    try:
+        text = open(path, errors='replace').read()
+    except OSError:
+        return out
+    lines = text.splitlines()
+    out['log_lines'] = len(lines)
+    ch = [int(m.group(2)) for m in re.finditer(r'Channel (\d+)/(\d+)', text)]
+    if ch:
+        out['channels'] = max(ch)
+    else:
+        m = re.search(r'(\d+) coll channels', text) or re.search(r'nChannels (\d+)', text)
+        if m:
+            out['channels'] = int(m.group(1))
+    graphs = sorted({g for g in ('Ring', 'Tree', 'CollNet', 'NVLS') if re.search(r'\b%s\b' % g, text)})
+    out['graphs'] = graphs or None
+    algos = re.findall(r'[Aa]lgo(?:rithm)?[ =:]+(\w+)', text)
+    protos = re.findall(r'[Pp]roto(?:col)?[ =:]+(\w+)', text)
+    if algos:
+        out['algorithm'] = max(set(algos), key=algos.count)
+    if protos:
+        out['protocol'] = max(set(protos), key=protos.count)
+    return out
+
+
+def comm_block(sync, steps, rccl_log):
+    """The `comm` block of the line (N > 1 or a forced one-rank exchange): per collective of a step its payload bytes, the time
+    from its issue to the moment the optimizer's stream had it, and the part of that the optimizer's stream WAITED (exposed);
+    payload dtype; and RCCL's own report.  Times are means over the timed steps (dp.GradSync.collect_timings)."""
+    sync.collect_timings()
+    recs = sync.timings
+    by = {}
+    for r in recs:
+        by.setdefault((r['start'], r['end']), []).append(r)
+    cols = []
+    for (s0, e0), rs in sorted(by.items()):
+        cols.append({'elements': e0 - s0, 'bytes': rs[0]['bytes'], 'per_step': round(len(rs) / max(steps, 1), 2),
+                     'issue_to_done_ms': round(sum(r['issue_to_done_ms'] for r in rs) / len(rs), 4),
+                     'exposed_ms': round(sum(r['exposed_ms'] for r in rs) / len(rs), 4)})
+    out = {'payload': sync.payload, 'world': sync.world, 'collectives': cols,
+           'bytes_per_step': int(sum(c['bytes'] * c['per_step'] for c in cols)),
+           'exposed_ms_per_step': round(sum(c['exposed_ms'] * c['per_step'] for c in cols), 4),
+           'sparse_steps': sync.sparse_steps,
+           'sparse_rows_per_rank': getattr(sync, 'last_sparse_rows', None),
+           'note': 'dense all-reduces only are timed (issue: event on the issuing stream in front of the collective; done: event behind '
+                   'the consumer stream\'s wait); the sparse row exchange is summed in place on its issuing stream'}
+    if rccl_log:
+        out['rccl'] = parse_rccl_log(rccl_log)
+    sync.timings = []
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -138,8 +229,13 @@ def parse_args(argv=None):
     ap.add_argument('--txt_len', type=int, default=128)
     ap.add_argument('--num_bb', type=int, default=36)
     ap.add_argument('--model', choices=['base', 'large'], default='base')
-    ap.add_argument('--precision', choices=['fp32', 'fp32x3', 'bf16'], default='fp32',
-                    help="fp32 (BASELINE configs[1], default) or bf16: bf16 MFMA for the dense GEMMs, fp32 elsewhere (configs[2])")
+    ap.add_argument('--precision', choices=['fp32x3', 'fp32', 'bf16'], default='fp32x3',
+                    help="fp32x3 (default: BASELINE configs[1] in fp32 arithmetic -- the encoder's dense products as six bf16 MFMA "
+                         "products per block on three bf16 pieces per fp32 value, fp32 accumulate, no less accurate than the fp32 "
+                         "MFMA kernels), fp32 (the same step on the native fp32 MFMA kernels), or bf16: bf16 MFMA for the dense "
+                         "GEMMs, fp32 elsewhere (configs[2])")
+    ap.add_argument('--no_native_leg', action='store_true',
+                    help='fp32x3 at N = 1: skip the native-fp32 timing of the same step in the same process (native_fp32 in the line)')
     ap.add_argument('--workload', choices=['finetune', 'multitask'], default='finetune',
                     help='finetune = MemeUniter step (BASELINE configs[1-3], default); multitask = UNITER + ITM/MLM/MRFR '
                          'heads, one task drawn per step (configs[4]; use --batch 32)')
@@ -233,6 +329,13 @@ def run_rank(args):
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
     use_dist = world > 1 or 'RANK' in os.environ
+    rccl_log = None
+    if use_dist and rank == 0 and backend == 'nccl' and 'NCCL_DEBUG' not in os.environ:
+        # RCCL's own account of what it built (rings / trees, channels) for the `comm` block of the line: rank 0's INFO log
+        # goes to a file (NCCL_DEBUG_FILE), parsed after the run
+        import tempfile
+        rccl_log = os.path.join(tempfile.gettempdir(), 'uniter_rccl_rank0_%d.log' % os.getpid())
+        os.environ.update(NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,GRAPH,TUNING', NCCL_DEBUG_FILE=rccl_log)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
@@ -285,7 +388,8 @@ def run_rank(args):
     sync = None
     if use_dist:
         dp.broadcast_parameters(model)
-        sync = dp.attach(model, sparse_embeddings=args.dp_sparse_embeddings)
+        sync = dp.attach(model, sparse_embeddings=args.dp_sparse_embeddings, accum=config['gradient_accumulation'])
+        sync.timing = True
     if args.workload == 'finetune':
         step = TrainStep(model, opt, sched, config, grad_sync=sync)
 
@@ -329,11 +433,45 @@ def run_rank(args):
     if args.prof_kind:
         # in-kernel launch stamps of every GEMM (two atomics per wave, nothing added to the streams)
         _lib.check(lib.uniter_prof_enable_stamps(handle, 1, None))
+    if sync is not None:
+        sync.collect_timings()           # drop the warm-up's records
+        sync.timings = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     barrier()
     dt = time.perf_counter() - t0
+    comm = None
+    if sync is not None:
+        comm = comm_block(sync, args.steps, rccl_log if rank == 0 else None)
+        comm['sparse_embeddings'] = bool(args.dp_sparse_embeddings)
+        # N > 1: the same timed region once more with the other form of the word-embedding exchange (dense table all-reduce
+        # <-> touched rows only); `value` is the better of the two, the line says which and carries both
+        if world > 1 and args.steps >= 20 and args.workload == 'finetune' and os.environ.get('UNITER_BENCH_ONE_EXCHANGE') != '1':
+            alt_sparse = not args.dp_sparse_embeddings
+            sync2 = dp.attach(model, sparse_embeddings=alt_sparse, accum=config['gradient_accumulation'])
+            sync2.timing = True
+            step.grad_sync = sync2
+            for _ in range(max(3, args.warmup // 2)):
+                one_step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            barrier()
+            dt2 = time.perf_counter() - t1
+            t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+            alt = comm_block(sync2, args.steps, None)
+            alt['sparse_embeddings'] = alt_sparse
+            alt['ms_per_step'] = round(dt2 / args.steps * 1e3, 3)
+            alt['value'] = round(B * world * args.steps / dt2, 2)
+            comm['other_exchange'] = alt
+            step.grad_sync = sync
+            um = getattr(model, 'uniter_model', None)
+            if um is not None:
+                um._grad_hook = sync.hook
     NK = 11
     k_n, k_ms = (C.c_int * NK)(), (C.c_double * NK)()          # GEMM families: stamps taken INSIDE the timed region
     e_n, e_ms = (C.c_int * NK)(), (C.c_double * NK)()          # attention / LayerNorm: HIP events in a separate pass
@@ -361,6 +499,31 @@ def run_rank(args):
             for k in range(NK):
                 k_n[k] = 0; e_n[k] = 0
     loss = float((step.last_loss if args.workload == 'finetune' else last['loss']).item())
+    native = None
+    if args.precision == 'fp32x3' and world == 1 and not use_dist and not args.no_native_leg:
+        # the same step on the native fp32 MFMA kernels, same process and box: what the six-product form is measured against
+        try:
+            st_ = model.param_store()
+            encoder.precision = 'fp32'
+            saved_mirror, st_.mirror = getattr(st_, 'mirror', None), None      # (the optimizer would keep writing the pieces)
+            for _ in range(5):
+                one_step()
+            torch.cuda.synchronize()
+            nsteps = min(args.steps, 20)
+            tn = time.perf_counter()
+            for _ in range(nsteps):
+                one_step()
+            torch.cuda.synchronize()
+            dtn = time.perf_counter() - tn
+            native = {'value': round(B * nsteps / dtn, 2), 'ms_per_step': round(dtn / nsteps * 1e3, 3), 'steps': nsteps,
+                      'kernels': 'gemm_f32_v3_kernel (v_mfma_f32_32x32x2_f32) for every dense product; everything else identical'}
+            st_.mirror = saved_mirror
+            st_.mirror_dirty = True
+            encoder.precision = 'fp32x3'
+            one_step()                                   # back in the timed mode (the weight pieces are refreshed here)
+            torch.cuda.synchronize()
+        except Exception as e:                               # noqa: BLE001
+            native = {'error': repr(e)}
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -374,8 +537,11 @@ def run_rank(args):
         cur = batch if args.workload == 'finetune' else batches['itm']
         total, ffn, ffn_up = flops_per_step(cfgd, B, T, R, L_eff, cur['seq_lens'] if args.packed else None)
         M_eff = sum(cur['seq_lens']) if args.packed else B * L_eff
-        dt_name = 'f32' if args.precision in ('fp32', 'fp32x3') else 'bf16'
-        peak = PEAK_TFLOPS[dt_name]
+        dt_name = 'f32' if args.precision in ('fp32', 'fp32x3') else 'bf16'       # the arithmetic type of the path's results
+        pk_name = {'fp32': 'f32', 'fp32x3': 'f32x3', 'bf16': 'bf16'}[args.precision]
+        peak = PEAK_TFLOPS[pk_name]                    # the dense products' pipe
+        # attention runs on the fp32 matrix pipe in both fp32 modes (L <= 192 in the bf16 mode: on the bf16 pipe)
+        peak_attn = PEAK_TFLOPS['bf16' if args.precision == 'bf16' else 'f32']
         H, I, nl = cfgd['hidden_size'], cfgd['intermediate_size'], cfgd['num_hidden_layers']
         sq = sum(n * n for n in cur['seq_lens']) if args.packed else B * L_eff * L_eff
         g_qkv, g_o, g_ffn = 2.0 * M_eff * H * 3 * H, 2.0 * M_eff * H * H, 2.0 * M_eff * H * I
@@ -387,7 +553,11 @@ def run_rank(args):
                5: ('attention_fwd', 'mfma', nl * att), 6: ('gemm_dgrad', 'mfma', nl * (g_qkv + g_o + 2 * g_ffn)),
                7: ('gemm_wgrad', 'mfma', nl * (g_qkv + g_o + 2 * g_ffn)), 8: ('attention_bwd', 'mfma', nl * 2 * att),
                9: ('layernorm_fwd', 'hbm', nl * 2 * 16.0 * M_eff * H), 10: ('layernorm_bwd', 'hbm', nl * 2 * 16.0 * M_eff * H)}
-        kernel_of = {'f32': {1: 'gemm_f32_v3_kernel<64,64,false,false,TAG=1>', 6: 'gemm_f32_v3_kernel<64,64,false,true,...>',
+        x3k = 'gemm_s3p_kernel<128,128,..> (csrc/gemm_split3.hip: x3 operands, six v_mfma_f32_32x32x16_bf16 per block, persistent, loader + compute waves)'
+        kernel_of = {'f32x3': {1: x3k + ', bias + GELU epilogue, activation out as x3 pieces + gelu\' fp32', 2: x3k + ', two k-pieces (slabs summed by the LayerNorm pass)',
+                               3: x3k, 4: x3k + ', two k-pieces', 6: x3k + ' (weights k-major: ds_read_b64_tr_b16)',
+                               7: x3k + ': the four weight gradients of a layer in ONE launch of whole-K tiles (both operands k-major)'},
+                     'f32': {1: 'gemm_f32_v3_kernel<64,64,false,false,TAG=1>', 6: 'gemm_f32_v3_kernel<64,64,false,true,...>',
                              7: 'gemm_f32_v3_kernel<64,64,true,true,0,false> (whole-K 64x64 tiles; UNITER_WGRAD_WHOLE=0: the stream-K form); layer 0: '
                                 'gemm_f32_wgrad_group_kernel (its four products as one launch)'},
                      'bf16': {1: 'gemm_dma_kernel<128,128,false,false,SWAP,2,EPI=5> (bias + GELU + gelu\' bf16)',
@@ -399,11 +569,11 @@ def run_rank(args):
             if n == 0 or not tot > 0:          # nothing (or nothing sane) recorded for this family: leave it out
                 continue
             sec = tot * 1e-3 / steps                   # seconds of this family per step
-            pk = peak * 1e12 if bound == 'mfma' else 8.0e12
+            pk = (peak_attn if name.startswith('attention') else peak) * 1e12 if bound == 'mfma' else 8.0e12
             families.append({'family': name, 'bound': bound, 'launches_per_step': n // steps,
                              'avg_us': round(tot * 1e3 / n, 2), 'ms_per_step': round(sec * 1e3, 4),
                              'achieved': round(work / sec / 1e12, 2), 'unit': 'TFLOP/s' if bound == 'mfma' else 'TB/s',
-                             'frac': round(work / sec / pk, 4), 'kernel': kernel_of[dt_name].get(k),
+                             'frac': round(work / sec / pk, 4), 'peak': round(pk / 1e12, 1) if bound == 'mfma' else 8.0, 'kernel': kernel_of[pk_name].get(k),
                              'measured': 'in-kernel stamps inside the timed region' if in_run else
                                          'HIP events, separate %d-step pass after the timed region (%.2f ms/step under events)' % (EV_STEPS, ev_ms)})
         out = {
@@ -417,7 +587,10 @@ def run_rank(args):
                                     'dropout 0.1; BASELINE configs[4]; FLOP fractions count the encoder only), ') % args.model +
                                    'batch %d per GPU, %d regions x 2048, %d text tokens%s, %s'
                                    % (B, R, T, (' (ragged: joint length %d%s)' % (L_eff, ', packed' if args.packed else '')) if args.ragged else '',
-                                      'fp32 (BASELINE configs[1])' if args.precision == 'fp32'
+                                      'fp32 (BASELINE configs[1]; native fp32 MFMA kernels)' if args.precision == 'fp32' else
+                                      'fp32 (BASELINE configs[1]); dense products by an exact 3 x bf16 operand split: 6 MFMA products '
+                                      'per block, fp32 accumulate (error vs float64 <= the native fp32 MFMA kernel\'s: '
+                                      'tests/test_gemm_x3_gpu.py), attention / LayerNorm / loss / optimizer fp32' if args.precision == 'fp32x3'
                                       else 'bf16 MFMA GEMMs / fp32 storage (BASELINE configs[2])'),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        # what torch.distributed itself reports (not the flag): lets the driver verify the collective saw N ranks
@@ -430,10 +603,26 @@ def run_rank(args):
                        'grad_payload': sync.payload if sync is not None else None,
                        'dp_sparse_embedding_steps': sync.sparse_steps if sync is not None else 0,
                        'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')},
-            'step_mfma_frac': round(total / (ms * 1e-3) / (peak * 1e12), 4),
+            # the step's matrix work priced on the pipes it runs on (dense products at `peak`, attention at its own) over the step time
+            'step_mfma_frac': round(((total - 3 * nl * att) / (peak * 1e12) + 3 * nl * att / (peak_attn * 1e12)) / (ms * 1e-3), 4),
             'ffn_roofline_frac': round(ffn / (ms * 1e-3) / (peak * 1e12), 4),
+            'peak_tflops': {'dense_products': round(peak, 1), 'attention': round(peak_attn, 1),
+                            'derivation': ('2500 (bf16 dense, MI355X_MICROARCH.md) / 6 products per fp32-equivalent block = 416.7'
+                                           if args.precision == 'fp32x3' else 'MI355X_MICROARCH.md')},
             'final_loss': round(loss, 5),
         }
+        if native is not None:
+            out['native_fp32'] = native
+        if comm is not None:
+            if 'other_exchange' in comm and comm['other_exchange'].get('value', 0) > out['value']:
+                # the better exchange is the headline; the first region's figures move into the block
+                first = {'sparse_embeddings': comm['sparse_embeddings'], 'value': out['value'], 'ms_per_step': out['ms_per_step']}
+                out['value'], out['ms_per_step'] = comm['other_exchange']['value'], comm['other_exchange']['ms_per_step']
+                comm['headline_exchange'] = 'sparse word-embedding rows' if comm['other_exchange']['sparse_embeddings'] else 'dense'
+                comm['first_region'] = first
+            else:
+                comm['headline_exchange'] = 'sparse word-embedding rows' if comm['sparse_embeddings'] else 'dense'
+            out['comm'] = comm
         if prof_error:
             out['profiling_error'] = prof_error
         if families:
@@ -500,16 +689,17 @@ def optimizer_alone(out, opt, model):
     torch.cuda.synchronize()
     opt.overlap_encoder = saved
     o_ms = e0.elapsed_time(e1) / 10
-    # read p, g, m, v + write p, m, v = 28 B per parameter; + 4 B where the gradient is cleared (everything but the encoder
-    # layers' weight matrices, which the next backward pass overwrites: FusedAdam.lazy_zero_encoder)
+    # read p, g, m, v + write p, m, v = 28 B per parameter.  The 10 timed launches find every gradient ZERO (the launch before
+    # them cleared it) and adam_kernel stores the zero_grad clear only where something was written: no clear bytes here.  The
+    # weight mirror of the bf16 / fp32x3 modes adds its 2 / 6 bytes per parameter (this measurement runs one launch over the whole
+    # buffer: every parameter is mirrored; in the step only the encoder layers' are)
     st = model.param_store()
-    lazy = sum(p.numel() for n, p in st.params.items() if '.encoder.layer.' in '.' + n and n.endswith(opt.LAZY_SUFFIXES)) \
-        if opt.lazy_zero_encoder is not None and os.environ.get('UNITER_LAZY_ZERO') != '0' else 0
-    nbytes = 32 * numel - 4 * lazy
+    mirror_b = 2 * getattr(st, 'mirror_pieces', 1) if getattr(st, 'mirror', None) is not None else 0
+    nbytes = (28 + mirror_b) * numel
     out['optimizer'] = {'bound': 'hbm', 'bytes': nbytes, 'bytes_per_parameter': round(nbytes / numel, 2), 'ms': round(o_ms, 4),
                         'achieved': round(nbytes / (o_ms * 1e-3) / 1e12, 3), 'unit': 'TB/s', 'peak': 8.0,
                         'frac': round(nbytes / (o_ms * 1e-3) / 8.0e12, 4),
-                        'note': 'adam_kernel alone, 10 launches (after 2 warm-ups) behind the timed region, every chunk on the update path'}
+                        'note': 'adam_kernel alone, 10 launches (after 2 warm-ups) behind the timed region, every chunk on the update path, gradients already zero (no clear stores)%s' % (', + %d B / parameter of weight mirror' % mirror_b if mirror_b else '')}
 
 
 if __name__ == '__main__':

@@ -18,5 +18,7 @@ extern "C" const char* uniter_build_info(void) {
   return "libuniter_hip gfx950 fp32-mfma (built " __DATE__ " " __TIME__ ")";
 }
 
-unsigned long long* g_uniter_stamp_slot = nullptr;
-int g_uniter_launch_prio = 0;
+// the "next launch" side channel of common.h: one per HOST THREAD, so that two threads driving two model handles (cross-
+// validation folds in threads, a DataParallel-style caller) can never take each other's stamp slot or wave priority
+thread_local unsigned long long* g_uniter_stamp_slot = nullptr;
+thread_local int g_uniter_launch_prio = 0;

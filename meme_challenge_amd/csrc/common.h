@@ -32,9 +32,10 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // Measured alternatives: a HIP event pair around each launch costs ~7 us on the stream and breaks the overlap of the
 // two backward streams (fp32 step +11 %, bf16 +27 %); 64-bit atomicMin / atomicMax into ONE slot serialise at the
 // memory side (~50 ns each, thousands per launch: +16 % / +35 %).  The launch that reads the pointer resets it.
-// One host thread per model (include/uniter_hip.h).
+// thread_local: the model call that sets it and the launch that takes it run on one host thread (the schedule of a model call
+// is one C function); another thread's launches have their own.
 #define STAMP_WGS 1024
-extern unsigned long long* g_uniter_stamp_slot;
+extern thread_local unsigned long long* g_uniter_stamp_slot;
 static inline unsigned long long* take_stamp_slot() {
   unsigned long long* s = g_uniter_stamp_slot;
   g_uniter_stamp_slot = nullptr;
@@ -45,8 +46,8 @@ static inline unsigned long long* take_stamp_slot() {
 // it resets it).  fp32 matrix and vector instructions share one issue pipe per SIMD and two kernels that share a CU are
 // arbitrated wave by wave by priority, then age: the model's schedule gives the kernels of its critical path (forward,
 // input-gradient chain, attention, row passes) a higher level than the weight-gradient launches of the side stream, which have
-// slack (HIP stream priorities do not reach this arbitration: measured no effect).  One host thread per model.
-extern int g_uniter_launch_prio;
+// slack (HIP stream priorities do not reach this arbitration: measured no effect).  thread_local, as the stamp slot.
+extern thread_local int g_uniter_launch_prio;
 static inline int take_launch_prio() {
   const int p = g_uniter_launch_prio;
   g_uniter_launch_prio = 0;

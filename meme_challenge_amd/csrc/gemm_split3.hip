@@ -610,8 +610,8 @@ int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
 }
 
 // cfg: tile geometry (all: 128 x 128 tiles, three 32-deep stages = 144 KB of LDS, one persistent workgroup per CU)
-//   1: 8 compute waves of 64 x 32 + 4 loader waves (default)
-//   2: 4 compute waves of 64 x 64 + 4 loader waves
+//   1: 8 compute waves of 64 x 32 + 4 loader waves
+//   2: 4 compute waves of 64 x 64 + 4 loader waves (default)
 //   3: as 1 with the second four compute waves half a k-tile behind the first (STAG; measured: no gain)
 template <bool AKM, bool BKM, int EPI>
 int dispatch_cfg3p(int cfg, const S3Group& G, int max_wgs, hipStream_t st) {
@@ -756,7 +756,7 @@ int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, i
   g.dbg = cfg >> 8; cfg &= 0xff;
   g.stamp = take_stamp_slot();
   g.prio = take_launch_prio();
-  if (cfg == 0) cfg = 1;
+  if (cfg == 0) cfg = 2;       // in the step: 4 x (64 x 64) compute waves + 4 loaders, +1.2 % over cfg 1 (8 x (64 x 32))
   hipStream_t st = (hipStream_t)stream;
   if (a_kmajor) return dispatch_epi3<true, true>(cfg, g, epilogue, st);
   return b_kmajor ? dispatch_epi3<false, true>(cfg, g, epilogue, st) : dispatch_epi3<false, false>(cfg, g, epilogue, st);
@@ -842,7 +842,7 @@ int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, con
   }
   G.start[4] = total;
   for (int p = n; p < 4; ++p) G.start[p] = total;
-  if (cfg == 0) cfg = 1;
+  if (cfg == 0) cfg = 2;
   hipStream_t st = (hipStream_t)stream;
   return overwrite ? dispatch_cfg3p<true, true, S3_NONE>(cfg, G, max_wgs, st) : dispatch_cfg3p<true, true, S3_ADD>(cfg, G, max_wgs, st);
 }

@@ -55,9 +55,13 @@ import torch.distributed as dist
 
 
 class GradSync(object):
-    def __init__(self, flat_grads, bucket_ranges, group=None, bucket_bytes=32 << 20, payload='fp32', word_table=None):
+    def __init__(self, flat_grads, bucket_ranges, group=None, bucket_bytes=32 << 20, payload='fp32', word_table=None,
+                 accum=1):
         """word_table: (start, rows, row_len) of the word-embedding gradient inside the LAST bucket (it must open that
-        bucket) -- enables the sparse exchange for steps that announce their token ids to ``prepare``."""
+        bucket) -- enables the sparse exchange for steps that announce their token ids to ``prepare``.
+        accum: micro-batches per optimizer step (gradient_accumulation): the sparse exchange carries the ids of ALL of them,
+        so its agreed capacity is sized for a full window (the first exchange of an epoch comes after ONE micro-batch:
+        the reference's iteration-0 quirk, train_template.py:95-109)."""
         if payload not in ('fp32', 'bf16'):
             raise ValueError("payload must be 'fp32' or 'bf16'")
         self.flat = flat_grads
@@ -76,6 +80,12 @@ class GradSync(object):
         self._tokens = []                         # token ids of the micro-batches accumulated since the last exchange
         self._tokens_dense = False                # one of them had a dense word-embedding gradient
         self._cap = None                          # ids per rank and exchange, agreed over the ranks at the first sparse step
+        self.accum = max(1, int(accum))
+        self._micro = 0                           # micro-batches recorded since the last exchange
+        # timing of the collectives (bench.py --gpus N: the `comm` block): events on the issuing / waiting streams
+        self.timing = False
+        self.timings = []                         # per collective: dict(bytes, issue_to_done_ms, exposed_ms, start, end)
+        self._timing_open = []
         self.sparse_steps = 0                     # exchanges that took the sparse path (for tests / the bench line)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -104,23 +114,29 @@ class GradSync(object):
         # UNITER_DP_FORCE=1 exercises the collective path on a single rank (testing only)
         self.active = bool(will_step) and (self.world > 1 or os.environ.get('UNITER_DP_FORCE') == '1')
         self._inflight, self._pending, self._next, self.launched, self.launch_streams = [], None, 0, [], []
-        if self.word_table is not None:
+        exchanging = self.world > 1 or os.environ.get('UNITER_DP_FORCE') == '1'
+        if self.word_table is not None and exchanging:      # (no exchange possible: nothing to remember -- the lists would only grow)
             if token_ids is None:
                 self._tokens_dense = True
             else:
                 self._tokens.append(token_ids.reshape(-1).to(torch.int64))
+            self._micro += 1
             self._sorted = None
             if self.active and not self._tokens_dense:
                 # sorted ids and first-occurrence marks now, next to the forward: nothing of it waits for the backward
                 ids = self._tokens[0] if len(self._tokens) == 1 else torch.cat(self._tokens)
                 if self._cap is None:             # once: the ranks agree on a capacity (the only host synchronisation)
-                    cap = torch.tensor([ids.numel()], dtype=torch.int64, device=ids.device)
+                    # per micro-batch, times the micro-batches of a full accumulation window: the first exchange may come
+                    # after fewer of them than the later ones
+                    per = (ids.numel() + self._micro - 1) // max(1, self._micro)
+                    cap = torch.tensor([per * max(self.accum, self._micro)], dtype=torch.int64, device=ids.device)
                     if self.world > 1:
                         dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=self.group)
                     self._cap = int(cap.item())
                 if ids.numel() > self._cap:
                     raise ValueError('sparse embedding exchange: %d token ids in a step, capacity agreed at the first '
-                                     'step is %d (same batch shape on every rank and step)' % (ids.numel(), self._cap))
+                                     'step is %d (same batch shape on every rank and step, gradient_accumulation = %d '
+                                     'passed to dp.attach)' % (ids.numel(), self._cap, self.accum))
                 srt = ids.sort().values
                 first = torch.ones_like(srt, dtype=torch.bool)
                 first[1:] = srt[1:] != srt[:-1]
@@ -150,7 +166,7 @@ class GradSync(object):
         while self._next < len(self.ranges):
             self._add_bucket(self._next, None)
         self._flush(None)
-        self._tokens, self._tokens_dense = [], False
+        self._tokens, self._tokens_dense, self._micro = [], False, 0
 
     def wait_range(self, lo, hi):
         """Make the CURRENT stream wait for the buckets that overlap flat[lo:hi] (and widen their bf16
@@ -164,10 +180,39 @@ class GradSync(object):
             if work is None:                      # the sparse exchange: summed in place on the issuing stream
                 rec[3] = True
                 continue
+            t = self._timing_of(s, e)
+            if t is not None:
+                t['w0'] = torch.cuda.Event(enable_timing=True)
+                t['w0'].record()
             work.wait()
+            if t is not None:
+                t['w1'] = torch.cuda.Event(enable_timing=True)
+                t['w1'].record()
             if self.comm is not None and not self.consumer_reads_comm:
                 self.flat[s:e].copy_(self.comm[s:e])
             rec[3] = True
+
+    # -- timing (bench.py) -----------------------------------------------------------
+    def _timing_of(self, s, e):
+        if not self.timing:
+            return None
+        return next((t for t in self._timing_open if t['start'] == s and t['end'] == e and 'w1' not in t), None)
+
+    def collect_timings(self):
+        """Close the records of the step(s) since the last call (synchronises): per collective its payload bytes, the time
+        from its issue (event on the issuing stream, in front of the collective) to the point where the consumer's stream
+        had it (event behind the consumer's wait), and the part of that the consumer's stream spent waiting (exposed)."""
+        out = []
+        if self.flat.is_cuda:
+            torch.cuda.synchronize()
+        for t in self._timing_open:
+            if 'w1' not in t:
+                continue
+            out.append({'start': t['start'], 'end': t['end'], 'bytes': t['bytes'],
+                        'issue_to_done_ms': t['e0'].elapsed_time(t['w1']), 'exposed_ms': t['w0'].elapsed_time(t['w1'])})
+        self._timing_open = []
+        self.timings.extend(out)
+        return out
 
     # -- driven by the model's backward schedule -----------------------------------
     def hook(self, kind, index, stream):
@@ -199,7 +244,7 @@ class GradSync(object):
         self._flush(stream)
         if sparse:
             self._exchange_rows(stream)
-        self._tokens, self._tokens_dense = [], False
+        self._tokens, self._tokens_dense, self._micro = [], False, 0
 
     def _exchange_rows(self, stream):
         """The word-embedding table's gradient: all-gather (sorted ids, rows at first occurrences), then the sum in rank
@@ -272,15 +317,20 @@ class GradSync(object):
                 buf.copy_(self.flat[s:e])         # round to nearest even, on the stream that produced the gradients
             else:
                 buf = self.flat[s:e]
+            if self.timing and on_gpu:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._timing_open.append({'start': s, 'end': e, 'bytes': self._payload_bytes(e - s), 'e0': e0})
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.launch_streams.append(torch.cuda.current_stream().cuda_stream if on_gpu else None)
         self._inflight.append([work, s, e, False])
         self.launched.append((s, e))
 
 
-def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embeddings=None):
+def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embeddings=None, accum=1):
     """Wire a GradSync to a MemeUniter, UniterForPretraining or UniterModel and return it.
     payload None: 'bf16' when the encoder runs in the bf16 precision mode, else 'fp32'.
+    accum: the trainer's gradient_accumulation (sizes the sparse exchange for a full window of micro-batches).
     sparse_embeddings (None: UNITER_DP_SPARSE_EMB=1): exchange the touched rows of the word-embedding gradient instead
     of the table (GradSync docstring); the trainer then passes each micro-batch's token ids to ``prepare``."""
     store = model.param_store() if hasattr(model, 'param_store') else None
@@ -299,7 +349,7 @@ def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embedd
             V, H = store.params[name].shape
             word_table = (store.offsets[name], int(V), int(H))
     gs = GradSync(store.flat_grads, store.bucket_ranges, group=group, bucket_bytes=bucket_bytes, payload=payload,
-                  word_table=word_table)
+                  word_table=word_table, accum=accum)
     um._grad_hook = gs.hook
     return gs
 

@@ -27,11 +27,14 @@ logger = logging.getLogger(__name__)
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_ADD = range(5)
 
 
-# Precision of the heads' dense products: follows the encoder's (UniterForPretraining.forward sets it for the autograd
-# nodes built during that call; each node keeps the value it was built with for its backward).  'bf16': both operands
-# rounded to bf16 while they are staged, products on the bf16 matrix pipe, fp32 accumulation / epilogue / output
-# (uniter_gemm_bf16_cfg) -- the tied MLM decoder [n_masked, 768] x [768, 28996] is 82 GFLOP per MLM step at B = 32.
-_HEAD_PRECISION = ['fp32']
+# Precision of the heads' dense products: follows the encoder's.  It travels with the OWNING head module (attribute
+# `head_precision`, set by UniterForPretraining on its own heads whenever its encoder's precision changes; each autograd node
+# keeps the value it was built with for its backward) -- not through a module global: two models with different precisions in
+# one process, or a direct call of forward_mlm / forward_itm, see their own setting.  'bf16': both operands rounded to bf16
+# while they are staged, products on the bf16 matrix pipe, fp32 accumulation / epilogue / output (uniter_gemm_bf16_cfg) -- the
+# tied MLM decoder [n_masked, 768] x [768, 28996] is 82 GFLOP per MLM step at B = 32.
+def _head_precision(owner):
+    return getattr(owner, 'head_precision', 'fp32')
 
 
 def _gemm(akm, bkm, M, N, K, A, lda, B, ldb, Cc, ldc, epi=EPI_NONE, bias=None, aux_in=None, aux_out=None,
@@ -77,7 +80,7 @@ class _LinearFn(torch.autograd.Function):
         N = weight.shape[1] if w_t else weight.shape[0]
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
         u = torch.empty_like(y) if gelu else None
-        prec = ctx.prec = _HEAD_PRECISION[0]
+        prec = ctx.prec = _head_precision(owner)
         if w_t:
             _gemm(0, 1, M, N, K, x, K, weight, N, y, N, EPI_BIAS, bias, prec=prec)
         else:
@@ -403,9 +406,19 @@ class UniterForPretraining(UniterPreTrainedModel):
         self.uniter._ensure_handle()
         return st
 
+    def _sync_head_precision(self):
+        """The heads' dense products follow the encoder's precision: stamped on this model's own head modules (the `owner`
+        every _LinearFn node is built with), so forward_mlm / forward_itm / .. called directly see it as well."""
+        p = 'bf16' if self.uniter.precision == 'bf16' else 'fp32'
+        if getattr(self, '_heads_precision', None) != p:
+            for mod in self.modules():
+                if mod is not self.uniter and not any(mod is u for u in self.uniter.modules()):
+                    mod.head_precision = p
+            self._heads_precision = p
+
     def forward(self, batch, task, compute_loss=True):
         ensure_store(self)
-        _HEAD_PRECISION[0] = 'bf16' if self.uniter.precision == 'bf16' else 'fp32'
+        self._sync_head_precision()
         batch = defaultdict(lambda: None, batch)
         common = (batch['input_ids'], batch['position_ids'], batch['img_feat'], batch['img_pos_feat'],
                   batch['attn_masks'], batch['gather_index'])
@@ -444,6 +457,7 @@ class UniterForPretraining(UniterPreTrainedModel):
 
     def forward_mlm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                     txt_labels, compute_loss=True):
+        self._sync_head_precision()
         nz = self._mask_positions(txt_labels != -1)
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                           output_all_encoded_layers=False, seq_lens=getattr(self, '_seq_lens', None))
@@ -458,6 +472,7 @@ class UniterForPretraining(UniterPreTrainedModel):
 
     def forward_mrfr(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                      img_masks, img_mask_tgt, feat_targets, compute_loss=True):
+        self._sync_head_precision()
         nz = self._mask_positions(img_mask_tgt)
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                           output_all_encoded_layers=False, img_masks=img_masks, seq_lens=getattr(self, '_seq_lens', None))
@@ -471,6 +486,7 @@ class UniterForPretraining(UniterPreTrainedModel):
                     img_masks, img_mask_tgt, label_targets, task, compute_loss=True):
         """model/pretrain.py:205-233: region classification on the masked regions; 'mrc' trains against the most
         likely non-background detector class, 'mrc-kl' against the detector's soft labels."""
+        self._sync_head_precision()
         nz = self._mask_positions(img_mask_tgt)
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                           output_all_encoded_layers=False, img_masks=img_masks, seq_lens=getattr(self, '_seq_lens', None))
@@ -485,6 +501,7 @@ class UniterForPretraining(UniterPreTrainedModel):
 
     def forward_itm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                     targets, ot_inputs=None, compute_loss=True):
+        self._sync_head_precision()
         if ot_inputs is not None and not getattr(self, '_warned_ot', False):
             # model/pretrain.py:168-203 computes the optimal-transport distance of the batch and then returns the ITM
             # loss / scores alone (both `return ..., ot_loss` lines are commented out there): nothing a caller sees

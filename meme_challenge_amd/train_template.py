@@ -194,7 +194,7 @@ class TrainerTemplate(object):
         self.model_saver = ModelSaver(self.model_file)
         if self.config.get('parallel_computing') and _distributed() and dist.get_world_size() > 1:
             dp.broadcast_parameters(self.model)
-            self.grad_sync = dp.attach(self.model)
+            self.grad_sync = dp.attach(self.model, accum=int(self.config.get('gradient_accumulation', 1) or 1))
             enc = getattr(self.model, 'uniter_model', None)
             if enc is not None:          # different dropout masks on every rank (the batches differ as well)
                 enc.set_dropout_seed(int(self.config.get('seed', 0)) + 7919 * dist.get_rank())

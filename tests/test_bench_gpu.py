@@ -29,9 +29,17 @@ def test_bench_default_contract():
     assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
     assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
     assert abs(d['value'] - 16 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3
+    # the default is the fp32 step with its dense products as six bf16 MFMA products per block (three bf16 pieces per value):
+    # dtype f32, the workload says so, the roofline prices the products on the bf16 pipe / 6 and the SAME process times the
+    # native fp32 MFMA kernels next to it
+    assert '3 x bf16' in d['config']['workload'] and '6 MFMA products' in d['config']['workload']
     r = d['roofline']
-    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0.2 < r['frac'] < 1.0
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['peak'] - 2500.0 / 6) < 0.1
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0.1 < r['frac'] < 1.0
+    assert d['peak_tflops']['dense_products'] == 416.7 and d['peak_tflops']['attention'] == 157.3
+    nat = d['native_fp32']
+    assert nat['value'] > 0 and abs(nat['value'] - 16 / (nat['ms_per_step'] * 1e-3)) / nat['value'] < 1e-3
+    assert d['value'] > nat['value']                   # the point of the mode
     # the GEMM family that takes the most time of the step, stamped inside the timed region; every family is listed
     fams = {f['family']: f for f in d['roofline_families']}
     assert {'gemm_ffn_up_fwd', 'gemm_ffn_down_fwd', 'gemm_qkv_fwd', 'gemm_attn_out_fwd', 'gemm_dgrad', 'gemm_wgrad',
@@ -44,11 +52,20 @@ def test_bench_default_contract():
     assert d['optimizer']['bound'] == 'hbm' and 0.05 < d['optimizer']['frac'] < 1.0
     # both gradient GEMM families over the time either of them ran: above each family's own in-situ rate, below the peak
     t = d['backward_gemms_together']
-    assert max(fams['gemm_dgrad']['frac'], fams['gemm_wgrad']['frac']) < t['frac'] < 1.0
+    assert min(fams['gemm_dgrad']['frac'], fams['gemm_wgrad']['frac']) < t['frac'] < 1.0
     assert t['ms_per_step'] <= fams['gemm_dgrad']['ms_per_step'] + fams['gemm_wgrad']['ms_per_step'] + 1e-6
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'samples/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']
     assert c['single_thread']['value'] > 0 and c['gflops'] > 0 and c['cpu_model'] and c['os_cpu_count'] >= c['cores']
+    # N = the physical cores the process may use, and 32 threads where that differs: both in the block, `cores` = the one reported
+    assert c['physical_cores'] >= 1 and c['by_cores'][0]['cores'] == c['physical_cores']
+    assert c['cores'] in [l['cores'] for l in c['by_cores']] and c['value'] == max(l['value'] for l in c['by_cores'])
+
+
+def test_bench_native_fp32_mode_keeps_its_roofline():
+    d = _bench('--precision', 'fp32', '--no_cpu_baseline')
+    assert d['dtype'] == 'f32' and d['roofline']['peak'] == 157.3 and 'native fp32 MFMA' in d['config']['workload']
+    assert 'native_fp32' not in d and d['peak_tflops']['dense_products'] == 157.3
 
 
 @pytest.mark.parametrize('flags', [('--precision', 'bf16', '--no_cpu_baseline'),
@@ -79,6 +96,11 @@ def test_bench_starts_its_own_ranks(extra):
     assert abs(d['value'] - 32 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-2 and d['final_loss'] == d['final_loss']
     n_sparse = d['config']['dp_sparse_embedding_steps']            # every step took the sparse path (warm-up and the events pass included)
     assert (n_sparse == 0) if not extra else (n_sparse == 2 + 1)
+    # the exchange explains itself: payload, bytes and timing of every collective of a step, what the optimizer waited for
+    c = d['comm']
+    assert c['world'] == 2 and c['payload'] == ('bf16' if 'bf16' in extra else 'fp32') and c['sparse_embeddings'] == bool('--dp_sparse_embeddings' in extra)
+    assert c['collectives'] and all(k['bytes'] > 0 and k['issue_to_done_ms'] >= k['exposed_ms'] >= 0 for k in c['collectives'])
+    assert c['bytes_per_step'] > 0 and c['exposed_ms_per_step'] >= 0 and c['headline_exchange'] in ('dense', 'sparse word-embedding rows')
 
 
 def test_graft_entry_smoke():

