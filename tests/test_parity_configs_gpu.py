@@ -245,10 +245,17 @@ def test_fused_clip_adam_step_at_base_size_matches_the_adam_oracle(precision, ad
     coef = min(1.0, 1.0 / (total + 1e-6))
     assert coef < 1.0                          # the clip is active
     ora.step({n: g * coef for n, g in gs.items()})
-    worst = 0.0
+    # Coupled Adam divides (g + wd p) by (|g + wd p| + eps) on the first step: where the two terms cancel to ~eps (a few hundred of
+    # 110 M elements) the quotient amplifies the last-bit difference between `g * 0.5 * coef` and the kernel's one multiplication by
+    # lr / eps = 3e4 -- so the bar is an rms over all parameters (fp32 round-off of the update) and a maximum of 1 % of one update
+    worst, sq, cnt = 0.0, 0.0, 0
     for n, p in m.named_parameters():
-        worst = max(worst, maxdiff(p, ora.p[n]))
-    assert worst < 2e-7, worst
+        d = (p.detach().cpu().double() - ora.p[n].double())
+        worst = max(worst, d.abs().max().item())
+        sq += float(d.pow(2).sum())
+        cnt += d.numel()
+    assert math.sqrt(sq / cnt) < 1e-8, math.sqrt(sq / cnt)          # (one ulp of a 0.02-sized weight is 1.9e-9)
+    assert worst < (2e-7 if adamw else 1e-2 * 3e-4), worst
     assert st.flat_grads.abs().max().item() == 0.0
     if precision == 'fp32x3':
         back = torch.empty(st.numel, device='cuda')
