@@ -137,23 +137,44 @@ def cpu_baseline(seconds_budget=30.0):
 
 
 def pmc_traffic(args, M, cfgd, build_info):
-    """Memory-side bytes per launch of the FFN-up forward GEMM from the committed rocprofv3 --pmc passes (separate
-    FETCH_SIZE / WRITE_SIZE runs of this command, tests/tools/run_profile.sh -> tests/tools/pmc_to_traffic.py;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside a timed
-    run, so this is a PROFILE ARTEFACT, reported only for the shape AND the library build it was taken on."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_pmc_traffic.json')
+    """Memory-side bytes per launch of the GEMM families from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of this command, tests/tools/run_profile_r04.sh -> tests/tools/pmc_to_traffic_r04.py; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside a timed run, so this is a PROFILE
+    ARTEFACT, reported only for the shape AND the library build it was taken on."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    if args.workload != 'finetune' or args.precision == 'bf16':
+        return None
+    if args.precision == 'fp32x3':
+        src = 'profiles/r04_pmc_traffic.json'
+        try:
+            allrec = json.load(open(os.path.join(here, src)))
+        except (OSError, ValueError):
+            return None
+        rec = allrec.get('gemm_ffn_up_fwd') or {}
+        shape = rec.get('shape') or {}
+        if (shape.get('M'), shape.get('N'), shape.get('K')) != (M, cfgd['intermediate_size'], cfgd['hidden_size']):
+            return None
+        if rec.get('build') and rec['build'] != build_info:
+            return None
+        out = {'source': src}
+        for fam in ('gemm_ffn_up_fwd', 'gemm_dgrad', 'gemm_wgrad'):
+            r = allrec.get(fam)
+            if r:
+                out[fam] = {'bytes_per_launch': int(r['traffic_bytes']), 'algorithmic_bytes': int(r['algorithmic_bytes']),
+                            'read_bytes': int(r['read_bytes']), 'write_bytes': int(r['write_bytes']), 'kernel': r.get('kernel')}
+        return out
+    src = 'profiles/r03_pmc_traffic.json'
     try:
-        allrec = json.load(open(path))
+        allrec = json.load(open(os.path.join(here, src)))
         rec = allrec['ffn_up_fwd']
     except (OSError, KeyError, ValueError):
         return None
     shape = rec.get('shape', {})
-    if args.precision != 'fp32' or args.workload != 'finetune' or (shape.get('M'), shape.get('N'), shape.get('K')) != (
-            M, cfgd['intermediate_size'], cfgd['hidden_size']):
+    if (shape.get('M'), shape.get('N'), shape.get('K')) != (M, cfgd['intermediate_size'], cfgd['hidden_size']):
         return None
     if rec.get('build') and rec['build'] != build_info:
         return None
-    out = {'gemm_ffn_up_fwd': {'bytes_per_launch': int(rec['traffic_bytes']), 'algorithmic_bytes': int(rec['algorithmic_bytes'])}}
+    out = {'source': src, 'gemm_ffn_up_fwd': {'bytes_per_launch': int(rec['traffic_bytes']), 'algorithmic_bytes': int(rec['algorithmic_bytes'])}}
     wg = allrec.get('wgrad') or allrec.get('wgrad_stream_k')
     if wg and wg.get('build') == rec.get('build'):
         # the weight-gradient family of the fp32 step (average over its four shapes)
@@ -648,9 +669,8 @@ def run_rank(args):
                                                   'measured': 'union of the stamped launch intervals of gemm_dgrad and gemm_wgrad inside the timed region'}
             tr = pmc_traffic(args, M_eff, cfgd, build_info)
             if tr is not None:
-                out['traffic_from_profile'] = dict(tr, source='profiles/r03_pmc_traffic.json (rocprofv3 --pmc passes of this '
-                                                              'command on this library build; FETCH_SIZE doubled per the gfx950 '
-                                                              'correction, WRITE_SIZE exact)')
+                out['traffic_from_profile'] = dict(tr, source='%s (rocprofv3 --pmc passes of this command on this library build; '
+                                                              'FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE exact)' % tr['source'])
                 if dom['family'] in tr:      # the dominant kernel's bytes per launch from those passes (same build only)
                     out['roofline']['traffic'] = tr[dom['family']]['bytes_per_launch']
                     out['roofline']['traffic_algorithmic'] = tr[dom['family']]['algorithmic_bytes']

@@ -17,9 +17,10 @@
 // descriptor covers the tensor and its range check zero-fills whole rows beyond `rows` in all three pieces.  Weights are
 // written piece-major [3][rows][ld] by the optimizer (row_stride ld, piece_stride rows * ld: a flat mirror per piece).
 //
-// Kernel: LDS-DMA ring as gemm_bf16_dma.hip (buffer_load_dwordx4 ... lds, no staging registers), 32-deep k-tiles of 3 + 3
-// piece images per stage, transposed accumulator (lane = output row), ALL LDS reads as inline assembly with explicit
-// lgkmcnt(0) waits (hipcc drains vmcnt before compiler-visible LDS reads while an LDS-DMA is in flight).
+// Kernel: persistent workgroups of loader waves (LDS-DMA ring as gemm_bf16_dma.hip: buffer_load_dwordx4 ... lds, no staging
+// registers) and compute waves (fragment reads + MFMAs + epilogue), 32-deep k-tiles of 3 + 3 piece images per stage, transposed
+// accumulator (lane = output row), ALL LDS reads as inline assembly with hand-counted lgkmcnt waits (hipcc drains vmcnt before
+// compiler-visible LDS reads while an LDS-DMA is in flight).
 // LDS images per piece and stage:
 //   k-contiguous operand ([rows][K]): [R][32] bf16, 64-B rows, 16-B chunk c of row r at c ^ ((r >> 2) & 3): the 16 lanes
 //     of a ds_read_b128 group cover all 64 banks.
@@ -175,15 +176,20 @@ __device__ __forceinline__ void lds_read_tr_o(u32x2_t& out, unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(out) : "v"(addr), "n"(OFF) : "memory");
 #endif
 }
-__device__ __forceinline__ void lgkm_wait0() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-}
 // ties a fragment's first use to the statements above it (the wait): an empty volatile asm that "rewrites" the register
 __device__ __forceinline__ void tie(u32x4_t& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" : "+v"(v)::"memory");
+#endif
+}
+__device__ __forceinline__ void tie2(u32x2_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v)::"memory");
+#endif
+}
+template <int N> __device__ __forceinline__ void lgkm_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 #endif
 }
 template <int N> __device__ __forceinline__ void wait_vm3() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -192,42 +198,49 @@ template <int N> __device__ __forceinline__ void wait_vm3() { asm volatile("s_wa
 template <int R, int NB, int KT>
 struct FragRegs {
   u32x4_t v[3][NB];
-  template <int KS>
-  __device__ __forceinline__ void read(const Frag3<R, false, NB, KT>& f, unsigned img_addr) {
+  static constexpr int READS_PER_PIECE = NB;
+  // piece P of k16-step KS, every block of the wave
+  template <int KS, int P>
+  __device__ __forceinline__ void read_piece(const Frag3<R, false, NB, KT>& f, unsigned img_addr) {
     constexpr int IMG = R * KT * 2;
-    static_for<0, 3>([&](auto pc) {
-      constexpr int P = decltype(pc)::value;
-      static_for<0, NB>([&](auto tc) {
-        constexpr int T = decltype(tc)::value;
-        lds_read_b128_o<P * IMG + T * 32 * KT * 2>(v[P][T], img_addr + f.ka[KS]);
-      });
+    static_for<0, NB>([&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      lds_read_b128_o<P * IMG + T * 32 * KT * 2>(v[P][T], img_addr + f.ka[KS]);
     });
   }
+  template <int P>
+  __device__ __forceinline__ void tie_piece() {
+#pragma unroll
+    for (int t = 0; t < NB; ++t) tie(v[P][t]);
+  }
+  template <int P, int T>
+  __device__ __forceinline__ bf16x8 get() const { return __builtin_bit_cast(bf16x8, v[P][T]); }
 };
 
 // k-major fragments: the two halves must stay separate registers until the wait (an asm output cannot be half a vector)
 template <int R, int NB, int KT>
 struct FragRegsKM {
   u32x2_t lo[3][NB], hi[3][NB];
-  template <int KS>
-  __device__ __forceinline__ void read(const Frag3<R, true, NB, KT>& f, unsigned img_addr) {
+  static constexpr int READS_PER_PIECE = 2 * NB;
+  template <int KS, int P>
+  __device__ __forceinline__ void read_piece(const Frag3<R, true, NB, KT>& f, unsigned img_addr) {
     constexpr int IMG = R * KT * 2;
-    static_for<0, 3>([&](auto pc) {
-      constexpr int P = decltype(pc)::value;
-      static_for<0, NB>([&](auto tc) {
-        constexpr int T = decltype(tc)::value;
-        lds_read_tr_o<P * IMG + KS * 16 * R * 2>(lo[P][T], img_addr + f.tr[T][0]);
-        lds_read_tr_o<P * IMG + KS * 16 * R * 2>(hi[P][T], img_addr + f.tr[T][1]);
-      });
+    static_for<0, NB>([&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      lds_read_tr_o<P * IMG + KS * 16 * R * 2>(lo[P][T], img_addr + f.tr[T][0]);
+      lds_read_tr_o<P * IMG + KS * 16 * R * 2>(hi[P][T], img_addr + f.tr[T][1]);
     });
   }
+  template <int P>
+  __device__ __forceinline__ void tie_piece() {
+#pragma unroll
+    for (int t = 0; t < NB; ++t) { tie2(lo[P][t]); tie2(hi[P][t]); }
+  }
+  template <int P, int T>
+  __device__ __forceinline__ bf16x8 get() const {
+    return __builtin_bit_cast(bf16x8, u32x4_t{lo[P][T][0], lo[P][T][1], hi[P][T][0], hi[P][T][1]});
+  }
 };
-
-__device__ __forceinline__ void tie2(u32x2_t& v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+v"(v)::"memory");
-#endif
-}
 
 // epilogue kinds of this kernel
 enum { S3_NONE = 0, S3_BIAS = 1, S3_ADD = 4, S3_BIAS_GELU_D = 5, S3_MUL = 6 };
@@ -359,7 +372,7 @@ struct S3Group {
 //   compute:                            for u: { barrier B_u;  read stage u % ST, MFMAs;  (last k-tile of an item: epilogue) }
 // B_u orders k-tile u's LDS-DMA before its reads (every loader waited for its own instructions) and the reads of k-tile u - 1
 // (each compute wave waits lgkmcnt(0) before its last MFMAs) before the LDS-DMA that overwrites their stage.
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, bool STAG, int EPI>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, int EPI>
 __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NWL), ((BM / WM) * (BN / WN) + NWL + 3) / 4)
 void gemm_s3p_kernel(const S3Group G) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -482,51 +495,50 @@ void gemm_s3p_kernel(const S3Group G) {
       typename std::conditional<AKM, FragRegsKM<BM, AB, KT>, FragRegs<BM, AB, KT>>::type a;
       typename std::conditional<BKM, FragRegsKM<BN, BB, KT>, FragRegs<BN, BB, KT>>::type b;
     };
+    constexpr int RP = decltype(Frs::a)::READS_PER_PIECE + decltype(Frs::b)::READS_PER_PIECE;      // LDS reads per piece pair
     f32x16 acc[AB][BB];
-    auto get_a = [&](Frs& f, auto pc, auto tc) -> bf16x8 {
-      constexpr int P = decltype(pc)::value, T = decltype(tc)::value;
-      if constexpr (AKM) return __builtin_bit_cast(bf16x8, u32x4_t{f.a.lo[P][T][0], f.a.lo[P][T][1], f.a.hi[P][T][0], f.a.hi[P][T][1]});
-      else return __builtin_bit_cast(bf16x8, f.a.v[P][T]);
+    // all fragments of one k16-step, piece by piece (A's and B's piece 0 first): LDS returns them in this order
+    auto read_step = [&](Frs& f, auto ksc, unsigned sA, unsigned sB) {
+      constexpr int KS_ = decltype(ksc)::value;
+      f.a.template read_piece<KS_, 0>(fa, sA); f.b.template read_piece<KS_, 0>(fb, sB);
+      f.a.template read_piece<KS_, 1>(fa, sA); f.b.template read_piece<KS_, 1>(fb, sB);
+      f.a.template read_piece<KS_, 2>(fa, sA); f.b.template read_piece<KS_, 2>(fb, sB);
     };
-    auto get_b = [&](Frs& f, auto pc, auto tc) -> bf16x8 {
-      constexpr int P = decltype(pc)::value, T = decltype(tc)::value;
-      if constexpr (BKM) return __builtin_bit_cast(bf16x8, u32x4_t{f.b.lo[P][T][0], f.b.lo[P][T][1], f.b.hi[P][T][0], f.b.hi[P][T][1]});
-      else return __builtin_bit_cast(bf16x8, f.b.v[P][T]);
-    };
-    auto tie_frs = [&](Frs& f) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-#pragma unroll
-        for (int t = 0; t < AB; ++t) {
-          if constexpr (AKM) { tie2(f.a.lo[p][t]); tie2(f.a.hi[p][t]); } else tie(f.a.v[p][t]);
-        }
-#pragma unroll
-        for (int t = 0; t < BB; ++t) {
-          if constexpr (BKM) { tie2(f.b.lo[p][t]); tie2(f.b.hi[p][t]); } else tie(f.b.v[p][t]);
-        }
-      }
-    };
-    // the six products of one k16-step on every accumulator block, smallest terms first
-    auto mma_step = [&](Frs& f) {
-      static_for<0, 6>([&](auto qc) {
-        constexpr int Q = decltype(qc)::value;
-        constexpr int PA = Q == 0 ? 0 : Q == 1 ? 2 : Q == 2 ? 1 : Q == 3 ? 0 : Q == 4 ? 1 : 0;
-        constexpr int PB = Q == 0 ? 2 : Q == 1 ? 0 : Q == 2 ? 1 : Q == 3 ? 1 : Q == 4 ? 0 : 0;
-        static_for<0, AB>([&](auto ac) {
-          constexpr int A_ = decltype(ac)::value;
-          static_for<0, BB>([&](auto bc) {
-            constexpr int B_ = decltype(bc)::value;
-            acc[A_][B_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                get_b(f, std::integral_constant<int, PB>{}, bc), get_a(f, std::integral_constant<int, PA>{}, ac), acc[A_][B_], 0, 0, 0);
-          });
+    // products (piece of A, piece of B) of one k16-step on every accumulator block
+    auto mma = [&](Frs& f, auto pac, auto pbc) {
+      constexpr int PA = decltype(pac)::value, PB = decltype(pbc)::value;
+      static_for<0, AB>([&](auto ac) {
+        constexpr int A_ = decltype(ac)::value;
+        static_for<0, BB>([&](auto bc) {
+          constexpr int B_ = decltype(bc)::value;
+          acc[A_][B_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b.template get<PB, B_>(), f.a.template get<PA, A_>(), acc[A_][B_], 0, 0, 0);
         });
       });
     };
-    // STAG: the second half of the compute waves (the SIMD partners of the first half: a workgroup's waves go round the four SIMDs)
-    // runs the MFMAs of a k-tile's second k16-step BEHIND the next k-tile's barrier, on fragments it read in front of it: while the
-    // first half waits for its fragment reads after a barrier, the partner's deferred MFMAs keep the matrix pipe busy, and from
-    // then on the two halves alternate between reading and multiplying instead of doing both in lockstep
-    const bool late = STAG && wave >= NWC / 2;
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    // One k16-step whose reads are in flight: the six products in the order the pieces land -- (1,1) needs only the first
+    // pieces, so the matrix pipe starts after a third of the step's LDS traffic instead of all of it (lgkmcnt counts down in issue
+    // order; it holds 15 at most, a wait that cannot be expressed waits for a little more).  `next` (the following step's reads)
+    // is issued in front of the last two products.  (sched_barrier: MFMAs are plain register operations to the compiler, free to
+    // sink below the volatile waits -- it did, and every wave then sat out its fragment reads with the matrix pipe idle.)
+    auto step = [&](Frs& f, auto&& next) {
+      lgkm_wait<(2 * RP > 15 ? 15 : 2 * RP)>();
+      f.a.template tie_piece<0>(); f.b.template tie_piece<0>();
+      if (!(dbg & 4)) mma(f, I0{}, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      lgkm_wait<(RP > 15 ? 15 : RP)>();
+      f.a.template tie_piece<1>(); f.b.template tie_piece<1>();
+      if (!(dbg & 4)) { mma(f, I0{}, I1{}); mma(f, I1{}, I0{}); mma(f, I1{}, I1{}); }
+      __builtin_amdgcn_sched_barrier(0);
+      lgkm_wait<0>();
+      f.a.template tie_piece<2>(); f.b.template tie_piece<2>();
+      next();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(dbg & 4)) { mma(f, I0{}, I2{}); mma(f, I2{}, I0{}); }
+      __builtin_amdgcn_sched_barrier(0);
+    };
     static_assert(KS == 2, "two k16-steps per k-tile");
     int stg = 0;
     for (int r = 0;; ++r) {
@@ -539,36 +551,17 @@ void gemm_s3p_kernel(const S3Group G) {
 #pragma unroll
           for (int rr = 0; rr < 16; ++rr) acc[a][b][rr] = 0.f;
       Frs f0, f1;
-      bool pending = false;       // f1 holds the fragments of a k16-step whose MFMAs have not run yet
       for (int kt = c.kb; kt < c.ke; ++kt) {
         if (!(dbg & 64)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const unsigned sA = lds0 + stg * STAGE, sB = sA + 3 * IMG_A;
-        if (!(dbg & 2)) {
-          f0.a.template read<0>(fa, sA);
-          f0.b.template read<0>(fb, sB);
-        }
-        if (pending && !(dbg & 4)) mma_step(f1);
-        // (sched_barrier: MFMAs are plain register operations to the compiler, free to sink below the volatile waits -- it did, and
-        // every wave then sat out its fragment reads with the matrix pipe idle)
-        __builtin_amdgcn_sched_barrier(0);
-        lgkm_wait0();
-        tie_frs(f0);
-        if (!(dbg & 2)) {
-          f1.a.template read<1>(fa, sA);
-          f1.b.template read<1>(fb, sB);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(dbg & 4)) mma_step(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        lgkm_wait0();           // in front of the next barrier either way: the loaders overwrite this stage behind it
-        tie_frs(f1);
-        if (late) pending = true;
-        else if (!(dbg & 4)) mma_step(f1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 2)) read_step(f0, I0{}, sA, sB);
+        step(f0, [&]() { if (!(dbg & 2)) read_step(f1, I1{}, sA, sB); });
+        // (the last wait of this step is lgkmcnt(0): every read of the stage is complete in front of the next barrier, behind
+        // which the loaders overwrite it)
+        step(f1, [&]() {});
         stg = stg == ST - 1 ? 0 : stg + 1;
       }
-      if (pending && !(dbg & 4)) mma_step(f1);
       s3_epilogue<WM, WN, EPI>(G.p[c.p], c.piece, c.m0, c.n0, wm, wn, i5, h, acc);
     }
   }
@@ -592,7 +585,7 @@ void plan_tiles3(S3Args& g, int BN) {
   if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, bool STAG, int EPI>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, int EPI>
 int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
   const int nwork = G.start[4];
   int grid = (nwork + 7) / 8 * 8;
@@ -603,7 +596,7 @@ int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
   }();
   const int cap = max_wgs >= 8 ? max_wgs / 8 * 8 : cus;       // one workgroup per CU: it owns the CU's LDS
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((gemm_s3p_kernel<BM, BN, WM, WN, AKM, BKM, ST, KT, NWL, STAG, EPI>), dim3(grid),
+  hipLaunchKernelGGL((gemm_s3p_kernel<BM, BN, WM, WN, AKM, BKM, ST, KT, NWL, EPI>), dim3(grid),
                      dim3(64 * ((BM / WM) * (BN / WN) + NWL)), 0, st, G);
   UCHECK_LAUNCH();
   return 0;
@@ -612,14 +605,12 @@ int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
 // cfg: tile geometry (all: 128 x 128 tiles, three 32-deep stages = 144 KB of LDS, one persistent workgroup per CU)
 //   1: 8 compute waves of 64 x 32 + 4 loader waves
 //   2: 4 compute waves of 64 x 64 + 4 loader waves (default)
-//   3: as 1 with the second four compute waves half a k-tile behind the first (STAG; measured: no gain)
 template <bool AKM, bool BKM, int EPI>
 int dispatch_cfg3p(int cfg, const S3Group& G, int max_wgs, hipStream_t st) {
   switch (cfg) {
-    case 1: return launch_s3p<128, 128, 64, 32, AKM, BKM, 3, 32, 4, false, EPI>(G, max_wgs, st);
-    case 2: return launch_s3p<128, 128, 64, 64, AKM, BKM, 3, 32, 4, false, EPI>(G, max_wgs, st);
-    case 3: return launch_s3p<128, 128, 64, 32, AKM, BKM, 3, 32, 4, true, EPI>(G, max_wgs, st);
-    default: uniter_set_error("gemm_x3: bad cfg %d (1..3)", cfg); return UNITER_E_ARG;
+    case 1: return launch_s3p<128, 128, 64, 32, AKM, BKM, 3, 32, 4, EPI>(G, max_wgs, st);
+    case 2: return launch_s3p<128, 128, 64, 64, AKM, BKM, 3, 32, 4, EPI>(G, max_wgs, st);
+    default: uniter_set_error("gemm_x3: bad cfg %d (1..2)", cfg); return UNITER_E_ARG;
   }
 }
 

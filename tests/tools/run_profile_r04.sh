@@ -1,0 +1,50 @@
+# Round-4 profile set.  Part 1 (bench lines + kernel stats + timelines + lab tools), part 2 (PMC passes: separate runs, never
+# with a trace domain besides --kernel-trace).  Usage on the GPU box: bash tests/tools/run_profile_r04.sh [1|2]
+set -x
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04p
+mkdir -p $O
+part=${1:-1}
+python -c "from meme_challenge_amd import _lib; print(_lib.lib().uniter_build_info().decode())" > $O/build_info.txt 2>/dev/null
+if [ "$part" = "1" ]; then
+timeout 400 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.json
+timeout 300 python bench.py --precision fp32 --no_cpu_baseline > $O/bench_native_fp32.json 2>> $O/bench.err
+timeout 300 python bench.py --precision bf16 --no_cpu_baseline > $O/bench_bf16.json 2>> $O/bench.err
+timeout 300 python bench.py --model large --batch 8 --num_bb 50 --no_cpu_baseline > $O/bench_large.json 2>> $O/bench.err
+timeout 300 python bench.py --model large --batch 8 --num_bb 50 --precision bf16 --no_cpu_baseline > $O/bench_large_bf16.json 2>> $O/bench.err
+timeout 300 python bench.py --workload multitask --batch 32 --no_cpu_baseline > $O/bench_multitask.json 2>> $O/bench.err
+timeout 300 python bench.py --workload multitask --batch 32 --precision bf16 --no_cpu_baseline > $O/bench_bf16_multitask.json 2>> $O/bench.err
+timeout 300 python bench.py --ragged --packed --no_cpu_baseline > $O/bench_ragged_packed.json 2>> $O/bench.err
+timeout 300 python bench.py --ragged --packed --precision bf16 --no_cpu_baseline > $O/bench_bf16_ragged_packed.json 2>> $O/bench.err
+UNITER_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --prewarm_s 0 --prof_kind 0 --no_cpu_baseline > $O/bench_gpus2_gloo_one_gpu.json 2>> $O/bench.err
+UNITER_DP_FORCE=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 timeout 300 python bench.py --no_cpu_baseline > $O/bench_rccl_one_rank_forced.json 2>> $O/bench.err
+UNITER_DP_FORCE=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29534 timeout 300 python bench.py --no_cpu_baseline --dp_sparse_embeddings > $O/bench_rccl_one_rank_forced_sparse.json 2>> $O/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 bench.py --no_cpu_baseline --no_native_leg --steps 25 --warmup 5 > $O/bench_under_rocprof.json 2>$O/rocprof.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16 -o st -- python3 bench.py --precision bf16 --no_cpu_baseline --steps 25 --warmup 5 > $O/bench_bf16_under_rocprof.json 2>>$O/rocprof.err
+find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv
+find $O/stats_bf16 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_bf16_kernel_stats.csv
+bash tests/tools/run_timeline.sh f32 --precision fp32x3; bash tests/tools/run_timeline.sh bf16
+cp gpurun_out/tl/timeline_f32.txt $O/timeline_f32x3.txt; cp gpurun_out/tl/timeline_bf16.txt $O/timeline_bf16.txt
+python tests/tools/attn_bench.py > $O/attention_isolated.txt 2>&1
+LAB_NSPLIT=1,2 timeout 400 python tests/tools/gemm_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_lab.txt
+LAB_ACC=0 LAB_NSPLIT=1 LAB_ONLY=ffnup_fwd,qkv_fwd,plain_fwd LAB_KSWEEP=32,768,1536,3072 LAB_WG_CFGS=2 timeout 300 python tests/tools/gemm_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_ksweep.txt
+if [ -f meme_challenge_amd/libuniter_hip_x3lab.so ]; then
+UNITER_LIB_VARIANT=x3lab LAB_ACC=0 LAB_NSPLIT=1 LAB_ONLY=ffnup_fwd LAB_KSWEEP=32,1536 LAB_CFGS=2,2d1,2d2,2d3,2d4,2d6,2d7,1,1d1,1d3,1d4,3,3d3 LAB_WG_CFGS=2 timeout 300 python tests/tools/gemm_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_ablation.txt
+UNITER_LIB_VARIANT=x3lab LAB_CFGS=2,2d1,2d3,2d4,1,1d3 timeout 200 python tests/tools/gemm_x3_clock.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_clock.txt
+fi
+python tests/tools/ln_bench.py > $O/ln_isolated.txt 2>&1
+(python tests/tools/cli_throughput.py fp32; python tests/tools/cli_throughput.py fp32x3; python tests/tools/cli_throughput.py bf16) 2>&1 | grep 'samples/s' > $O/cli_throughput_raw.txt
+fi
+if [ "$part" = "2" ]; then
+pm() { name=$1; shift; ctr=$1; shift; timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$name -o p -- python3 bench.py --no_cpu_baseline --no_native_leg --steps 3 --warmup 1 --prof_kind 0 "$@" > /dev/null 2>$O/pmc_$name.err; python tests/tools/pmc_summary.py $O/pmc_$name $O/pmc_$name.csv; }
+pm fetch FETCH_SIZE
+pm write WRITE_SIZE
+pm mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES"
+pm fetch_bf16 FETCH_SIZE --precision bf16
+pm write_bf16 WRITE_SIZE --precision bf16
+python tests/tools/pmc_to_traffic_r04.py $O $O/pmc_traffic.json > $O/pmc_traffic.txt
+python tests/tools/pmc_table.py $O/ > $O/kernel_table.md; python tests/tools/pmc_table.py $O/ bf16 > $O/kernel_table_bf16.md
+fi
+find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete
+du -sh $O
