@@ -331,6 +331,11 @@ def main(argv=None):
 
 
 def run_rank(args):
+    # ONE line on stdout: libraries under us write to file descriptor 1 as well (gloo's connection notes, RCCL's version banner
+    # under NCCL_DEBUG=INFO).  Descriptor 1 points at stderr for the whole run; the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
@@ -686,7 +691,8 @@ def run_rank(args):
                 out['cpu_baseline'] = cpu_baseline()
             except Exception as e:                               # noqa: BLE001
                 out['cpu_baseline_error'] = repr(e)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if use_dist:
         dist.destroy_process_group()
     return 0

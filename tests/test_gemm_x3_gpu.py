@@ -111,7 +111,7 @@ def test_every_model_shape_is_no_less_accurate_than_the_fp32_mfma_kernel(shape):
                                     None, None, N, 0, L.cur_stream()), 'gemm_f32')
     e32 = _errs(C32, ref)
     A3, B3 = split3(A), split3(B)
-    for cfg in (1, 2):
+    for cfg in (1, 2, 3):
         C = torch.full((M, N), float('nan'), device='cuda')
         L.check(x3_gemm(cfg, 1, akm, bkm, M, N, K, A3, B3, C, None, EPI_NONE, None, None, None), 'gemm_x3')
         e = _errs(C, ref)
@@ -162,7 +162,7 @@ def _run(cfg, akm, bkm, M, N, K, epi, nsplit=1, out='f32', piece_major_b=False, 
         assert (auxo.double().cpu() - aux_ref).abs().max().item() < tol, tag
 
 
-@pytest.mark.parametrize('cfg', [1, 2])
+@pytest.mark.parametrize('cfg', [1, 2, 3])
 @pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 1)], ids=['forward', 'dgrad', 'wgrad'])
 def test_layouts_and_edges(cfg, layout):
     akm, bkm = layout
@@ -176,7 +176,7 @@ def test_layouts_and_edges(cfg, layout):
         _run(cfg, 1, 1, M=128, N=256, K=1458, epi=EPI_ADD)                      # ragged K, dW += (aux = prior value)
 
 
-@pytest.mark.parametrize('cfg', [1, 2])
+@pytest.mark.parametrize('cfg', [1, 2, 3])
 def test_epilogues_and_outputs(cfg):
     for epi in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_D):
         for out in ('f32', 'x3', 'both'):
@@ -187,7 +187,7 @@ def test_epilogues_and_outputs(cfg):
     _run(cfg, 1, 1, M=200, N=256, K=128, epi=EPI_ADD)
 
 
-@pytest.mark.parametrize('cfg', [1, 2])
+@pytest.mark.parametrize('cfg', [1, 2, 3])
 @pytest.mark.parametrize('nsplit', [2, 3, 4])
 def test_split_k_slabs(cfg, nsplit):
     _run(cfg, 0, 0, M=300, N=256, K=640, epi=EPI_BIAS, nsplit=nsplit)
@@ -218,7 +218,7 @@ def _group_call(cfg, Ms, Ns, K, As, Bs, Cs, overwrite, max_wgs=0):
                                          PA(*[c.data_ptr() for c in Cs]), overwrite, max_wgs, L.cur_stream())
 
 
-@pytest.mark.parametrize('cfg', [1, 2])
+@pytest.mark.parametrize('cfg', [1, 2, 3])
 @pytest.mark.parametrize('shapes,K', [([(128, 128)], 64), ([(136, 200), (256, 128), (8, 8)], 200),
                                       ([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 2624),
                                       ([(256, 64), (64, 256), (192, 64), (64, 64)], 1458)])

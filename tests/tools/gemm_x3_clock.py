@@ -25,7 +25,7 @@ for tok in os.environ.get('LAB_CFGS', '1,1d3,1d4').split(','):
     ghz = (cyc[ok] / rt[ok] * 0.1)
     st, en = b[:, 2].double(), b[:, 3].double()
     t0 = st[ok].min()
-    conc = [int(((st <= t) & (en > t) & ok).sum()) for t in torch.linspace(float(t0), float(en[ok].max()), 9)[1:-1]]
+    conc = [int(((st <= t) & (en > t) & ok).sum()) for t in torch.linspace(float(t0), float(en[ok].max()), 9, dtype=torch.float64)[1:-1]]
     print('         launch span %.1f us; workgroups running at 7 instants across it: %s; starts within %.1f us' % (
         (en[ok].max() - t0).item() / 100, conc, (st[ok].max() - t0).item() / 100))
     print('%-8s workgroup lifetime %.1f us (median), %.0f cycles, clock %.2f GHz (min %.2f max %.2f)' % (
