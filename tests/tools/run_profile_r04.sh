@@ -28,10 +28,10 @@ bash tests/tools/run_timeline.sh f32 --precision fp32x3; bash tests/tools/run_ti
 cp gpurun_out/tl/timeline_f32.txt $O/timeline_f32x3.txt; cp gpurun_out/tl/timeline_bf16.txt $O/timeline_bf16.txt
 python tests/tools/attn_bench.py > $O/attention_isolated.txt 2>&1
 LAB_NSPLIT=1,2 timeout 400 python tests/tools/gemm_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_lab.txt
-LAB_ACC=0 LAB_NSPLIT=1 LAB_ONLY=ffnup_fwd,qkv_fwd,plain_fwd LAB_KSWEEP=32,768,1536,3072 LAB_WG_CFGS=2 timeout 300 python tests/tools/gemm_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_ksweep.txt
+LAB_ACC=0 LAB_NSPLIT=1 LAB_ONLY=ffnup_fwd,qkv_fwd,plain_fwd LAB_KSWEEP=32,768,1536,3072 LAB_WG_CFGS=3 timeout 300 python tests/tools/gemm_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_ksweep.txt
 if [ -f meme_challenge_amd/libuniter_hip_x3lab.so ]; then
-UNITER_LIB_VARIANT=x3lab LAB_ACC=0 LAB_NSPLIT=1 LAB_ONLY=ffnup_fwd LAB_KSWEEP=32,1536 LAB_CFGS=2,2d1,2d2,2d3,2d4,2d6,2d7,1,1d1,1d3,1d4,3,3d3 LAB_WG_CFGS=2 timeout 300 python tests/tools/gemm_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_ablation.txt
-UNITER_LIB_VARIANT=x3lab LAB_CFGS=2,2d1,2d3,2d4,1,1d3 timeout 200 python tests/tools/gemm_x3_clock.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_clock.txt
+UNITER_LIB_VARIANT=x3lab LAB_ACC=0 LAB_NSPLIT=1 LAB_ONLY=ffnup_fwd LAB_KSWEEP=32,1536 LAB_CFGS=3,3d1,3d2,3d3,3d4,3d6,3d7,2,2d1,2d3,2d4,1,1d1,1d3,1d4 LAB_WG_CFGS=3 timeout 300 python tests/tools/gemm_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_ablation.txt
+UNITER_LIB_VARIANT=x3lab LAB_CFGS=3,3d1,3d3,3d4,2,2d1,2d3,2d4,1,1d3 timeout 200 python tests/tools/gemm_x3_clock.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_clock.txt
 fi
 python tests/tools/ln_bench.py > $O/ln_isolated.txt 2>&1
 (python tests/tools/cli_throughput.py fp32; python tests/tools/cli_throughput.py fp32x3; python tests/tools/cli_throughput.py bf16) 2>&1 | grep 'samples/s' > $O/cli_throughput_raw.txt
