@@ -1,0 +1,633 @@
+// Fused self-attention of the fp32x3 mode: every product of BertSelfAttention (model/layer.py:80-100) and of its autograd runs on
+// the bf16 matrix pipe with fp32 results -- each operand value as three bf16 pieces (x = x1 + x2 + x3 exactly), six
+// v_mfma_f32_16x16x32_bf16 products per block (gemm_split3.hip has the arithmetic) -- instead of on the fp32 MFMAs of
+// attention_f32.hip, which run at 1/16 of the bf16 rate.  Scores, softmax, dropout, LSE and deltas are fp32 as there.
+//
+// Work decomposition (L <= 192): one workgroup per (batch, head), ONE WAVE PER 16 ROWS -- 12 waves at L = 164..192, three per SIMD,
+// no partial results to merge.  With the 16x16x32 MFMA the accumulator of
+//     S^T[key][query] = K . Q^T      (lane = query l & 15, registers = keys 4 (l >> 4) + r of a 16-key block)
+// is, two 16-key blocks together, the B operand of the 32-deep step of
+//     O^T[d][query] = V^T . P^T      (element j of lane group g: key 16 (j >> 2) + 4 g + (j & 3))
+// with no lane movement; the A operand V^T comes out of the ROW-MAJOR image of V by ds_read_b64_tr_b16 in exactly that key order
+// (two reads of 4 keys x 16 d).  So each operand has ONE LDS image per piece -- [row][64 d] bf16, 128-byte rows, 16-byte chunk c of
+// row r at c ^ f(r), f(r) = 4 ((r >> 1) & 1) | ((r >> 2) & 3): row reads (ds_read_b128) at most 2-way, transposed reads
+// conflict-free -- and K, V (forward, dQ pass) or Q, dO (dK / dV pass) fit as 2 x 3 images of 24 KB in the 160-KB LDS.
+//
+// Backward, one launch, NO hand-over through memory: pass 1 (wave = 16 queries, all keys) recomputes S^T and dP^T = V . dO^T and
+// accumulates dQ^T = K^T . dS^T; pass 2 (wave = 16 keys, all queries; Q and dO restaged over K and V) recomputes
+// S = Q . K^T and dP = dO . V^T in the other orientation and accumulates dV^T = dO^T . Pd and dK^T = Q^T . dS.  The recomputation
+// costs 48 of the 168 MFMAs per 32 x 32 tile pair -- on the bf16 pipe less than the 2 x 28 MB of scratch traffic it replaces.
+//
+// Dropout: the keep flags are READ (uniter_attn_keep_bits_gen draws them ahead of the forward pass); both passes of the backward
+// read the same words.  Layouts as attention_f32.hip: qkv [rows, 3H], ctx / dctx [rows, H], lse / delta [B, nh, L], x3 outputs
+// [rows][3][ld].  head_dim == 64.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+constexpr int D = 64;
+constexpr int MAXL = 192;
+constexpr int ROWB = 128;                 // bytes per image row (64 bf16)
+constexpr float NEG_INF = -__builtin_huge_valf();
+
+struct Args {
+  const float* qkv;        // [rows, 3H]
+  const float* mask;       // [B, L] or NULL (varlen)
+  const int* cu;           // [B+1] or NULL
+  float* ctx; u16* ctx_x3; // forward outputs (backward: ctx is an input)
+  float* lse;              // [B, nh, L]
+  const float* dctx;
+  float* dqkv; u16* dqkv_x3;
+  float* bias_part;        // optional [B, 3H] per-sample column sums of dqkv
+  float* delta;            // [B, nh, L]
+  const u16* keep_bits;    // [B*nh, L, Lr/32, 2] keep flags (attention_f32.hip, attn_keep_bits_kernel), NULL without dropout
+  float drop_scale;        // 1 / (1 - p)
+  int B, L, nh, H, prio;
+  float scale;
+};
+
+struct Span { int row0, Lb, nb; };
+__device__ __forceinline__ Span span_of(const Args& a, int b) {
+  Span s;
+  s.row0 = a.cu ? a.cu[b] : b * a.L;
+  s.Lb = a.cu ? a.cu[b + 1] - s.row0 : a.L;
+  s.nb = (s.Lb + 31) >> 5;
+  return s;
+}
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};      // v_cvt_pk_bf16_f32: round to nearest even
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bflo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bfhi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// the three bf16 pieces of two fp32 values (exact: every residual is representable)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& w1, unsigned& w2, unsigned& w3) {
+  w1 = pack2(x0, x1);
+  float r0 = x0 - bflo(w1), r1 = x1 - bfhi(w1);
+  w2 = pack2(r0, r1);
+  r0 -= bflo(w2); r1 -= bfhi(w2);
+  w3 = pack2(r0, r1);
+}
+// pieces of 8 values as MFMA fragments
+__device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, bf16x8 (&f)[3]) {
+  unsigned w[3][4];
+  split2(x[0], x[1], w[0][0], w[1][0], w[2][0]);
+  split2(x[2], x[3], w[0][1], w[1][1], w[2][1]);
+  split2(y[0], y[1], w[0][2], w[1][2], w[2][2]);
+  split2(y[2], y[3], w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) f[p] = __builtin_bit_cast(bf16x8, u32x4{w[p][0], w[p][1], w[p][2], w[p][3]});
+}
+
+// chunk swizzle of the images (header)
+__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+// One [L, 64] fp32 operand on its way into its three piece images: this thread's four 16-byte pieces are all loaded before
+// anything is written (blockDim.x = 4 Lr threads).  Rows >= L are zero.
+struct Stage3 {
+  f32x4 v[4];
+  __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
+      v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx < Lr * 16 && r < L) v[it] = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c4 * 4);
+    }
+  }
+  __device__ __forceinline__ void store(u8* img, int IMG, int Lr, int tid, int nthr) const {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
+      if (idx < Lr * 16) {
+        unsigned a1, a2, a3, b1, b2, b3;
+        split2(v[it][0], v[it][1], a1, a2, a3);
+        split2(v[it][2], v[it][3], b1, b2, b3);
+        u8* p = img + r * ROWB + 16 * ((c4 >> 1) ^ swz(r)) + 8 * (c4 & 1);
+        *reinterpret_cast<u32x2*>(p) = u32x2{a1, b1};
+        *reinterpret_cast<u32x2*>(p + IMG) = u32x2{a2, b2};
+        *reinterpret_cast<u32x2*>(p + 2 * IMG) = u32x2{a3, b3};
+      }
+    }
+  }
+};
+
+// B operand of a product that sums over d, from the lane's own fp32 row: step s, lane group g -> d = 32 s + 8 g .. + 7
+__device__ __forceinline__ void row_frags3(bf16x8 (&f)[2][3], const float* __restrict__ row, bool valid, int g) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x;
+    if (valid) {
+      x = *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g);
+      y = *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g + 4);
+    }
+    split8(x, y, f[s]);
+  }
+}
+
+// per-lane byte offsets into an image: row reads (A operand, k = d) and transposed reads (A operand, k = image rows)
+struct LaneOffs {
+  int row[2];      // step s: row i, chunk 4 s + g
+  int tr[4];       // d-block db: row 4 g + (i >> 2), columns 16 db + 4 (i & 3) .. + 3
+  __device__ __forceinline__ void init(int i, int g) {
+    const int fi = swz(i);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) row[s] = i * ROWB + 16 * ((4 * s + g) ^ fi);
+    const int tr_row = 4 * g + (i >> 2), p4 = i & 3, ft = swz(tr_row);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) tr[db] = tr_row * ROWB + 16 * ((2 * db + (p4 >> 1)) ^ ft) + 8 * (p4 & 1);
+  }
+};
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+// rows r0 .. r0 + 15 of piece image `img`: the lane's row, 8 consecutive d of step s
+__device__ __forceinline__ bf16x8 frag_row(const u8* img, int r0, int off) {
+  return *reinterpret_cast<const bf16x8*>(img + r0 * ROWB + off);
+}
+// image rows r0 .. r0 + 31 as the 32-deep k of an A operand whose rows are 16 image columns: accumulator k order
+// (element j of lane group g: row r0 + 16 (j >> 2) + 4 g + (j & 3)).  Needs EXEC all ones (wave-uniform control flow around it).
+__device__ __forceinline__ bf16x8 frag_tr(const u8* img, int r0, int off) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + r0 * ROWB + off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + (r0 + 16) * ROWB + off));
+  return __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// c += a . b for operands in three pieces: the six products above 2^-24 |a b|
+template <int LAB = 0>
+__device__ __forceinline__ void mac6(f32x4& c, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+  if constexpr (LAB & 4) {      // measurement build only: the fragments are read, the products are not issued
+    asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
+    return;
+  }
+  c = MFMA16(a[0], b[0], c);
+  c = MFMA16(a[0], b[1], c);
+  c = MFMA16(a[1], b[0], c);
+  c = MFMA16(a[1], b[1], c);
+  c = MFMA16(a[0], b[2], c);
+  c = MFMA16(a[2], b[0], c);
+}
+
+// sums over the four lane groups (the lanes that share l & 15)
+__device__ __forceinline__ float groups_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float groups_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+// one output row (lane's query or key): acc[db][r] = element d = 16 db + 4 g + r; fp32 and / or the three pieces
+__device__ __forceinline__ void store_row(float* __restrict__ row, u16* __restrict__ row_x3, int ps, const f32x4 (&acc)[4],
+                                          float mul, int g) {
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const f32x4 v = {acc[db][0] * mul, acc[db][1] * mul, acc[db][2] * mul, acc[db][3] * mul};
+    if (row) *reinterpret_cast<f32x4*>(row + 16 * db + 4 * g) = v;
+    if (row_x3) {
+      unsigned a1, a2, a3, b1, b2, b3;
+      split2(v[0], v[1], a1, a2, a3);
+      split2(v[2], v[3], b1, b2, b3);
+      u16* p = row_x3 + 16 * db + 4 * g;
+      *reinterpret_cast<u32x2*>(p) = u32x2{a1, b1};
+      *reinterpret_cast<u32x2*>(p + ps) = u32x2{a2, b2};
+      *reinterpret_cast<u32x2*>(p + 2 * ps) = u32x2{a3, b3};
+    }
+  }
+}
+
+// column sums of an output block over the wave's valid rows -> red[0..63] (LDS, pre-zeroed)
+__device__ __forceinline__ void acc_colsum(float* red, const f32x4 (&acc)[4], bool valid, int i, int g) {
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = valid ? acc[db][r] : 0.f;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (i == 0) atomicAdd(red + 16 * db + 4 * g + r, v);
+    }
+  }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+__device__ __forceinline__ void stage_mask(float* mb, const Args& a, int b, int Lb, int Lr, int tid, int nthr) {
+  for (int k = tid; k < Lr; k += nthr)
+    mb[k] = k < Lb ? (a.mask ? (1.0f - a.mask[(size_t)b * a.L + k]) * -10000.0f : 0.f) : NEG_INF;
+}
+
+// keep flags of a 2 x 16-row accumulator pair whose LANE is the query: one word (attention_f32.hip: bit 4 gg + t of word
+// (bh, q, key block, half) = key 32 kb + 8 gg + 4 half + t): keys 16 b2 + 4 g + r -> word g & 1, bit 4 (2 b2 + (g >> 1)) + r
+__device__ __forceinline__ float keep_mult(unsigned word, int b2, int g, int r, float scale) {
+  return ((word >> (4 * (2 * b2 + (g >> 1)) + r)) & 1u) ? scale : 0.f;
+}
+
+// ---------------------------------------------------------------- forward ---
+// LDS: K pieces | V pieces | mask bias
+__global__ __launch_bounds__(768) void attn_x3_fwd_kernel(const Args a, int Lr) {
+  set_wave_prio(a.prio);
+  const int IMG = Lr * ROWB;
+  u8* Ki = smem_raw;
+  u8* Vi = smem_raw + 3 * IMG;
+  float* mb = reinterpret_cast<float*>(smem_raw + 6 * IMG);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int i = lane & 15, g = lane >> 4;
+  const int nblk = Lr >> 5;
+  const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const Span sp = span_of(a, b);
+  const int Lb = sp.Lb, ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
+  const int q = wave * 16 + i;
+  const bool vq = q < Lb;
+  bf16x8 qf[2][3];
+  {
+    Stage3 sk, sv;
+    sk.load(base + a.H, ld, Lb, Lr, tid, nthr);
+    sv.load(base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+    row_frags3(qf, base + (size_t)q * ld, vq, g);
+    stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+    sk.store(Ki, IMG, Lr, tid, nthr);
+    sv.store(Vi, IMG, Lr, tid, nthr);
+  }
+  __syncthreads();
+  LaneOffs lo;
+  lo.init(i, g);
+  const int nk = wave * 16 < Lb ? sp.nb : 0;           // wave-uniform
+  const bool drop = a.keep_bits != nullptr;
+  const u16* kbits = a.keep_bits + (((size_t)bh * a.L + (vq ? q : 0)) * nblk) * 2 + (g & 1);
+  f32x4 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_INF, l_run = 0.f;
+  for (int kc = 0; kc < nk; ++kc) {
+    const int k0 = kc * 32;
+    unsigned word = 0xffffu;
+    if (drop) word = kbits[kc * 2];
+    f32x4 s[2];
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {                     // S^T[key][query] = K . Q^T
+      s[b2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        bf16x8 ka[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ka[p] = frag_row(Ki + p * IMG, k0 + 16 * b2, lo.row[st]);
+        mac6(s[b2], ka, qf[st]);
+      }
+    }
+    float mx = NEG_INF;
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + k0 + 16 * b2 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[b2][r] = s[b2][r] * a.scale + bias[r];
+        mx = fmaxf(mx, s[b2][r]);
+      }
+    }
+    mx = groups_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[b2][r] = __expf(s[b2][r] - m_new); ls += s[b2][r]; }
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[db][r] *= alpha;
+    if (drop) {
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[b2][r] *= keep_mult(word, b2, g, r, a.drop_scale);
+    }
+    bf16x8 pb[3];
+    split8(s[0], s[1], pb);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {                     // O^T[d][query] += V^T . Pd^T
+      bf16x8 va[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) va[p] = frag_tr(Vi + p * IMG, k0, lo.tr[db]);
+      mac6(o[db], va, pb);
+    }
+  }
+  const float l_tot = groups_sum(l_run);
+  if (vq) {
+    const size_t row = (size_t)sp.row0 + q;
+    store_row(a.ctx ? a.ctx + row * a.H + head * D : nullptr, a.ctx_x3 ? a.ctx_x3 + row * 3 * a.H + head * D : nullptr, a.H, o,
+              1.0f / l_tot, g);
+    if (g == 0 && a.lse) a.lse[(size_t)bh * a.L + q] = m_run + __logf(l_tot);
+  }
+}
+
+// --------------------------------------------------------------- backward ---
+// LDS: operand pieces 1 | operand pieces 2 | mask bias | lse | delta | column sums
+// LAB (measurement builds, -DUNITER_X3_LAB + UNITER_ATTN_X3_LAB=bits): 1 = no pass-1 loop, 2 = no pass-2 loop, 4 = no MFMAs
+template <int LAB>
+__global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) {
+  set_wave_prio(a.prio);
+  const int IMG = Lr * ROWB;
+  u8* I1 = smem_raw;                    // pass 1: K, pass 2: Q
+  u8* I2 = smem_raw + 3 * IMG;          // pass 1: V, pass 2: dO
+  float* mb = reinterpret_cast<float*>(smem_raw + 6 * IMG);
+  float* lse_s = mb + Lr;
+  float* delta_s = lse_s + Lr;
+  float* red = delta_s + Lr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int i = lane & 15, g = lane >> 4;
+  const int nblk = Lr >> 5;
+  const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
+  const Span sp = span_of(a, b);
+  const int Lb = sp.Lb, ld = 3 * a.H;
+  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
+  const float* dobase = a.dctx + (size_t)sp.row0 * a.H + head * D;
+  const int rw = wave * 16 + i;          // this lane's row: a query in pass 1, a key in pass 2
+  const bool vr = rw < Lb;
+  const bool drop = a.keep_bits != nullptr;
+  const int nloop = wave * 16 < Lb ? sp.nb : 0;         // wave-uniform: 32-row chunks of the other index
+  LaneOffs lo;
+  lo.init(i, g);
+
+  // ---- pass 1: dQ (and delta) for queries rw; keys from the images of K and V
+  {
+    bf16x8 qf[2][3], dof[2][3];
+    float delta = 0.f;
+    {
+      Stage3 sk, sv;
+      sk.load(base + a.H, ld, Lb, Lr, tid, nthr);
+      sv.load(base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+      row_frags3(qf, base + (size_t)rw * ld, vr, g);
+      // this lane's 16 of the 64 values of its dO and O rows (d = 32 s + 8 g + 0..7): the k-slots of the dO operand
+      const float* dorow = dobase + (size_t)rw * a.H;
+      const float* orow = a.ctx + ((size_t)sp.row0 + rw) * a.H + head * D;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x, ox = x, oy = x;
+        if (vr) {
+          x = *reinterpret_cast<const f32x4*>(dorow + 32 * s + 8 * g);
+          y = *reinterpret_cast<const f32x4*>(dorow + 32 * s + 8 * g + 4);
+          ox = *reinterpret_cast<const f32x4*>(orow + 32 * s + 8 * g);
+          oy = *reinterpret_cast<const f32x4*>(orow + 32 * s + 8 * g + 4);
+        }
+        delta += x[0] * ox[0] + x[1] * ox[1] + x[2] * ox[2] + x[3] * ox[3] + y[0] * oy[0] + y[1] * oy[1] + y[2] * oy[2] + y[3] * oy[3];
+        split8(x, y, dof[s]);
+      }
+      stage_mask(mb, a, b, Lb, Lr, tid, nthr);
+      for (int t = tid; t < 192; t += nthr) red[t] = 0.f;
+      sk.store(I1, IMG, Lr, tid, nthr);
+      sv.store(I2, IMG, Lr, tid, nthr);
+    }
+    delta = groups_sum(delta);
+    const float lse = vr ? a.lse[(size_t)bh * a.L + rw] : -NEG_INF;      // +inf: every probability of a padded query is 0
+    if (g == 0) {
+      if (vr) a.delta[(size_t)bh * a.L + rw] = delta;
+      lse_s[rw] = lse;
+      delta_s[rw] = vr ? delta : 0.f;
+    }
+    __syncthreads();
+
+    const u16* kbits = a.keep_bits + (((size_t)bh * a.L + (vr ? rw : 0)) * nblk) * 2 + (g & 1);
+    f32x4 dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < ((LAB & 1) ? 0 : nloop); ++kc) {
+      const int k0 = kc * 32;
+      unsigned word = 0xffffu;
+      if (drop) word = kbits[kc * 2];
+      f32x4 s[2], dp[2];
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        s[b2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[b2] = s[b2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          bf16x8 ka[3], va[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            ka[p] = frag_row(I1 + p * IMG, k0 + 16 * b2, lo.row[st]);
+            va[p] = frag_row(I2 + p * IMG, k0 + 16 * b2, lo.row[st]);
+          }
+          mac6<LAB>(s[b2], ka, qf[st]);                       // S^T[key][query] = K . Q^T
+          mac6<LAB>(dp[b2], va, dof[st]);                     // dP^T[key][query] = V . dO^T
+        }
+      }
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(mb + k0 + 16 * b2 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[b2][r] * a.scale + bias[r] - lse);
+          const float m = drop ? keep_mult(word, b2, g, r, a.drop_scale) : 1.f;
+          s[b2][r] = p * (dp[b2][r] * m - delta) * a.scale;
+        }
+      }
+      bf16x8 db3[3];
+      split8(s[0], s[1], db3);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {                   // dQ^T[d][query] += K^T . dS^T
+        bf16x8 kt[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) kt[p] = frag_tr(I1 + p * IMG, k0, lo.tr[db]);
+        mac6<LAB>(dq[db], kt, db3);
+      }
+    }
+    if (vr) {
+      const size_t row = (size_t)sp.row0 + rw;
+      store_row(a.dqkv ? a.dqkv + row * ld + head * D : nullptr, a.dqkv_x3 ? a.dqkv_x3 + row * 3 * ld + head * D : nullptr, ld, dq,
+                1.0f, g);
+    }
+    if (a.bias_part) acc_colsum(red, dq, vr, i, g);
+  }
+
+  // ---- pass 2: dK, dV for keys rw; queries from the images of Q and dO (restaged over K and V)
+  bf16x8 kf[2][3], vf[2][3];
+  {
+    Stage3 sq, sdo;
+    sq.load(base, ld, Lb, Lr, tid, nthr);
+    sdo.load(dobase, a.H, Lb, Lr, tid, nthr);
+    row_frags3(kf, base + a.H + (size_t)rw * ld, vr, g);
+    row_frags3(vf, base + 2 * a.H + (size_t)rw * ld, vr, g);
+    __syncthreads();                                     // every wave is done with K and V
+    sq.store(I1, IMG, Lr, tid, nthr);
+    sdo.store(I2, IMG, Lr, tid, nthr);
+  }
+  __syncthreads();
+  {
+    const float bias = mb[rw];
+    // keep flag of (query, this lane's key): word (key >> 5, (key >> 2) & 1) of the query, bit 4 ((key & 31) >> 3) + (key & 3)
+    const u16* kbits = a.keep_bits + ((size_t)bh * a.L * nblk + (rw >> 5)) * 2 + ((rw >> 2) & 1);
+    const int kbit = 4 * ((rw & 31) >> 3) + (rw & 3);
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
+    for (int qc = 0; qc < ((LAB & 2) ? 0 : nloop); ++qc) {
+      const int q0 = qc * 32;
+      f32x4 s[2], dp[2];
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        s[b2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[b2] = s[b2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          bf16x8 qa[3], da[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            qa[p] = frag_row(I1 + p * IMG, q0 + 16 * b2, lo.row[st]);
+            da[p] = frag_row(I2 + p * IMG, q0 + 16 * b2, lo.row[st]);
+          }
+          mac6<LAB>(s[b2], qa, kf[st]);                       // S[query][key] = Q . K^T
+          mac6<LAB>(dp[b2], da, vf[st]);                      // dP[query][key] = dO . V^T
+        }
+      }
+      f32x4 pd[2];
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int qr = q0 + 16 * b2 + 4 * g;             // rows (queries) qr .. qr + 3 of this lane
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + qr);
+        const f32x4 dl4 = *reinterpret_cast<const f32x4*>(delta_s + qr);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float m = 1.f;
+          if (drop) {
+            const int qq = qr + r < Lb ? qr + r : 0;
+            m = ((kbits[(size_t)qq * nblk * 2] >> kbit) & 1u) ? a.drop_scale : 0.f;
+          }
+          const float p = __expf(s[b2][r] * a.scale + bias - lse4[r]);
+          pd[b2][r] = p * m;
+          s[b2][r] = p * (dp[b2][r] * m - dl4[r]) * a.scale;
+        }
+      }
+      // the two output products one after the other (each with its own pieces and fragments live: 168 registers per lane)
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        bf16x8 pb3[3];
+        split8(pd[0], pd[1], pb3);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {                 // dV^T[d][key] += dO^T . Pd
+          bf16x8 dt[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) dt[p] = frag_tr(I2 + p * IMG, q0, lo.tr[db]);
+          mac6<LAB>(dv[db], dt, pb3);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        bf16x8 db3[3];
+        split8(s[0], s[1], db3);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {                 // dK^T[d][key] += Q^T . dS
+          bf16x8 qt[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) qt[p] = frag_tr(I1 + p * IMG, q0, lo.tr[db]);
+          mac6<LAB>(dk[db], qt, db3);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (vr) {
+      const size_t row = (size_t)sp.row0 + rw;
+      store_row(a.dqkv ? a.dqkv + row * ld + a.H + head * D : nullptr,
+                a.dqkv_x3 ? a.dqkv_x3 + row * 3 * ld + a.H + head * D : nullptr, ld, dk, 1.0f, g);
+      store_row(a.dqkv ? a.dqkv + row * ld + 2 * a.H + head * D : nullptr,
+                a.dqkv_x3 ? a.dqkv_x3 + row * 3 * ld + 2 * a.H + head * D : nullptr, ld, dv, 1.0f, g);
+    }
+    if (a.bias_part) {
+      acc_colsum(red + 64, dk, vr, i, g);
+      acc_colsum(red + 128, dv, vr, i, g);
+      __syncthreads();
+      for (int t = tid; t < 192; t += nthr)
+        a.bias_part[(size_t)b * 3 * a.H + (t >> 6) * a.H + head * D + (t & 63)] = red[t];
+    }
+  }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  UCHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)bytes));
+  return 0;
+}
+
+int fill(Args& a, int B, int L, int nh, float p_drop, const void* keep_bits, const char* who) {
+  UCHECK_ARG(B > 0 && L > 0 && nh > 0, "%s: bad dims B=%d L=%d nh=%d", who, B, L, nh);
+  UCHECK_SHAPE(L <= MAXL, "%s: L %d > %d", who, L, MAXL);
+  UCHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: bad dropout p", who);
+  UCHECK_ARG(p_drop == 0.f || keep_bits, "%s: dropout needs the keep flags (uniter_attn_keep_bits_gen)", who);
+  a.B = B; a.L = L; a.nh = nh; a.H = nh * D;
+  a.scale = 0.125f;        // 1/sqrt(64), model/layer.py:86
+  a.keep_bits = p_drop > 0.f ? static_cast<const u16*>(keep_bits) : nullptr;
+  a.drop_scale = 1.0f / (1.0f - p_drop);
+  static const int prio = [] { const char* e = getenv("UNITER_ATTN_PRIO"); return e ? atoi(e) : 2; }();
+  a.prio = prio;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int uniter_attn_x3_max_len(void) { return MAXL; }
+
+extern "C" int uniter_attn_x3_fwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx, void* ctx_x3,
+                                  float* lse, const void* keep_bits, int B, int L, int nh, float p_drop, void* stream) {
+  UCHECK_ARG(qkv && (ctx || ctx_x3) && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
+             "attn_x3_fwd: null pointer, or not exactly one of attn_mask / cu_seqlens");
+  UCHECK_ARG(((uintptr_t)ctx_x3 & 7) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0, "attn_x3_fwd: misaligned pointer");
+  Args a = {};
+  UCHECK_RC(fill(a, B, L, nh, p_drop, keep_bits, "attn_x3_fwd"));
+  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_x3 = (u16*)ctx_x3; a.lse = lse;
+  const int Lr = (L + 31) / 32 * 32;
+  const size_t lds = (size_t)6 * Lr * ROWB + (size_t)Lr * 4;
+  UCHECK_RC(set_lds(attn_x3_fwd_kernel, lds));
+  hipLaunchKernelGGL(attn_x3_fwd_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int uniter_attn_x3_bwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, const float* ctx,
+                                  const float* lse, const float* dctx, float* dqkv, void* dqkv_x3, float* bias_part,
+                                  const void* keep_bits, float* delta, int B, int L, int nh, float p_drop, void* stream) {
+  UCHECK_ARG(qkv && ctx && lse && dctx && (dqkv || dqkv_x3) && delta && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
+             "attn_x3_bwd: null pointer, or not exactly one of attn_mask / cu_seqlens");
+  UCHECK_ARG(((uintptr_t)dqkv_x3 & 7) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0 &&
+                 ((uintptr_t)dctx & 15) == 0 && ((uintptr_t)dqkv & 15) == 0, "attn_x3_bwd: misaligned pointer");
+  Args a = {};
+  UCHECK_RC(fill(a, B, L, nh, p_drop, keep_bits, "attn_x3_bwd"));
+  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
+  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_x3 = (u16*)dqkv_x3; a.bias_part = bias_part; a.delta = delta;
+  const int Lr = (L + 31) / 32 * 32;
+  const size_t lds = (size_t)6 * Lr * ROWB + (size_t)3 * Lr * 4 + 192 * 4;
+#ifdef UNITER_X3_LAB
+  const char* e = getenv("UNITER_ATTN_X3_LAB");
+  const int lab = e ? atoi(e) : 0;
+#define X3A_LAB_CASE(N)                                                                                          \
+  if (lab == N) {                                                                                                \
+    UCHECK_RC(set_lds(attn_x3_bwd_kernel<N>, lds));                                                              \
+    hipLaunchKernelGGL(attn_x3_bwd_kernel<N>, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr);     \
+    UCHECK_LAUNCH();                                                                                             \
+    return 0;                                                                                                    \
+  }
+  X3A_LAB_CASE(1) X3A_LAB_CASE(2) X3A_LAB_CASE(3) X3A_LAB_CASE(4) X3A_LAB_CASE(5) X3A_LAB_CASE(6)
+#undef X3A_LAB_CASE
+#endif
+  UCHECK_RC(set_lds(attn_x3_bwd_kernel<0>, lds));
+  hipLaunchKernelGGL(attn_x3_bwd_kernel<0>, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr);
+  UCHECK_LAUNCH();
+  return 0;
+}

@@ -328,6 +328,12 @@ int gemm_v2(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, in
   return gemm_bf16v2_run(0, nsplit, 0, bkm, M, N, K, A, lda, B, ldb, C, ldc, (long)M * ldc, Cb, ldcb, epi, bias, aux_in,
                          aux_in_b16, aux_out, aux_out_b16, ld_aux, 0, st);
 }
+// precision 3: the attention's products on the bf16 pipe too (csrc/attention_x3.hip) -- L <= 192 and, with dropout, keep flags drawn
+// ahead of the kernel.  UNITER_ATTN_X3=0 keeps the fp32-MFMA kernels of attention_f32.hip (A/B measurements).
+bool attn_x3_products(int L, float p_drop, bool keep_flags_ready) {
+  static const bool on = [] { const char* e = getenv("UNITER_ATTN_X3"); return !(e && e[0] == '0'); }();
+  return on && L <= uniter_attn_x3_max_len() && (p_drop == 0.f || keep_flags_ready);
+}
 // precision 3: A = x3 activations [M][3][K]; W = the piece-major x3 mirror of an encoder weight (row stride ldw, piece stride =
 // the flat parameter buffer's length); outputs fp32 (nsplit slabs) or x3 [M][3][N]; aux operands fp32 (csrc/gemm_split3.hip)
 int gemm_x3(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, int K, const void* A, const unsigned short* W,
@@ -620,6 +626,9 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
         UCHECK_RC(uniter_attn_bf16_fwd_pre(lb.qkv, 1, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
                                            lb.ctx, lb.ctxb, lb.lse, save ? lb.keepb : nullptr, keep_pre ? 1 : 0, B, L, nh, pa,
                                            seed, offset, SITE_ATTN_PROBS(l), st));
+      else if (x3 && attn_x3_products(L, pa, keep_pre))      // the attention's own products on the bf16 pipe as well
+        UCHECK_RC(uniter_attn_x3_fwd(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr, lb.ctx,
+                                     lb.ctxb, lb.lse, pa > 0.f ? lb.keepb : nullptr, B, L, nh, pa, st));
       else if (x3 && L <= uniter_attn_varlen_max_len())      // the context leaves the kernel as x3 pieces too
         UCHECK_RC(uniter_attn_fwd_pre_x3(lb.qkv, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
                                          lb.ctx, lb.ctxb, lb.lse, save ? lb.keepb : nullptr, keep_pre ? 1 : 0, B, L, nh, pa,
@@ -844,6 +853,10 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                                      nullptr /* fp32 dqkv has no reader in this mode: bias partials are fused */,
                                      lb.dqkvb, lb.qb_part, lb.keepb, lb.delta, B, L, nh, pa, m->seed, m->offset,
                                      SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
+    else if (fused_qb && x3 && attn_x3_products(L, pa, pa > 0.f))      // (the forward pass of a saved plan left the keep flags)
+      UCHECK_RC(uniter_attn_x3_bwd(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
+                                   pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, nullptr, lb.dqkvb,
+                                   lb.qb_part, pa > 0.f ? lb.keepb : nullptr, lb.delta, B, L, nh, pa, st));
     else if (fused_qb && x3)      // dqkv leaves the kernel as x3 pieces only: nothing reads an fp32 copy in this mode
       UCHECK_RC(uniter_attn_bwd_ex_x3(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
                                       pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, nullptr, lb.dqkvb,

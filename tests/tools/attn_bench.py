@@ -15,11 +15,18 @@ for p in (0.0, 0.1):
     def bwd(): L.check(lib.uniter_attn_bwd(L.ptr(qkv), L.ptr(mask), L.ptr(ctx), L.ptr(lse), L.ptr(dctx), L.ptr(dqkv), L.ptr(delta), B, Lq, nh, p, 1, 2, 3, L.ptr(ws), wsb, L.cur_stream()))
     def fwd16(): L.check(lib.uniter_attn_bf16_fwd(L.ptr(qkvb), 1, L.ptr(mask), None, L.ptr(ctx), None, L.ptr(lse), kp, B, Lq, nh, p, 1, 2, 3, L.cur_stream()))
     def bwd16(): L.check(lib.uniter_attn_bf16_bwd(L.ptr(qkvb), 1, L.ptr(mask), None, L.ptr(ctx), L.ptr(lse), L.ptr(dctx), L.ptr(dqkv), None, None, kp, L.ptr(delta), B, Lq, nh, p, 1, 2, 3, L.ptr(ws), wsb, L.cur_stream()))
-    for name, f in (('fwd', fwd), ('bwd(dq+dkv)', bwd), ('bf16 fwd', fwd16), ('bf16 bwd', bwd16)):
+    if p > 0: L.check(lib.uniter_attn_keep_bits_gen(kp, 0, 1, B, Lq, nh, p, 1, 2, 3, 0, L.cur_stream()))
+    ctx3 = torch.empty(B * Lq, 3, H, dtype=torch.bfloat16, device='cuda'); dqkv3 = torch.empty(B * Lq, 3, 3 * H, dtype=torch.bfloat16, device='cuda')
+    part = torch.empty(B, 3 * H, device='cuda')
+    def fwdx(): L.check(lib.uniter_attn_x3_fwd(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(ctx3), L.ptr(lse), kp if p > 0 else None, B, Lq, nh, p, L.cur_stream()))
+    def bwdx(): L.check(lib.uniter_attn_x3_bwd(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(lse), L.ptr(dctx), None, L.ptr(dqkv3), L.ptr(part), kp if p > 0 else None, L.ptr(delta), B, Lq, nh, p, L.cur_stream()))
+    def fwd3(): L.check(lib.uniter_attn_fwd_pre_x3(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(ctx3), L.ptr(lse), kp, 1 if p > 0 else 0, B, Lq, nh, p, 1, 2, 3, L.cur_stream()))
+    def bwd3(): L.check(lib.uniter_attn_bwd_ex_x3(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(lse), L.ptr(dctx), None, L.ptr(dqkv3), L.ptr(part), kp, L.ptr(delta), B, Lq, nh, p, 1, 2, 3, L.ptr(ws), wsb, L.cur_stream()))
+    for name, f in (('fwd', fwd), ('bwd(dq+dkv)', bwd), ('fwd pieces out', fwd3), ('bwd pieces out', bwd3), ('x3 fwd', fwdx), ('x3 bwd', bwdx), ('bf16 fwd', fwd16), ('bf16 bwd', bwd16)):
         for _ in range(3): f()
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20): f()
         e1.record(); torch.cuda.synchronize()
-        print('p=%.1f %-12s %.1f us' % (p, name, e0.elapsed_time(e1) / 20 * 1e3), flush=True)
+        print('p=%.1f %-15s %.1f us' % (p, name, e0.elapsed_time(e1) / 20 * 1e3), flush=True)

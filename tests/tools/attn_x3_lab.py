@@ -1,0 +1,29 @@
+"""Where the x3 attention backward spends its time: the lab build (-DUNITER_X3_LAB, UNITER_LIB_VARIANT=x3lab) compiles measurement
+forms of attn_x3_bwd_kernel selected by UNITER_ATTN_X3_LAB (1 = no pass-1 loop, 2 = no pass-2 loop, 4 = fragments read but no MFMAs)."""
+import os, sys, torch
+sys.path.insert(0, '.')
+from meme_challenge_amd import _lib as L
+lib = L.lib()
+B, Lq, nh = 16, int(os.environ.get('LAB_L', 164)), 12
+H = nh * 64
+p = 0.1
+qkv = torch.randn(B * Lq, 3 * H, device='cuda'); mask = torch.ones(B, Lq, device='cuda')
+ctx = torch.empty(B * Lq, H, device='cuda'); lse = torch.empty(B, nh, Lq, device='cuda')
+dctx = torch.randn(B * Lq, H, device='cuda'); delta = torch.empty(B, nh, Lq, device='cuda')
+keep = torch.zeros(lib.uniter_attn_keep_bits_bytes(B, Lq, nh) // 2, dtype=torch.int16, device='cuda'); kp = L.ptr(keep)
+L.check(lib.uniter_attn_keep_bits_gen(kp, 0, 1, B, Lq, nh, p, 1, 2, 3, 0, L.cur_stream()))
+ctx3 = torch.empty(B * Lq, 3, H, dtype=torch.bfloat16, device='cuda'); dqkv3 = torch.empty(B * Lq, 3, 3 * H, dtype=torch.bfloat16, device='cuda')
+part = torch.empty(B, 3 * H, device='cuda')
+def fwdx(): L.check(lib.uniter_attn_x3_fwd(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(ctx3), L.ptr(lse), kp, B, Lq, nh, p, L.cur_stream()))
+def bwdx(): L.check(lib.uniter_attn_x3_bwd(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(lse), L.ptr(dctx), None, L.ptr(dqkv3), L.ptr(part), kp, L.ptr(delta), B, Lq, nh, p, L.cur_stream()))
+fwdx()
+names = {0: 'complete', 1: 'no pass-1 loop', 2: 'no pass-2 loop', 3: 'no loops (staging, stores)', 4: 'no MFMAs', 5: 'pass 2 without MFMAs', 6: 'pass 1 without MFMAs'}
+for lab in [int(x) for x in os.environ.get('LAB_FORMS', '0,1,2,3,4,5,6').split(',')]:
+    os.environ['UNITER_ATTN_X3_LAB'] = str(lab)
+    for _ in range(3): bwdx()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): bwdx()
+    e1.record(); torch.cuda.synchronize()
+    print('x3 bwd L=%d form %d %-28s %.1f us' % (Lq, lab, names[lab], e0.elapsed_time(e1) / 20 * 1e3), flush=True)
