@@ -566,8 +566,10 @@ def run_rank(args):
         dt_name = 'f32' if args.precision in ('fp32', 'fp32x3') else 'bf16'       # the arithmetic type of the path's results
         pk_name = {'fp32': 'f32', 'fp32x3': 'f32x3', 'bf16': 'bf16'}[args.precision]
         peak = PEAK_TFLOPS[pk_name]                    # the dense products' pipe
-        # attention runs on the fp32 matrix pipe in both fp32 modes (L <= 192 in the bf16 mode: on the bf16 pipe)
-        peak_attn = PEAK_TFLOPS['bf16' if args.precision == 'bf16' else 'f32']
+        # attention: fp32 MFMAs in the fp32 mode; in the fp32x3 mode its products are x3 products too (L <= 192,
+        # csrc/attention_x3.hip; UNITER_ATTN_X3=0 keeps the fp32 MFMAs); bf16 mode: the bf16 pipe
+        attn_x3 = args.precision == 'fp32x3' and L_eff <= 192 and os.environ.get('UNITER_ATTN_X3', '1')[:1] != '0'
+        peak_attn = PEAK_TFLOPS['bf16' if args.precision == 'bf16' else ('f32x3' if attn_x3 else 'f32')]
         H, I, nl = cfgd['hidden_size'], cfgd['intermediate_size'], cfgd['num_hidden_layers']
         sq = sum(n * n for n in cur['seq_lens']) if args.packed else B * L_eff * L_eff
         g_qkv, g_o, g_ffn = 2.0 * M_eff * H * 3 * H, 2.0 * M_eff * H * H, 2.0 * M_eff * H * I

@@ -10,8 +10,8 @@
 //     O^T[d][query] = V^T . P^T      (element j of lane group g: key 16 (j >> 2) + 4 g + (j & 3))
 // with no lane movement; the A operand V^T comes out of the ROW-MAJOR image of V by ds_read_b64_tr_b16 in exactly that key order
 // (two reads of 4 keys x 16 d).  So each operand has ONE LDS image per piece -- [row][64 d] bf16, 128-byte rows, 16-byte chunk c of
-// row r at c ^ f(r), f(r) = 4 ((r >> 1) & 1) | ((r >> 2) & 3): row reads (ds_read_b128) at most 2-way, transposed reads
-// conflict-free -- and K, V (forward, dQ pass) or Q, dO (dK / dV pass) fit as 2 x 3 images of 24 KB in the 160-KB LDS.
+// row r at c ^ (r & 6): row reads (ds_read_b128) and transposed reads both conflict-free (searched over the linear swizzles
+// with the bank rules of MI355X_MICROARCH.md) -- and K, V (forward, dQ pass) or Q, dO (dK / dV pass) fit as 2 x 3 images of 24 KB in the 160-KB LDS.
 //
 // Backward, one launch, NO hand-over through memory: pass 1 (wave = 16 queries, all keys) recomputes S^T and dP^T = V . dO^T and
 // accumulates dQ^T = K^T . dS^T; pass 2 (wave = 16 keys, all queries; Q and dO restaged over K and V) recomputes
@@ -37,6 +37,7 @@ typedef unsigned char u8;
 constexpr int D = 64;
 constexpr int MAXL = 192;
 constexpr int ROWB = 128;                 // bytes per image row (64 bf16)
+constexpr int IMG = MAXL * ROWB;          // bytes per piece image, whatever the length: piece and block offsets are instruction immediates
 constexpr float NEG_INF = -__builtin_huge_valf();
 
 struct Args {
@@ -91,7 +92,7 @@ __device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, bf16x8 (&
 }
 
 // chunk swizzle of the images (header)
-__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ int swz(int r) { return r & 6; }
 
 // One [L, 64] fp32 operand on its way into its three piece images: this thread's four 16-byte pieces are all loaded before
 // anything is written (blockDim.x = 4 Lr threads).  Rows >= L are zero.
@@ -105,7 +106,7 @@ struct Stage3 {
       if (idx < Lr * 16 && r < L) v[it] = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c4 * 4);
     }
   }
-  __device__ __forceinline__ void store(u8* img, int IMG, int Lr, int tid, int nthr) const {
+  __device__ __forceinline__ void store(u8* img, int Lr, int tid, int nthr) const {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
@@ -139,13 +140,23 @@ __device__ __forceinline__ void row_frags3(bf16x8 (&f)[2][3], const float* __res
 struct LaneOffs {
   int row[2];      // step s: row i, chunk 4 s + g
   int tr[4];       // d-block db: row 4 g + (i >> 2), columns 16 db + 4 (i & 3) .. + 3
+  int row2[2], tr2[4];   // the same into the second operand's images (+ 3 IMG): registers of their own, so that piece and block
+                         // offsets stay within the 16-bit immediates of the LDS instructions for both operands
   __device__ __forceinline__ void init(int i, int g) {
     const int fi = swz(i);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) row[s] = i * ROWB + 16 * ((4 * s + g) ^ fi);
+    for (int s = 0; s < 2; ++s) {
+      row[s] = i * ROWB + 16 * ((4 * s + g) ^ fi);
+      row2[s] = row[s] + 3 * IMG;
+      asm volatile("" : "+v"(row2[s]));
+    }
     const int tr_row = 4 * g + (i >> 2), p4 = i & 3, ft = swz(tr_row);
 #pragma unroll
-    for (int db = 0; db < 4; ++db) tr[db] = tr_row * ROWB + 16 * ((2 * db + (p4 >> 1)) ^ ft) + 8 * (p4 & 1);
+    for (int db = 0; db < 4; ++db) {
+      tr[db] = tr_row * ROWB + 16 * ((2 * db + (p4 >> 1)) ^ ft) + 8 * (p4 & 1);
+      tr2[db] = tr[db] + 3 * IMG;
+      asm volatile("" : "+v"(tr2[db]));
+    }
   }
 };
 
@@ -190,32 +201,45 @@ __device__ __forceinline__ float groups_max(float v) {
   return v;
 }
 
-// one output row (lane's query or key): acc[db][r] = element d = 16 db + 4 g + r; fp32 and / or the three pieces
-__device__ __forceinline__ void store_row(float* __restrict__ row, u16* __restrict__ row_x3, int ps, const f32x4 (&acc)[4],
-                                          float mul, int g) {
+// one output row (lane's query or key): acc[db][r] = element d = 16 db + 4 g + r; fp32 and / or the three pieces.  The pieces
+// leave two d-blocks at a time: v_permlane16_swap hands lane group 1's (3's) values of block db to group 0 (2) and group 0's
+// (2's) values of block db + 1 to group 1 (3), so every lane stores 8 consecutive d -- one 16-byte store per piece instead of two
+// of 8 bytes (the store tail of an attention kernel is issue-bound, MI355X_MICROARCH.md).  Every lane of the wave must call it
+// (the swap crosses lanes); `valid` masks the stores only.
+__device__ __forceinline__ void store_row(bool valid, float* __restrict__ row, u16* __restrict__ row_x3, int ps,
+                                          const f32x4 (&acc)[4], float mul, int g) {
+  f32x4 v[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) {
-    const f32x4 v = {acc[db][0] * mul, acc[db][1] * mul, acc[db][2] * mul, acc[db][3] * mul};
-    if (row) *reinterpret_cast<f32x4*>(row + 16 * db + 4 * g) = v;
-    if (row_x3) {
-      unsigned a1, a2, a3, b1, b2, b3;
-      split2(v[0], v[1], a1, a2, a3);
-      split2(v[2], v[3], b1, b2, b3);
-      u16* p = row_x3 + 16 * db + 4 * g;
-      *reinterpret_cast<u32x2*>(p) = u32x2{a1, b1};
-      *reinterpret_cast<u32x2*>(p + ps) = u32x2{a2, b2};
-      *reinterpret_cast<u32x2*>(p + 2 * ps) = u32x2{a3, b3};
+    v[db] = f32x4{acc[db][0] * mul, acc[db][1] * mul, acc[db][2] * mul, acc[db][3] * mul};
+    if (valid && row) *reinterpret_cast<f32x4*>(row + 16 * db + 4 * g) = v[db];
+  }
+  if (row_x3) {
+#pragma unroll
+    for (int db = 0; db < 4; db += 2) {
+      unsigned wa[3][2], wb[3][2];
+      split2(v[db][0], v[db][1], wa[0][0], wa[1][0], wa[2][0]);
+      split2(v[db][2], v[db][3], wa[0][1], wa[1][1], wa[2][1]);
+      split2(v[db + 1][0], v[db + 1][1], wb[0][0], wb[1][0], wb[2][0]);
+      split2(v[db + 1][2], v[db + 1][3], wb[0][1], wb[1][1], wb[2][1]);
+      u16* dst = row_x3 + (db + (g & 1)) * 16 + 8 * (g >> 1);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const auto r0 = __builtin_amdgcn_permlane16_swap(wa[p][0], wb[p][0], false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(wa[p][1], wb[p][1], false, false);
+        if (valid) *reinterpret_cast<u32x4*>(dst + p * ps) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+      }
     }
   }
 }
 
 // column sums of an output block over the wave's valid rows -> red[0..63] (LDS, pre-zeroed)
-__device__ __forceinline__ void acc_colsum(float* red, const f32x4 (&acc)[4], bool valid, int i, int g) {
+__device__ __forceinline__ void acc_colsum(float* red, const f32x4 (&acc)[4], float mul, bool valid, int i, int g) {
 #pragma unroll
   for (int db = 0; db < 4; ++db) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float v = valid ? acc[db][r] : 0.f;
+      float v = valid ? acc[db][r] * mul : 0.f;
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
       if (i == 0) atomicAdd(red + 16 * db + 4 * g + r, v);
@@ -240,7 +264,6 @@ __device__ __forceinline__ float keep_mult(unsigned word, int b2, int g, int r, 
 // LDS: K pieces | V pieces | mask bias
 __global__ __launch_bounds__(768) void attn_x3_fwd_kernel(const Args a, int Lr) {
   set_wave_prio(a.prio);
-  const int IMG = Lr * ROWB;
   u8* Ki = smem_raw;
   u8* Vi = smem_raw + 3 * IMG;
   float* mb = reinterpret_cast<float*>(smem_raw + 6 * IMG);
@@ -260,23 +283,30 @@ __global__ __launch_bounds__(768) void attn_x3_fwd_kernel(const Args a, int Lr) 
     sv.load(base + 2 * a.H, ld, Lb, Lr, tid, nthr);
     row_frags3(qf, base + (size_t)q * ld, vq, g);
     stage_mask(mb, a, b, Lb, Lr, tid, nthr);
-    sk.store(Ki, IMG, Lr, tid, nthr);
-    sv.store(Vi, IMG, Lr, tid, nthr);
+    sk.store(Ki, Lr, tid, nthr);
+    sv.store(Vi, Lr, tid, nthr);
   }
   __syncthreads();
   LaneOffs lo;
   lo.init(i, g);
   const int nk = wave * 16 < Lb ? sp.nb : 0;           // wave-uniform
   const bool drop = a.keep_bits != nullptr;
-  const u16* kbits = a.keep_bits + (((size_t)bh * a.L + (vq ? q : 0)) * nblk) * 2 + (g & 1);
+  // the keep words of this lane's query for every key chunk, ahead of the loop (one memory latency instead of one per chunk)
+  unsigned words[MAXL / 32];
+#pragma unroll
+  for (int kc = 0; kc < MAXL / 32; ++kc) {
+    words[kc] = 0xffffu;
+    if (drop && kc < nblk) words[kc] = a.keep_bits[(((size_t)bh * a.L + (vq ? q : 0)) * nblk + kc) * 2 + (g & 1)];
+  }
   f32x4 o[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = NEG_INF, l_run = 0.f;
   for (int kc = 0; kc < nk; ++kc) {
     const int k0 = kc * 32;
-    unsigned word = 0xffffu;
-    if (drop) word = kbits[kc * 2];
+    unsigned word = words[0];
+#pragma unroll
+    for (int c = 1; c < MAXL / 32; ++c) word = kc == c ? words[c] : word;
     f32x4 s[2];
 #pragma unroll
     for (int b2 = 0; b2 < 2; ++b2) {                     // S^T[key][query] = K . Q^T
@@ -325,32 +355,32 @@ __global__ __launch_bounds__(768) void attn_x3_fwd_kernel(const Args a, int Lr) 
     for (int db = 0; db < 4; ++db) {                     // O^T[d][query] += V^T . Pd^T
       bf16x8 va[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) va[p] = frag_tr(Vi + p * IMG, k0, lo.tr[db]);
+      for (int p = 0; p < 3; ++p) va[p] = frag_tr(Ki + p * IMG, k0, lo.tr2[db]);
       mac6(o[db], va, pb);
     }
   }
   const float l_tot = groups_sum(l_run);
-  if (vq) {
-    const size_t row = (size_t)sp.row0 + q;
-    store_row(a.ctx ? a.ctx + row * a.H + head * D : nullptr, a.ctx_x3 ? a.ctx_x3 + row * 3 * a.H + head * D : nullptr, a.H, o,
+  {
+    const size_t row = (size_t)sp.row0 + (vq ? q : 0);
+    store_row(vq, a.ctx ? a.ctx + row * a.H + head * D : nullptr, a.ctx_x3 ? a.ctx_x3 + row * 3 * a.H + head * D : nullptr, a.H, o,
               1.0f / l_tot, g);
-    if (g == 0 && a.lse) a.lse[(size_t)bh * a.L + q] = m_run + __logf(l_tot);
+    if (vq && g == 0 && a.lse) a.lse[(size_t)bh * a.L + q] = m_run + __logf(l_tot);
   }
 }
 
 // --------------------------------------------------------------- backward ---
-// LDS: operand pieces 1 | operand pieces 2 | mask bias | lse | delta | column sums
+// LDS: operand pieces 1 | operand pieces 2 | mask bias | lse | delta | column sums | keep words
 // LAB (measurement builds, -DUNITER_X3_LAB + UNITER_ATTN_X3_LAB=bits): 1 = no pass-1 loop, 2 = no pass-2 loop, 4 = no MFMAs
 template <int LAB>
 __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) {
   set_wave_prio(a.prio);
-  const int IMG = Lr * ROWB;
   u8* I1 = smem_raw;                    // pass 1: K, pass 2: Q
   u8* I2 = smem_raw + 3 * IMG;          // pass 1: V, pass 2: dO
   float* mb = reinterpret_cast<float*>(smem_raw + 6 * IMG);
   float* lse_s = mb + Lr;
   float* delta_s = lse_s + Lr;
   float* red = delta_s + Lr;
+  u16* kb_s = reinterpret_cast<u16*>(red + 192);      // the head's keep words [query][key chunk][2] (both passes read them)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
   const int i = lane & 15, g = lane >> 4;
   const int nblk = Lr >> 5;
@@ -367,8 +397,8 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
   lo.init(i, g);
 
   // ---- pass 1: dQ (and delta) for queries rw; keys from the images of K and V
+  bf16x8 qf[2][3], dof[2][3];
   {
-    bf16x8 qf[2][3], dof[2][3];
     float delta = 0.f;
     {
       Stage3 sk, sv;
@@ -392,8 +422,12 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
       }
       stage_mask(mb, a, b, Lb, Lr, tid, nthr);
       for (int t = tid; t < 192; t += nthr) red[t] = 0.f;
-      sk.store(I1, IMG, Lr, tid, nthr);
-      sv.store(I2, IMG, Lr, tid, nthr);
+      if (drop) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(a.keep_bits + (size_t)bh * a.L * nblk * 2);
+        for (int t = tid; t < Lb * nblk; t += nthr) reinterpret_cast<unsigned*>(kb_s)[t] = src[t];
+      }
+      sk.store(I1, Lr, tid, nthr);
+      sv.store(I2, Lr, tid, nthr);
     }
     delta = groups_sum(delta);
     const float lse = vr ? a.lse[(size_t)bh * a.L + rw] : -NEG_INF;      // +inf: every probability of a padded query is 0
@@ -404,7 +438,7 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
     }
     __syncthreads();
 
-    const u16* kbits = a.keep_bits + (((size_t)bh * a.L + (vr ? rw : 0)) * nblk) * 2 + (g & 1);
+    const u16* kbits = kb_s + (vr ? rw : 0) * nblk * 2 + (g & 1);
     f32x4 dq[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -423,7 +457,7 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
 #pragma unroll
           for (int p = 0; p < 3; ++p) {
             ka[p] = frag_row(I1 + p * IMG, k0 + 16 * b2, lo.row[st]);
-            va[p] = frag_row(I2 + p * IMG, k0 + 16 * b2, lo.row[st]);
+            va[p] = frag_row(I1 + p * IMG, k0 + 16 * b2, lo.row2[st]);
           }
           mac6<LAB>(s[b2], ka, qf[st]);                       // S^T[key][query] = K . Q^T
           mac6<LAB>(dp[b2], va, dof[st]);                     // dP^T[key][query] = V . dO^T
@@ -436,7 +470,7 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
         for (int r = 0; r < 4; ++r) {
           const float p = __expf(s[b2][r] * a.scale + bias[r] - lse);
           const float m = drop ? keep_mult(word, b2, g, r, a.drop_scale) : 1.f;
-          s[b2][r] = p * (dp[b2][r] * m - delta) * a.scale;
+          s[b2][r] = p * (dp[b2][r] * m - delta);      // x scale (a power of two) when dQ leaves
         }
       }
       bf16x8 db3[3];
@@ -449,31 +483,38 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
         mac6<LAB>(dq[db], kt, db3);
       }
     }
-    if (vr) {
-      const size_t row = (size_t)sp.row0 + rw;
-      store_row(a.dqkv ? a.dqkv + row * ld + head * D : nullptr, a.dqkv_x3 ? a.dqkv_x3 + row * 3 * ld + head * D : nullptr, ld, dq,
-                1.0f, g);
+    {
+      const size_t row = (size_t)sp.row0 + (vr ? rw : 0);
+      store_row(vr, a.dqkv ? a.dqkv + row * ld + head * D : nullptr, a.dqkv_x3 ? a.dqkv_x3 + row * 3 * ld + head * D : nullptr, ld,
+                dq, a.scale, g);
     }
-    if (a.bias_part) acc_colsum(red, dq, vr, i, g);
+    if (a.bias_part) acc_colsum(red, dq, a.scale, vr, i, g);
   }
 
-  // ---- pass 2: dK, dV for keys rw; queries from the images of Q and dO (restaged over K and V)
+  // ---- pass 2: dK, dV for keys rw; queries from the images of Q and dO.  Nothing is loaded again: this wave's K and V rows
+  // come out of the images before they are overwritten, and the images of Q and dO are the row fragments the waves already
+  // hold -- lane (i, g) has exactly chunk 4 s + g of row rw of every piece.
   bf16x8 kf[2][3], vf[2][3];
-  {
-    Stage3 sq, sdo;
-    sq.load(base, ld, Lb, Lr, tid, nthr);
-    sdo.load(dobase, a.H, Lb, Lr, tid, nthr);
-    row_frags3(kf, base + a.H + (size_t)rw * ld, vr, g);
-    row_frags3(vf, base + 2 * a.H + (size_t)rw * ld, vr, g);
-    __syncthreads();                                     // every wave is done with K and V
-    sq.store(I1, IMG, Lr, tid, nthr);
-    sdo.store(I2, IMG, Lr, tid, nthr);
-  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      kf[s][p] = frag_row(I1 + p * IMG, wave * 16, lo.row[s]);
+      vf[s][p] = frag_row(I1 + p * IMG, wave * 16, lo.row2[s]);
+    }
+  __syncthreads();                                       // every wave is done with K and V
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      *reinterpret_cast<bf16x8*>(I1 + p * IMG + wave * 16 * ROWB + lo.row[s]) = qf[s][p];
+      *reinterpret_cast<bf16x8*>(I1 + p * IMG + wave * 16 * ROWB + lo.row2[s]) = dof[s][p];
+    }
   __syncthreads();
   {
     const float bias = mb[rw];
     // keep flag of (query, this lane's key): word (key >> 5, (key >> 2) & 1) of the query, bit 4 ((key & 31) >> 3) + (key & 3)
-    const u16* kbits = a.keep_bits + ((size_t)bh * a.L * nblk + (rw >> 5)) * 2 + ((rw >> 2) & 1);
+    const u16* kbits = kb_s + (rw >> 5) * 2 + ((rw >> 2) & 1);
     const int kbit = 4 * ((rw & 31) >> 3) + (rw & 3);
     f32x4 dk[4], dv[4];
 #pragma unroll
@@ -491,7 +532,7 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
 #pragma unroll
           for (int p = 0; p < 3; ++p) {
             qa[p] = frag_row(I1 + p * IMG, q0 + 16 * b2, lo.row[st]);
-            da[p] = frag_row(I2 + p * IMG, q0 + 16 * b2, lo.row[st]);
+            da[p] = frag_row(I1 + p * IMG, q0 + 16 * b2, lo.row2[st]);
           }
           mac6<LAB>(s[b2], qa, kf[st]);                       // S[query][key] = Q . K^T
           mac6<LAB>(dp[b2], da, vf[st]);                      // dP[query][key] = dO . V^T
@@ -508,11 +549,11 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
           float m = 1.f;
           if (drop) {
             const int qq = qr + r < Lb ? qr + r : 0;
-            m = ((kbits[(size_t)qq * nblk * 2] >> kbit) & 1u) ? a.drop_scale : 0.f;
+            m = ((kbits[qq * nblk * 2] >> kbit) & 1u) ? a.drop_scale : 0.f;
           }
           const float p = __expf(s[b2][r] * a.scale + bias - lse4[r]);
           pd[b2][r] = p * m;
-          s[b2][r] = p * (dp[b2][r] * m - dl4[r]) * a.scale;
+          s[b2][r] = p * (dp[b2][r] * m - dl4[r]);     // x scale when dK leaves
         }
       }
       // the two output products one after the other (each with its own pieces and fragments live: 168 registers per lane)
@@ -524,7 +565,7 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
         for (int db = 0; db < 4; ++db) {                 // dV^T[d][key] += dO^T . Pd
           bf16x8 dt[3];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) dt[p] = frag_tr(I2 + p * IMG, q0, lo.tr[db]);
+          for (int p = 0; p < 3; ++p) dt[p] = frag_tr(I1 + p * IMG, q0, lo.tr2[db]);
           mac6<LAB>(dv[db], dt, pb3);
         }
       }
@@ -542,16 +583,16 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (vr) {
-      const size_t row = (size_t)sp.row0 + rw;
-      store_row(a.dqkv ? a.dqkv + row * ld + a.H + head * D : nullptr,
-                a.dqkv_x3 ? a.dqkv_x3 + row * 3 * ld + a.H + head * D : nullptr, ld, dk, 1.0f, g);
-      store_row(a.dqkv ? a.dqkv + row * ld + 2 * a.H + head * D : nullptr,
+    {
+      const size_t row = (size_t)sp.row0 + (vr ? rw : 0);
+      store_row(vr, a.dqkv ? a.dqkv + row * ld + a.H + head * D : nullptr,
+                a.dqkv_x3 ? a.dqkv_x3 + row * 3 * ld + a.H + head * D : nullptr, ld, dk, a.scale, g);
+      store_row(vr, a.dqkv ? a.dqkv + row * ld + 2 * a.H + head * D : nullptr,
                 a.dqkv_x3 ? a.dqkv_x3 + row * 3 * ld + 2 * a.H + head * D : nullptr, ld, dv, 1.0f, g);
     }
     if (a.bias_part) {
-      acc_colsum(red + 64, dk, vr, i, g);
-      acc_colsum(red + 128, dv, vr, i, g);
+      acc_colsum(red + 64, dk, a.scale, vr, i, g);
+      acc_colsum(red + 128, dv, 1.0f, vr, i, g);
       __syncthreads();
       for (int t = tid; t < 192; t += nthr)
         a.bias_part[(size_t)b * 3 * a.H + (t >> 6) * a.H + head * D + (t & 63)] = red[t];
@@ -588,12 +629,12 @@ extern "C" int uniter_attn_x3_fwd(const float* qkv, const float* attn_mask, cons
                                   float* lse, const void* keep_bits, int B, int L, int nh, float p_drop, void* stream) {
   UCHECK_ARG(qkv && (ctx || ctx_x3) && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_x3_fwd: null pointer, or not exactly one of attn_mask / cu_seqlens");
-  UCHECK_ARG(((uintptr_t)ctx_x3 & 7) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0, "attn_x3_fwd: misaligned pointer");
+  UCHECK_ARG(((uintptr_t)ctx_x3 & 15) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0, "attn_x3_fwd: misaligned pointer");
   Args a = {};
   UCHECK_RC(fill(a, B, L, nh, p_drop, keep_bits, "attn_x3_fwd"));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_x3 = (u16*)ctx_x3; a.lse = lse;
   const int Lr = (L + 31) / 32 * 32;
-  const size_t lds = (size_t)6 * Lr * ROWB + (size_t)Lr * 4;
+  const size_t lds = (size_t)6 * IMG + (size_t)Lr * 4;
   UCHECK_RC(set_lds(attn_x3_fwd_kernel, lds));
   hipLaunchKernelGGL(attn_x3_fwd_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr);
   UCHECK_LAUNCH();
@@ -605,14 +646,14 @@ extern "C" int uniter_attn_x3_bwd(const float* qkv, const float* attn_mask, cons
                                   const void* keep_bits, float* delta, int B, int L, int nh, float p_drop, void* stream) {
   UCHECK_ARG(qkv && ctx && lse && dctx && (dqkv || dqkv_x3) && delta && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_x3_bwd: null pointer, or not exactly one of attn_mask / cu_seqlens");
-  UCHECK_ARG(((uintptr_t)dqkv_x3 & 7) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0 &&
+  UCHECK_ARG(((uintptr_t)dqkv_x3 & 15) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0 &&
                  ((uintptr_t)dctx & 15) == 0 && ((uintptr_t)dqkv & 15) == 0, "attn_x3_bwd: misaligned pointer");
   Args a = {};
   UCHECK_RC(fill(a, B, L, nh, p_drop, keep_bits, "attn_x3_bwd"));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
   a.dctx = dctx; a.dqkv = dqkv; a.dqkv_x3 = (u16*)dqkv_x3; a.bias_part = bias_part; a.delta = delta;
   const int Lr = (L + 31) / 32 * 32;
-  const size_t lds = (size_t)6 * Lr * ROWB + (size_t)3 * Lr * 4 + 192 * 4;
+  const size_t lds = (size_t)6 * IMG + (size_t)3 * Lr * 4 + 192 * 4 + (size_t)Lr * (Lr / 32) * 4;
 #ifdef UNITER_X3_LAB
   const char* e = getenv("UNITER_ATTN_X3_LAB");
   const int lab = e ? atoi(e) : 0;

@@ -36,7 +36,7 @@ def test_bench_default_contract():
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['peak'] - 2500.0 / 6) < 0.1
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0.1 < r['frac'] < 1.0
-    assert d['peak_tflops']['dense_products'] == 416.7 and d['peak_tflops']['attention'] == 157.3
+    assert d['peak_tflops']['dense_products'] == 416.7 and d['peak_tflops']['attention'] == 416.7      # L = 164: the attention's products are x3 products too
     nat = d['native_fp32']
     assert nat['value'] > 0 and abs(nat['value'] - 16 / (nat['ms_per_step'] * 1e-3)) / nat['value'] < 1e-3
     assert d['value'] > nat['value']                   # the point of the mode
@@ -65,7 +65,7 @@ def test_bench_default_contract():
 def test_bench_native_fp32_mode_keeps_its_roofline():
     d = _bench('--precision', 'fp32', '--no_cpu_baseline')
     assert d['dtype'] == 'f32' and d['roofline']['peak'] == 157.3 and 'native fp32 MFMA' in d['config']['workload']
-    assert 'native_fp32' not in d and d['peak_tflops']['dense_products'] == 157.3
+    assert 'native_fp32' not in d and d['peak_tflops']['dense_products'] == 157.3 and d['peak_tflops']['attention'] == 157.3
 
 
 @pytest.mark.parametrize('flags', [('--precision', 'bf16', '--no_cpu_baseline'),
