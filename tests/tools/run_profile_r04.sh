@@ -26,12 +26,14 @@ find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_ke
 find $O/stats_bf16 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_bf16_kernel_stats.csv
 bash tests/tools/run_timeline.sh f32 --precision fp32x3; bash tests/tools/run_timeline.sh bf16
 cp gpurun_out/tl/timeline_f32.txt $O/timeline_f32x3.txt; cp gpurun_out/tl/timeline_bf16.txt $O/timeline_bf16.txt
-python tests/tools/attn_bench.py > $O/attention_isolated.txt 2>&1
+python tests/tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > $O/attention_isolated.txt
+UNITER_ATTN_X3=0 timeout 300 python bench.py --no_cpu_baseline --no_native_leg > $O/bench_attention_on_fp32_mfma.json 2>> $O/bench.err
 LAB_NSPLIT=1,2 timeout 400 python tests/tools/gemm_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_lab.txt
 LAB_ACC=0 LAB_NSPLIT=1 LAB_ONLY=ffnup_fwd,qkv_fwd,plain_fwd LAB_KSWEEP=32,768,1536,3072 LAB_WG_CFGS=3 timeout 300 python tests/tools/gemm_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_ksweep.txt
 if [ -f meme_challenge_amd/libuniter_hip_x3lab.so ]; then
 UNITER_LIB_VARIANT=x3lab LAB_ACC=0 LAB_NSPLIT=1 LAB_ONLY=ffnup_fwd LAB_KSWEEP=32,1536 LAB_CFGS=3,3d1,3d2,3d3,3d4,3d6,3d7,2,2d1,2d3,2d4,1,1d1,1d3,1d4 LAB_WG_CFGS=3 timeout 300 python tests/tools/gemm_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_ablation.txt
 UNITER_LIB_VARIANT=x3lab LAB_CFGS=3,3d1,3d3,3d4,2,2d1,2d3,2d4,1,1d3 timeout 200 python tests/tools/gemm_x3_clock.py 2>&1 | grep -v amdgpu.ids > $O/gemm_x3_clock.txt
+UNITER_LIB_VARIANT=x3lab timeout 200 python tests/tools/attn_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/attn_x3_lab.txt
 fi
 python tests/tools/ln_bench.py > $O/ln_isolated.txt 2>&1
 (python tests/tools/cli_throughput.py fp32; python tests/tools/cli_throughput.py fp32x3; python tests/tools/cli_throughput.py bf16) 2>&1 | grep 'samples/s' > $O/cli_throughput_raw.txt
@@ -43,6 +45,7 @@ pm write WRITE_SIZE
 pm mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES"
 pm fetch_bf16 FETCH_SIZE --precision bf16
 pm write_bf16 WRITE_SIZE --precision bf16
+bash tests/tools/attn_x3_pmc.sh > $O/attn_x3_pmc.txt 2>&1
 python tests/tools/pmc_to_traffic_r04.py $O $O/pmc_traffic.json > $O/pmc_traffic.txt
 python tests/tools/pmc_table.py $O/ > $O/kernel_table.md; python tests/tools/pmc_table.py $O/ bf16 > $O/kernel_table_bf16.md
 fi
