@@ -305,13 +305,16 @@ int uniter_attn_bwd_ex_x3(const float* qkv, const float* attn_mask, const int32_
  * uniter_attn_keep_bits_gen drew (keep_bits may be NULL only with p_drop == 0); the backward pass needs no workspace: it
  * recomputes the scores in its dK / dV pass instead of handing probabilities over through memory.  Outputs: ctx and / or
  * ctx_x3 [rows][3][H]; dqkv (may be NULL) and / or dqkv_x3 [rows][3][3H]; bias_part [B, 3H] optional; lse, delta [B, nh, L].
+ * dctx may arrive as dctx_slabs k-pieces of the attention-output input gradient (slab s at dctx + s * dctx_slab_stride
+ * elements; the product then fills the chip with two k-pieces per tile): the kernel sums them while it reads them.
  * model/layer.py:80-100. */
 int uniter_attn_x3_max_len(void);
 int uniter_attn_x3_fwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, float* ctx, void* ctx_x3,
                        float* lse, const void* keep_bits, int B, int L, int nh, float p_drop, void* stream);
 int uniter_attn_x3_bwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, const float* ctx,
-                       const float* lse, const float* dctx, float* dqkv, void* dqkv_x3, float* bias_part,
-                       const void* keep_bits, float* delta, int B, int L, int nh, float p_drop, void* stream);
+                       const float* lse, const float* dctx, int dctx_slabs, size_t dctx_slab_stride, float* dqkv,
+                       void* dqkv_x3, float* bias_part, const void* keep_bits, float* delta, int B, int L, int nh,
+                       float p_drop, void* stream);
 /* The same two operations on the bf16 matrix pipe (precision mode 2): Q, K, V rounded to bf16 while
  * staged, fp32 scores / softmax / dropout / LSE, probabilities and score gradients rounded to bf16 as
  * MFMA operands.  Same arguments and Philox element indices as the _ex forms; L <= 192;

@@ -46,7 +46,8 @@ struct Args {
   const int* cu;           // [B+1] or NULL
   float* ctx; u16* ctx_x3; // forward outputs (backward: ctx is an input)
   float* lse;              // [B, nh, L]
-  const float* dctx;
+  const float* dctx;       // [dctx_slabs][rows, H]: k-pieces of the attention-output input gradient, summed while they are read
+  int dctx_slabs; size_t dctx_slab_stride;
   float* dqkv; u16* dqkv_x3;
   float* bias_part;        // optional [B, 3H] per-sample column sums of dqkv
   float* delta;            // [B, nh, L]
@@ -414,6 +415,10 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
         if (vr) {
           x = *reinterpret_cast<const f32x4*>(dorow + 32 * s + 8 * g);
           y = *reinterpret_cast<const f32x4*>(dorow + 32 * s + 8 * g + 4);
+          for (int sl = 1; sl < a.dctx_slabs; ++sl) {
+            x += *reinterpret_cast<const f32x4*>(dorow + sl * a.dctx_slab_stride + 32 * s + 8 * g);
+            y += *reinterpret_cast<const f32x4*>(dorow + sl * a.dctx_slab_stride + 32 * s + 8 * g + 4);
+          }
           ox = *reinterpret_cast<const f32x4*>(orow + 32 * s + 8 * g);
           oy = *reinterpret_cast<const f32x4*>(orow + 32 * s + 8 * g + 4);
         }
@@ -642,8 +647,11 @@ extern "C" int uniter_attn_x3_fwd(const float* qkv, const float* attn_mask, cons
 }
 
 extern "C" int uniter_attn_x3_bwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, const float* ctx,
-                                  const float* lse, const float* dctx, float* dqkv, void* dqkv_x3, float* bias_part,
-                                  const void* keep_bits, float* delta, int B, int L, int nh, float p_drop, void* stream) {
+                                  const float* lse, const float* dctx, int dctx_slabs, size_t dctx_slab_stride, float* dqkv,
+                                  void* dqkv_x3, float* bias_part, const void* keep_bits, float* delta, int B, int L, int nh,
+                                  float p_drop, void* stream) {
+  UCHECK_ARG(dctx_slabs >= 1 && dctx_slabs <= 4 && (dctx_slabs == 1 || dctx_slab_stride % 4 == 0),
+             "attn_x3_bwd: dctx_slabs %d (1..4) / slab stride not a multiple of 4 elements", dctx_slabs);
   UCHECK_ARG(qkv && ctx && lse && dctx && (dqkv || dqkv_x3) && delta && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
              "attn_x3_bwd: null pointer, or not exactly one of attn_mask / cu_seqlens");
   UCHECK_ARG(((uintptr_t)dqkv_x3 & 15) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0 &&
@@ -651,7 +659,8 @@ extern "C" int uniter_attn_x3_bwd(const float* qkv, const float* attn_mask, cons
   Args a = {};
   UCHECK_RC(fill(a, B, L, nh, p_drop, keep_bits, "attn_x3_bwd"));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
-  a.dctx = dctx; a.dqkv = dqkv; a.dqkv_x3 = (u16*)dqkv_x3; a.bias_part = bias_part; a.delta = delta;
+  a.dctx = dctx; a.dctx_slabs = dctx_slabs; a.dctx_slab_stride = dctx_slab_stride;
+  a.dqkv = dqkv; a.dqkv_x3 = (u16*)dqkv_x3; a.bias_part = bias_part; a.delta = delta;
   const int Lr = (L + 31) / 32 * 32;
   const size_t lds = (size_t)6 * IMG + (size_t)3 * Lr * 4 + 192 * 4 + (size_t)Lr * (Lr / 32) * 4;
 #ifdef UNITER_X3_LAB

@@ -211,7 +211,7 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
       b = LayerBufs();
       alloc_fwd(b);
       b.dz2 = cv.f(M * H); b.g2 = cv.f(M * H); b.du = cv.f(M * I); b.dy1 = cv.f(s_ki * M * H); b.dz1 = cv.f(M * H);
-      b.g1 = cv.f(M * H); b.dctx = cv.f(M * H); b.dqkv = cv.f(M * 3 * H); b.delta = cv.f((size_t)B * nh * L);
+      b.g1 = cv.f(M * H); b.dctx = cv.f(s_kh * M * H); b.dqkv = cv.f(M * 3 * H); b.delta = cv.f((size_t)B * nh * L);
       b.dx = cv.f(s_k3h * M * H);
       b.du_csum = cv.f((size_t)((M + 31) / 32) * I);
       b.qb_part = cv.f((size_t)B * 3 * H);
@@ -791,6 +791,9 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   // the L <= 192 attention backward kernels also emit the per-sample column sums of dqkv (the fused
   // query|key|value bias gradient before its sum over the batch): no 24 MB re-read of dqkv
   const bool fused_qb = L <= uniter_attn_varlen_max_len();
+  // precision 3 with the x3 attention backward: the attention-output input gradient leaves as k-pieces (the kernel sums them)
+  static const bool dctx_split = [] { const char* e = getenv("UNITER_DCTX_SPLIT"); return !(e && e[0] == '0'); }();      // A/B switch
+  const int ns_dctx = (x3 && fused_qb && dctx_split && attn_x3_products(L, pa, pa > 0.f)) ? pl.ns_kh : 1;
   const int epi_du = pl.gelu_d ? UNITER_EPI_MUL : UNITER_EPI_DGELU;
   if (res) {
     UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, I, H, lb.g2b, H, m->WB(l, L_W2), I, nullptr, I, 1, lb.dub, I,
@@ -839,7 +842,8 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, H, lb.g1b, H, m->WB(l, L_OW), H, lb.dctx, H, 1, nullptr, 0,
                       UNITER_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 0));
   } else if (x3) {
-    UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, H, lb.g1b, m->WB(l, L_OW), H, lb.dctx, 1, nullptr, UNITER_EPI_NONE,
+    // (two k-pieces when the x3 attention backward follows: it sums the slabs while it reads them -- 126 tiles do not fill the chip)
+    UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, H, lb.g1b, m->WB(l, L_OW), H, lb.dctx, ns_dctx, nullptr, UNITER_EPI_NONE,
                       nullptr, nullptr, nullptr));
   } else {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, H, H, g1, H, m->LP(l, L_OW), H, lb.dctx, H, UNITER_EPI_NONE,
@@ -855,8 +859,8 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                                      SITE_ATTN_PROBS(l), pl.attn_ws, pl.attn_ws_bytes, st));
     else if (fused_qb && x3 && attn_x3_products(L, pa, pa > 0.f))      // (the forward pass of a saved plan left the keep flags)
       UCHECK_RC(uniter_attn_x3_bwd(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
-                                   pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, nullptr, lb.dqkvb,
-                                   lb.qb_part, pa > 0.f ? lb.keepb : nullptr, lb.delta, B, L, nh, pa, st));
+                                   pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, ns_dctx, (size_t)M * H,
+                                   nullptr, lb.dqkvb, lb.qb_part, pa > 0.f ? lb.keepb : nullptr, lb.delta, B, L, nh, pa, st));
     else if (fused_qb && x3)      // dqkv leaves the kernel as x3 pieces only: nothing reads an fp32 copy in this mode
       UCHECK_RC(uniter_attn_bwd_ex_x3(lb.qkv, pl.packed ? nullptr : m->batch.attention_mask,
                                       pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, nullptr, lb.dqkvb,

@@ -71,7 +71,7 @@ def test_attention_x3_fwd_bwd_matches_float64_and_the_fp32_kernels(B, L, nh, p):
         part = torch.full((B, 3 * H), nan, device='cuda')
         delta = torch.full((B, nh, L), nan, device='cuda')
         if x3_products:
-            Lb.check(lib.uniter_attn_x3_bwd(Lb.ptr(dq), Lb.ptr(dm), None, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), Lb.ptr(dqkv),
+            Lb.check(lib.uniter_attn_x3_bwd(Lb.ptr(dq), Lb.ptr(dm), None, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), 1, 0, Lb.ptr(dqkv),
                                             Lb.ptr(dqkv3), Lb.ptr(part), kp, Lb.ptr(delta), B, L, nh, p, Lb.cur_stream()))
         else:
             wsb = lib.uniter_attn_bwd_ws_bytes(B, L, nh)
@@ -111,10 +111,24 @@ def test_attention_x3_fwd_bwd_matches_float64_and_the_fp32_kernels(B, L, nh, p):
     ctx_only = torch.full((B * L, H), nan, device='cuda')
     Lb.check(lib.uniter_attn_x3_fwd(Lb.ptr(dq), Lb.ptr(dm), None, Lb.ptr(ctx_only), None, None, kp, B, L, nh, p, Lb.cur_stream()))
     d3_only = torch.full((B * L, 3, 3 * H), nan, dtype=torch.bfloat16, device='cuda')
-    Lb.check(lib.uniter_attn_x3_bwd(Lb.ptr(dq), Lb.ptr(dm), None, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), None, Lb.ptr(d3_only),
+    Lb.check(lib.uniter_attn_x3_bwd(Lb.ptr(dq), Lb.ptr(dm), None, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), 1, 0, None, Lb.ptr(d3_only),
                                     None, kp, Lb.ptr(delta), B, L, nh, p, Lb.cur_stream()))
     torch.cuda.synchronize()
     assert torch.equal(ctx_only, ctx) and torch.equal(d3_only, dqkv3)
+    # dctx as two k-pieces of the attention-output input gradient: summed while read, the same bits as the summed tensor
+    g2 = torch.Generator().manual_seed(7)
+    a_ = torch.randn(B * L, H, generator=g2).cuda()
+    slabs = torch.stack([a_, dd - a_]).contiguous()
+    summed = (slabs[0] + slabs[1]).contiguous()
+    outs = []
+    for ptr_, ns, stride in ((Lb.ptr(summed), 1, 0), (Lb.ptr(slabs), 2, B * L * H)):
+        o3 = torch.full((B * L, 3, 3 * H), nan, dtype=torch.bfloat16, device='cuda')
+        dl = torch.full((B, nh, L), nan, device='cuda')
+        Lb.check(lib.uniter_attn_x3_bwd(Lb.ptr(dq), Lb.ptr(dm), None, Lb.ptr(ctx), Lb.ptr(lse), ptr_, ns, stride, None, Lb.ptr(o3),
+                                        None, kp, Lb.ptr(dl), B, L, nh, p, Lb.cur_stream()))
+        torch.cuda.synchronize()
+        outs.append((o3, dl))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize('lens,nh,p', [([164, 40, 1, 97], 2, 0.1), ([33, 192], 3, 0.0), ([5], 1, 0.2)])
@@ -141,7 +155,7 @@ def test_attention_x3_packed_batches_match_the_padded_form(lens, nh, p):
         dqkv = torch.zeros(n, 3 * H, device='cuda'); d3 = torch.zeros(n, 3, 3 * H, dtype=torch.bfloat16, device='cuda')
         part = torch.zeros(B, 3 * H, device='cuda'); delta = torch.zeros(B, nh, L, device='cuda')
         Lb.check(lib.uniter_attn_x3_fwd(Lb.ptr(q), m, c, Lb.ptr(ctx), None, Lb.ptr(lse), kp, B, L, nh, p, Lb.cur_stream()))
-        Lb.check(lib.uniter_attn_x3_bwd(Lb.ptr(q), m, c, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(d), Lb.ptr(dqkv), Lb.ptr(d3), Lb.ptr(part),
+        Lb.check(lib.uniter_attn_x3_bwd(Lb.ptr(q), m, c, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(d), 1, 0, Lb.ptr(dqkv), Lb.ptr(d3), Lb.ptr(part),
                                         kp, Lb.ptr(delta), B, L, nh, p, Lb.cur_stream()))
         torch.cuda.synchronize()
         return ctx, lse, dqkv, part

@@ -15,7 +15,7 @@ L.check(lib.uniter_attn_keep_bits_gen(kp, 0, 1, B, Lq, nh, p, 1, 2, 3, 0, L.cur_
 ctx3 = torch.empty(B * Lq, 3, H, dtype=torch.bfloat16, device='cuda'); dqkv3 = torch.empty(B * Lq, 3, 3 * H, dtype=torch.bfloat16, device='cuda')
 part = torch.empty(B, 3 * H, device='cuda')
 def fwdx(): L.check(lib.uniter_attn_x3_fwd(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(ctx3), L.ptr(lse), kp, B, Lq, nh, p, L.cur_stream()))
-def bwdx(): L.check(lib.uniter_attn_x3_bwd(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(lse), L.ptr(dctx), None, L.ptr(dqkv3), L.ptr(part), kp, L.ptr(delta), B, Lq, nh, p, L.cur_stream()))
+def bwdx(): L.check(lib.uniter_attn_x3_bwd(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(lse), L.ptr(dctx), 1, 0, None, L.ptr(dqkv3), L.ptr(part), kp, L.ptr(delta), B, Lq, nh, p, L.cur_stream()))
 fwdx()
 names = {0: 'complete', 1: 'no pass-1 loop', 2: 'no pass-2 loop', 3: 'no loops (staging, stores)', 4: 'no MFMAs', 5: 'pass 2 without MFMAs', 6: 'pass 1 without MFMAs'}
 for lab in [int(x) for x in os.environ.get('LAB_FORMS', '0,1,2,3,4,5,6').split(',')]:
