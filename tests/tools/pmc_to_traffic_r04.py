@@ -41,9 +41,9 @@ def main(src, out):
         'adam': (lambda n: 'adam_kernel' in n, None),
     }
     any_dgrad = re.compile(r'gemm_s3p_kernel<\d+, \d+, \d+, \d+, false, true, ')
-    # all four input-gradient products of a layer (FFN-down x gelu', FFN-up + residual (two slabs), attention output, QKV + residual (two slabs))
+    # all four input-gradient products of a layer (FFN-down x gelu', FFN-up + residual (two slabs), attention output (two slabs), QKV + residual (two slabs))
     fams['gemm_dgrad'] = (lambda n: bool(any_dgrad.search(n)),
-                          ((M * H * 6 + I * H * 6 + M * I * 10) + (M * I * 6 + I * H * 6 + M * H * 12) + (M * H * 6 + H * H * 6 + M * H * 4)
+                          ((M * H * 6 + I * H * 6 + M * I * 10) + (M * I * 6 + I * H * 6 + M * H * 12) + (M * H * 6 + H * H * 6 + M * H * 8)
                            + (M * 3 * H * 6 + 3 * H * H * 6 + M * H * 12)) // 4)
     fams['gemm_dgrad_add'] = (fams['gemm_dgrad_add'][0], ((M * I * 6 + I * H * 6 + M * H * 8) + (M * 3 * H * 6 + 3 * H * H * 6 + M * H * 8)) // 2)
     res = {}
