@@ -581,7 +581,7 @@ def run_rank(args):
                5: ('attention_fwd', 'mfma', nl * att), 6: ('gemm_dgrad', 'mfma', nl * (g_qkv + g_o + 2 * g_ffn)),
                7: ('gemm_wgrad', 'mfma', nl * (g_qkv + g_o + 2 * g_ffn)), 8: ('attention_bwd', 'mfma', nl * 2 * att),
                9: ('layernorm_fwd', 'hbm', nl * 2 * 16.0 * M_eff * H), 10: ('layernorm_bwd', 'hbm', nl * 2 * 16.0 * M_eff * H)}
-        x3k = 'gemm_s3p_kernel<128,128,..> (csrc/gemm_split3.hip: x3 operands, six v_mfma_f32_32x32x16_bf16 per block, persistent, loader + compute waves)'
+        x3k = 'gemm_s3p_kernel<128,128,..> (csrc/gemm_split3.hip: x3 operands, six v_mfma_f32_16x16x32_bf16 per block, persistent, loader + compute waves)'
         kernel_of = {'f32x3': {1: x3k + ', bias + GELU epilogue, activation out as x3 pieces + gelu\' fp32', 2: x3k + ', two k-pieces (slabs summed by the LayerNorm pass)',
                                3: x3k, 4: x3k + ', two k-pieces', 6: x3k + ' (weights k-major: ds_read_b64_tr_b16)',
                                7: x3k + ': the four weight gradients of a layer in ONE launch of whole-K tiles (both operands k-major)'},
@@ -618,7 +618,8 @@ def run_rank(args):
                                       'fp32 (BASELINE configs[1]; native fp32 MFMA kernels)' if args.precision == 'fp32' else
                                       'fp32 (BASELINE configs[1]); dense products by an exact 3 x bf16 operand split: 6 MFMA products '
                                       'per block, fp32 accumulate (error vs float64 <= the native fp32 MFMA kernel\'s: '
-                                      'tests/test_gemm_x3_gpu.py), attention / LayerNorm / loss / optimizer fp32' if args.precision == 'fp32x3'
+                                      'tests/test_gemm_x3_gpu.py); the attention\'s own products the same way (L <= 192, csrc/attention_x3.hip), softmax / LayerNorm / '
+                                      'loss / optimizer fp32' if args.precision == 'fp32x3'
                                       else 'bf16 MFMA GEMMs / fp32 storage (BASELINE configs[2])'),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        # what torch.distributed itself reports (not the flag): lets the driver verify the collective saw N ranks

@@ -230,7 +230,8 @@ def test_bf16_resident_equals_hybrid_and_follows_weight_updates(shapes_base):
     (1, 500, 12, [500], [12], False),                 # positions up to max_position_embeddings = 512
     (3, 40, 36, [40, 2, 17], [36, 36, 1], True),      # ragged on both sides
 ])
-def test_edge_shapes_match_oracle(B, T, R, tl, nbb, train):
+@pytest.mark.parametrize('precision', FP32_MODES)
+def test_edge_shapes_match_oracle(B, T, R, tl, nbb, train, precision):
     """Edge cases the reference's collate can produce: single-token samples, sequences beyond
     the LDS-resident attention kernels, the position table's end, heavy raggedness -- forward, loss and all
     gradients against the CPU oracle on the same weights (dropout masks replayed in train mode)."""
@@ -238,7 +239,7 @@ def test_edge_shapes_match_oracle(B, T, R, tl, nbb, train):
     CFG = dict(TINY, max_position_embeddings=512)
     sd = O.synth_state_dict(CFG, seed=3, img_dim=TINY_IMG_DIM, ln_jitter=0.05)
     b = O.synth_batch(B, T, R, seed=17, vocab=CFG['vocab_size'], img_dim=TINY_IMG_DIM, txt_lens=tl, num_bbs=nbb)
-    m = build(CFG, TINY_IMG_DIM, sd)
+    m = build(CFG, TINY_IMG_DIM, sd, precision)         # fp32x3: x3 attention up to L = 192, the fp32-MFMA kernels beyond
     m = m.train() if train else m.eval()
     seed, offset = 0xC0FFEE, 4
     m.uniter_model.set_dropout_seed(seed, offset)
