@@ -315,6 +315,15 @@ int uniter_attn_x3_bwd(const float* qkv, const float* attn_mask, const int32_t* 
                        const float* lse, const float* dctx, int dctx_slabs, size_t dctx_slab_stride, float* dqkv,
                        void* dqkv_x3, float* bias_part, const void* keep_bits, float* delta, int B, int L, int nh,
                        float p_drop, void* stream);
+/* The bf16 mode's attention (uniter_attn_bf16_fwd_pre / uniter_attn_bf16_bwd below: same arithmetic, same rounding points) in the
+ * decomposition of csrc/attention_x3.hip: one wave per 16 rows, one LDS image per operand read row-wise and transposed, backward in
+ * ONE launch without the Pd / dS scratch (its dK / dV pass recomputes the scores).  qkv fp32 or bf16 (qkv_is_bf16); L <= 192; keep
+ * flags drawn ahead (uniter_attn_keep_bits_gen) when p_drop > 0; ctx_bf16 [rows][H], dqkv_bf16 [rows][3H]; dqkv fp32 optional. */
+int uniter_attn_b16x_fwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+                         void* ctx_bf16, float* lse, const void* keep_bits, int B, int L, int nh, float p_drop, void* stream);
+int uniter_attn_b16x_bwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens,
+                         const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16, float* bias_part,
+                         const void* keep_bits, float* delta, int B, int L, int nh, float p_drop, void* stream);
 /* The same two operations on the bf16 matrix pipe (precision mode 2): Q, K, V rounded to bf16 while
  * staged, fp32 scores / softmax / dropout / LSE, probabilities and score gradients rounded to bf16 as
  * MFMA operands.  Same arguments and Philox element indices as the _ex forms; L <= 192;

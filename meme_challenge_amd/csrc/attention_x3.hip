@@ -22,6 +22,7 @@
 // read the same words.  Layouts as attention_f32.hip: qkv [rows, 3H], ctx / dctx [rows, H], lse / delta [B, nh, L], x3 outputs
 // [rows][3][ld].  head_dim == 64.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -41,7 +42,7 @@ constexpr int IMG = MAXL * ROWB;          // bytes per piece image, whatever the
 constexpr float NEG_INF = -__builtin_huge_valf();
 
 struct Args {
-  const float* qkv;        // [rows, 3H]
+  const void* qkv;         // [rows, 3H] fp32 (bf16 in the bf16 mode's QB16 kernels)
   const float* mask;       // [B, L] or NULL (varlen)
   const int* cu;           // [B+1] or NULL
   float* ctx; u16* ctx_x3; // forward outputs (backward: ctx is an input)
@@ -81,81 +82,120 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& w1, unsigne
   r0 -= bflo(w2); r1 -= bfhi(w2);
   w3 = pack2(r0, r1);
 }
-// pieces of 8 values as MFMA fragments
-__device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, bf16x8 (&f)[3]) {
+// pieces of 8 values as MFMA fragments (NP = 3: the exact split; NP = 1: rounded to bf16, the bf16 mode's operands)
+template <int NP>
+__device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, bf16x8 (&f)[NP]) {
+  if constexpr (NP == 1) {
+    f[0] = __builtin_bit_cast(bf16x8, u32x4{pack2(x[0], x[1]), pack2(x[2], x[3]), pack2(y[0], y[1]), pack2(y[2], y[3])});
+    return;
+  }
   unsigned w[3][4];
   split2(x[0], x[1], w[0][0], w[1][0], w[2][0]);
   split2(x[2], x[3], w[0][1], w[1][1], w[2][1]);
   split2(y[0], y[1], w[0][2], w[1][2], w[2][2]);
   split2(y[2], y[3], w[0][3], w[1][3], w[2][3]);
 #pragma unroll
-  for (int p = 0; p < 3; ++p) f[p] = __builtin_bit_cast(bf16x8, u32x4{w[p][0], w[p][1], w[p][2], w[p][3]});
+  for (int p = 0; p < NP; ++p) f[p] = __builtin_bit_cast(bf16x8, u32x4{w[p][0], w[p][1], w[p][2], w[p][3]});
 }
 
 // chunk swizzle of the images (header)
 __device__ __forceinline__ int swz(int r) { return r & 6; }
 
-// One [L, 64] fp32 operand on its way into its three piece images: this thread's four 16-byte pieces are all loaded before
-// anything is written (blockDim.x = 4 Lr threads).  Rows >= L are zero.
-struct Stage3 {
-  f32x4 v[4];
-  __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
+// One [L, 64] operand on its way into its NP piece images: this thread's 16-byte pieces are all loaded before anything is
+// written (blockDim.x = 4 Lr threads).  Rows >= L are zero.  B16: the source is bf16 and is copied as stored (NP == 1).
+template <int NP, bool B16>
+struct Stage {
+  f32x4 v[B16 ? 2 : 4];
+  __device__ __forceinline__ void load(const void* __restrict__ base_, int ld, int L, int Lr, int tid, int nthr) {
+    if constexpr (B16) {
+      const u16* base = static_cast<const u16*>(base_);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
-      v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (idx < Lr * 16 && r < L) v[it] = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c4 * 4);
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * nthr, r = idx >> 3, c8 = idx & 7;
+        v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < Lr * 8 && r < L) v[it] = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c8 * 8);
+      }
+    } else {
+      const float* base = static_cast<const float*>(base_);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
+        v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < Lr * 16 && r < L) v[it] = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + c4 * 4);
+      }
     }
   }
   __device__ __forceinline__ void store(u8* img, int Lr, int tid, int nthr) const {
+    if constexpr (B16) {
+      static_assert(NP == 1, "a bf16 source has one piece");
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
-      if (idx < Lr * 16) {
-        unsigned a1, a2, a3, b1, b2, b3;
-        split2(v[it][0], v[it][1], a1, a2, a3);
-        split2(v[it][2], v[it][3], b1, b2, b3);
-        u8* p = img + r * ROWB + 16 * ((c4 >> 1) ^ swz(r)) + 8 * (c4 & 1);
-        *reinterpret_cast<u32x2*>(p) = u32x2{a1, b1};
-        *reinterpret_cast<u32x2*>(p + IMG) = u32x2{a2, b2};
-        *reinterpret_cast<u32x2*>(p + 2 * IMG) = u32x2{a3, b3};
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * nthr, r = idx >> 3, c8 = idx & 7;
+        if (idx < Lr * 8) *reinterpret_cast<f32x4*>(img + r * ROWB + 16 * (c8 ^ swz(r))) = v[it];
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
+        if (idx < Lr * 16) {
+          u8* p = img + r * ROWB + 16 * ((c4 >> 1) ^ swz(r)) + 8 * (c4 & 1);
+          if constexpr (NP == 1) {
+            *reinterpret_cast<u32x2*>(p) = u32x2{pack2(v[it][0], v[it][1]), pack2(v[it][2], v[it][3])};
+          } else {
+            unsigned a1, a2, a3, b1, b2, b3;
+            split2(v[it][0], v[it][1], a1, a2, a3);
+            split2(v[it][2], v[it][3], b1, b2, b3);
+            *reinterpret_cast<u32x2*>(p) = u32x2{a1, b1};
+            *reinterpret_cast<u32x2*>(p + IMG) = u32x2{a2, b2};
+            *reinterpret_cast<u32x2*>(p + 2 * IMG) = u32x2{a3, b3};
+          }
+        }
       }
     }
   }
 };
 
-// B operand of a product that sums over d, from the lane's own fp32 row: step s, lane group g -> d = 32 s + 8 g .. + 7
-__device__ __forceinline__ void row_frags3(bf16x8 (&f)[2][3], const float* __restrict__ row, bool valid, int g) {
+// B operand of a product that sums over d, from the lane's own row: step s, lane group g -> d = 32 s + 8 g .. + 7
+template <int NP, bool B16>
+__device__ __forceinline__ void row_frags(bf16x8 (&f)[2][NP], const void* __restrict__ row_, bool valid, int g) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x;
-    if (valid) {
-      x = *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g);
-      y = *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g + 4);
+    if constexpr (B16) {
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (valid) x = *reinterpret_cast<const f32x4*>(static_cast<const u16*>(row_) + 32 * s + 8 * g);
+      f[s][0] = __builtin_bit_cast(bf16x8, x);
+    } else {
+      const float* row = static_cast<const float*>(row_);
+      f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x;
+      if (valid) {
+        x = *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g);
+        y = *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g + 4);
+      }
+      split8<NP>(x, y, f[s]);
     }
-    split8(x, y, f[s]);
   }
 }
 
 // per-lane byte offsets into an image: row reads (A operand, k = d) and transposed reads (A operand, k = image rows)
+template <int NP>
 struct LaneOffs {
   int row[2];      // step s: row i, chunk 4 s + g
   int tr[4];       // d-block db: row 4 g + (i >> 2), columns 16 db + 4 (i & 3) .. + 3
-  int row2[2], tr2[4];   // the same into the second operand's images (+ 3 IMG): registers of their own, so that piece and block
+  int row2[2], tr2[4];   // the same into the second operand's images (+ NP IMG): registers of their own, so that piece and block
                          // offsets stay within the 16-bit immediates of the LDS instructions for both operands
   __device__ __forceinline__ void init(int i, int g) {
     const int fi = swz(i);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       row[s] = i * ROWB + 16 * ((4 * s + g) ^ fi);
-      row2[s] = row[s] + 3 * IMG;
+      row2[s] = row[s] + NP * IMG;
       asm volatile("" : "+v"(row2[s]));
     }
     const int tr_row = 4 * g + (i >> 2), p4 = i & 3, ft = swz(tr_row);
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       tr[db] = tr_row * ROWB + 16 * ((2 * db + (p4 >> 1)) ^ ft) + 8 * (p4 & 1);
-      tr2[db] = tr[db] + 3 * IMG;
+      tr2[db] = tr[db] + NP * IMG;
       asm volatile("" : "+v"(tr2[db]));
     }
   }
@@ -176,18 +216,20 @@ __device__ __forceinline__ bf16x8 frag_tr(const u8* img, int r0, int off) {
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 // c += a . b for operands in three pieces: the six products above 2^-24 |a b|
-template <int LAB = 0>
-__device__ __forceinline__ void mac6(f32x4& c, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
-  if constexpr (LAB & 4) {      // measurement build only: the fragments are read, the products are not issued
+template <int NP, int LAB = 0>
+__device__ __forceinline__ void mac(f32x4& c, const bf16x8 (&a)[NP], const bf16x8 (&b)[NP]) {
+  if constexpr (NP == 1) {      // bf16 operands: one product
+    c = MFMA16(a[0], b[0], c);
+  } else if constexpr (LAB & 4) {      // measurement build only: the fragments are read, the products are not issued
     asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]));
-    return;
+  } else {
+    c = MFMA16(a[0], b[0], c);
+    c = MFMA16(a[0], b[1], c);
+    c = MFMA16(a[1], b[0], c);
+    c = MFMA16(a[1], b[1], c);
+    c = MFMA16(a[0], b[2], c);
+    c = MFMA16(a[2], b[0], c);
   }
-  c = MFMA16(a[0], b[0], c);
-  c = MFMA16(a[0], b[1], c);
-  c = MFMA16(a[1], b[0], c);
-  c = MFMA16(a[1], b[1], c);
-  c = MFMA16(a[0], b[2], c);
-  c = MFMA16(a[2], b[0], c);
 }
 
 // sums over the four lane groups (the lanes that share l & 15)
@@ -207,6 +249,7 @@ __device__ __forceinline__ float groups_max(float v) {
 // (2's) values of block db + 1 to group 1 (3), so every lane stores 8 consecutive d -- one 16-byte store per piece instead of two
 // of 8 bytes (the store tail of an attention kernel is issue-bound, MI355X_MICROARCH.md).  Every lane of the wave must call it
 // (the swap crosses lanes); `valid` masks the stores only.
+template <int NP>
 __device__ __forceinline__ void store_row(bool valid, float* __restrict__ row, u16* __restrict__ row_x3, int ps,
                                           const f32x4 (&acc)[4], float mul, int g) {
   f32x4 v[4];
@@ -219,13 +262,18 @@ __device__ __forceinline__ void store_row(bool valid, float* __restrict__ row, u
 #pragma unroll
     for (int db = 0; db < 4; db += 2) {
       unsigned wa[3][2], wb[3][2];
-      split2(v[db][0], v[db][1], wa[0][0], wa[1][0], wa[2][0]);
-      split2(v[db][2], v[db][3], wa[0][1], wa[1][1], wa[2][1]);
-      split2(v[db + 1][0], v[db + 1][1], wb[0][0], wb[1][0], wb[2][0]);
-      split2(v[db + 1][2], v[db + 1][3], wb[0][1], wb[1][1], wb[2][1]);
+      if constexpr (NP == 1) {      // the bf16 copy of the bf16 mode
+        wa[0][0] = pack2(v[db][0], v[db][1]); wa[0][1] = pack2(v[db][2], v[db][3]);
+        wb[0][0] = pack2(v[db + 1][0], v[db + 1][1]); wb[0][1] = pack2(v[db + 1][2], v[db + 1][3]);
+      } else {
+        split2(v[db][0], v[db][1], wa[0][0], wa[1][0], wa[2][0]);
+        split2(v[db][2], v[db][3], wa[0][1], wa[1][1], wa[2][1]);
+        split2(v[db + 1][0], v[db + 1][1], wb[0][0], wb[1][0], wb[2][0]);
+        split2(v[db + 1][2], v[db + 1][3], wb[0][1], wb[1][1], wb[2][1]);
+      }
       u16* dst = row_x3 + (db + (g & 1)) * 16 + 8 * (g >> 1);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NP; ++p) {
         const auto r0 = __builtin_amdgcn_permlane16_swap(wa[p][0], wb[p][0], false, false);
         const auto r1 = __builtin_amdgcn_permlane16_swap(wa[p][1], wb[p][1], false, false);
         if (valid) *reinterpret_cast<u32x4*>(dst + p * ps) = u32x4{r0[0], r1[0], r0[1], r1[1]};
@@ -263,32 +311,34 @@ __device__ __forceinline__ float keep_mult(unsigned word, int b2, int g, int r, 
 
 // ---------------------------------------------------------------- forward ---
 // LDS: K pieces | V pieces | mask bias
+template <int NP, bool QB16>
 __global__ __launch_bounds__(768) void attn_x3_fwd_kernel(const Args a, int Lr) {
   set_wave_prio(a.prio);
   u8* Ki = smem_raw;
-  u8* Vi = smem_raw + 3 * IMG;
-  float* mb = reinterpret_cast<float*>(smem_raw + 6 * IMG);
+  u8* Vi = smem_raw + NP * IMG;
+  float* mb = reinterpret_cast<float*>(smem_raw + 2 * NP * IMG);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
   const int i = lane & 15, g = lane >> 4;
   const int nblk = Lr >> 5;
   const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
   const Span sp = span_of(a, b);
   const int Lb = sp.Lb, ld = 3 * a.H;
-  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
+  typedef typename std::conditional<QB16, u16, float>::type src_t;
+  const src_t* base = static_cast<const src_t*>(a.qkv) + (size_t)sp.row0 * ld + head * D;
   const int q = wave * 16 + i;
   const bool vq = q < Lb;
-  bf16x8 qf[2][3];
+  bf16x8 qf[2][NP];
   {
-    Stage3 sk, sv;
+    Stage<NP, QB16> sk, sv;
     sk.load(base + a.H, ld, Lb, Lr, tid, nthr);
     sv.load(base + 2 * a.H, ld, Lb, Lr, tid, nthr);
-    row_frags3(qf, base + (size_t)q * ld, vq, g);
+    row_frags<NP, QB16>(qf, base + (size_t)q * ld, vq, g);
     stage_mask(mb, a, b, Lb, Lr, tid, nthr);
     sk.store(Ki, Lr, tid, nthr);
     sv.store(Vi, Lr, tid, nthr);
   }
   __syncthreads();
-  LaneOffs lo;
+  LaneOffs<NP> lo;
   lo.init(i, g);
   const int nk = wave * 16 < Lb ? sp.nb : 0;           // wave-uniform
   const bool drop = a.keep_bits != nullptr;
@@ -303,7 +353,21 @@ __global__ __launch_bounds__(768) void attn_x3_fwd_kernel(const Args a, int Lr) 
 #pragma unroll
   for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = NEG_INF, l_run = 0.f;
+  // NP == 1 (bf16 mode): the key range as TWO online softmaxes (first ceil(nb / 2) chunks, the rest) merged at the end -- the
+  // blocking of attention_bf16.hip's forward kernel, which the bf16 oracle restates (oracle/uniter_oracle.py,
+  // _online_softmax_pv_b16): a probability is rounded to bf16 relative to ITS range's running maximum, and a rounding
+  // modelled differently decorrelates every later bf16 rounding within a few layers
+  const int hb = NP == 1 ? (sp.nb + 1) >> 1 : nk;
+  f32x4 o_a[NP == 1 ? 4 : 1];
+  float m_a = NEG_INF, l_a = 0.f;
   for (int kc = 0; kc < nk; ++kc) {
+    if constexpr (NP == 1) {
+      if (kc == hb) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) { o_a[db] = o[db]; o[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        m_a = m_run; l_a = l_run; m_run = NEG_INF; l_run = 0.f;
+      }
+    }
     const int k0 = kc * 32;
     unsigned word = words[0];
 #pragma unroll
@@ -314,10 +378,10 @@ __global__ __launch_bounds__(768) void attn_x3_fwd_kernel(const Args a, int Lr) 
       s[b2] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        bf16x8 ka[3];
+        bf16x8 ka[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) ka[p] = frag_row(Ki + p * IMG, k0 + 16 * b2, lo.row[st]);
-        mac6(s[b2], ka, qf[st]);
+        for (int p = 0; p < NP; ++p) ka[p] = frag_row(Ki + p * IMG, k0 + 16 * b2, lo.row[st]);
+        mac<NP>(s[b2], ka, qf[st]);
       }
     }
     float mx = NEG_INF;
@@ -350,20 +414,32 @@ __global__ __launch_bounds__(768) void attn_x3_fwd_kernel(const Args a, int Lr) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[b2][r] *= keep_mult(word, b2, g, r, a.drop_scale);
     }
-    bf16x8 pb[3];
-    split8(s[0], s[1], pb);
+    bf16x8 pb[NP];
+    split8<NP>(s[0], s[1], pb);
 #pragma unroll
     for (int db = 0; db < 4; ++db) {                     // O^T[d][query] += V^T . Pd^T
-      bf16x8 va[3];
+      bf16x8 va[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) va[p] = frag_tr(Ki + p * IMG, k0, lo.tr2[db]);
-      mac6(o[db], va, pb);
+      for (int p = 0; p < NP; ++p) va[p] = frag_tr(Ki + p * IMG, k0, lo.tr2[db]);
+      mac<NP>(o[db], va, pb);
+    }
+  }
+  if constexpr (NP == 1) {
+    if (nk > hb) {
+      const float m_new = fmaxf(m_a, m_run);
+      const float wa = __expf(m_a - m_new), wb = m_run == NEG_INF ? 0.f : __expf(m_run - m_new);
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[db][r] = o_a[db][r] * wa + o[db][r] * wb;
+      l_run = l_a * wa + l_run * wb;
+      m_run = m_new;
     }
   }
   const float l_tot = groups_sum(l_run);
   {
     const size_t row = (size_t)sp.row0 + (vq ? q : 0);
-    store_row(vq, a.ctx ? a.ctx + row * a.H + head * D : nullptr, a.ctx_x3 ? a.ctx_x3 + row * 3 * a.H + head * D : nullptr, a.H, o,
+    store_row<NP>(vq, a.ctx ? a.ctx + row * a.H + head * D : nullptr, a.ctx_x3 ? a.ctx_x3 + row * NP * a.H + head * D : nullptr, a.H, o,
               1.0f / l_tot, g);
     if (vq && g == 0 && a.lse) a.lse[(size_t)bh * a.L + q] = m_run + __logf(l_tot);
   }
@@ -372,12 +448,12 @@ __global__ __launch_bounds__(768) void attn_x3_fwd_kernel(const Args a, int Lr) 
 // --------------------------------------------------------------- backward ---
 // LDS: operand pieces 1 | operand pieces 2 | mask bias | lse | delta | column sums | keep words
 // LAB (measurement builds, -DUNITER_X3_LAB + UNITER_ATTN_X3_LAB=bits): 1 = no pass-1 loop, 2 = no pass-2 loop, 4 = no MFMAs
-template <int LAB>
+template <int NP, bool QB16, int LAB>
 __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) {
   set_wave_prio(a.prio);
   u8* I1 = smem_raw;                    // pass 1: K, pass 2: Q
-  u8* I2 = smem_raw + 3 * IMG;          // pass 1: V, pass 2: dO
-  float* mb = reinterpret_cast<float*>(smem_raw + 6 * IMG);
+  u8* I2 = smem_raw + NP * IMG;         // pass 1: V, pass 2: dO
+  float* mb = reinterpret_cast<float*>(smem_raw + 2 * NP * IMG);
   float* lse_s = mb + Lr;
   float* delta_s = lse_s + Lr;
   float* red = delta_s + Lr;
@@ -388,24 +464,25 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
   const int bh = blockIdx.x, b = bh / a.nh, head = bh - b * a.nh;
   const Span sp = span_of(a, b);
   const int Lb = sp.Lb, ld = 3 * a.H;
-  const float* base = a.qkv + (size_t)sp.row0 * ld + head * D;
+  typedef typename std::conditional<QB16, u16, float>::type src_t;
+  const src_t* base = static_cast<const src_t*>(a.qkv) + (size_t)sp.row0 * ld + head * D;
   const float* dobase = a.dctx + (size_t)sp.row0 * a.H + head * D;
   const int rw = wave * 16 + i;          // this lane's row: a query in pass 1, a key in pass 2
   const bool vr = rw < Lb;
   const bool drop = a.keep_bits != nullptr;
   const int nloop = wave * 16 < Lb ? sp.nb : 0;         // wave-uniform: 32-row chunks of the other index
-  LaneOffs lo;
+  LaneOffs<NP> lo;
   lo.init(i, g);
 
   // ---- pass 1: dQ (and delta) for queries rw; keys from the images of K and V
-  bf16x8 qf[2][3], dof[2][3];
+  bf16x8 qf[2][NP], dof[2][NP];
   {
     float delta = 0.f;
     {
-      Stage3 sk, sv;
+      Stage<NP, QB16> sk, sv;
       sk.load(base + a.H, ld, Lb, Lr, tid, nthr);
       sv.load(base + 2 * a.H, ld, Lb, Lr, tid, nthr);
-      row_frags3(qf, base + (size_t)rw * ld, vr, g);
+      row_frags<NP, QB16>(qf, base + (size_t)rw * ld, vr, g);
       // this lane's 16 of the 64 values of its dO and O rows (d = 32 s + 8 g + 0..7): the k-slots of the dO operand
       const float* dorow = dobase + (size_t)rw * a.H;
       const float* orow = a.ctx + ((size_t)sp.row0 + rw) * a.H + head * D;
@@ -423,7 +500,7 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
           oy = *reinterpret_cast<const f32x4*>(orow + 32 * s + 8 * g + 4);
         }
         delta += x[0] * ox[0] + x[1] * ox[1] + x[2] * ox[2] + x[3] * ox[3] + y[0] * oy[0] + y[1] * oy[1] + y[2] * oy[2] + y[3] * oy[3];
-        split8(x, y, dof[s]);
+        split8<NP>(x, y, dof[s]);
       }
       stage_mask(mb, a, b, Lb, Lr, tid, nthr);
       for (int t = tid; t < 192; t += nthr) red[t] = 0.f;
@@ -458,14 +535,14 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
         dp[b2] = s[b2];
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-          bf16x8 ka[3], va[3];
+          bf16x8 ka[NP], va[NP];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < NP; ++p) {
             ka[p] = frag_row(I1 + p * IMG, k0 + 16 * b2, lo.row[st]);
             va[p] = frag_row(I1 + p * IMG, k0 + 16 * b2, lo.row2[st]);
           }
-          mac6<LAB>(s[b2], ka, qf[st]);                       // S^T[key][query] = K . Q^T
-          mac6<LAB>(dp[b2], va, dof[st]);                     // dP^T[key][query] = V . dO^T
+          mac<NP, LAB>(s[b2], ka, qf[st]);                       // S^T[key][query] = K . Q^T
+          mac<NP, LAB>(dp[b2], va, dof[st]);                     // dP^T[key][query] = V . dO^T
         }
       }
 #pragma unroll
@@ -478,19 +555,19 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
           s[b2][r] = p * (dp[b2][r] * m - delta);      // x scale (a power of two) when dQ leaves
         }
       }
-      bf16x8 db3[3];
-      split8(s[0], s[1], db3);
+      bf16x8 db3[NP];
+      split8<NP>(s[0], s[1], db3);
 #pragma unroll
       for (int db = 0; db < 4; ++db) {                   // dQ^T[d][query] += K^T . dS^T
-        bf16x8 kt[3];
+        bf16x8 kt[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) kt[p] = frag_tr(I1 + p * IMG, k0, lo.tr[db]);
-        mac6<LAB>(dq[db], kt, db3);
+        for (int p = 0; p < NP; ++p) kt[p] = frag_tr(I1 + p * IMG, k0, lo.tr[db]);
+        mac<NP, LAB>(dq[db], kt, db3);
       }
     }
     {
       const size_t row = (size_t)sp.row0 + (vr ? rw : 0);
-      store_row(vr, a.dqkv ? a.dqkv + row * ld + head * D : nullptr, a.dqkv_x3 ? a.dqkv_x3 + row * 3 * ld + head * D : nullptr, ld,
+      store_row<NP>(vr, a.dqkv ? a.dqkv + row * ld + head * D : nullptr, a.dqkv_x3 ? a.dqkv_x3 + row * NP * ld + head * D : nullptr, ld,
                 dq, a.scale, g);
     }
     if (a.bias_part) acc_colsum(red, dq, a.scale, vr, i, g);
@@ -499,11 +576,11 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
   // ---- pass 2: dK, dV for keys rw; queries from the images of Q and dO.  Nothing is loaded again: this wave's K and V rows
   // come out of the images before they are overwritten, and the images of Q and dO are the row fragments the waves already
   // hold -- lane (i, g) has exactly chunk 4 s + g of row rw of every piece.
-  bf16x8 kf[2][3], vf[2][3];
+  bf16x8 kf[2][NP], vf[2][NP];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
       kf[s][p] = frag_row(I1 + p * IMG, wave * 16, lo.row[s]);
       vf[s][p] = frag_row(I1 + p * IMG, wave * 16, lo.row2[s]);
     }
@@ -511,7 +588,7 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
       *reinterpret_cast<bf16x8*>(I1 + p * IMG + wave * 16 * ROWB + lo.row[s]) = qf[s][p];
       *reinterpret_cast<bf16x8*>(I1 + p * IMG + wave * 16 * ROWB + lo.row2[s]) = dof[s][p];
     }
@@ -533,14 +610,14 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
         dp[b2] = s[b2];
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-          bf16x8 qa[3], da[3];
+          bf16x8 qa[NP], da[NP];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < NP; ++p) {
             qa[p] = frag_row(I1 + p * IMG, q0 + 16 * b2, lo.row[st]);
             da[p] = frag_row(I1 + p * IMG, q0 + 16 * b2, lo.row2[st]);
           }
-          mac6<LAB>(s[b2], qa, kf[st]);                       // S[query][key] = Q . K^T
-          mac6<LAB>(dp[b2], da, vf[st]);                      // dP[query][key] = dO . V^T
+          mac<NP, LAB>(s[b2], qa, kf[st]);                       // S[query][key] = Q . K^T
+          mac<NP, LAB>(dp[b2], da, vf[st]);                      // dP[query][key] = dO . V^T
         }
       }
       f32x4 pd[2];
@@ -564,36 +641,36 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
       // the two output products one after the other (each with its own pieces and fragments live: 168 registers per lane)
       __builtin_amdgcn_sched_barrier(0);
       {
-        bf16x8 pb3[3];
-        split8(pd[0], pd[1], pb3);
+        bf16x8 pb3[NP];
+        split8<NP>(pd[0], pd[1], pb3);
 #pragma unroll
         for (int db = 0; db < 4; ++db) {                 // dV^T[d][key] += dO^T . Pd
-          bf16x8 dt[3];
+          bf16x8 dt[NP];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) dt[p] = frag_tr(I1 + p * IMG, q0, lo.tr2[db]);
-          mac6<LAB>(dv[db], dt, pb3);
+          for (int p = 0; p < NP; ++p) dt[p] = frag_tr(I1 + p * IMG, q0, lo.tr2[db]);
+          mac<NP, LAB>(dv[db], dt, pb3);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       {
-        bf16x8 db3[3];
-        split8(s[0], s[1], db3);
+        bf16x8 db3[NP];
+        split8<NP>(s[0], s[1], db3);
 #pragma unroll
         for (int db = 0; db < 4; ++db) {                 // dK^T[d][key] += Q^T . dS
-          bf16x8 qt[3];
+          bf16x8 qt[NP];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) qt[p] = frag_tr(I1 + p * IMG, q0, lo.tr[db]);
-          mac6<LAB>(dk[db], qt, db3);
+          for (int p = 0; p < NP; ++p) qt[p] = frag_tr(I1 + p * IMG, q0, lo.tr[db]);
+          mac<NP, LAB>(dk[db], qt, db3);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     {
       const size_t row = (size_t)sp.row0 + (vr ? rw : 0);
-      store_row(vr, a.dqkv ? a.dqkv + row * ld + a.H + head * D : nullptr,
-                a.dqkv_x3 ? a.dqkv_x3 + row * 3 * ld + a.H + head * D : nullptr, ld, dk, a.scale, g);
-      store_row(vr, a.dqkv ? a.dqkv + row * ld + 2 * a.H + head * D : nullptr,
-                a.dqkv_x3 ? a.dqkv_x3 + row * 3 * ld + 2 * a.H + head * D : nullptr, ld, dv, 1.0f, g);
+      store_row<NP>(vr, a.dqkv ? a.dqkv + row * ld + a.H + head * D : nullptr,
+                a.dqkv_x3 ? a.dqkv_x3 + row * NP * ld + a.H + head * D : nullptr, ld, dk, a.scale, g);
+      store_row<NP>(vr, a.dqkv ? a.dqkv + row * ld + 2 * a.H + head * D : nullptr,
+                a.dqkv_x3 ? a.dqkv_x3 + row * NP * ld + 2 * a.H + head * D : nullptr, ld, dv, 1.0f, g);
     }
     if (a.bias_part) {
       acc_colsum(red + 64, dk, a.scale, vr, i, g);
@@ -626,6 +703,41 @@ int fill(Args& a, int B, int L, int nh, float p_drop, const void* keep_bits, con
   return 0;
 }
 
+template <int NP, bool QB16>
+int launch_fwd(const Args& a, hipStream_t st) {
+  const int Lr = (a.L + 31) / 32 * 32;
+  const size_t lds = (size_t)2 * NP * IMG + (size_t)Lr * 4;
+  UCHECK_RC(set_lds(attn_x3_fwd_kernel<NP, QB16>, lds));
+  hipLaunchKernelGGL((attn_x3_fwd_kernel<NP, QB16>), dim3(a.B * a.nh), dim3(Lr * 4), lds, st, a, Lr);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+template <int NP, bool QB16>
+int launch_bwd(const Args& a, hipStream_t st) {
+  const int Lr = (a.L + 31) / 32 * 32;
+  const size_t lds = (size_t)2 * NP * IMG + (size_t)3 * Lr * 4 + 192 * 4 + (size_t)Lr * (Lr / 32) * 4;
+#ifdef UNITER_X3_LAB
+  if constexpr (NP == 3 && !QB16) {
+    const char* e = getenv("UNITER_ATTN_X3_LAB");
+    const int lab = e ? atoi(e) : 0;
+#define X3A_LAB_CASE(N)                                                                                                  \
+    if (lab == N) {                                                                                                      \
+      UCHECK_RC(set_lds(attn_x3_bwd_kernel<3, false, N>, lds));                                                          \
+      hipLaunchKernelGGL((attn_x3_bwd_kernel<3, false, N>), dim3(a.B * a.nh), dim3(Lr * 4), lds, st, a, Lr);             \
+      UCHECK_LAUNCH();                                                                                                   \
+      return 0;                                                                                                          \
+    }
+    X3A_LAB_CASE(1) X3A_LAB_CASE(2) X3A_LAB_CASE(3) X3A_LAB_CASE(4) X3A_LAB_CASE(5) X3A_LAB_CASE(6)
+#undef X3A_LAB_CASE
+  }
+#endif
+  UCHECK_RC(set_lds(attn_x3_bwd_kernel<NP, QB16, 0>, lds));
+  hipLaunchKernelGGL((attn_x3_bwd_kernel<NP, QB16, 0>), dim3(a.B * a.nh), dim3(Lr * 4), lds, st, a, Lr);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int uniter_attn_x3_max_len(void) { return MAXL; }
@@ -638,12 +750,7 @@ extern "C" int uniter_attn_x3_fwd(const float* qkv, const float* attn_mask, cons
   Args a = {};
   UCHECK_RC(fill(a, B, L, nh, p_drop, keep_bits, "attn_x3_fwd"));
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_x3 = (u16*)ctx_x3; a.lse = lse;
-  const int Lr = (L + 31) / 32 * 32;
-  const size_t lds = (size_t)6 * IMG + (size_t)Lr * 4;
-  UCHECK_RC(set_lds(attn_x3_fwd_kernel, lds));
-  hipLaunchKernelGGL(attn_x3_fwd_kernel, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr);
-  UCHECK_LAUNCH();
-  return 0;
+  return launch_fwd<3, false>(a, (hipStream_t)stream);
 }
 
 extern "C" int uniter_attn_x3_bwd(const float* qkv, const float* attn_mask, const int32_t* cu_seqlens, const float* ctx,
@@ -661,23 +768,37 @@ extern "C" int uniter_attn_x3_bwd(const float* qkv, const float* attn_mask, cons
   a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
   a.dctx = dctx; a.dctx_slabs = dctx_slabs; a.dctx_slab_stride = dctx_slab_stride;
   a.dqkv = dqkv; a.dqkv_x3 = (u16*)dqkv_x3; a.bias_part = bias_part; a.delta = delta;
-  const int Lr = (L + 31) / 32 * 32;
-  const size_t lds = (size_t)6 * IMG + (size_t)3 * Lr * 4 + 192 * 4 + (size_t)Lr * (Lr / 32) * 4;
-#ifdef UNITER_X3_LAB
-  const char* e = getenv("UNITER_ATTN_X3_LAB");
-  const int lab = e ? atoi(e) : 0;
-#define X3A_LAB_CASE(N)                                                                                          \
-  if (lab == N) {                                                                                                \
-    UCHECK_RC(set_lds(attn_x3_bwd_kernel<N>, lds));                                                              \
-    hipLaunchKernelGGL(attn_x3_bwd_kernel<N>, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr);     \
-    UCHECK_LAUNCH();                                                                                             \
-    return 0;                                                                                                    \
-  }
-  X3A_LAB_CASE(1) X3A_LAB_CASE(2) X3A_LAB_CASE(3) X3A_LAB_CASE(4) X3A_LAB_CASE(5) X3A_LAB_CASE(6)
-#undef X3A_LAB_CASE
-#endif
-  UCHECK_RC(set_lds(attn_x3_bwd_kernel<0>, lds));
-  hipLaunchKernelGGL(attn_x3_bwd_kernel<0>, dim3(B * nh), dim3(Lr * 4), lds, (hipStream_t)stream, a, Lr);
-  UCHECK_LAUNCH();
-  return 0;
+  return launch_bwd<3, false>(a, (hipStream_t)stream);
+}
+
+// The bf16 mode's attention in the same decomposition (one wave per 16 rows, one LDS image per operand read row-wise and
+// transposed, backward without the scratch hand-over): operands rounded to bf16 where they become MFMA operands, ONE product per
+// block -- the arithmetic of attention_bf16.hip (uniter_attn_bf16_fwd_pre / uniter_attn_bf16_bwd), whose kernels remain the
+// path for keep flags drawn inside the kernel.  ctx_bf16 [rows][H], dqkv_bf16 [rows][3H].
+extern "C" int uniter_attn_b16x_fwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens, float* ctx,
+                                    void* ctx_bf16, float* lse, const void* keep_bits, int B, int L, int nh, float p_drop,
+                                    void* stream) {
+  UCHECK_ARG(qkv && (ctx || ctx_bf16) && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
+             "attn_b16x_fwd: null pointer, or not exactly one of attn_mask / cu_seqlens");
+  UCHECK_ARG(((uintptr_t)ctx_bf16 & 15) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0, "attn_b16x_fwd: misaligned pointer");
+  Args a = {};
+  UCHECK_RC(fill(a, B, L, nh, p_drop, keep_bits, "attn_b16x_fwd"));
+  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = ctx; a.ctx_x3 = (u16*)ctx_bf16; a.lse = lse;
+  return qkv_is_bf16 ? launch_fwd<1, true>(a, (hipStream_t)stream) : launch_fwd<1, false>(a, (hipStream_t)stream);
+}
+
+extern "C" int uniter_attn_b16x_bwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens,
+                                    const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16,
+                                    float* bias_part, const void* keep_bits, float* delta, int B, int L, int nh, float p_drop,
+                                    void* stream) {
+  UCHECK_ARG(qkv && ctx && lse && dctx && (dqkv || dqkv_bf16) && delta && ((attn_mask != nullptr) != (cu_seqlens != nullptr)),
+             "attn_b16x_bwd: null pointer, or not exactly one of attn_mask / cu_seqlens");
+  UCHECK_ARG(((uintptr_t)dqkv_bf16 & 15) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0 &&
+                 ((uintptr_t)dctx & 15) == 0 && ((uintptr_t)dqkv & 15) == 0, "attn_b16x_bwd: misaligned pointer");
+  Args a = {};
+  UCHECK_RC(fill(a, B, L, nh, p_drop, keep_bits, "attn_b16x_bwd"));
+  a.qkv = qkv; a.mask = attn_mask; a.cu = cu_seqlens; a.ctx = const_cast<float*>(ctx); a.lse = const_cast<float*>(lse);
+  a.dctx = dctx; a.dctx_slabs = 1; a.dctx_slab_stride = 0;
+  a.dqkv = dqkv; a.dqkv_x3 = (u16*)dqkv_bf16; a.bias_part = bias_part; a.delta = delta;
+  return qkv_is_bf16 ? launch_bwd<1, true>(a, (hipStream_t)stream) : launch_bwd<1, false>(a, (hipStream_t)stream);
 }

@@ -334,6 +334,12 @@ bool attn_x3_products(int L, float p_drop, bool keep_flags_ready) {
   static const bool on = [] { const char* e = getenv("UNITER_ATTN_X3"); return !(e && e[0] == '0'); }();
   return on && L <= uniter_attn_x3_max_len() && (p_drop == 0.f || keep_flags_ready);
 }
+// precision 2: the bf16 attention in attention_x3.hip's decomposition (no scratch hand-over).  UNITER_ATTN_B16X=0 keeps
+// attention_bf16.hip's kernels (A/B measurements).
+bool attn_b16x(int L, float p_drop, bool keep_flags_ready) {
+  static const bool on = [] { const char* e = getenv("UNITER_ATTN_B16X"); return !(e && e[0] == '0'); }();
+  return on && L <= uniter_attn_x3_max_len() && (p_drop == 0.f || keep_flags_ready);
+}
 // precision 3: A = x3 activations [M][3][K]; W = the piece-major x3 mirror of an encoder weight (row stride ldw, piece stride =
 // the flat parameter buffer's length); outputs fp32 (nsplit slabs) or x3 [M][3][N]; aux operands fp32 (csrc/gemm_split3.hip)
 int gemm_x3(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, int K, const void* A, const unsigned short* W,
@@ -622,7 +628,10 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
                      UNITER_EPI_BIAS, m->LP(l, L_QB), nullptr, nullptr, 0, 0));
     {
       ProfScope ps(m, UNITER_K_ATTN_FWD, st);
-      if (attn_b16)      // precision 2: the attention products run on the bf16 pipe as well
+      if (attn_b16 && attn_b16x(L, pa, keep_pre))      // precision 2: the attention products run on the bf16 pipe as well
+        UCHECK_RC(uniter_attn_b16x_fwd(lb.qkv, 1, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr, lb.ctx,
+                                       lb.ctxb, lb.lse, pa > 0.f ? lb.keepb : nullptr, B, L, nh, pa, st));
+      else if (attn_b16)
         UCHECK_RC(uniter_attn_bf16_fwd_pre(lb.qkv, 1, packed ? nullptr : b->attention_mask, packed ? b->cu_seqlens : nullptr,
                                            lb.ctx, lb.ctxb, lb.lse, save ? lb.keepb : nullptr, keep_pre ? 1 : 0, B, L, nh, pa,
                                            seed, offset, SITE_ATTN_PROBS(l), st));
@@ -851,7 +860,11 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   }
   {
     ProfScope ps(m, UNITER_K_ATTN_BWD, st);
-    if (attn_b16)
+    if (attn_b16 && attn_b16x(L, pa, pa > 0.f))      // (the forward pass of a saved plan left the keep flags)
+      UCHECK_RC(uniter_attn_b16x_bwd(lb.qkv, 1, pl.packed ? nullptr : m->batch.attention_mask,
+                                     pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx, nullptr, lb.dqkvb,
+                                     lb.qb_part, pa > 0.f ? lb.keepb : nullptr, lb.delta, B, L, nh, pa, st));
+    else if (attn_b16)
       UCHECK_RC(uniter_attn_bf16_bwd(lb.qkv, 1, pl.packed ? nullptr : m->batch.attention_mask,
                                      pl.packed ? m->batch.cu_seqlens : nullptr, lb.ctx, lb.lse, lb.dctx,
                                      nullptr /* fp32 dqkv has no reader in this mode: bias partials are fused */,

@@ -53,7 +53,11 @@ def _reference(qkv, dctx, lens, B, L, nh, p, seed, offset, site, emulate):
 @pytest.mark.parametrize('B,L,nh,p,lens,varlen', [
     (2, 164, 2, 0.0, [164, 164], False), (2, 164, 2, 0.1, [164, 90], False), (3, 100, 12, 0.1, [100, 1, 37], False),
     (2, 20, 1, 0.25, [20, 7], False), (3, 164, 2, 0.1, [164, 40, 97], True), (2, 192, 1, 0.0, [192, 130], True)])
-def test_attention_bf16_fwd_bwd(B, L, nh, p, lens, varlen):
+@pytest.mark.parametrize('kind', ['bf16', 'b16x'])
+def test_attention_bf16_fwd_bwd(B, L, nh, p, lens, varlen, kind):
+    """kind 'bf16': csrc/attention_bf16.hip (two waves per 32-row block, Pd / dS through a scratch); 'b16x': the same arithmetic in
+    csrc/attention_x3.hip's decomposition (one wave per 16 rows, no scratch, keep flags drawn ahead) -- one reference, one set of
+    tolerances."""
     from meme_challenge_amd import _lib as Lb
     lib = Lb.lib()
     H = nh * 64
@@ -81,7 +85,20 @@ def test_attention_bf16_fwd_bwd(B, L, nh, p, lens, varlen):
     ws = torch.full((max(wsb, 4) // 2,), float('nan'), dtype=torch.bfloat16, device='cuda')
     keep = torch.zeros(lib.uniter_attn_keep_bits_bytes(B, L, nh) // 2, dtype=torch.int16, device='cuda')
 
+    if kind == 'b16x' and p > 0:
+        Lb.check(lib.uniter_attn_keep_bits_gen(Lb.ptr(keep), 0, 1, B, L, nh, p, seed, offset, site, 0, Lb.cur_stream()))
+
+    def run_x(kp):
+        kp = Lb.ptr(keep) if p > 0 else None
+        Lb.check(lib.uniter_attn_b16x_fwd(Lb.ptr(qsrc), qb16, mptr, cptr, Lb.ptr(ctx), Lb.ptr(ctxb), Lb.ptr(lse), kp, B, L, nh, p,
+                                          Lb.cur_stream()))
+        Lb.check(lib.uniter_attn_b16x_bwd(Lb.ptr(qsrc), qb16, mptr, cptr, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), Lb.ptr(dqkv),
+                                          Lb.ptr(dqkvb), Lb.ptr(bpart), kp, Lb.ptr(delta), B, L, nh, p, Lb.cur_stream()))
+        torch.cuda.synchronize()
+
     def run(kp):
+        if kind == 'b16x':
+            return run_x(kp)
         Lb.check(lib.uniter_attn_bf16_fwd(Lb.ptr(qsrc), qb16, mptr, cptr, Lb.ptr(ctx), Lb.ptr(ctxb), Lb.ptr(lse), kp, B, L, nh, p,
                                           seed, offset, site, Lb.cur_stream()))
         Lb.check(lib.uniter_attn_bf16_bwd(Lb.ptr(qsrc), qb16, mptr, cptr, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), Lb.ptr(dqkv),
@@ -100,7 +117,11 @@ def test_attention_bf16_fwd_bwd(B, L, nh, p, lens, varlen):
     assert torch.equal(plain[0], ctx) and torch.equal(plain[1], dqkv)
     # bf16-only output (what the model asks for: nothing reads the fp32 gradient in precision mode 2)
     only_b = torch.zeros_like(dqkvb)
-    Lb.check(lib.uniter_attn_bf16_bwd(Lb.ptr(qsrc), qb16, mptr, cptr, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), None, Lb.ptr(only_b),
+    if kind == 'b16x':
+        Lb.check(lib.uniter_attn_b16x_bwd(Lb.ptr(qsrc), qb16, mptr, cptr, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), None, Lb.ptr(only_b),
+                                          Lb.ptr(bpart), Lb.ptr(keep) if p > 0 else None, Lb.ptr(delta), B, L, nh, p, Lb.cur_stream()))
+    else:
+      Lb.check(lib.uniter_attn_bf16_bwd(Lb.ptr(qsrc), qb16, mptr, cptr, Lb.ptr(ctx), Lb.ptr(lse), Lb.ptr(dd), None, Lb.ptr(only_b),
                                       Lb.ptr(bpart), Lb.ptr(keep), Lb.ptr(delta), B, L, nh, p, seed, offset, site,
                                       Lb.ptr(ws), wsb, Lb.cur_stream()))
     torch.cuda.synchronize()

@@ -22,7 +22,9 @@ for p in (0.0, 0.1):
     def bwdx(): L.check(lib.uniter_attn_x3_bwd(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(lse), L.ptr(dctx), 1, 0, None, L.ptr(dqkv3), L.ptr(part), kp if p > 0 else None, L.ptr(delta), B, Lq, nh, p, L.cur_stream()))
     def fwd3(): L.check(lib.uniter_attn_fwd_pre_x3(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(ctx3), L.ptr(lse), kp, 1 if p > 0 else 0, B, Lq, nh, p, 1, 2, 3, L.cur_stream()))
     def bwd3(): L.check(lib.uniter_attn_bwd_ex_x3(L.ptr(qkv), L.ptr(mask), None, L.ptr(ctx), L.ptr(lse), L.ptr(dctx), None, L.ptr(dqkv3), L.ptr(part), kp, L.ptr(delta), B, Lq, nh, p, 1, 2, 3, L.ptr(ws), wsb, L.cur_stream()))
-    for name, f in (('fwd', fwd), ('bwd(dq+dkv)', bwd), ('fwd pieces out', fwd3), ('bwd pieces out', bwd3), ('x3 fwd', fwdx), ('x3 bwd', bwdx), ('bf16 fwd', fwd16), ('bf16 bwd', bwd16)):
+    def fwdbx(): L.check(lib.uniter_attn_b16x_fwd(L.ptr(qkvb), 1, L.ptr(mask), None, L.ptr(ctx), L.ptr(ctx3), L.ptr(lse), kp if p > 0 else None, B, Lq, nh, p, L.cur_stream()))
+    def bwdbx(): L.check(lib.uniter_attn_b16x_bwd(L.ptr(qkvb), 1, L.ptr(mask), None, L.ptr(ctx), L.ptr(lse), L.ptr(dctx), None, L.ptr(dqkv3), L.ptr(part), kp if p > 0 else None, L.ptr(delta), B, Lq, nh, p, L.cur_stream()))
+    for name, f in (('fwd', fwd), ('bwd(dq+dkv)', bwd), ('fwd pieces out', fwd3), ('bwd pieces out', bwd3), ('x3 fwd', fwdx), ('x3 bwd', bwdx), ('bf16 fwd', fwd16), ('bf16 bwd', bwd16), ('b16x fwd', fwdbx), ('b16x bwd', bwdbx)):
         for _ in range(3): f()
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
