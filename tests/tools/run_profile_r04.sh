@@ -36,6 +36,7 @@ UNITER_LIB_VARIANT=x3lab LAB_CFGS=3,3d1,3d3,3d4,2,2d1,2d3,2d4,1,1d3 timeout 200 
 UNITER_LIB_VARIANT=x3lab timeout 200 python tests/tools/attn_x3_lab.py 2>&1 | grep -v amdgpu.ids > $O/attn_x3_lab.txt
 fi
 python tests/tools/ln_bench.py > $O/ln_isolated.txt 2>&1
+(for s in 1234 77; do echo "== uniter_attn_b16x_* (default), batch seed $s"; python tests/tools/b16x_diag.py $s 2>&1 | grep -v amdgpu | tail -8; echo "== attention_bf16.hip (UNITER_ATTN_B16X=0), batch seed $s"; UNITER_ATTN_B16X=0 python tests/tools/b16x_diag.py $s 2>&1 | grep -v amdgpu | tail -8; done) > $O/b16x_vs_oracle.txt
 (python tests/tools/cli_throughput.py fp32; python tests/tools/cli_throughput.py fp32x3; python tests/tools/cli_throughput.py bf16) 2>&1 | grep 'samples/s' > $O/cli_throughput_raw.txt
 fi
 if [ "$part" = "2" ]; then
