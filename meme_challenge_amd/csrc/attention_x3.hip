@@ -18,6 +18,11 @@
 // S = Q . K^T and dP = dO . V^T in the other orientation and accumulates dV^T = dO^T . Pd and dK^T = Q^T . dS.  The recomputation
 // costs 48 of the 168 MFMAs per 32 x 32 tile pair -- on the bf16 pipe less than the 2 x 28 MB of scratch traffic it replaces.
 //
+// The kernels are templates over the number of pieces: NP = 3 is the fp32x3 mode (uniter_attn_x3_fwd / _bwd), NP = 1 the bf16
+// mode in the same decomposition (uniter_attn_b16x_fwd / _bwd: operands rounded to bf16 where they become MFMA operands, one
+// product per block, Q / K / V optionally bf16 in memory; its forward keeps attention_bf16.hip's two online-softmax ranges so that
+// probabilities are rounded where the bf16 oracle rounds them).
+//
 // Dropout: the keep flags are READ (uniter_attn_keep_bits_gen draws them ahead of the forward pass); both passes of the backward
 // read the same words.  Layouts as attention_f32.hip: qkv [rows, 3H], ctx / dctx [rows, H], lse / delta [B, nh, L], x3 outputs
 // [rows][3][ld].  head_dim == 64.

@@ -128,7 +128,7 @@ def _check_bf16_step_against_bf16_oracle(cfg, B, T, R, seed):
         eh, eo = _rms_rel(g, gf[n]), _rms_rel(gb[n], gf[n])
         fac, slack = _two_sided_slack(n, g.numel())
         assert eh <= fac * eo + slack, (n, eh, eo)
-        assert _rms_rel(g, gb[n]) <= 2.0 * eo + 2e-4, (n, _rms_rel(g, gb[n]), eo)
+        assert _rms_rel(g, gb[n]) <= (fac + 0.4) * eo + slack, (n, _rms_rel(g, gb[n]), eo)      # two draws apart: 2.0 (2.4) x
         ratios.append(eh / max(eo, 1e-30))
         checked += 1
     assert checked >= 15 * nl
@@ -438,7 +438,7 @@ def test_config5_multitask_b32_bf16_two_sided(task, train):
         eh, eo = _rms_rel(p.grad, ref), _rms_rel(gb[n], ref)
         fac, slack = _two_sided_slack(n, p.grad.numel())
         assert eh <= fac * eo + slack, (task, n, eh, eo)
-        assert _rms_rel(p.grad, gb[n]) <= 2.0 * eo + 2e-4, (task, n, _rms_rel(p.grad, gb[n]), eo)
+        assert _rms_rel(p.grad, gb[n]) <= (fac + 0.4) * eo + slack, (task, n, _rms_rel(p.grad, gb[n]), eo)
         ratios.append(eh / max(eo, 1e-30))
         if not n.startswith('uniter.'):
             head_ratios.append((n, eh, eo))
