@@ -542,7 +542,8 @@ def run_rank(args):
             torch.cuda.synchronize()
             dtn = time.perf_counter() - tn
             native = {'value': round(B * nsteps / dtn, 2), 'ms_per_step': round(dtn / nsteps * 1e3, 3), 'steps': nsteps,
-                      'kernels': 'gemm_f32_v3_kernel (v_mfma_f32_32x32x2_f32) for every dense product; everything else identical'}
+                      'kernels': 'gemm_f32_v3_kernel (v_mfma_f32_32x32x2_f32) for every dense product and the fp32-MFMA attention of '
+                                 'attention_f32.hip (precision fp32, the library default); everything else identical'}
             st_.mirror = saved_mirror
             st_.mirror_dirty = True
             encoder.precision = 'fp32x3'
