@@ -324,6 +324,17 @@ int uniter_attn_b16x_fwd(const void* qkv, int qkv_is_bf16, const float* attn_mas
 int uniter_attn_b16x_bwd(const void* qkv, int qkv_is_bf16, const float* attn_mask, const int32_t* cu_seqlens,
                          const float* ctx, const float* lse, const float* dctx, float* dqkv, void* dqkv_bf16, float* bias_part,
                          const void* keep_bits, float* delta, int B, int L, int nh, float p_drop, void* stream);
+/* Optimal-transport distance of the ITM pretraining task (IPOT): optimal_transport_dist of model/ot.py:69-85 (cosine cost matrix
+ * :11-21, `iteration` proximal steps of ipot :36-66 with k = 1 -- the reference's ipot fails for k > 1 --, trace(C T) :84), called
+ * from model/pretrain.py:168-193 on the text rows txt_emb [B, M, D] and region rows img_emb [B, N, D] of the encoder output;
+ * txt_pad [B, M] / img_pad [B, N]: 1 = padding.  fp32 throughout like the reference.  One workgroup per sample with the cost
+ * matrix and the plan in LDS: M * N <= 12288 and (3 M N + 35 (M + N)) * 4 bytes <= 160 KB (128 x 64 fits, 128 x 96 does not:
+ * UNITER_E_SHAPE).  T [B, N, M] (optional in the forward call) is the transport plan the backward
+ * call needs: the gradient reaches the embeddings through the cost matrix only (the reference detaches T). */
+int uniter_ot_dist_fwd(const float* txt_emb, const float* img_emb, const unsigned char* txt_pad, const unsigned char* img_pad,
+                       float* dist, float* T, int B, int M, int N, int D, float beta, int iteration, void* stream);
+int uniter_ot_dist_bwd(const float* txt_emb, const float* img_emb, const float* T, const float* grad_dist, float* d_txt,
+                       float* d_img, int B, int M, int N, int D, void* stream);
 /* The same two operations on the bf16 matrix pipe (precision mode 2): Q, K, V rounded to bf16 while
  * staged, fp32 scores / softmax / dropout / LSE, probabilities and score gradients rounded to bf16 as
  * MFMA operands.  Same arguments and Philox element indices as the _ex forms; L <= 192;

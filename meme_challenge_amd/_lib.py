@@ -93,6 +93,8 @@ _SIGS = {
     'uniter_attn_x3_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _SZ, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     'uniter_attn_b16x_fwd': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     'uniter_attn_b16x_bwd': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    'uniter_ot_dist_fwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    'uniter_ot_dist_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'uniter_attn_fwd_varlen': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P]),
     'uniter_attn_bwd_varlen': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),

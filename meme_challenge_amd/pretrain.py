@@ -502,14 +502,25 @@ class UniterForPretraining(UniterPreTrainedModel):
     def forward_itm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                     targets, ot_inputs=None, compute_loss=True):
         self._sync_head_precision()
-        if ot_inputs is not None and not getattr(self, '_warned_ot', False):
-            # model/pretrain.py:168-203 computes the optimal-transport distance of the batch and then returns the ITM
-            # loss / scores alone (both `return ..., ot_loss` lines are commented out there): nothing a caller sees
-            # depends on it, so the IPOT iterations of model/ot.py are not run here
-            logger.info('forward_itm: ot_inputs given -- the reference discards the OT distance it computes from them; skipped')
-            self._warned_ot = True
         seq = self.uniter(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                           output_all_encoded_layers=False, seq_lens=getattr(self, '_seq_lens', None))
+        # model/pretrain.py:168-193 computes the optimal-transport distance of the batch and then returns the ITM loss / scores
+        # alone (both `return ..., ot_loss` lines are commented out there): nothing a caller sees depends on it.  Here it is
+        # computed only on request (`compute_ot_loss = True`) and left in `self.ot_loss` as (positive pairs, negative pairs).
+        self.ot_loss = None
+        if ot_inputs is not None and getattr(self, 'compute_ot_loss', False):
+            from .ot import optimal_transport_dist
+            b, tl, il = seq.size(0), input_ids.size(1), img_feat.size(1)
+            max_l = max(int(ot_inputs['scatter_max']) + 1, tl + il)
+            idx = ot_inputs['ot_scatter'].unsqueeze(-1).expand_as(seq)
+            ctx_emb = torch.zeros(b, max_l, seq.size(-1), dtype=seq.dtype, device=seq.device).scatter_(dim=1, index=idx, src=seq)
+            ot_dist = optimal_transport_dist(ctx_emb[:, :tl, :].float(), ctx_emb[:, tl:tl + il, :].float(), ot_inputs['txt_pad'],
+                                             ot_inputs['img_pad']).to(seq.dtype)
+            self.ot_loss = (ot_dist.masked_select(targets == 1), ot_dist.masked_select(targets == 0))
+        elif ot_inputs is not None and not getattr(self, '_warned_ot', False):
+            logger.info('forward_itm: ot_inputs given -- the reference discards the OT distance it computes from them; '
+                        'set compute_ot_loss = True to have it in self.ot_loss')
+            self._warned_ot = True
         pooled = self.uniter.pooler(seq)
         scores = self.itm_output(pooled)
         if not compute_loss:

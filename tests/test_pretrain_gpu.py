@@ -148,3 +148,41 @@ def test_cross_entropy_and_gather_kernels():
     L.check(lib.uniter_row_scatter_add(L.ptr(out), L.ptr(idx), L.ptr(dst), 4, 128, 50, L.cur_stream()))
     exp = torch.ones(50, 128, device='cuda'); exp[idx] += src[idx]
     assert torch.equal(dst, exp)
+
+
+def test_itm_ot_loss_on_request_matches_the_oracle(pre):
+    """forward_itm with ot_inputs and `compute_ot_loss = True`: the optimal-transport distances of model/pretrain.py:168-193
+    (scatter of the encoder output into [text | regions], model/ot.py on the two halves) in `ot_loss` -- what the reference
+    computes and then drops -- against the oracle's IPOT on the same encoder output; the returned ITM loss is unchanged."""
+    from oracle import ot_oracle as OT
+    m = _model(pre).eval()
+    b = {k: v.cuda() for k, v in batch_from_npz(pre).items()}
+    B, tl, il = b['input_ids'].shape[0], b['input_ids'].shape[1], b['img_feat'].shape[1]
+    L = b['gather_index'].shape[1]
+    # the joint sequence is [text tokens | regions | padding] per sample (gather_index): position j of the output goes to slot
+    # j for text and to tl + (j - text length) for regions -- what the reference's collate writes into ot_scatter
+    amask = b['attn_masks'] if 'attn_masks' in b else b['attention_mask']
+    txt_len = (b['input_ids'] != 0).sum(1)
+    tot = amask.sum(1)
+    scatter = torch.zeros(B, L, dtype=torch.long, device='cuda')
+    txt_pad = torch.ones(B, tl, dtype=torch.bool, device='cuda'); img_pad = torch.ones(B, il, dtype=torch.bool, device='cuda')
+    for i in range(B):
+        t, n = int(txt_len[i]), int(tot[i])
+        scatter[i, :t] = torch.arange(t); scatter[i, t:n] = tl + torch.arange(n - t); scatter[i, n:] = tl + il      # padding -> a dump slot
+        txt_pad[i, :t] = False; img_pad[i, :n - t] = False
+    ot_inputs = {'ot_scatter': scatter, 'scatter_max': tl + il, 'txt_pad': txt_pad, 'img_pad': img_pad}
+    with torch.no_grad():
+        plain = m(b, 'itm')
+        assert m.ot_loss is None
+        m.compute_ot_loss = True
+        with_ot = m(dict(b, ot_inputs=ot_inputs), 'itm')
+        pos, neg = m.ot_loss
+        seq = m.uniter(b['input_ids'], b['position_ids'], b['img_feat'], b['img_pos_feat'], amask, b['gather_index'],
+                       output_all_encoded_layers=False)
+    assert torch.equal(plain, with_ot)
+    ctx = torch.zeros(B, tl + il + 1, seq.shape[-1], dtype=torch.float64).scatter_(1, scatter.cpu().unsqueeze(-1).expand(B, L, seq.shape[-1]), seq.cpu().double())
+    ref, _, _ = OT.optimal_transport_dist(ctx[:, :tl], ctx[:, tl:tl + il], txt_pad.cpu(), img_pad.cpu())
+    tg = b['targets'].cpu()
+    assert pos.numel() + neg.numel() == B and pos.numel() == int((tg == 1).sum())
+    assert (pos.cpu().double() - ref[tg == 1]).abs().max().item() < 1e-4 if pos.numel() else True
+    assert (neg.cpu().double() - ref[tg == 0]).abs().max().item() < 1e-4 if neg.numel() else True
