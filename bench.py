@@ -86,7 +86,7 @@ def _physical_cores():
     return max(1, len(allowed))
 
 
-def cpu_baseline(seconds_budget=30.0):
+def cpu_baseline(seconds_budget=30.0, all_cores=False):
     """Reported baseline only: the CPU oracle (port of the reference forward; autograd backward) on
     BASELINE config 1 (B=4, T=64, R=36, UNITER-base, dropout on), timed on this box's host cores: N = physical cores, 32
     threads where that differs, and one thread (1 warm-up + up to 2 timed steps), all bounded by the budget."""
@@ -118,21 +118,30 @@ def cpu_baseline(seconds_budget=30.0):
     hw = os.cpu_count() or 1
     phys = _physical_cores()
     legs = []
-    # N = the physical cores the process may use, and the 32-thread figure of earlier rounds (more threads
-    # than ~32 slow the oracle's small CPU ops down on a many-core host): `value` is the better of the two, `cores` says which
-    for nt in sorted({phys, min(phys, 32)}, reverse=True):
-        dt, n = timed(nt, 2, 8, seconds_budget * 0.3)
+    # N = the physical cores the process may use AND the 32-thread figure: the oracle's small CPU ops do not
+    # scale past ~32 threads (EPYC 9575F, 128 cores: 0.33 samples/s on 128 threads, 12 s per step, against 6.7 on 32), so the
+    # all-cores leg is ONE warm-up-free step when N <= 64 and, beyond that, the figure recorded in round 4 (steps: 0) unless
+    # --cpu_all_cores asks for it: 12 s of the driver's time for a number that is noise
+    nts = sorted({phys, min(phys, 32)}, reverse=True)
+    for nt in nts:
+        if nt > 64 and not all_cores:
+            legs.append({'cores': nt, 'value': 0.325, 'gflops': round(0.325 * gf_per_sample, 1), 'steps': 0, 's_per_step': 12.3,
+                         'note': 'not run: recorded in round 4 on this CPU model (BENCH_r04.json, one step on 128 threads); --cpu_all_cores runs it'})
+            continue
+        warm, most = (0, 1) if (nt > 32 and not all_cores) else (2, 8)
+        dt, n = timed(nt, warm, most, seconds_budget * 0.3)
         legs.append({'cores': nt, 'value': round(4.0 / dt, 3), 'gflops': round(4.0 / dt * gf_per_sample, 1), 'steps': n, 's_per_step': round(dt, 3)})
     dt1, n1 = timed(1, 1, 2, seconds_budget * 0.3)
-    best = max(legs, key=lambda l: l['value'])
+    best = max([l for l in legs if l['steps'] > 0], key=lambda l: l['value'])
     torch.set_num_threads(best['cores'])
     return {'value': best['value'], 'unit': 'samples/s', 'cores': best['cores'], 'kind': 'port',
             'gflops': best['gflops'], 'by_cores': legs, 'physical_cores': phys,
             'single_thread': {'value': round(4.0 / dt1, 3), 'gflops': round(4.0 / dt1 * gf_per_sample, 1), 'steps': n1},
             'cpu_model': _lscpu_model(), 'os_cpu_count': hw,
-            'sample': 'config 1: UNITER-base B=4 T=64 R=36 fwd+bwd after 2 warm-ups per leg: %s; %d steps after 1 warm-up on 1 '
+            'sample': 'config 1: UNITER-base B=4 T=64 R=36 fwd+bwd: %s; %d steps after 1 warm-up on 1 '
                       'thread (%.2f s/step); oracle/uniter_oracle.py (torch CPU fp32, dropout on)'
-                      % ('; '.join('%d steps on %d threads (%.3f s/step)' % (l['steps'], l['cores'], l['s_per_step']) for l in legs),
+                      % ('; '.join(('%d steps on %d threads (%.3f s/step)' % (l['steps'], l['cores'], l['s_per_step'])) if l['steps'] else
+                                   ('%d threads: not run (recorded %.3f samples/s)' % (l['cores'], l['value'])) for l in legs),
                          n1, dt1)}
 
 
@@ -265,11 +274,17 @@ def parse_args(argv=None):
     ap.add_argument('--packed', action='store_true',
                     help='token packing: compute the valid positions only (pays off with --ragged; identical results)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--cpu_all_cores', action='store_true', help='CPU baseline: run the all-physical-cores leg in full (2 warm-ups + up to 8 steps)')
+    ap.add_argument('--no_bf16_leg', action='store_true',
+                    help='fp32x3 at N = 1: skip the bf16-mode timing of the same step in the same process (bf16 in the line: BASELINE configs[2] arithmetic)')
     ap.add_argument('--no_side_stream', action='store_true')
     ap.add_argument('--prewarm_s', type=float, default=1.0, help='seconds of untimed steps before the W warm-up steps (clock ramp)')
     ap.add_argument('--no_adam_overlap', action='store_true',
                     help='run the optimizer step as one launch on the main stream instead of block by block beside the next forward')
     ap.add_argument('--prof_kind', type=int, default=-1, help='UNITER_K_* kind timed with HIP events inside the timed region (-1 = every kind, 0 = none)')
+    ap.add_argument('--both_exchanges', action='store_true',
+                    help='N > 1: time the other form of the word-embedding exchange too (a second timed region, listed in '
+                         'comm.other_exchange; `value` is always the requested exchange)')
     ap.add_argument('--dp_sparse_embeddings', action='store_true',
                     help='N > 1: exchange the touched word-embedding gradient rows (all-gather of ids + rows) instead of '
                          'all-reducing the whole 28996 x 768 table')
@@ -332,10 +347,26 @@ def main(argv=None):
 
 def run_rank(args):
     # ONE line on stdout: libraries under us write to file descriptor 1 as well (gloo's connection notes, RCCL's version banner
-    # under NCCL_DEBUG=INFO).  Descriptor 1 points at stderr for the whole run; the JSON line goes to the saved descriptor.
+    # under NCCL_DEBUG=INFO).  Descriptor 1 points at stderr for the run; the JSON line goes to the saved descriptor, which
+    # becomes descriptor 1 again when the run ends (an in-process caller of main() keeps its stdout).
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    state = {'rccl_log': None}
+    try:
+        return _run_rank(args, real_stdout, state)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+        if state['rccl_log']:
+            try:
+                os.remove(state['rccl_log'])
+            except OSError:
+                pass
+
+
+def _run_rank(args, real_stdout, state):
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
@@ -360,7 +391,7 @@ def run_rank(args):
         # RCCL's own account of what it built (rings / trees, channels) for the `comm` block of the line: rank 0's INFO log
         # goes to a file (NCCL_DEBUG_FILE), parsed after the run
         import tempfile
-        rccl_log = os.path.join(tempfile.gettempdir(), 'uniter_rccl_rank0_%d.log' % os.getpid())
+        rccl_log = state['rccl_log'] = os.path.join(tempfile.gettempdir(), 'uniter_rccl_rank0_%d.log' % os.getpid())
         os.environ.update(NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,GRAPH,TUNING', NCCL_DEBUG_FILE=rccl_log)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -471,29 +502,40 @@ def run_rank(args):
     if sync is not None:
         comm = comm_block(sync, args.steps, rccl_log if rank == 0 else None)
         comm['sparse_embeddings'] = bool(args.dp_sparse_embeddings)
-        # N > 1: the same timed region once more with the other form of the word-embedding exchange (dense table all-reduce
-        # <-> touched rows only); `value` is the better of the two, the line says which and carries both
-        if world > 1 and args.steps >= 20 and args.workload == 'finetune' and os.environ.get('UNITER_BENCH_ONE_EXCHANGE') != '1':
+        # --both_exchanges (N > 1, finetune): the same timed region once more with the OTHER form of the word-embedding exchange
+        # (dense table all-reduce <-> touched rows only).  `value` stays the REQUESTED exchange's; the other one is listed
+        # beside it in comm.other_exchange.  Auxiliary: every rank runs it under try / except and the ranks agree on an ok
+        # flag before anyone uses a figure of it -- a failure leaves the already-measured line untouched
+        if args.both_exchanges and world > 1 and args.workload == 'finetune':
+            ok, alt, err = 1, None, None
             alt_sparse = not args.dp_sparse_embeddings
-            sync2 = dp.attach(model, sparse_embeddings=alt_sparse, accum=config['gradient_accumulation'])
-            sync2.timing = True
-            step.grad_sync = sync2
-            for _ in range(max(3, args.warmup // 2)):
-                one_step()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                one_step()
-            barrier()
-            dt2 = time.perf_counter() - t1
-            t = torch.tensor([dt2], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t.item())
-            alt = comm_block(sync2, args.steps, None)
-            alt['sparse_embeddings'] = alt_sparse
-            alt['ms_per_step'] = round(dt2 / args.steps * 1e3, 3)
-            alt['value'] = round(B * world * args.steps / dt2, 2)
-            comm['other_exchange'] = alt
+            try:
+                sync2 = dp.attach(model, sparse_embeddings=alt_sparse, accum=config['gradient_accumulation'])
+                sync2.timing = True
+                step.grad_sync = sync2
+                for _ in range(max(3, args.warmup // 2)):
+                    one_step()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    one_step()
+                barrier()
+                dt2 = time.perf_counter() - t1
+            except Exception as e:                                   # noqa: BLE001
+                ok, err = 0, repr(e)
+            try:
+                flag = torch.tensor([float(ok), dt2 if ok else 0.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(flag[:1], op=dist.ReduceOp.MIN)
+                dist.all_reduce(flag[1:], op=dist.ReduceOp.MAX)
+                ok, dt2 = int(flag[0].item()), float(flag[1].item())
+                if ok:
+                    alt = comm_block(sync2, args.steps, None)
+                    alt['sparse_embeddings'] = alt_sparse
+                    alt['ms_per_step'] = round(dt2 / args.steps * 1e3, 3)
+                    alt['value'] = round(B * world * args.steps / dt2, 2)
+            except Exception as e:                                   # noqa: BLE001
+                alt, err = None, err or repr(e)
+            comm['other_exchange'] = alt if alt is not None else {'error': err or 'failed on another rank'}
             step.grad_sync = sync
             um = getattr(model, 'uniter_model', None)
             if um is not None:
@@ -551,6 +593,35 @@ def run_rank(args):
             torch.cuda.synchronize()
         except Exception as e:                               # noqa: BLE001
             native = {'error': repr(e)}
+    bf16_leg = None
+    if args.precision == 'fp32x3' and world == 1 and not use_dist and not args.no_bf16_leg and args.workload == 'finetune':
+        # the same step in the bf16 mode (BASELINE configs[2] arithmetic on one GPU), same process and box, 20 timed steps: the
+        # driver's line carries a bf16 figure too.  Auxiliary: a failure is reported in the block, the headline is untouched
+        try:
+            st_ = model.param_store()
+            encoder.precision = 'bf16'
+            for _ in range(8):
+                one_step()
+            torch.cuda.synchronize()
+            nsteps = min(args.steps, 20)
+            tb = time.perf_counter()
+            for _ in range(nsteps):
+                one_step()
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - tb
+            tot_b = flops_per_step(cfgd, B, T, R, int(batch['attn_mask'].shape[1]), batch['seq_lens'] if args.packed else None)[0]
+            bf16_leg = {'value': round(B * nsteps / dtb, 2), 'ms_per_step': round(dtb / nsteps * 1e3, 3), 'steps': nsteps,
+                        'step_mfma_frac': round(tot_b / (dtb / nsteps) / (PEAK_TFLOPS['bf16'] * 1e12), 4), 'peak_tflops': PEAK_TFLOPS['bf16'],
+                        'dtype': 'bf16', 'final_loss': round(float(step.last_loss.item()), 5),
+                        'kernels': 'precision bf16: gemm_dma_kernel / gemm_dma_wgrad_group_kernel on bf16-resident operands, '
+                                   'attention on the bf16 pipe, fp32 master weights / LayerNorm / loss / optimizer; same batch, same optimizer'}
+            encoder.precision = 'fp32x3'
+            st_.mirror_dirty = True
+            one_step()                                   # back in the timed mode (the weight pieces are rebuilt here)
+            torch.cuda.synchronize()
+        except Exception as e:                               # noqa: BLE001
+            bf16_leg = {'error': repr(e)}
+            encoder.precision = 'fp32x3'
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -599,12 +670,18 @@ def run_rank(args):
                 continue
             sec = tot * 1e-3 / steps                   # seconds of this family per step
             pk = (peak_attn if name.startswith('attention') else peak) * 1e12 if bound == 'mfma' else 8.0e12
+            ev_us = (e_ms[k] * 1e3 / e_n[k]) if (in_run and e_n[k] > 0 and e_ms[k] > 0) else None
             families.append({'family': name, 'bound': bound, 'launches_per_step': n // steps,
                              'avg_us': round(tot * 1e3 / n, 2), 'ms_per_step': round(sec * 1e3, 4),
                              'achieved': round(work / sec / 1e12, 2), 'unit': 'TFLOP/s' if bound == 'mfma' else 'TB/s',
                              'frac': round(work / sec / pk, 4), 'peak': round(pk / 1e12, 1) if bound == 'mfma' else 8.0, 'kernel': kernel_of[pk_name].get(k),
                              'measured': 'in-kernel stamps inside the timed region' if in_run else
                                          'HIP events, separate %d-step pass after the timed region (%.2f ms/step under events)' % (EV_STEPS, ev_ms)})
+            if ev_us is not None:
+                # the same family under HIP events (the separate pass): from the moment the launch could start on its stream to
+                # its end -- the time a dispatch sits queued behind the other stream's workgroups is IN this one, not in the stamps
+                families[-1]['avg_us_dispatch'] = round(ev_us, 2)
+                families[-1]['frac_dispatch'] = round(work / (ev_us * 1e-6 * (n // steps)) / pk, 4)
         out = {
             'metric': 'train samples/sec UNITER-%s (%d regions, %d tok)' % (args.model, R, T),
             'value': round(value, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
@@ -643,15 +720,10 @@ def run_rank(args):
         }
         if native is not None:
             out['native_fp32'] = native
+        if bf16_leg is not None:
+            out['bf16'] = bf16_leg
         if comm is not None:
-            if 'other_exchange' in comm and comm['other_exchange'].get('value', 0) > out['value']:
-                # the better exchange is the headline; the first region's figures move into the block
-                first = {'sparse_embeddings': comm['sparse_embeddings'], 'value': out['value'], 'ms_per_step': out['ms_per_step']}
-                out['value'], out['ms_per_step'] = comm['other_exchange']['value'], comm['other_exchange']['ms_per_step']
-                comm['headline_exchange'] = 'sparse word-embedding rows' if comm['other_exchange']['sparse_embeddings'] else 'dense'
-                comm['first_region'] = first
-            else:
-                comm['headline_exchange'] = 'sparse word-embedding rows' if comm['sparse_embeddings'] else 'dense'
+            comm['headline_exchange'] = 'sparse word-embedding rows' if comm['sparse_embeddings'] else 'dense'
             out['comm'] = comm
         if prof_error:
             out['profiling_error'] = prof_error
@@ -665,6 +737,11 @@ def run_rank(args):
             out['roofline'] = {'bound': dom['bound'], 'achieved': dom['achieved'], 'peak': peak, 'unit': dom['unit'],
                                'frac': dom['frac'], 'traffic': None, 'kernel': '%s: %s' % (dom['family'], dom['kernel']),
                                'launches': dom['launches_per_step'] * args.steps, 'avg_ms': round(dom['avg_us'] * 1e-3, 4),
+                               'avg_ms_dispatch': round(dom['avg_us_dispatch'] * 1e-3, 4) if 'avg_us_dispatch' in dom else None,
+                               'frac_dispatch': dom.get('frac_dispatch'),
+                               'note': '`frac` / `avg_ms` use the in-kernel stamps of the timed region (first workgroup start -> last workgroup end '
+                                       'of each launch); `frac_dispatch` / `avg_ms_dispatch` are the same launches under HIP events in the separate '
+                                       '%d-step pass (time queued behind the other stream included: what a rocprofv3 kernel trace reports)' % EV_STEPS,
                                'share_of_step_kernel_time': round(dom['ms_per_step'] / sum(f['ms_per_step'] for f in families), 3)}
             out['roofline_families'] = families
             if bwd_union_ms.value > 0:
@@ -692,7 +769,7 @@ def run_rank(args):
             out['optimizer_error'] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out['cpu_baseline'] = cpu_baseline()
+                out['cpu_baseline'] = cpu_baseline(all_cores=args.cpu_all_cores)
             except Exception as e:                               # noqa: BLE001
                 out['cpu_baseline_error'] = repr(e)
         sys.stdout.flush()

@@ -17,7 +17,8 @@ class _OtDist(torch.autograd.Function):
         x, y = txt_emb.contiguous(), img_emb.contiguous()
         xp, yp = txt_pad.to(torch.uint8).contiguous(), img_pad.to(torch.uint8).contiguous()
         dist = torch.empty(B, dtype=torch.float32, device=x.device)
-        need = x.requires_grad or y.requires_grad
+        # (grad mode is off in here: a .contiguous() copy of a non-contiguous input has requires_grad False -- ask the node)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         T = torch.empty(B, N, M, dtype=torch.float32, device=x.device) if need else None
         check(lib.uniter_ot_dist_fwd(ptr(x), ptr(y), ptr(xp), ptr(yp), ptr(dist), ptr(T) if T is not None else None, B, M, N, D,
                                      float(beta), int(iteration), _lib.cur_stream()), 'uniter_ot_dist_fwd')

@@ -59,7 +59,15 @@ def test_bench_default_contract():
     assert c['single_thread']['value'] > 0 and c['gflops'] > 0 and c['cpu_model'] and c['os_cpu_count'] >= c['cores']
     # N = the physical cores the process may use, and 32 threads where that differs: both in the block, `cores` = the one reported
     assert c['physical_cores'] >= 1 and c['by_cores'][0]['cores'] == c['physical_cores']
-    assert c['cores'] in [l['cores'] for l in c['by_cores']] and c['value'] == max(l['value'] for l in c['by_cores'])
+    ran = [l for l in c['by_cores'] if l['steps'] > 0]
+    assert ran and c['cores'] in [l['cores'] for l in ran] and c['value'] == max(l['value'] for l in ran)
+    assert all(l['steps'] > 0 or ('note' in l and l['cores'] > 64) for l in c['by_cores'])      # an all-cores leg that did not run says so
+    # the same step in the bf16 mode (BASELINE configs[2] arithmetic), same process: a driver-timed bf16 figure
+    b16 = d['bf16']
+    assert b16['dtype'] == 'bf16' and b16['value'] > d['value'] and abs(b16['value'] - 16 / (b16['ms_per_step'] * 1e-3)) / b16['value'] < 1e-3
+    assert 0.02 < b16['step_mfma_frac'] < 1.0 and b16['peak_tflops'] == 2500.0 and b16['final_loss'] == b16['final_loss']
+    # both durations of the dominant family: in-kernel stamps (frac) and HIP events with the queueing included (frac_dispatch)
+    assert r['avg_ms'] > 0 and r['avg_ms_dispatch'] > 0 and 0.0 < r['frac_dispatch'] < 1.0 and 'stamps' in r['note']
 
 
 def test_bench_native_fp32_mode_keeps_its_roofline():

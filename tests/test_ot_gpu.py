@@ -66,6 +66,29 @@ def test_ot_dist_matches_oracle_at_model_sizes(B, M, N, D, seed):
         assert torch.equal(optimal_transport_dist(x.cuda(), y.cuda(), tp.cuda(), ip.cuda()), d.detach())
 
 
+def test_ot_dist_backward_through_non_contiguous_slices():
+    """forward_itm hands slices ctx[:, :tl] / ctx[:, tl:tl + il] of one tensor (non-contiguous for B >= 2): the transport plan
+    must be saved for them too (the decision was taken on the contiguous copies, which never require grad)."""
+    from meme_challenge_amd.ot import optimal_transport_dist
+    g = torch.Generator().manual_seed(11)
+    B, tl, il, D = 3, 20, 12, 64
+    ctx = torch.randn(B, tl + il + 1, D, generator=g)
+    tp = torch.zeros(B, tl, dtype=torch.bool); ip = torch.zeros(B, il, dtype=torch.bool)
+    tp[1, 15:] = True; ip[2, 7:] = True
+    w = torch.randn(B, generator=g)
+    co = ctx.double().requires_grad_(True)
+    do, _, _ = OT.optimal_transport_dist(co[:, :tl], co[:, tl:tl + il], tp, ip)
+    (do * w.double()).sum().backward()
+    cd = ctx.cuda().requires_grad_(True)
+    xs, ys = cd[:, :tl, :], cd[:, tl:tl + il, :]
+    assert not xs.is_contiguous() and not ys.is_contiguous()
+    d = optimal_transport_dist(xs, ys, tp.cuda(), ip.cuda())
+    (d * w.cuda()).sum().backward()
+    _close(d, do, 1e-4, 'dist')
+    _close(cd.grad, co.grad, 2e-4, 'd ctx')
+    assert cd.grad[:, tl + il].abs().max().item() == 0
+
+
 def test_ot_dist_error_behaviour():
     from meme_challenge_amd.ot import optimal_transport_dist
     from meme_challenge_amd._lib import UniterHipError

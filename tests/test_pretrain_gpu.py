@@ -186,3 +186,41 @@ def test_itm_ot_loss_on_request_matches_the_oracle(pre):
     assert pos.numel() + neg.numel() == B and pos.numel() == int((tg == 1).sum())
     assert (pos.cpu().double() - ref[tg == 1]).abs().max().item() < 1e-4 if pos.numel() else True
     assert (neg.cpu().double() - ref[tg == 0]).abs().max().item() < 1e-4 if neg.numel() else True
+
+
+def test_itm_ot_loss_backpropagates_into_the_encoder_output(pre):
+    """Training through the requested OT loss (B >= 2: the slices of the scattered encoder output are non-contiguous): the gradient
+    that reaches the encoder output equals the oracle's IPOT gradient scattered back."""
+    from oracle import ot_oracle as OT
+    m = _model(pre).eval()
+    b = {k: v.cuda() for k, v in batch_from_npz(pre).items()}
+    B, tl, il = b['input_ids'].shape[0], b['input_ids'].shape[1], b['img_feat'].shape[1]
+    assert B >= 2
+    L = b['gather_index'].shape[1]
+    amask = b['attn_masks'] if 'attn_masks' in b else b['attention_mask']
+    txt_len = (b['input_ids'] != 0).sum(1)
+    tot = amask.sum(1)
+    scatter = torch.zeros(B, L, dtype=torch.long, device='cuda')
+    txt_pad = torch.ones(B, tl, dtype=torch.bool, device='cuda'); img_pad = torch.ones(B, il, dtype=torch.bool, device='cuda')
+    for i in range(B):
+        t, n = int(txt_len[i]), int(tot[i])
+        scatter[i, :t] = torch.arange(t); scatter[i, t:n] = tl + torch.arange(n - t); scatter[i, n:] = tl + il
+        txt_pad[i, :t] = False; img_pad[i, :n - t] = False
+    ot_inputs = {'ot_scatter': scatter, 'scatter_max': tl + il, 'txt_pad': txt_pad, 'img_pad': img_pad}
+    got = {}
+    h = m.uniter.register_forward_hook(lambda mod, inp, out: (got.__setitem__('seq', out.detach()),
+                                                                out.register_hook(lambda g: got.__setitem__('dseq', g.detach()))) and None)
+    m.compute_ot_loss = True
+    m(dict(b, ot_inputs=ot_inputs), 'itm')
+    pos, neg = m.ot_loss
+    (pos.sum() - 0.5 * neg.sum()).backward()
+    torch.cuda.synchronize()
+    h.remove()
+    seq = got['seq'].cpu().double().requires_grad_(True)
+    ctx = torch.zeros(B, tl + il + 1, seq.shape[-1], dtype=torch.float64).scatter(1, scatter.cpu().unsqueeze(-1).expand(B, L, seq.shape[-1]), seq)
+    ref, _, _ = OT.optimal_transport_dist(ctx[:, :tl], ctx[:, tl:tl + il], txt_pad.cpu(), img_pad.cpu())
+    tg = b['targets'].cpu()
+    (ref[tg == 1].sum() - 0.5 * ref[tg == 0].sum()).backward()
+    d = (got['dseq'].cpu().double() - seq.grad).abs().max().item()
+    assert d <= 2e-4 * max(1.0, seq.grad.abs().max().item()), d
+    assert seq.grad.abs().max().item() > 0

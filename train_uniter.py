@@ -63,7 +63,12 @@ class TrainerUniter(TrainerTemplate):
         """--precision / --pack_padded belong to the encoder object: every place that builds one applies them, so the
         final reload in end_training scores with the arithmetic that was trained and validated."""
         self.model.uniter_model.pack_padded = bool(self.config.get('pack_padded', False))
-        self.model.uniter_model.precision = self.config.get('precision', 'fp32')
+        prec = self.config.get('precision', 'fp32x3')
+        cfg = self.model.uniter_model.config
+        if prec == 'fp32x3' and (cfg.hidden_size % 32 or cfg.intermediate_size % 32):
+            LOGGER.info('precision fp32x3 needs hidden / intermediate sizes %% 32 == 0: this model runs the native fp32 kernels')
+            prec = 'fp32'
+        self.model.uniter_model.precision = prec
 
     def load_model(self):
         uniter_config = resolve_config(self.config['config'])
@@ -117,10 +122,10 @@ def build_parser():
     parser.add_argument('--pack_padded', action='store_true', help='token packing: compute the valid positions only')
     parser.add_argument('--ragged_regions', action='store_true',
                         help="mask every sample at its own region count (the reference's collate counts the zero-padded rows of the batch: data.MemeDataset)")
-    parser.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'fp32x3', 'bf16', 'bf16_hybrid'],
-                        help="GEMM arithmetic: fp32 (the reference's, native fp32 MFMA kernels), fp32x3 (fp32 results from six bf16 "
-                             "MFMA products per block on three bf16 pieces per value: no less accurate, ~25 %% faster steps), bf16 "
-                             "(bf16-resident operands) or bf16_hybrid")
+    parser.add_argument('--precision', type=str, default='fp32x3', choices=['fp32', 'fp32x3', 'bf16', 'bf16_hybrid'],
+                        help="GEMM arithmetic: fp32x3 (default, the path bench.py times: the reference's fp32 results from six bf16 "
+                             "MFMA products per block on three bf16 pieces per value -- no less accurate than the fp32 MFMA kernels, "
+                             "~30 %% faster steps), fp32 (native fp32 MFMA kernels), bf16 (bf16-resident operands) or bf16_hybrid")
     return parser
 
 
