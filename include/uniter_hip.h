@@ -209,6 +209,36 @@ int uniter_gemm_x3_cfg(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, i
  * workgroups walk the tiles; default one per CU); cfg as uniter_gemm_x3_cfg. */
 int uniter_wgrad_x3_group(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
                           const void* const* B, float* const* dW, int overwrite, int max_wgs, void* stream);
+/* The same launch with RIDERS: the side work a layer's backward pass would otherwise launch separately, done by the workgroups
+ * of the weight-gradient launch itself (round 5; model/layer.py:76-78,112,140,153 backward, train_template.py:104 clip norm):
+ *  - colsum_out[m] += sum_k A[0][k][m]: the column sums of product 0's A operand (A = dY: the bias gradient that belongs to
+ *    this weight gradient), by three more MFMAs per row block and k-tile in the tiles of the first tile column;
+ *  - up to 3 column-reduction jobs out[j][c / seg][c % seg] += sum_p part[j][p * stride + c] for c < n[j] (the LayerNorm
+ *    backward passes' [dgamma | dbeta | dbias] partial rows, the attention backward's per-sample query|key|value bias
+ *    partials), 64 columns per item, run by the workgroups with one tile less while the first k-tiles are staged;
+ *  - ssq[4 * workgroup + wave] = the sum of squares of EVERYTHING that wave wrote (weight-gradient tiles after the add,
+ *    colsum_out, reduced vectors), in double: the clip norm's share of this launch as unreduced partial sums in fixed slots
+ *    (no atomics: bit-reproducible); uniter_sumsq_combine joins them.  uniter_wgrad_x3_group_slots = slots written (4 x grid).
+ * `grid`, `nred`, `first_item` are filled in by the call.  cfg must be 0 or 3. */
+typedef struct uniter_x3_riders {
+  double* ssq;
+  float* colsum_out;
+  int grid, njobs, nred;
+  const float* part[3];
+  int nparts[3], stride[3], n[3], seg[3];
+  float* out[3][3];
+  int first_item[4];
+} uniter_x3_riders_t;
+int uniter_wgrad_x3_group_riders(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
+                                 const void* const* B, float* const* dW, int overwrite, int max_wgs,
+                                 uniter_x3_riders_t* riders, void* stream);
+int uniter_wgrad_x3_group_slots(int n, const int* M, const int* N, int max_wgs);
+/* The same riders on the grouped bf16 weight-gradient launch (uniter_wgrad_bf16_group; precision bf16): overwrite = 1 stores
+ * instead of adding, max_wgs > 0 caps the grid; cfg must be 0 or 1 (two LDS stages). */
+int uniter_wgrad_bf16_group_riders(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
+                                   const void* const* B, float* const* dW, int overwrite, int max_wgs,
+                                   uniter_x3_riders_t* riders, void* stream);
+int uniter_wgrad_bf16_group_slots(int n, const int* M, const int* N, int max_wgs);
 /* out[c] += sum_r X[r, c] for an x3 tensor X [rows][3][ldx] (bias gradient of intermediate.dense from dU). */
 int uniter_colsum_x3_add(const void* x3, int rows, int cols, int ldx, float* out, void* stream);
 /* uniter_ln_fwd_slabs / uniter_ln_bwd_rows_slabs whose operand copy for the next GEMM is x3 [M][3][H] instead of bf16 */
@@ -607,6 +637,19 @@ size_t uniter_model_ws_bytes(const uniter_model_t* m, int B, int T, int R, int L
 int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* batch, float* hidden_out,
                          int all_layers, int train, uint64_t seed, uint32_t offset,
                          void* ws, size_t ws_bytes, void* stream);
+/* Precision 3: the clip norm's share of the encoder layers (train_template.py:104: clip_grad_norm_ over ALL parameters) taken
+ * by the layers' own weight-gradient launches.  With `parts` set, uniter_model_backward_layer(l) leaves the sum of squares of
+ * EVERY gradient of layer l's bucket (4 weights, 12 vectors) as uniter_model_norm_partials_per_layer() unreduced partial sums
+ * at parts + l * stride_doubles (fixed slots, bit-reproducible); uniter_sumsq_combine joins them with the other buckets'.
+ * parts = NULL switches it off.  Precisions 2 (bf16) and 3 (fp32x3).  _per_layer (valid after a training-mode forward: it answers
+ * for that forward's plan) returns 0 when the current precision / switches / plan have no such riders: the caller
+ * then reduces the bucket itself (uniter_grad_sumsq_part). */
+int uniter_model_set_norm_partials(uniter_model_t* m, double* parts, size_t stride_doubles);
+/* A stream for launches of the forward pass that depend on nothing the step computes -- the dropout keep flags of the attention
+ * probabilities (a function of seed and offset alone: 60 us of Philox rounds for twelve layers) -- so that they run BESIDE the head
+ * of the forward pass instead of in front of it; the first attention kernel waits for them.  NULL (default): on `stream`. */
+int uniter_model_set_aux_stream(uniter_model_t* m, void* aux_stream);
+int uniter_model_norm_partials_per_layer(const uniter_model_t* m);
 /* Gradient accumulation semantics without the clearing pass (optimizer.zero_grad, train_template.py:107): after an optimizer
  * step that did NOT clear the encoder layers' weight gradients (uniter_adam_step*: chunk flag + 4), announce it here and the
  * NEXT backward pass writes query|key|value / attention-output / intermediate / output weight gradients with `=` instead of

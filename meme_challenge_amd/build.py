@@ -67,7 +67,7 @@ def build(force=False, verbose=True, variant=None):
         res = list(ex.map(lambda s: _compile(s, hd, force, objdir), srcs))
     objs = [o for o, _ in res]
     if any(c for _, c in res) or not os.path.exists(LIB):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--no-undefined', '-o', LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))

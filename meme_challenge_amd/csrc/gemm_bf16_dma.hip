@@ -22,7 +22,9 @@
 // stores its fp32 partial tile to C + s * c_split_stride (piece 0 applies the epilogue); the CONSUMER
 // (LayerNorm forward / backward row pass) adds the slabs -- no atomics, no in-kernel hand-off.
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
+#include "riders.h"
 
 namespace {
 
@@ -194,8 +196,15 @@ __device__ __forceinline__ int xcd_work_item(int nwork, int round = 0) {
 }
 
 // one work item w = (tile, k-piece) of the product g
-template <int BM, int BN, bool AKM, bool BKM, bool SWAP, int ST, int EPI>
-__device__ __forceinline__ void gemm_dma_tile(const GArgsD& g, const int w, unsigned char* smem) {
+// what a tile of a launch with riders hands back / is asked for (gemm_dma_wgrad_group_kernel<.., XTR = true>)
+struct TileRider {
+  float* colsum_out;   // non-null: also sum this tile's A operand (k-major) over k, out[m] += .. (the tile's first 64-column strip only)
+  int colsum_M;
+  float ss;            // out: this lane's sum of squares of what the tile stored (and of the column sums it wrote)
+};
+
+template <int BM, int BN, bool AKM, bool BKM, bool SWAP, int ST, int EPI, bool XTR = false>
+__device__ __forceinline__ void gemm_dma_tile(const GArgsD& g, const int w, unsigned char* smem, TileRider* rt = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtins / asm: the host pass gets an empty body (it only needs the launch stub)
   constexpr int WNN = BN / 64, NW = (BM / 64) * WNN;
   constexpr int IMG_A = BM * 128, IMG_B = BN * 128, STAGE = IMG_A + IMG_B;
@@ -236,6 +245,18 @@ __device__ __forceinline__ void gemm_dma_tile(const GArgsD& g, const int w, unsi
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) acc[a][b][rr] = 0.f;
+  // riders: the column sums of the k-major A operand over k, as ones . A on the matrix pipe (two more MFMAs per k16-step for
+  // the waves that hold the tile's first 64 columns, in the tiles of the first tile column)
+  f32x16 acc1[XTR ? 2 : 1];
+  bool colsum = false;
+  if constexpr (XTR) {
+    colsum = rt->colsum_out != nullptr && n0 == 0 && wn == 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) acc1[a][rr] = 0.f;
+  }
+  const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
 #define ISSUE(KTILE, STG)                                                        \
   do {                                                                           \
@@ -285,6 +306,12 @@ __device__ __forceinline__ void gemm_dma_tile(const GArgsD& g, const int w, unsi
     _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                        \
       acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[BUF][b], xa[BUF][a], acc[a][b], 0, 0, 0) \
                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[BUF][a], xb[BUF][b], acc[a][b], 0, 0, 0); \
+    if constexpr (XTR && AKM && BKM && SWAP) {                                                           \
+      if (colsum) {                                                                                      \
+        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, xa[BUF][0], acc1[0], 0, 0, 0);          \
+        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, xa[BUF][1], acc1[1], 0, 0, 0);          \
+      }                                                                                                  \
+    }                                                                                                    \
   }
 #define COMPUTE(STG)                                                                                     \
   {                                                                                                      \
@@ -450,6 +477,10 @@ __device__ __forceinline__ void gemm_dma_tile(const GArgsD& g, const int w, unsi
             const int n = nb + 8 * gq + 4 * h;
             const f32x4 o = {v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsC, n < g.N ? (m * g.ldc + n) * 4 : OOB, 0, 0);
+            if constexpr (XTR) {      // only what was stored counts (a k-major operand's overhang columns read the next row, not zeros)
+              const float s4 = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+              rt->ss += (m < g.M && n < g.N) ? s4 : 0.f;
+            }
           }
         }
         if (TWO && !g.aux_out_bf16) {
@@ -482,6 +513,20 @@ __device__ __forceinline__ void gemm_dma_tile(const GArgsD& g, const int w, unsi
               const u32x4_t o = {r0[0], r1[0], r0[1], r1[1]};
               __builtin_amdgcn_raw_buffer_store_b128(o, rsX, ok ? (m * g.ld_aux + n8) * 2 : OOB, 0, 0);
             }
+          }
+        }
+      }
+    }
+    if constexpr (XTR) {
+      if (colsum && h == 0) {
+        // every accumulator row of the ones-product holds the same sums: lanes 0..31 own column m of row block a
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int m = m0 + wm * 64 + a * 32 + i5;
+          if (m < rt->colsum_M) {
+            const float o = rt->colsum_out[m] + acc1[a][0];
+            rt->colsum_out[m] = o;
+            rt->ss = __builtin_fmaf(o, o, rt->ss);
           }
         }
       }
@@ -526,11 +571,21 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), (ST * (BM + BN) * 128 <
 struct GGroupD {
   GArgsD p[4];
   int start[5];     // first work item of product p; start[n..4] = total
+  uniter_x3_riders_t x;   // riders (kernels instantiated with XTR only): include/uniter_hip.h
 };
 
-template <int ST, bool ACC>
+template <int ST, bool ACC, bool XTR = false>
 __global__ __launch_bounds__(256, (ST == 2 ? 2 : 1)) void gemm_dma_wgrad_group_kernel(const GGroupD G) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * 256 * 128];
+  // riders (XTR, round 5): the column-reduction items of this workgroup first -- dealt from the END of the grid, where the
+  // workgroups with one tile less sit -- then, per tile, the sum of squares of what it stored (and, for product 0's first
+  // tile column, the column sums of its A operand)
+  double wss = 0.0;
+  if constexpr (XTR) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = (int)gridDim.x - 1 - (int)blockIdx.x; r < G.x.nred; r += (int)gridDim.x)
+      wss += (double)riders_reduce_item(G.x, r, wave, lane);
+  }
   // a grid smaller than the tile count (G.max_wgs): the workgroup walks its XCD's chunk in strides of the grid -- fewer
   // workgroups of this launch resident per CU, so the input-gradient chain on the other stream finds free slots
   bool any = false;
@@ -543,8 +598,16 @@ __global__ __launch_bounds__(256, (ST == 2 ? 2 : 1)) void gemm_dma_wgrad_group_k
     const int p = (w >= G.start[1]) + (w >= G.start[2]) + (w >= G.start[3]);
     // ACC: dW += (the output is its own aux operand); !ACC: dW = (the first backward pass after an optimizer step that left
     // the gradient uncleared: no read of dW, and the optimizer wrote no zeros -- uniter_model_set_wgrad_overwrite)
-    gemm_dma_tile<128, 128, true, true, true, ST, ACC ? UNITER_EPI_ADD : UNITER_EPI_NONE>(G.p[p], w - G.start[p], smem);
+    if constexpr (XTR) {
+      TileRider rt;
+      rt.colsum_out = p == 0 ? G.x.colsum_out : nullptr; rt.colsum_M = G.p[0].M; rt.ss = 0.f;
+      gemm_dma_tile<128, 128, true, true, true, ST, ACC ? UNITER_EPI_ADD : UNITER_EPI_NONE, true>(G.p[p], w - G.start[p], smem, &rt);
+      wss += (double)rt.ss;
+    } else {
+      gemm_dma_tile<128, 128, true, true, true, ST, ACC ? UNITER_EPI_ADD : UNITER_EPI_NONE>(G.p[p], w - G.start[p], smem);
+    }
   }
+  if constexpr (XTR) riders_store_ssq(G.x, wss, threadIdx.x >> 6, threadIdx.x & 63);
   if (any) stamp_end(G.p[0].stamp);
 }
 
@@ -650,10 +713,46 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
 
 // dW_p[M_p, N_p] += A_p^T B_p for up to four products of one reduction length K (A_p [K, M_p], B_p [K, N_p] bf16,
 // dW_p fp32 with leading dimension N_p), one launch; cfg 1 = two LDS stages (two workgroups per CU), 4 = three.
+// workgroups of the grouped launch over `total` tiles: a multiple of 8, capped (max_wgs > 0: by the caller; else
+// UNITER_WGRAD_GROUP_WGS, default 256 = one workgroup per CU walking its tiles)
+static int wgrad_group_grid(int total, int max_wgs) {
+  int grid = (total + 7) / 8 * 8;
+  // UNITER_WGRAD_GROUP_WGS: cap of the grid (a multiple of 8; 0 = one workgroup per tile).  Default 256 = one workgroup of this
+  // launch per CU, walking its tiles: the launch alone takes what two co-resident workgroups take (a lone 4-wave tile runs
+  // its k-loop at 0.57 us per k-tile against 0.93 for two), and every CU keeps a slot for the other stream's kernels.
+  // Measured again once the attention backward took its CU in one launch (four same-box rounds): UNITER-base 4.75 -> 4.71 ms,
+  // UNITER-large 9.65 -> 9.49, config 5 at B = 32 8.19 -> 8.00 ms per step; 192 / 320 / 384 workgroups 4.77-4.80, 128 5.13
+  static const int cap_env = [] { const char* e = getenv("UNITER_WGRAD_GROUP_WGS"); return e ? atoi(e) / 8 * 8 : 256; }();
+  const int cap = max_wgs >= 8 ? max_wgs / 8 * 8 : cap_env;
+  if (cap >= 8 && grid > cap) grid = cap;
+  return grid;
+}
+static int wgrad_group_tiles(int n, const int* Mo, const int* No) {
+  int total = 0;
+  for (int p = 0; p < n; ++p) total += ((Mo[p] + 127) / 128) * ((No[p] + 127) / 128);
+  return total;
+}
+// sum-of-squares slots a launch with riders writes (4 per workgroup)
+int gemm_bf16v2_wgrad_group_slots(int n, const int* Mo, const int* No, int max_wgs) {
+  if (!Mo || !No || n < 1 || n > 4) return 0;
+  return 4 * wgrad_group_grid(wgrad_group_tiles(n, Mo, No), max_wgs);
+}
+// the smallest grid on which the tiles take no more rounds than on one workgroup per CU
+int gemm_bf16v2_wgrad_group_balanced_wgs(int n, const int* Mo, const int* No) {
+  if (!Mo || !No || n < 1 || n > 4) return 0;
+  const int total = wgrad_group_tiles(n, Mo, No);
+  const int full = wgrad_group_grid(total, 0);
+  const int rounds = (total + full - 1) / full;
+  const int wgs = ((total + rounds - 1) / rounds + 7) / 8 * 8;
+  return wgs < full ? wgs : full;
+}
+
 int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A,
-                            const void* const* B, float* const* dW, void* stream, int overwrite) {
+                            const void* const* B, float* const* dW, void* stream, int overwrite, int max_wgs,
+                            uniter_x3_riders_t* riders) {
   UCHECK_ARG(n >= 1 && n <= 4 && K > 0 && Mo && No && A && B && dW, "wgrad_group: bad argument");
   GGroupD G;
+  memset(&G.x, 0, sizeof(G.x));
   unsigned long long* stamp = take_stamp_slot();
   int total = 0;
   for (int p = 0; p < 4; ++p) {
@@ -674,15 +773,18 @@ int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K,
   }
   G.start[4] = total;
   for (int p = n; p < 4; ++p) G.start[p] = total;
-  int grid = (total + 7) / 8 * 8;
-  // UNITER_WGRAD_GROUP_WGS: cap of the grid (a multiple of 8; 0 = one workgroup per tile).  Default 256 = one workgroup of this
-  // launch per CU, walking its tiles: the launch alone takes what two co-resident workgroups take (a lone 4-wave tile runs
-  // its k-loop at 0.57 us per k-tile against 0.93 for two), and every CU keeps a slot for the other stream's kernels.
-  // Measured again once the attention backward took its CU in one launch (four same-box rounds): UNITER-base 4.75 -> 4.71 ms,
-  // UNITER-large 9.65 -> 9.49, config 5 at B = 32 8.19 -> 8.00 ms per step; 192 / 320 / 384 workgroups 4.77-4.80, 128 5.13
-  static const int cap = [] { const char* e = getenv("UNITER_WGRAD_GROUP_WGS"); return e ? atoi(e) / 8 * 8 : 256; }();
-  if (cap >= 8 && grid > cap) grid = cap;
+  const int grid = wgrad_group_grid(total, max_wgs);
   hipStream_t st = (hipStream_t)stream;
+  if (riders) {
+    UCHECK_ARG(cfg != 4, "wgrad_group: riders ride on the two-stage form (cfg 1)");
+    riders->grid = grid;
+    UCHECK_RC(riders_prepare(*riders, "wgrad_bf16_group"));
+    G.x = *riders;
+    if (overwrite) hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<2, false, true>), dim3(grid), dim3(256), 0, st, G);
+    else hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<2, true, true>), dim3(grid), dim3(256), 0, st, G);
+    UCHECK_LAUNCH();
+    return 0;
+  }
   if (cfg == 4) {
     if (overwrite) hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<3, false>), dim3(grid), dim3(256), 0, st, G);
     else hipLaunchKernelGGL((gemm_dma_wgrad_group_kernel<3, true>), dim3(grid), dim3(256), 0, st, G);
@@ -696,7 +798,16 @@ int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K,
 
 extern "C" int uniter_wgrad_bf16_group(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
                                        const void* const* B, float* const* dW, void* stream) {
-  return gemm_bf16v2_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, 0);
+  return gemm_bf16v2_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, 0, 0, nullptr);
+}
+
+extern "C" int uniter_wgrad_bf16_group_riders(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
+                                              const void* const* B, float* const* dW, int overwrite, int max_wgs,
+                                              uniter_x3_riders_t* riders, void* stream) {
+  return gemm_bf16v2_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, overwrite, max_wgs, riders);
+}
+extern "C" int uniter_wgrad_bf16_group_slots(int n, const int* M, const int* N, int max_wgs) {
+  return gemm_bf16v2_wgrad_group_slots(n, M, N, max_wgs);
 }
 
 // Split-K choice for the GEMMs whose N is the hidden size (measured on MI355X, tests/tools/gemm_v2_lab.py,

@@ -27,9 +27,11 @@
 //   k-major operand ([K][cols]): the image of gemm_bf16_dma.hip cut to 32 k-rows: 256-B segments, chunk c of k-row k at
 //     c ^ (((k & 3) << 2) | ((k >> 2) & 3)), gathered by ds_read_b64_tr_b16.
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include <utility>
 #include "common.h"
+#include "riders.h"
 
 namespace {
 
@@ -517,6 +519,7 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, int piece, int m0
 struct S3Group {
   S3Args p[4];
   int start[5];
+  uniter_x3_riders_t x;     // side work of a grouped weight-gradient launch (kernels instantiated with XTR only)
 };
 
 // ---- persistent form with loader waves ------------------------------------------------------------------------------------
@@ -533,7 +536,7 @@ struct S3Group {
 //   compute:                            for u: { barrier B_u;  read stage u % ST, MFMAs;  (last k-tile of an item: epilogue) }
 // B_u orders k-tile u's LDS-DMA before its reads (every loader waited for its own instructions) and the reads of k-tile u - 1
 // (each compute wave waits lgkmcnt(0) before its last MFMAs) before the LDS-DMA that overwrites their stage.
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, bool M16, int EPI>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, bool M16, int EPI, bool XTR = false>
 __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NWL), ((BM / WM) * (BN / WN) + NWL + 3) / 4)
 void gemm_s3p_kernel(const S3Group G) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -542,7 +545,7 @@ void gemm_s3p_kernel(const S3Group G) {
   constexpr int KS = KT / 16;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * STAGE];
   const int nwork = G.start[4];
-  if (xcd_work_item3(nwork, 0) < 0) return;
+  if (!XTR && xcd_work_item3(nwork, 0) < 0) return;        // (with riders every workgroup stays: it owns sum-of-squares slots)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   stamp_begin(G.p[0].stamp);
@@ -671,6 +674,16 @@ void gemm_s3p_kernel(const S3Group G) {
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<int, 2> I2;
+    // riders (XTR): the sum of squares of everything this wave writes, in double; the column-reduction items of this workgroup --
+    // dealt from the END of the grid, where the workgroups with one tile less sit -- run first, while the loader waves fill the
+    // first stages of the tile loop
+    double wss = 0.0;
+    if constexpr (XTR) {
+      for (int r = (int)gridDim.x - 1 - (int)blockIdx.x; r < G.x.nred; r += (int)gridDim.x)
+        wss += (double)riders_reduce_item(G.x, r, wave, lane);
+    }
+    f32x4 acc1[XTR ? MB : 1];      // XTR: column sums of the k-major A operand (ones . A on the matrix pipe)
+    const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
     int stg = 0;
     for (int r = 0;; ++r) {
       const Item c = item(r);
@@ -679,6 +692,13 @@ void gemm_s3p_kernel(const S3Group G) {
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // product 0's tiles of the first tile column also sum the columns of its A operand over k (the bias gradient that belongs to
+      // this weight gradient: A = dY): the waves that hold the tile's first 64 columns run 3 more MFMAs per row block and k-tile
+      const bool colsum = XTR && AKM && G.x.colsum_out && c.p == 0 && c.n0 == 0 && wn == 0;
+      if constexpr (XTR) {
+#pragma unroll
+        for (int a = 0; a < MB; ++a) acc1[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       Frs f;
       for (int kt = c.kb; kt < c.ke; ++kt) {
         if (!(dbg & 64)) __builtin_amdgcn_s_barrier();
@@ -702,9 +722,54 @@ void gemm_s3p_kernel(const S3Group G) {
         f.a.template tie_piece<2>(); f.b.template tie_piece<2>();
         if (!(dbg & 4)) { mma(f, I0{}, I2{}); mma(f, I2{}, I0{}); }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (XTR && AKM) {
+          if (colsum) {
+            static_for<0, MB>([&](auto ac) {
+              constexpr int A_ = decltype(ac)::value;
+              acc1[A_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, f.a.template get<0, A_>(), acc1[A_], 0, 0, 0);
+              acc1[A_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, f.a.template get<1, A_>(), acc1[A_], 0, 0, 0);
+              acc1[A_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, f.a.template get<2, A_>(), acc1[A_], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         stg = stg == ST - 1 ? 0 : stg + 1;
       }
       s3_epilogue16<WM, WN, EPI>(G.p[c.p], c.piece, c.m0, c.n0, wm, wn, lane, acc);
+      if constexpr (XTR) {
+        // (the epilogue left the values it stored in `acc`; a k-major operand's overhang columns read its next piece, not zeros:
+        // only what was stored counts)
+        float ss = 0.f;
+#pragma unroll
+        for (int a = 0; a < MB; ++a) {
+          const bool row_ok = c.m0 + wm * WM + a * 16 + (lane & 15) < G.p[c.p].M;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const bool ok = row_ok && c.n0 + wn * WN + b * 16 + 4 * (lane >> 4) < G.p[c.p].N;
+            float s4 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s4 = __builtin_fmaf(acc[a][b][j], acc[a][b][j], s4);
+            ss += ok ? s4 : 0.f;
+          }
+        }
+        if (colsum && lane < 16) {
+          // every accumulator row of the ones-product holds the same sums: lanes 0..15 own column m of row block a
+#pragma unroll
+          for (int a = 0; a < MB; ++a) {
+            const int m = c.m0 + wm * WM + a * 16 + lane;
+            if (m < G.p[0].M) {
+              const float o = G.x.colsum_out[m] + acc1[a][0];
+              G.x.colsum_out[m] = o;
+              ss = __builtin_fmaf(o, o, ss);
+            }
+          }
+        }
+        wss += (double)ss;
+      }
+    }
+    if constexpr (XTR) {
+      static_assert(!XTR || NWC == 4, "riders: four sum-of-squares slots per workgroup");
+      riders_store_ssq(G.x, wss, wave, lane);
     }
   } else {
     // ------------------------------------------------------------------ compute waves, v_mfma_f32_32x32x16_bf16 ----
@@ -809,9 +874,8 @@ void plan_tiles3(S3Args& g, int BN) {
   if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, bool M16, int EPI>
-int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
-  const int nwork = G.start[4];
+// workgroups of a persistent launch over `nwork` items: a multiple of 8 (one chunk of the work per XCD), one per CU at most
+int x3_grid(int nwork, int max_wgs) {
   int grid = (nwork + 7) / 8 * 8;
   static const int cus = [] {
     int dev = 0, n = 256;
@@ -819,8 +883,13 @@ int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
     return n > 8 ? n / 8 * 8 : 256;
   }();
   const int cap = max_wgs >= 8 ? max_wgs / 8 * 8 : cus;       // one workgroup per CU: it owns the CU's LDS
-  if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((gemm_s3p_kernel<BM, BN, WM, WN, AKM, BKM, ST, KT, NWL, M16, EPI>), dim3(grid),
+  return grid > cap ? cap : grid;
+}
+
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, bool M16, int EPI, bool XTR = false>
+int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
+  const int grid = x3_grid(G.start[4], max_wgs);
+  hipLaunchKernelGGL((gemm_s3p_kernel<BM, BN, WM, WN, AKM, BKM, ST, KT, NWL, M16, EPI, XTR>), dim3(grid),
                      dim3(64 * ((BM / WM) * (BN / WN) + NWL)), 0, st, G);
   UCHECK_LAUNCH();
   return 0;
@@ -943,6 +1012,24 @@ bool x3_fits(size_t rows, int rs, int ps, int ext) { return ((rows + 256) * (siz
 
 }  // namespace
 
+int riders_prepare(uniter_x3_riders_t& x, const char* who) {
+  UCHECK_ARG(x.njobs >= 0 && x.njobs <= 3, "%s: at most 3 column-reduction jobs", who);
+  int items = 0;
+  for (int j = 0; j < x.njobs; ++j) {
+    UCHECK_ARG(x.part[j] && x.nparts[j] > 0 && x.n[j] > 0 && x.seg[j] > 0 && x.stride[j] >= x.n[j], "%s: bad reduction job %d", who, j);
+    UCHECK_SHAPE(x.stride[j] % 4 == 0 && x.seg[j] % 4 == 0 && x.n[j] % 4 == 0 && x.n[j] <= 3 * x.seg[j] && ((uintptr_t)x.part[j] & 15) == 0,
+                 "%s: reduction job %d: stride, segment and column count must be multiples of 4, 16-byte aligned partials", who, j);
+    for (int o = 0; o < 3; ++o)
+      UCHECK_SHAPE(((uintptr_t)x.out[j][o] & 15) == 0, "%s: reduction job %d: output %d is not 16-byte aligned", who, j, o);
+    x.first_item[j] = items;
+    items += (x.n[j] + 63) / 64;
+  }
+  for (int j = x.njobs; j < 4; ++j) x.first_item[j] = items;
+  x.nred = items;
+  UCHECK_SHAPE(!x.colsum_out || ((uintptr_t)x.colsum_out & 3) == 0, "%s: colsum_out alignment", who);
+  return 0;
+}
+
 // C / Cx = epi(A . B^T) on x3 operands (fp32-accurate, six bf16 MFMA products per block, fp32 accumulate).
 int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, int psa,
                 const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* Cx, int ldcx, int pscx,
@@ -1037,9 +1124,10 @@ extern "C" int uniter_colsum_x3_add(const void* x3, int rows, int cols, int ldx,
 // dW_p[M_p, N_p] (+)= A_p^T B_p for up to four products of one reduction length K (A_p [K][3][M_p], B_p [K][3][N_p] x3,
 // dW_p fp32 with leading dimension N_p), one launch of whole-K tiles.
 int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A, const void* const* B,
-                        float* const* dW, void* stream, int overwrite, int max_wgs) {
+                        float* const* dW, void* stream, int overwrite, int max_wgs, uniter_x3_riders_t* riders) {
   UCHECK_ARG(n >= 1 && n <= 4 && K > 0 && Mo && No && A && B && dW, "wgrad_x3_group: bad argument");
   S3Group G;
+  memset(&G.x, 0, sizeof(G.x));
   unsigned long long* stamp = take_stamp_slot();
   int total = 0;
   for (int p = 0; p < 4; ++p) {
@@ -1063,10 +1151,48 @@ int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, con
   for (int p = n; p < 4; ++p) G.start[p] = total;
   if (cfg == 0) cfg = 3;
   hipStream_t st = (hipStream_t)stream;
+  if (riders) {
+    // riders ride on the default geometry only (4 compute waves of 64 x 64 on v_mfma_f32_16x16x32_bf16)
+    UCHECK_ARG(cfg == 3, "wgrad_x3_group: riders need cfg 3 (the default)");
+    uniter_x3_riders_t& x = *riders;
+    x.grid = x3_grid(total, max_wgs);
+    UCHECK_RC(riders_prepare(x, "wgrad_x3_group"));
+    G.x = x;
+    return overwrite ? launch_s3p<128, 128, 64, 64, true, true, 3, 32, 4, true, S3_NONE, true>(G, max_wgs, st)
+                     : launch_s3p<128, 128, 64, 64, true, true, 3, 32, 4, true, S3_ADD, true>(G, max_wgs, st);
+  }
   return overwrite ? dispatch_cfg3p<true, true, S3_NONE>(cfg, G, max_wgs, st) : dispatch_cfg3p<true, true, S3_ADD>(cfg, G, max_wgs, st);
+}
+
+// sum-of-squares slots a launch with riders writes (4 per workgroup) for these products
+int gemm_x3_wgrad_group_slots(int n, const int* Mo, const int* No, int max_wgs) {
+  if (!Mo || !No || n < 1 || n > 4) return 0;
+  int total = 0;
+  for (int p = 0; p < n; ++p) total += ((Mo[p] + 127) / 128) * ((No[p] + 127) / 128);
+  return 4 * x3_grid(total, max_wgs);
+}
+
+// the smallest grid (a multiple of 8) on which these products' tiles take no more rounds than on one workgroup per CU
+int gemm_x3_wgrad_group_balanced_wgs(int n, const int* Mo, const int* No) {
+  if (!Mo || !No || n < 1 || n > 4) return 0;
+  int total = 0;
+  for (int p = 0; p < n; ++p) total += ((Mo[p] + 127) / 128) * ((No[p] + 127) / 128);
+  const int full = x3_grid(total, 0);
+  const int rounds = (total + full - 1) / full;
+  const int wgs = ((total + rounds - 1) / rounds + 7) / 8 * 8;
+  return wgs < full ? wgs : full;
+}
+
+extern "C" int uniter_wgrad_x3_group_riders(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
+                                            const void* const* B, float* const* dW, int overwrite, int max_wgs,
+                                            uniter_x3_riders_t* riders, void* stream) {
+  return gemm_x3_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, overwrite, max_wgs, riders);
+}
+extern "C" int uniter_wgrad_x3_group_slots(int n, const int* M, const int* N, int max_wgs) {
+  return gemm_x3_wgrad_group_slots(n, M, N, max_wgs);
 }
 
 extern "C" int uniter_wgrad_x3_group(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
                                      const void* const* B, float* const* dW, int overwrite, int max_wgs, void* stream) {
-  return gemm_x3_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, overwrite, max_wgs);
+  return gemm_x3_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, overwrite, max_wgs, nullptr);
 }

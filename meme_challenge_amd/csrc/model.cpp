@@ -39,11 +39,16 @@ int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, i
                 int epilogue, const float* bias, const float* aux_in, float* aux_out, int ld_aux, void* stream);
 int gemm_x3_pick_split(int M, int N, int K);
 int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A, const void* const* B,
-                        float* const* dW, void* stream, int overwrite, int max_wgs);
+                        float* const* dW, void* stream, int overwrite, int max_wgs, uniter_x3_riders_t* riders);
+int gemm_x3_wgrad_group_slots(int n, const int* Mo, const int* No, int max_wgs);
+int gemm_x3_wgrad_group_balanced_wgs(int n, const int* Mo, const int* No);
 int gemm_bf16v2_pick_split(int M, int N, int K);
 int gemm_bf16v2_wgrad_pieces(int M, int N, int K);
 int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A,
-                            const void* const* B, float* const* dW, void* stream, int overwrite);
+                            const void* const* B, float* const* dW, void* stream, int overwrite, int max_wgs,
+                            uniter_x3_riders_t* riders);
+int gemm_bf16v2_wgrad_group_slots(int n, const int* Mo, const int* No, int max_wgs);
+int gemm_bf16v2_wgrad_group_balanced_wgs(int n, const int* Mo, const int* No);
 int finalize_partials(const float* part, int nparts, size_t stride, float* out, int N, int beta, hipStream_t st);
 int finalize_partials_jobs(int njobs, const float* const* part, const int* nparts, const size_t* stride,
                            float* const (*outs)[3], const int* nout, const int* seg, hipStream_t st);
@@ -146,6 +151,10 @@ struct uniter_model {
   uint32_t offset = 0;
   hipStream_t st = nullptr, side = nullptr;
   bool bwd_open = false;
+  hipStream_t aux = nullptr;      // uniter_model_set_aux_stream: launches that depend on nothing the step computes (dropout keep flags)
+  hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr;
+  double* norm_parts = nullptr;   // uniter_model_set_norm_partials: layer l's clip-norm partial sums at norm_parts + l * norm_stride
+  size_t norm_stride = 0;
   bool wg_overwrite = false; // the next backward pass overwrites the encoder's weight gradients (uniter_model_set_wgrad_overwrite)
   uint64_t generation = 0;   // bumped by every forward: a backward must belong to the LATEST forward (one plan / workspace per model)
 
@@ -351,6 +360,35 @@ int gemm_x3(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, in
   return gemm_x3_run(cfg, nsplit, 0, bkm, M, N, K, A, 3 * K, K, W, ldw, (int)m->mirror_numel, C, N, (long)M * N, Cx, 3 * N, N, epi,
                      bias, aux_in, aux_out, N, st);
 }
+// precision 3: side work of a layer's backward rides on its grouped weight-gradient launch (default geometry only)
+bool x3_riders_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("UNITER_X3_RIDERS");
+    const char* c = getenv("UNITER_X3_CFG");
+    return !(e && e[0] == '0') && (!c || atoi(c) == 0 || atoi(c) == 3);
+  }();
+  return on;
+}
+// precision 2: the same riders on the grouped bf16 weight-gradient launch (UNITER_B16_RIDERS=0: separate launches)
+bool b16_riders_enabled() {
+  static const bool on = [] { const char* e = getenv("UNITER_B16_RIDERS"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// the side work of layer l's backward as riders of its grouped weight-gradient launch (product 0 must be dW1 = dU^T y1: its A
+// operand's column sums are intermediate.dense's bias gradient)
+void fill_layer_riders(uniter_x3_riders_t& x, const uniter_model* m, int l, const LayerBufs& lb, int M, int B, int H, bool fused_qb) {
+  x.colsum_out = m->LG(l, L_B1);
+  const int lnp = ln_bwd_partial_rows(M);
+  x.njobs = fused_qb ? 3 : 2;
+  x.part[0] = (const float*)lb.ln_ws2; x.part[1] = (const float*)lb.ln_ws1; x.part[2] = lb.qb_part;
+  x.nparts[0] = x.nparts[1] = lnp; x.nparts[2] = B;
+  x.stride[0] = x.stride[1] = x.stride[2] = 3 * H;
+  x.n[0] = x.n[1] = x.n[2] = 3 * H;
+  x.seg[0] = x.seg[1] = H; x.seg[2] = 3 * H;
+  x.out[0][0] = m->LG(l, L_LN2_G); x.out[0][1] = m->LG(l, L_LN2_B); x.out[0][2] = m->LG(l, L_B2);
+  x.out[1][0] = m->LG(l, L_LN1_G); x.out[1][1] = m->LG(l, L_LN1_B); x.out[1][2] = m->LG(l, L_OB);
+  x.out[2][0] = m->LG(l, L_QB);
+}
 int split_x3(const float* src, unsigned short* dst, int rows, int cols, hipStream_t st) {
   return uniter_split3(src, rows, cols, cols, dst, (size_t)3 * cols, (size_t)cols, st);
 }
@@ -493,6 +531,8 @@ extern "C" void uniter_model_destroy(uniter_model_t* m) {
   for (auto e : m->ev_mid) if (e) hipEventDestroy(e);
   for (auto e : m->prof_ev) if (e) hipEventDestroy(e);
   if (m->stamp_buf) (void)hipFree(m->stamp_buf);
+  if (m->ev_aux0) hipEventDestroy(m->ev_aux0);
+  if (m->ev_aux1) hipEventDestroy(m->ev_aux1);
   delete m;
 }
 
@@ -548,14 +588,28 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   // a function of (seed, offset) alone, so it runs while the optimizer still streams the word table the text branch waits for
   // (the L <= 192 kernels then read them; the backward pass reads the same words)
   static const bool pregen_env = [] { const char* e = getenv("UNITER_KEEP_PREGEN"); return !e || e[0] != '0'; }();
+  bool keep_on_aux = false;
   bool keep_pre = pregen_env && save && pa > 0.f && L <= uniter_attn_varlen_max_len() && (attn_b16 || packed || save);
   if (keep_pre) {
     const size_t stride = nl > 1 ? (size_t)((char*)pl.layers[1].keepb - (char*)pl.layers[0].keepb) : 0;
     for (int l = 1; l < nl && keep_pre; ++l)
       keep_pre = (size_t)((char*)pl.layers[l].keepb - (char*)pl.layers[0].keepb) == stride * l;
-    if (keep_pre)
+    if (keep_pre) {
+      // round 5: on the auxiliary stream when the caller gave one (uniter_model_set_aux_stream) -- 60 us of Philox rounds that
+      // depend on (seed, offset) alone, beside the head of the forward pass (region projection, embeddings: small launches that
+      // leave the chip empty) instead of in front of it; layer 0's attention waits for the event
+      hipStream_t ks = st;
+      if (m->aux && m->aux != st) {
+        if (!m->ev_aux0) UCHECK_HIP(hipEventCreateWithFlags(&m->ev_aux0, hipEventDisableTiming));
+        if (!m->ev_aux1) UCHECK_HIP(hipEventCreateWithFlags(&m->ev_aux1, hipEventDisableTiming));
+        UCHECK_HIP(hipEventRecord(m->ev_aux0, st));            // the flags' last readers (the previous backward pass) ran on `st`
+        UCHECK_HIP(hipStreamWaitEvent(m->aux, m->ev_aux0, 0));
+        ks = m->aux;
+      }
       UCHECK_RC(uniter_attn_keep_bits_gen(pl.layers[0].keepb, stride, nl, B, L, nh, pa, seed, offset, SITE_ATTN_PROBS(0),
-                                          SITE_ATTN_PROBS(1) - SITE_ATTN_PROBS(0), st));
+                                          SITE_ATTN_PROBS(1) - SITE_ATTN_PROBS(0), ks));
+      if (ks != st) { UCHECK_HIP(hipEventRecord(m->ev_aux1, ks)); keep_on_aux = true; }
+    }
   }
 
   // parameters still being written by an optimizer step on another stream (uniter_model_set_ready_events)
@@ -613,6 +667,7 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   for (int l = 0; l < nl; ++l) {
     LayerBufs& lb = pl.layers[l];
     if (gated) UCHECK_HIP(hipStreamWaitEvent(st, m->ready[1 + l], 0));
+    if (l == 0 && keep_on_aux) UCHECK_HIP(hipStreamWaitEvent(st, m->ev_aux1, 0));      // the keep flags of every layer are drawn
     float* y2 = packed ? lb.y2 : (all_layers ? hidden_out + l * PH : (l == nl - 1 ? hidden_out : lb.y2));
     if (attn_b16)      // the bf16 attention kernels read Q, K, V as bf16: write only that (in the qkv buffer's place)
       UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_QKV_FWD, st, 0, M, 3 * H, H, xb, H, m->WB(l, L_QW), H, nullptr, 3 * H, 1,
@@ -843,7 +898,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     float* const dWs[3] = {m->LG(l, L_W1), m->LG(l, L_W2), m->LG(l, L_OW)};
     {
       ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-      UCHECK_RC(gemm_bf16v2_wgrad_group(1, 3, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0));
+      UCHECK_RC(gemm_bf16v2_wgrad_group(1, 3, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, 0, nullptr));
     }
     UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
   }
@@ -906,9 +961,14 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     UCHECK_HIP(hipEventRecord(m->ev_main[l], st));
     UCHECK_HIP(hipStreamWaitEvent(sd, m->ev_main[l], 0));
   }
+  // precision 3 (round 5): the column reductions below, the bias gradient of intermediate.dense and the layer's share of the clip
+  // norm RIDE on the grouped weight-gradient launch (uniter_wgrad_x3_group_riders) -- no finalize / column-sum / sum-of-squares
+  // launches on this stream.  UNITER_X3_RIDERS=0 keeps the separate launches (A/B measurements)
+  const bool riders_b16 = res && pl.wg_group == 1 && b16_riders_enabled();
+  const bool riders_on = (x3 && x3_riders_enabled()) || riders_b16;
   // LayerNorm / dense-bias gradients: the column reductions of the two row passes above, the attention backward's
   // per-sample query|key|value bias partials and (fp32 mode) the dU column partials -- ONE launch for all of them
-  {
+  if (!riders_on) {
     const int lnp = ln_bwd_partial_rows(M);
     const float* parts[4] = {(const float*)lb.ln_ws2, (const float*)lb.ln_ws1, fused_qb ? lb.qb_part : nullptr,
                              (!res && !x3 && fuse_db1) ? lb.du_csum : nullptr};
@@ -930,18 +990,35 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
       const void* const Bs[1] = {xb};
       float* const dWs[1] = {m->LG(l, L_QW)};
       ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-      UCHECK_RC(gemm_bf16v2_wgrad_group(1, 1, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0));
+      UCHECK_RC(gemm_bf16v2_wgrad_group(1, 1, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, 0, nullptr));
     } else if (pl.wg_group) {
       // all four weight gradients of the layer as one launch: 432 whole-K tiles for 512 workgroup slots (UNITER-base)
       const int Mo[4] = {I, H, 3 * H, H}, No[4] = {H, I, H, H};
       const void* const As[4] = {lb.dub, lb.g2b, lb.dqkvb, lb.g1b};
       const void* const Bs[4] = {lb.y1b, lb.hactb, xb, lb.ctxb};
       float* const dWs[4] = {m->LG(l, L_W1), m->LG(l, L_W2), m->LG(l, L_QW), m->LG(l, L_OW)};
-      {
+      // layer 0's launch runs beside the embedding backward's row passes: the smallest grid that takes no more rounds (see precision 3)
+      static const bool wgs_forced = getenv("UNITER_WGRAD_GROUP_WGS") != nullptr;
+      const int b16_wgs = (l == 0 && !wgs_forced) ? gemm_bf16v2_wgrad_group_balanced_wgs(4, Mo, No) : 0;
+      if (riders_b16) {
+        uniter_x3_riders_t x;
+        memset(&x, 0, sizeof(x));
+        const int slots = gemm_bf16v2_wgrad_group_slots(4, Mo, No, b16_wgs);
+        if (m->norm_parts) {
+          UCHECK_ARG((size_t)slots <= m->norm_stride, "backward_layer: %d clip-norm slots per layer, room for %zu (uniter_model_set_norm_partials)",
+                     slots, m->norm_stride);
+          x.ssq = m->norm_parts + (size_t)l * m->norm_stride;
+        }
+        fill_layer_riders(x, m, l, lb, M, B, H, fused_qb);
         ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-        UCHECK_RC(gemm_bf16v2_wgrad_group(pl.wg_group == 4 ? 4 : 1, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0));
+        UCHECK_RC(gemm_bf16v2_wgrad_group(1, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, b16_wgs, &x));
+      } else {
+        {
+          ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
+          UCHECK_RC(gemm_bf16v2_wgrad_group(pl.wg_group == 4 ? 4 : 1, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, b16_wgs, nullptr));
+        }
+        UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
       }
-      UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
     } else {
       UCHECK_RC(wgrad_b16(m, pl, sd, H, I, M, lb.g2b, lb.hactb, m->LG(l, L_W2)));
       UCHECK_RC(wgrad_b16(m, pl, sd, I, H, M, lb.dub, lb.y1b, m->LG(l, L_W1)));
@@ -958,12 +1035,32 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     const void* const Bs[4] = {lb.y1b, lb.hactb, xb, lb.ctxb};
     float* const dWs[4] = {m->LG(l, L_W1), m->LG(l, L_W2), m->LG(l, L_QW), m->LG(l, L_OW)};
     static const int x3_cfg = [] { const char* e = getenv("UNITER_X3_CFG"); return e ? atoi(e) : 0; }();
-    static const int x3_wgs = [] { const char* e = getenv("UNITER_WGRAD_X3_WGS"); return e ? atoi(e) : 0; }();
-    {
+    static const int x3_wgs_env = [] { const char* e = getenv("UNITER_WGRAD_X3_WGS"); return e ? atoi(e) : -1; }();
+    // layer 0's launch runs BEHIND the input-gradient chain, beside the embedding backward's row passes on the main stream: the
+    // smallest grid that needs no more rounds (432 tiles: 216 workgroups walk two tiles each, as 256 would) leaves 40 CUs to
+    // those passes -- their 190-register waves find no room on a CU a persistent 144-KB workgroup holds (img_embed_bwd 112 us
+    // for 576 rows when it has to wait for one).  UNITER_WGRAD_X3_WGS = n forces a grid for every layer (0 = one per CU)
+    const int x3_wgs = x3_wgs_env >= 0 ? x3_wgs_env : (l == 0 ? gemm_x3_wgrad_group_balanced_wgs(4, Mo, No) : 0);
+    if (riders_on) {
+      // product 0 is dW1 = dU^T y1: its A operand's column sums are intermediate.dense's bias gradient
+      uniter_x3_riders_t x;
+      memset(&x, 0, sizeof(x));
+      const int slots = gemm_x3_wgrad_group_slots(4, Mo, No, x3_wgs);
+      if (m->norm_parts) {
+        UCHECK_ARG((size_t)slots <= m->norm_stride, "backward_layer: %d clip-norm slots per layer, room for %zu (uniter_model_set_norm_partials)",
+                   slots, m->norm_stride);
+        x.ssq = m->norm_parts + (size_t)l * m->norm_stride;
+      }
+      fill_layer_riders(x, m, l, lb, M, B, H, fused_qb);
       ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-      UCHECK_RC(gemm_x3_wgrad_group(x3_cfg, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, x3_wgs));
+      UCHECK_RC(gemm_x3_wgrad_group(x3_cfg, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, x3_wgs, &x));
+    } else {
+      {
+        ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
+        UCHECK_RC(gemm_x3_wgrad_group(x3_cfg, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, x3_wgs, nullptr));
+      }
+      UCHECK_RC(uniter_colsum_x3_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
     }
-    UCHECK_RC(uniter_colsum_x3_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
   } else {
     const int wb = m->wg_overwrite ? -1 : 1;      // -1: overwrite (or clear, then accumulate) -- see gemm()
     // UNITER_WGRAD_GROUP_F32=1: EVERY layer's four weight gradients as ONE persistent launch of whole-K tiles (1728 tiles for
@@ -1057,6 +1154,33 @@ extern "C" int uniter_model_backward_embed(uniter_model_t* m) {
   m->bwd_open = false;
   m->wg_overwrite = false;       // one backward pass: the next one accumulates again
   return 0;
+}
+
+extern "C" int uniter_model_set_aux_stream(uniter_model_t* m, void* aux_stream) {
+  UCHECK_ARG(m, "set_aux_stream: null model");
+  m->aux = (hipStream_t)aux_stream;
+  return 0;
+}
+
+extern "C" int uniter_model_set_norm_partials(uniter_model_t* m, double* parts, size_t stride_doubles) {
+  UCHECK_ARG(m && (parts == nullptr || stride_doubles > 0), "set_norm_partials: bad argument");
+  m->norm_parts = parts;
+  m->norm_stride = parts ? stride_doubles : 0;
+  return 0;
+}
+
+extern "C" int uniter_model_norm_partials_per_layer(const uniter_model_t* m) {
+  if (!m) return 0;
+  const int H = m->cfg.hidden_size, I = m->cfg.intermediate_size;
+  const int Mo[4] = {I, H, 3 * H, H}, No[4] = {H, I, H, H};
+  if (m->precision == 2) {
+    // (the grouped launch is the default form of this precision: UNITER_WGRAD_GROUP unset or 1; very long batches fall back)
+    // (answers for the plan of the LAST forward: the grouped launch is that plan's choice -- very long batches keep stream-K)
+    return (m->plan.res && m->plan.mode != 0 && m->plan.wg_group == 1 && b16_riders_enabled()) ? gemm_bf16v2_wgrad_group_slots(4, Mo, No, 0) : 0;
+  }
+  if (m->precision != 3 || !x3_riders_enabled()) return 0;
+  static const int x3_wgs = [] { const char* e = getenv("UNITER_WGRAD_X3_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+  return gemm_x3_wgrad_group_slots(4, Mo, No, x3_wgs);
 }
 
 extern "C" int uniter_model_set_wgrad_overwrite(uniter_model_t* m, int on) {

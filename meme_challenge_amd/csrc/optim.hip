@@ -52,16 +52,26 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ part, int n,
-                                                          double* __restrict__ out) {
-  __shared__ double red[4];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+// (round 5: the fp32x3 backward leaves ~1000 partial sums per layer -- 1024 threads, four independent loads in flight each; the
+// order of the additions depends on n alone: bit-reproducible)
+__global__ __launch_bounds__(1024) void sumsq_final_kernel(const double* __restrict__ part, int n,
+                                                           double* __restrict__ out) {
+  __shared__ double red[16];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * 1024 < n; i += 4 * 1024) { a0 += part[i]; a1 += part[i + 1024]; a2 += part[i + 2048]; a3 += part[i + 3072]; }
+  for (; i < n; i += 1024) a0 += part[i];
+  double acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[0] = t;
+  }
 }
 
 struct AdamArgs {
@@ -167,7 +177,7 @@ extern "C" int uniter_grad_sumsq(const float* grads, const uint8_t* chunk_flags,
   const int nb = sumsq_blocks(n);
   hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, grads, chunk_flags, n / 4, (double*)ws, (const unsigned short*)nullptr);
   UCHECK_LAUNCH();
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, sumsq);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, st, (const double*)ws, nb, sumsq);
   UCHECK_LAUNCH();
   return 0;
 }
@@ -182,7 +192,7 @@ extern "C" int uniter_grad_sumsq_bf16(const void* grads_bf16, const uint8_t* chu
   hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, (const float*)nullptr, chunk_flags, n / 4, (double*)ws,
                      (const unsigned short*)grads_bf16);
   UCHECK_LAUNCH();
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, sumsq);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, st, (const double*)ws, nb, sumsq);
   UCHECK_LAUNCH();
   return 0;
 }
@@ -202,7 +212,7 @@ extern "C" int uniter_grad_sumsq_part(const float* grads, const uint8_t* chunk_f
 
 extern "C" int uniter_sumsq_combine(const double* parts, int n, double* out, void* stream) {
   UCHECK_ARG(parts && out && n >= 1, "sumsq_combine: bad argument");
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, parts, n, out);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, parts, n, out);
   UCHECK_LAUNCH();
   return 0;
 }

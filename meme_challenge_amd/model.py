@@ -547,6 +547,12 @@ class _UniterFn(torch.autograd.Function):
         nbytes = lib.uniter_model_ws_bytes(model._handle, B, batch.T if batch.input_ids else 0,
                                            batch.R if batch.img_feat else 0, L, mode)
         ws = model._get_ws(nbytes, mode)
+        if mode != 0 and model.use_side_stream and os.environ.get('UNITER_AUX_STREAM') != '0':
+            # the dropout keep flags of the attention are drawn beside the head of the forward pass, on a third stream
+            aux = _lib.shared_stream(dev, 'aux')
+            check(lib.uniter_model_set_aux_stream(model._handle, C.c_void_p(aux.cuda_stream)), 'uniter_model_set_aux_stream')
+        else:
+            check(lib.uniter_model_set_aux_stream(model._handle, None), 'uniter_model_set_aux_stream')
         check(lib.uniter_model_forward(model._handle, C.byref(batch), ptr(hidden), int(all_layers),
                                        mode, seed, offset, ptr(ws), nbytes, _lib.cur_stream()),
               'uniter_model_forward')
@@ -643,6 +649,9 @@ class UniterModel(UniterPreTrainedModel):
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._offset = 0
         self._grad_hook = None       # callable(kind, index) used by the DP gradient exchange
+        # (device double buffer, doubles per layer): where the fp32x3 backward leaves each layer's clip-norm partial sums
+        # (uniter_model_set_norm_partials; trainer.FusedAdam.attach_norm_hooks); None = nobody asked
+        self._norm_parts = None
         self._side_stream = None
         self.use_side_stream = True
         # 'fp32'; 'bf16': bf16 MFMA GEMMs on bf16-resident operands (weight mirror + bf16 activation copies),
@@ -779,6 +788,9 @@ class UniterModel(UniterPreTrainedModel):
             # pass overwrites them; the flag holds for one pass, later micro-batches accumulate
             check(lib.uniter_model_set_wgrad_overwrite(self._handle, 1), 'uniter_model_set_wgrad_overwrite')
             st.wgrad_stale = False
+        np_ = self._norm_parts
+        check(lib.uniter_model_set_norm_partials(self._handle, np_[0].data_ptr() if np_ is not None else None,
+                                                 np_[1] if np_ is not None else 0), 'uniter_model_set_norm_partials')
         check(lib.uniter_model_backward_begin(self._handle, C.byref(batch), ptr(d_hidden),
                                               int(all_layers), seed, offset, ptr(ws), nbytes,
                                               _lib.cur_stream(), side_ptr), 'uniter_model_backward_begin')
@@ -793,6 +805,12 @@ class UniterModel(UniterPreTrainedModel):
         st.touch(self._touched_names(batch))
         if hook is not None:
             hook('embed', None, main)
+
+    def norm_partials_per_layer(self):
+        """Partial sums of the clip norm each layer's backward leaves by itself in the CURRENT precision (fp32x3: its
+        weight-gradient launch carries them), 0 = none: the caller reduces the layer's gradient bucket itself."""
+        self._ensure_handle()          # (applies the precision to the handle)
+        return int(_lib.lib().uniter_model_norm_partials_per_layer(self._handle))
 
     def _set_ready_events(self, events):
         """Per-block 'parameters final' events of an optimizer step overlapped with this forward

@@ -162,6 +162,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     NORM_BLOCKS = 256           # workgroups (= partial sums) per layer slice, on the side stream beside the input-gradient chain
     NORM_BLOCKS_LAST = 2048     # the embeddings' slice runs alone behind the backward pass: the whole chip
+    FUSED_SLOTS = 1024          # fp32x3: slots a layer's weight-gradient launch writes itself (4 per workgroup, one workgroup per CU)
 
     def attach_norm_hooks(self, encoder):
         """Take the clip norm (clip_grad_norm_, train_template.py:104) slice by slice DURING the backward pass: the
@@ -175,37 +176,63 @@ class FusedAdam(torch.optim.Optimizer):
             return False
         st = self.store
         nb = len(st.bucket_ranges)
-        self._np_buf = torch.zeros((nb - 1) * self.NORM_BLOCKS + self.NORM_BLOCKS_LAST, dtype=torch.float64, device=st.device)
-        self._np_blocks, self._np_seen = 0, set()
         nl = encoder.config.num_hidden_layers
         if nb not in (nl + 1, nl + 2):
             return False
         first_layer = nb - nl - 1            # index of layer nl-1's bucket (0 when there is no head bucket)
+        # partial sums per bucket: [head (optional) | layer 0 .. nl-1 (uniform stride: the fp32x3 backward writes layer l's own
+        # partial sums at l * stride, uniter_model_set_norm_partials) | embeddings]
+        lstride = max(self.NORM_BLOCKS, self.FUSED_SLOTS)
+        head_n = self.NORM_BLOCKS if first_layer == 1 else 0
+        self._np_buf = torch.zeros(head_n + nl * lstride + self.NORM_BLOCKS_LAST, dtype=torch.float64, device=st.device)
+        layers_view = self._np_buf[head_n:head_n + nl * lstride]
+        self._np_blocks, self._np_seen = 0, set()
         lib = _lib.lib()
+        state = {'fused': False}
+
+        def region(k):
+            """(offset in doubles, slots) of bucket k's partial sums"""
+            if k < first_layer:
+                return 0, self.NORM_BLOCKS
+            if k == nb - 1:
+                return head_n + nl * lstride, self.NORM_BLOCKS_LAST
+            layer = nl - 1 - (k - first_layer)
+            return head_n + layer * lstride, self.NORM_BLOCKS
 
         def reduce_bucket(k, stream):
             lo, hi = st.bucket_ranges[k]
+            off, n = region(k)
             sp = stream.cuda_stream if stream is not None else _lib.cur_stream()
             check(lib.uniter_grad_sumsq_part(st.flat_grads.data_ptr() + 4 * lo, None, hi - lo,
-                                             self._np_buf.data_ptr() + 8 * k * self.NORM_BLOCKS,
-                                             self.NORM_BLOCKS_LAST if k == nb - 1 else self.NORM_BLOCKS, sp),
-                  'uniter_grad_sumsq_part')
+                                             self._np_buf.data_ptr() + 8 * off, n, sp), 'uniter_grad_sumsq_part')
             self._np_seen.add(k)
 
         def hook(kind, index, stream):
             if kind == 'begin':
                 self._np_seen = set()
                 self._np_blocks = 0
+                # fp32x3: every layer's weight-gradient launch leaves the layer's share itself (bit-reproducible slots); any other
+                # precision: one reduction launch per layer bucket on the weight-gradient stream.  A switch of precision between
+                # two backward passes (bench.py's native-fp32 leg) changes which slots are written: clear the stale ones
+                per_layer = encoder.norm_partials_per_layer()
+                fused = 0 < per_layer <= lstride
+                if fused != state['fused']:
+                    layers_view.zero_()
+                    state['fused'] = fused
                 if first_layer == 1:
                     reduce_bucket(0, stream)                 # head / pooler: final before the encoder's backward starts
             elif kind == 'layer':
-                reduce_bucket(first_layer + (nl - 1 - index), stream)
+                if state['fused']:
+                    self._np_seen.add(first_layer + (nl - 1 - index))
+                else:
+                    reduce_bucket(first_layer + (nl - 1 - index), stream)
             elif kind == 'embed':
                 reduce_bucket(nb - 1, stream)
                 if len(self._np_seen) == nb:
                     self._np_blocks = self._np_buf.numel()   # armed: every bucket of THIS backward is in
 
         encoder._grad_hook = hook
+        encoder._norm_parts = (layers_view, lstride)
         self._norm_hook = hook
         return True
 

@@ -245,6 +245,159 @@ def test_weight_gradient_group(cfg, shapes, K):
             assert torch.equal(c, c2) and torch.equal(c, c3)
 
 
+@pytest.mark.parametrize('shapes,K,wgs', [([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 2624, 0),
+                                          ([(256, 64), (64, 256), (192, 64), (64, 64)], 1458, 0),
+                                          ([(136, 200), (256, 128), (8, 8)], 200, 0),
+                                          ([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 333, 64)])
+@pytest.mark.parametrize('overwrite', [0, 1])
+def test_weight_gradient_group_riders(shapes, K, wgs, overwrite):
+    """The riders of the grouped weight-gradient launch (uniter_wgrad_x3_group_riders): the same dW as the plain launch bit for
+    bit; colsum_out += the column sums of product 0's A operand (fp64 reference); three column-reduction jobs with one, three
+    and two outputs (fp64 reference; columns that are no multiple of 64, more partial rows than slices and fewer); and the sum
+    of squares of EVERYTHING written, as 4 x grid partial sums whose total equals the fp64 sum over all outputs; bit-identical
+    when repeated."""
+    from meme_challenge_amd import _lib as L
+    g = torch.Generator(device='cuda').manual_seed(len(shapes) * 77 + K)
+    Af = [torch.randn(K, M, device='cuda', generator=g) for M, N in shapes]
+    Bf = [torch.randn(K, N, device='cuda', generator=g) * 0.05 for M, N in shapes]
+    C0 = [torch.randn(M, N, device='cuda', generator=g) for M, N in shapes]
+    As, Bs = [split3(a) for a in Af], [split3(b) for b in Bf]
+    Ms, Ns = [m for m, _ in shapes], [n for _, n in shapes]
+    n = len(shapes)
+    H = 192
+    # job 0: 328 partial rows of [3 H] -> three outputs of H; job 1: 5 partial rows, one output of 3 H; job 2: 70 rows of [2 H + 8]
+    # (stride 3 H) -> two outputs, the second one short
+    parts = [torch.randn(328, 3 * H, device='cuda', generator=g), torch.randn(5, 3 * H, device='cuda', generator=g),
+             torch.randn(70, 3 * H, device='cuda', generator=g)]
+    job_n, job_seg, job_nout = [3 * H, 3 * H, H + 8], [H, 3 * H, H], [3, 1, 2]
+    out0 = [[torch.randn(H, device='cuda', generator=g) for _ in range(3)], [torch.randn(3 * H, device='cuda', generator=g)],
+            [torch.randn(H, device='cuda', generator=g), torch.randn(H, device='cuda', generator=g)]]
+    cs0 = torch.randn(Ms[0], device='cuda', generator=g)
+    IA, PA = ctypes.c_int * n, ctypes.c_void_p * n
+    slots = L.lib().uniter_wgrad_x3_group_slots(n, IA(*Ms), IA(*Ns), wgs)
+    assert slots > 0 and slots % 32 == 0
+
+    def run(with_riders):
+        Cs = [c.clone() for c in C0]
+        outs = [[o.clone() for o in job] for job in out0]
+        cs = cs0.clone()
+        ssq = torch.full((slots,), float('nan'), dtype=torch.float64, device='cuda')
+        if with_riders:
+            x = L.X3RidersC()
+            x.ssq, x.colsum_out, x.njobs = ssq.data_ptr(), cs.data_ptr(), 3
+            for j in range(3):
+                x.part[j] = parts[j].data_ptr(); x.nparts[j] = parts[j].shape[0]; x.stride[j] = 3 * H
+                x.n[j] = job_n[j]; x.seg[j] = job_seg[j]
+                for o in range(job_nout[j]):
+                    x.out[j][o] = outs[j][o].data_ptr()
+            L.check(L.lib().uniter_wgrad_x3_group_riders(0, n, IA(*Ms), IA(*Ns), K, PA(*[a.data_ptr() for a in As]),
+                                                         PA(*[b.data_ptr() for b in Bs]), PA(*[c.data_ptr() for c in Cs]), overwrite,
+                                                         wgs, ctypes.byref(x), L.cur_stream()), 'wgrad_x3_group_riders')
+            assert x.grid * 4 == slots and x.nred == sum((k + 63) // 64 for k in job_n)
+        else:
+            L.check(_group_call(0, Ms, Ns, K, As, Bs, Cs, overwrite, wgs), 'wgrad_x3_group')
+        torch.cuda.synchronize()
+        return Cs, outs, cs, ssq
+
+    plain = run(False)
+    a, b = run(True), run(True)
+    for c_plain, c_a, c_b in zip(plain[0], a[0], b[0]):
+        assert torch.equal(c_plain, c_a) and torch.equal(c_a, c_b)                     # the products themselves: untouched by the riders
+    assert torch.equal(a[3], b[3]) and torch.isfinite(a[3]).all()                       # every slot written, reproducibly
+    total = 0.0
+    # column sums of product 0's A operand
+    ref = cs0.double().cpu() + Af[0].double().cpu().sum(0)
+    assert (a[2].double().cpu() - ref).abs().max().item() < 2e-6 * math.sqrt(K) * 4 and torch.equal(a[2], b[2])
+    total += float((a[2].double() ** 2).sum())
+    for j in range(3):
+        full = parts[j].double().cpu().sum(0)[:job_n[j]]
+        for o in range(job_nout[j]):
+            seg = full[o * job_seg[j]:(o + 1) * job_seg[j]]
+            exp = out0[j][o].double().cpu().clone()
+            exp[:seg.numel()] += seg
+            assert (a[1][j][o].double().cpu() - exp).abs().max().item() < 1e-5 * math.sqrt(parts[j].shape[0]), (j, o)
+            assert torch.equal(a[1][j][o], b[1][j][o])
+            if seg.numel() < exp.numel():                                               # columns beyond n: untouched, uncounted
+                assert torch.equal(a[1][j][o][seg.numel():], out0[j][o][seg.numel():])
+            total += float((a[1][j][o][:seg.numel()].double() ** 2).sum())
+    for c in a[0]:
+        total += float((c.double() ** 2).sum())
+    got = float(a[3].sum())
+    assert abs(got - total) <= 1e-6 * total, (got, total)
+
+
+ROBUST = [  # name, scale of A, scale of B, binade spread of A's rows, zero column
+    ('tiny_2^-105', 2.0 ** -105, 1.0, 0, False), ('huge_2^100', 2.0 ** 100, 1.0, 0, False),
+    ('both_small_2^-60', 2.0 ** -60, 2.0 ** -60, 0, False), ('rows_over_20_binades', 1.0, 1.0, 20, False),
+    ('zero_column', 1.0, 1.0, 0, True), ('tiny_rows_spread', 2.0 ** -95, 1.0, 20, True)]
+
+
+@pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 1)], ids=['forward', 'dgrad', 'wgrad'])
+@pytest.mark.parametrize('case', ROBUST, ids=[c[0] for c in ROBUST])
+def test_extreme_operands_are_no_less_accurate_than_the_fp32_mfma_kernel(case, layout):
+    """The x3 accuracy bar away from randn (thin spot i): operands at the bottom of the range in which the split is
+    exact (|x| >= 2^-109: the third piece, 16 binades lower, is still a NORMAL bf16 above 2^-126), operands near the top of the
+    range, rows that span 20 binades (one accumulation chain sees them all through k) and a column of exact zeros -- same bar
+    as the model shapes: maximum and rms error <= 1.5 x the native fp32 MFMA kernel's on the same operands, against float64.
+    Below 2^-109 an fp32 value has no exact three-piece bf16 form (bf16 subnormals stop at 2^-133):
+    test_below_the_exact_split_range_the_error_grows_gracefully."""
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    name, sa, sb, spread, zero_col = case
+    akm, bkm = layout
+    M, N, K = (768, 512, 1312) if akm else (1312, 512, 768)
+    A, B = _operands(akm, bkm, M, N, K, seed=len(name) + 3 * akm + bkm)
+    g = torch.Generator(device='cuda').manual_seed(17)
+    if spread:
+        e = torch.randint(-spread // 2, spread // 2 + 1, (A.shape[0], 1), device='cuda', generator=g).float()
+        A = A * torch.exp2(e)          # k-contiguous A: rows of the output; k-major A: k-rows (one chain sums over all of them)
+    A = (A * sa).contiguous(); B = (B * sb).contiguous()
+    if zero_col:
+        A[:, 5] = 0.0; B[:, 7] = 0.0
+    assert torch.isfinite(A).all() and torch.isfinite(B).all()
+    ref = _ref(akm, bkm, A, B)
+    C32 = torch.empty(M, N, device='cuda')
+    L.check(lib.uniter_gemm_f32_cfg(0, akm, bkm, M, N, K, L.ptr(A), A.shape[1], L.ptr(B), B.shape[1], L.ptr(C32), N, 0, None,
+                                    None, None, N, 0, L.cur_stream()), 'gemm_f32')
+    e32 = _errs(C32, ref)
+    A3, B3 = split3(A), split3(B)
+    # the split itself is exact here too -- for every element >= 2^-109; a randn operand scaled to 2^-105 also holds elements a
+    # few binades lower, whose last bits fall below bf16's subnormals: an ABSOLUTE error <= 2^-134, nothing against the row's scale
+    small = A.abs() < 2.0 ** -108
+    assert torch.equal(join3(A3)[~small], A[~small]) and torch.equal(join3(B3), B)
+    assert (join3(A3) - A).abs().max().item() <= 2.0 ** -133
+    C = torch.full((M, N), float('nan'), device='cuda')
+    L.check(x3_gemm(0, 1, akm, bkm, M, N, K, A3, B3, C, None, EPI_NONE, None, None, None), 'gemm_x3')
+    assert torch.isfinite(C).all()
+    e = _errs(C, ref)
+    scale = ref.abs().max().item()
+    assert scale > 0
+    # (an fp32 result below 2^-126 is itself subnormal: both kernels are then compared on what fp32 can hold)
+    floor = 2.0 ** -149
+    assert e[0] <= 1.5 * e32[0] + floor and e[1] <= 1.5 * e32[1] + floor, (name, layout, e, e32, scale)
+
+
+def test_below_the_exact_split_range_the_error_grows_gracefully():
+    """|x| ~ 2^-120 (1e-36: thirty binades below any gradient of the model): the residual pieces are bf16 subnormals (x2 ~ 2^-128,
+    x3 below the last subnormal 2^-133), so x1 + x2 + x3 = x only to ~2^-13 relative, and what the product keeps depends on
+    whether the matrix pipe honours subnormal bf16 inputs.  Pinned here: the result is finite, never worse than ONE bf16 piece
+    (2^-8 relative to the product's scale), and the measured regime is reported (DESIGN.md section 6 quotes it)."""
+    from meme_challenge_amd import _lib as L
+    M, N, K = 512, 256, 768
+    A, B = _operands(0, 0, M, N, K, seed=5)
+    A = (A * 2.0 ** -120).contiguous()
+    ref = _ref(0, 0, A, B)
+    A3, B3 = split3(A), split3(B)
+    split_err = ((join3(A3).double() - A.double()).abs().max() / A.double().abs().max()).item()
+    C = torch.full((M, N), float('nan'), device='cuda')
+    L.check(x3_gemm(0, 1, 0, 0, M, N, K, A3, B3, C, None, EPI_NONE, None, None, None), 'gemm_x3')
+    assert torch.isfinite(C).all()
+    rel = _errs(C, ref)[0] / ref.abs().max().item()
+    print('x3 at 2^-120: split error %.3g relative, product error %.3g relative (%s)'
+          % (split_err, rel, 'subnormal pieces honoured by the MFMA' if rel < 2.0 ** -11 else 'subnormal pieces flushed'))
+    assert split_err <= 2.0 ** -12 and rel <= 2.0 ** -8
+
+
 def test_colsum_of_pieces():
     from meme_challenge_amd import _lib as L
     g = torch.Generator(device='cuda').manual_seed(3)
