@@ -213,26 +213,33 @@ int uniter_wgrad_x3_group(int cfg, int n, const int* M, const int* N, int K, con
  * of the weight-gradient launch itself (round 5; model/layer.py:76-78,112,140,153 backward, train_template.py:104 clip norm):
  *  - colsum_out[m] += sum_k A[0][k][m]: the column sums of product 0's A operand (A = dY: the bias gradient that belongs to
  *    this weight gradient), by three more MFMAs per row block and k-tile in the tiles of the first tile column;
- *  - up to 3 column-reduction jobs out[j][c / seg][c % seg] += sum_p part[j][p * stride + c] for c < n[j] (the LayerNorm
+ *  - up to 4 column-reduction jobs out[j][c / seg][c % seg] += sum_p part[j][p * stride + c] for c < n[j] (the LayerNorm
  *    backward passes' [dgamma | dbeta | dbias] partial rows, the attention backward's per-sample query|key|value bias
  *    partials), 64 columns per item, run by the workgroups with one tile less while the first k-tiles are staged;
  *  - ssq[4 * workgroup + wave] = the sum of squares of EVERYTHING that wave wrote (weight-gradient tiles after the add,
  *    colsum_out, reduced vectors), in double: the clip norm's share of this launch as unreduced partial sums in fixed slots
- *    (no atomics: bit-reproducible); uniter_sumsq_combine joins them.  uniter_wgrad_x3_group_slots = slots written (4 x grid).
- * `grid`, `nred`, `first_item` are filled in by the call.  cfg must be 0 or 3. */
+ *    (no atomics: bit-reproducible); uniter_sumsq_combine joins them.  uniter_wgrad_x3_group_slots = slots written.
+ * `grid`, `nred`, `first_item` are filled in by the call.  cfg 0 (choose), 3 (128 x 128 tiles, 4 slots per workgroup) or 4 (128 x 256
+ * tiles, 8 slots per workgroup: one per compute wave). */
 typedef struct uniter_x3_riders {
   double* ssq;
   float* colsum_out;
   int grid, njobs, nred;
-  const float* part[3];
-  int nparts[3], stride[3], n[3], seg[3];
-  float* out[3][3];
-  int first_item[4];
+  const float* part[4];
+  int nparts[4], stride[4], n[4], seg[4];
+  float* out[4][3];
+  int first_item[5];
 } uniter_x3_riders_t;
+/* uniter_gemm_x3_cfg with epilogue UNITER_EPI_MUL, one k-piece, that also leaves partial column sums of its output in
+ * colsum_part [(M + 63) / 64][N] (row i = the sum of output rows 64 i .. 64 i + 63): the bias gradient of a dense layer from the
+ * product that WRITES its dY (dU of model/layer.py:140's backward), finished by a column-reduction job of the riders above. */
+int uniter_gemm_x3_colpart(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, int psa,
+                           const void* B, int ldb, int psb, float* C, int ldc, void* C_x3, int ldcx, int pscx,
+                           const float* aux_in, int ld_aux, float* colsum_part, void* stream);
 int uniter_wgrad_x3_group_riders(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
                                  const void* const* B, float* const* dW, int overwrite, int max_wgs,
                                  uniter_x3_riders_t* riders, void* stream);
-int uniter_wgrad_x3_group_slots(int n, const int* M, const int* N, int max_wgs);
+int uniter_wgrad_x3_group_slots(int cfg, int n, const int* M, const int* N, int max_wgs);
 /* The same riders on the grouped bf16 weight-gradient launch (uniter_wgrad_bf16_group; precision bf16): overwrite = 1 stores
  * instead of adding, max_wgs > 0 caps the grid; cfg must be 0 or 1 (two LDS stages). */
 int uniter_wgrad_bf16_group_riders(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
@@ -649,6 +656,12 @@ int uniter_model_set_norm_partials(uniter_model_t* m, double* parts, size_t stri
  * probabilities (a function of seed and offset alone: 60 us of Philox rounds for twelve layers) -- so that they run BESIDE the head
  * of the forward pass instead of in front of it; the first attention kernel waits for them.  NULL (default): on `stream`. */
 int uniter_model_set_aux_stream(uniter_model_t* m, void* aux_stream);
+/* Data parallel (replaces nothing in the reference: its nn.DataParallel, train_template.py:58-59, has no overlap to protect): the
+ * persistent matrix kernels of this model's forward / backward calls -- one 144-KB workgroup per CU in the fp32x3 mode, the grouped
+ * bf16 weight-gradient launch -- leave `cus` CUs free for the kernels of the gradient exchange (RCCL) that runs beside the backward
+ * pass.  Without it a collective's workgroups take CUs as persistent workgroups exit, and the launch that counted on all 256 runs its
+ * last workgroups -- and their whole static share of the tiles -- behind them.  0 (default) = every CU. */
+int uniter_model_set_cu_reserve(uniter_model_t* m, int cus);
 int uniter_model_norm_partials_per_layer(const uniter_model_t* m);
 /* Gradient accumulation semantics without the clearing pass (optimizer.zero_grad, train_template.py:107): after an optimizer
  * step that did NOT clear the encoder layers' weight gradients (uniter_adam_step*: chunk flag + 4), announce it here and the

@@ -30,8 +30,8 @@ class UniterConfigC(C.Structure):
 class X3RidersC(C.Structure):
     """uniter_x3_riders_t (include/uniter_hip.h): side work riding on a grouped x3 weight-gradient launch"""
     _fields_ = [('ssq', C.c_void_p), ('colsum_out', C.c_void_p), ('grid', C.c_int), ('njobs', C.c_int), ('nred', C.c_int),
-                ('part', C.c_void_p * 3), ('nparts', C.c_int * 3), ('stride', C.c_int * 3), ('n', C.c_int * 3), ('seg', C.c_int * 3),
-                ('out', (C.c_void_p * 3) * 3), ('first_item', C.c_int * 4)]
+                ('part', C.c_void_p * 4), ('nparts', C.c_int * 4), ('stride', C.c_int * 4), ('n', C.c_int * 4), ('seg', C.c_int * 4),
+                ('out', (C.c_void_p * 3) * 4), ('first_item', C.c_int * 5)]
 
 
 class UniterBatchC(C.Structure):
@@ -80,12 +80,14 @@ _SIGS = {
     'uniter_ln_fwd_slabs_x3': (_I, [_P, _I, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _U32, _P]),
     'uniter_ln_bwd_rows_slabs_x3': (_I, [_P, _I, _SZ, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_wgrad_x3_group': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
+    'uniter_gemm_x3_colpart': (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P]),
     'uniter_wgrad_x3_group_riders': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
-    'uniter_wgrad_x3_group_slots': (_I, [_I, _P, _P, _I]),
+    'uniter_wgrad_x3_group_slots': (_I, [_I, _I, _P, _P, _I]),
     'uniter_wgrad_bf16_group_riders': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     'uniter_wgrad_bf16_group_slots': (_I, [_I, _P, _P, _I]),
     'uniter_model_set_norm_partials': (_I, [_P, _P, _SZ]),
     'uniter_model_set_aux_stream': (_I, [_P, _P]),
+    'uniter_model_set_cu_reserve': (_I, [_P, _I]),
     'uniter_model_norm_partials_per_layer': (_I, [_P]),
     'uniter_colsum_x3_add': (_I, [_P, _I, _I, _I, _P, _P]),
     'uniter_cast_bf16': (_I, [_P, _P, _SZ, _P]),

@@ -22,3 +22,4 @@ extern "C" const char* uniter_build_info(void) {
 // validation folds in threads, a DataParallel-style caller) can never take each other's stamp slot or wave priority
 thread_local unsigned long long* g_uniter_stamp_slot = nullptr;
 thread_local int g_uniter_launch_prio = 0;
+thread_local int g_uniter_cu_reserve = 0;

@@ -54,6 +54,11 @@ static inline int take_launch_prio() {
   return p;
 }
 
+// CUs the persistent matrix kernels leave free (uniter_model_set_cu_reserve: the collectives of a data-parallel exchange run beside the
+// backward pass and need CUs of their own -- a persistent launch that counts on all of them leaves its last workgroups queued behind
+// the collective's and their whole share of the tiles late).  Set by every model call from its handle; thread_local as the channels above.
+extern thread_local int g_uniter_cu_reserve;
+
 #ifdef __HIPCC__
 // uniform branch around the immediate-operand instruction
 __device__ __forceinline__ void set_wave_prio(int level) {

@@ -723,7 +723,11 @@ static int wgrad_group_grid(int total, int max_wgs) {
   // Measured again once the attention backward took its CU in one launch (four same-box rounds): UNITER-base 4.75 -> 4.71 ms,
   // UNITER-large 9.65 -> 9.49, config 5 at B = 32 8.19 -> 8.00 ms per step; 192 / 320 / 384 workgroups 4.77-4.80, 128 5.13
   static const int cap_env = [] { const char* e = getenv("UNITER_WGRAD_GROUP_WGS"); return e ? atoi(e) / 8 * 8 : 256; }();
-  const int cap = max_wgs >= 8 ? max_wgs / 8 * 8 : cap_env;
+  int cap = max_wgs >= 8 ? max_wgs / 8 * 8 : cap_env;
+  if (g_uniter_cu_reserve > 0 && cap >= 8) {              // CUs left to the data-parallel exchange's kernels (common.h)
+    const int room = (256 - g_uniter_cu_reserve) / 8 * 8;
+    if (room >= 8 && cap > room) cap = room;
+  }
   if (cap >= 8 && grid > cap) grid = cap;
   return grid;
 }

@@ -55,6 +55,8 @@ struct S3Args {
   unsigned long long* stamp;
   int prio;
   int dbg;
+  float* colpart;     // optional (v_mfma_f32_16x16x32_bf16 geometries): partial column sums of the values the epilogue leaves, one row of N
+                      // floats per 64 output rows (row 2 (m0 / 128) + wm): the bias gradient that belongs to a dY this product writes
 };
 
 #define OOB 0x7ffffff0        /* buffer offset beyond every descriptor: load returns 0, store is dropped */
@@ -257,20 +259,29 @@ template <int R, bool KM, int NB>
 struct Frag16 {
   unsigned ka;              // k-contiguous: offset in the wave's first 16-row block (block t: + t * 16 rows = t * 1024 B)
   unsigned tr[NB][2];       // k-major: offsets of the two transposed reads of block t
+  // k-major, compact form (the lean compute path: 168 registers): tr[t][h] = kb + h * 4 * R * 2 + (xk ^ ((t << 5) | (h << 4))) for
+  // a wave whose first block is a multiple of 4 and NB = 4 -- the block index enters the swizzled chunk number on bits the lane's
+  // swizzle XORs, so the address is one v_xad_u32 per read instead of eight registers per operand
+  unsigned kb, xk;
   __device__ __forceinline__ void init(int lane, int blk0) {
     const int r = lane & 15, g = lane >> 4;
     if constexpr (!KM) {
       ka = (blk0 * 16 + r) * 64 + ((g ^ chunk_swz<true>((r >> 2) & 3)) << 4);
     } else {
-      static_assert(!KM || R == 128, "k-major 16x16x32 fragments: 128-wide tiles");
+      static_assert(!KM || R == 128 || R == 256, "k-major 16x16x32 fragments: 128- or 256-wide tiles");
       const int q = r >> 2, p = r & 3;
       const int s1 = (q << 2) | ((2 * g) & 3), s2 = (q << 2) | ((2 * g + 1) & 3);
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
-        const int c = 2 * (blk0 + t) + (p >> 1);             // 16-byte chunk of the block's columns
-        tr[t][0] = (8 * g + q) * 256 + 8 * (p & 1) + ((c ^ s1) << 4);
-        tr[t][1] = (8 * g + 4 + q) * 256 + 8 * (p & 1) + ((c ^ s2) << 4);
+        // a k-row is R * 2 bytes: one (R = 128) or two (R = 256) 256-byte segments of 16 swizzled 16-byte chunks
+        const int cb = blk0 + t;                                // 16-column block of the tile
+        const int c = 2 * (cb & 7) + (p >> 1);                  // 16-byte chunk of the block's columns inside its segment
+        const int seg = (cb >> 3) * 256;
+        tr[t][0] = (8 * g + q) * (R * 2) + seg + 8 * (p & 1) + ((c ^ s1) << 4);
+        tr[t][1] = (8 * g + 4 + q) * (R * 2) + seg + 8 * (p & 1) + ((c ^ s2) << 4);
       }
+      kb = (8 * g + q) * (R * 2) + (blk0 >> 3) * 256 + 8 * (p & 1);
+      xk = ((2 * (blk0 & 7) + (p >> 1)) ^ s1) << 4;
     }
   }
 };
@@ -315,6 +326,48 @@ struct FragRegs16KM {
   template <int P, int T>
   __device__ __forceinline__ bf16x8 get() const {
     return __builtin_bit_cast(bf16x8, u32x4_t{lo[P][T][0], lo[P][T][1], hi[P][T][0], hi[P][T][1]});
+  }
+};
+
+// ONE piece of an operand's fragments (the lean compute path: B one piece at a time in two alternating register sets)
+template <int R, bool KM, int NB> struct Piece16;
+template <int R, int NB>
+struct Piece16<R, false, NB> {
+  u32x4_t v[NB];
+  static constexpr int READS = NB;
+  template <int P>
+  __device__ __forceinline__ void read(const Frag16<R, false, NB>& f, unsigned img_addr) {
+    static_for<0, NB>([&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      lds_read_b128_o<P * R * 64 + T * 1024>(v[T], img_addr + f.ka);
+    });
+  }
+  __device__ __forceinline__ void tie_all() {
+#pragma unroll
+    for (int t = 0; t < NB; ++t) tie(v[t]);
+  }
+  template <int T> __device__ __forceinline__ bf16x8 get() const { return __builtin_bit_cast(bf16x8, v[T]); }
+};
+template <int R, int NB>
+struct Piece16<R, true, NB> {
+  u32x2_t lo[NB], hi[NB];
+  static constexpr int READS = 2 * NB;
+  template <int P>
+  __device__ __forceinline__ void read(const Frag16<R, true, NB>& f, unsigned img_addr) {
+    static_assert(NB == 4, "compact k-major addressing: four 16-column blocks per wave");
+    const unsigned base = img_addr + f.kb;
+    static_for<0, NB>([&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      lds_read_tr_o<P * R * 64>(lo[T], base + (f.xk ^ (unsigned)(T << 5)));
+      lds_read_tr_o<P * R * 64 + 4 * R * 2>(hi[T], base + (f.xk ^ (unsigned)((T << 5) | 16)));
+    });
+  }
+  __device__ __forceinline__ void tie_all() {
+#pragma unroll
+    for (int t = 0; t < NB; ++t) { tie2(lo[t]); tie2(hi[t]); }
+  }
+  template <int T> __device__ __forceinline__ bf16x8 get() const {
+    return __builtin_bit_cast(bf16x8, u32x4_t{lo[T][0], lo[T][1], hi[T][0], hi[T][1]});
   }
 };
 
@@ -467,6 +520,9 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, int piece, int m0
         ax[a][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsI, n < g.N ? (m * g.ld_aux + n) * 4 : OOB, 0, 0));
       }
   }
+  f32x4 csum[EPI == S3_MUL ? NB : 1];                        // column sums of this wave's 64 rows (g.colpart)
+#pragma unroll
+  for (int b = 0; b < (EPI == S3_MUL ? NB : 1); ++b) csum[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < MB; ++a) {
     const int m = m0 + wm * WM + a * 16 + r;                 // this lane's output row
@@ -489,6 +545,12 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, int piece, int m0
       if (Cp) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsC, n < g.N ? (m * g.ldc + n) * 4 : OOB, 0, 0);
       if (TWO) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x2[b]), rsX, n < g.N ? (m * g.ld_aux + n) * 4 : OOB, 0, 0);
     }
+    if constexpr (EPI == S3_MUL) {      // (the one epilogue whose output is a dY with a bias gradient: dU)
+      if (g.colpart && first) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) csum[b] += acc[a][b];     // (rows beyond M hold zeros: zero operand rows, zero aux)
+      }
+    }
     // x3 output: two column blocks at a time -- v_permlane16_swap hands the odd 16-lane rows of block b to the even rows and the
     // even rows of block b + 1 to the odd ones, so every lane ends with 8 consecutive columns: one 16-byte store per piece
     if (g.Cx) {
@@ -509,6 +571,22 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, int piece, int m0
           __builtin_amdgcn_raw_buffer_store_b128(o, rsCx, ok ? (m * g.ldcx + p * g.pscx + n8) * 2 : OOB, 0, 0);
         }
       }
+    }
+  }
+  if constexpr (EPI == S3_MUL) if (g.colpart && first) {
+    // the 16 lanes of a quarter wave hold the 16 rows of a block: four shuffle steps inside the quarter, then lane r == 0 of each
+    // quarter stores its four columns of every block
+    static_assert(WM == 64, "column partials: one row of partial sums per 64 output rows");
+    float* prow = g.colpart + (size_t)((m0 / 64) + wm) * g.N;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      f32x4 t = csum[b];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] += __shfl_xor(t[e], o, 64);
+      const int n = n0 + wn * WN + b * 16 + 4 * gq;
+      if (r == 0 && n < g.N) *reinterpret_cast<f32x4*>(prow + n) = t;
     }
   }
 #endif
@@ -679,11 +757,44 @@ void gemm_s3p_kernel(const S3Group G) {
     // first stages of the tile loop
     double wss = 0.0;
     if constexpr (XTR) {
-      for (int r = (int)gridDim.x - 1 - (int)blockIdx.x; r < G.x.nred; r += (int)gridDim.x)
-        wss += (double)riders_reduce_item(G.x, r, wave, lane);
+      if (wave < 4)        // (an item is four 16-column strips: the first four compute waves)
+        for (int r = (int)gridDim.x - 1 - (int)blockIdx.x; r < G.x.nred; r += (int)gridDim.x)
+          wss += (double)riders_reduce_item(G.x, r, wave, lane);
     }
-    f32x4 acc1[XTR ? MB : 1];      // XTR: column sums of the k-major A operand (ones . A on the matrix pipe)
+    f32x4 acc1[(XTR && NWC == 4) ? MB : 1];      // XTR: column sums of the k-major A operand (ones . A on the matrix pipe)
     const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+    // riders, behind a tile's epilogue: the sum of squares of what this lane stored (the epilogue left the values in `acc`; a
+    // k-major operand's overhang columns read its next piece, not zeros: only what was stored counts), and the column sums
+    auto tile_riders = [&](const Item& c, bool colsum) -> float {
+      float ss = 0.f;
+#pragma unroll
+      for (int a = 0; a < MB; ++a) {
+        const bool row_ok = c.m0 + wm * WM + a * 16 + (lane & 15) < G.p[c.p].M;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const bool ok = row_ok && c.n0 + wn * WN + b * 16 + 4 * (lane >> 4) < G.p[c.p].N;
+          float s4 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s4 = __builtin_fmaf(acc[a][b][j], acc[a][b][j], s4);
+          ss += ok ? s4 : 0.f;
+        }
+      }
+      if constexpr (XTR && NWC == 4) {
+        if (colsum && lane < 16) {
+          // every accumulator row of the ones-product holds the same sums: lanes 0..15 own column m of row block a
+#pragma unroll
+          for (int a = 0; a < MB; ++a) {
+            const int m = c.m0 + wm * WM + a * 16 + lane;
+            if (m < G.p[0].M) {
+              const float o = G.x.colsum_out[m] + acc1[a][0];
+              G.x.colsum_out[m] = o;
+              ss = __builtin_fmaf(o, o, ss);
+            }
+          }
+        }
+      }
+      return ss;
+    };
     int stg = 0;
     for (int r = 0;; ++r) {
       const Item c = item(r);
@@ -694,10 +805,61 @@ void gemm_s3p_kernel(const S3Group G) {
         for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
       // product 0's tiles of the first tile column also sum the columns of its A operand over k (the bias gradient that belongs to
       // this weight gradient: A = dY): the waves that hold the tile's first 64 columns run 3 more MFMAs per row block and k-tile
-      const bool colsum = XTR && AKM && G.x.colsum_out && c.p == 0 && c.n0 == 0 && wn == 0;
-      if constexpr (XTR) {
+      const bool colsum = XTR && AKM && NWC == 4 && G.x.colsum_out && c.p == 0 && c.n0 == 0 && wn == 0;
+      if constexpr (XTR && NWC == 4) {
 #pragma unroll
         for (int a = 0; a < MB; ++a) acc1[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if constexpr (NWC > 4) {
+        // ---- lean form (12 waves per workgroup: 168 registers): A's three pieces resident (48 registers), B ONE piece at a time
+        // in two alternating sets (2 x 16): products a1 b1, a2 b1, a3 b1, a1 b2, a2 b2, a1 b3
+        typedef Piece16<BM, AKM, MB> PA_;
+        typedef Piece16<BN, BKM, NB> PB_;
+        constexpr int RA = PA_::READS, RB = PB_::READS;
+        auto mma1 = [&](const PA_& pa, const PB_& pb) {
+          static_for<0, MB>([&](auto ac) {
+            constexpr int A_ = decltype(ac)::value;
+            static_for<0, NB>([&](auto bc) {
+              constexpr int B_ = decltype(bc)::value;
+              acc[A_][B_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb.template get<B_>(), pa.template get<A_>(), acc[A_][B_], 0, 0, 0);
+            });
+          });
+        };
+        for (int kt = c.kb; kt < c.ke; ++kt) {
+          if (!(dbg & 64)) __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          const unsigned sA = lds0 + stg * STAGE, sB = sA + 3 * IMG_A;
+          PA_ a0, a1, a2;
+          PB_ bx, by;
+          a0.template read<0>(fa, sA); bx.template read<0>(fb, sB);
+          a1.template read<1>(fa, sA); a2.template read<2>(fa, sA);
+          by.template read<1>(fb, sB);
+          lgkm_wait<(2 * RA + RB > 15 ? 15 : 2 * RA + RB)>();
+          a0.tie_all(); bx.tie_all();
+          mma1(a0, bx);
+          __builtin_amdgcn_sched_barrier(0);
+          lgkm_wait<(RA + RB > 15 ? 15 : RA + RB)>();
+          a1.tie_all();
+          mma1(a1, bx);
+          __builtin_amdgcn_sched_barrier(0);
+          lgkm_wait<(RB > 15 ? 15 : RB)>();
+          a2.tie_all();
+          mma1(a2, bx);
+          __builtin_amdgcn_sched_barrier(0);
+          bx.template read<2>(fb, sB);              // (the third piece takes the first one's registers)
+          lgkm_wait<(RB > 15 ? 15 : RB)>();
+          by.tie_all();
+          mma1(a0, by); mma1(a1, by);
+          __builtin_amdgcn_sched_barrier(0);
+          lgkm_wait<0>();          // every read of the stage is complete in front of the next barrier
+          bx.tie_all();
+          mma1(a0, bx);
+          __builtin_amdgcn_sched_barrier(0);
+          stg = stg == ST - 1 ? 0 : stg + 1;
+        }
+        s3_epilogue16<WM, WN, EPI>(G.p[c.p], c.piece, c.m0, c.n0, wm, wn, lane, acc);
+        if constexpr (XTR) wss += (double)tile_riders(c, false);
+        continue;
       }
       Frs f;
       for (int kt = c.kb; kt < c.ke; ++kt) {
@@ -736,40 +898,10 @@ void gemm_s3p_kernel(const S3Group G) {
         stg = stg == ST - 1 ? 0 : stg + 1;
       }
       s3_epilogue16<WM, WN, EPI>(G.p[c.p], c.piece, c.m0, c.n0, wm, wn, lane, acc);
-      if constexpr (XTR) {
-        // (the epilogue left the values it stored in `acc`; a k-major operand's overhang columns read its next piece, not zeros:
-        // only what was stored counts)
-        float ss = 0.f;
-#pragma unroll
-        for (int a = 0; a < MB; ++a) {
-          const bool row_ok = c.m0 + wm * WM + a * 16 + (lane & 15) < G.p[c.p].M;
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            const bool ok = row_ok && c.n0 + wn * WN + b * 16 + 4 * (lane >> 4) < G.p[c.p].N;
-            float s4 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s4 = __builtin_fmaf(acc[a][b][j], acc[a][b][j], s4);
-            ss += ok ? s4 : 0.f;
-          }
-        }
-        if (colsum && lane < 16) {
-          // every accumulator row of the ones-product holds the same sums: lanes 0..15 own column m of row block a
-#pragma unroll
-          for (int a = 0; a < MB; ++a) {
-            const int m = c.m0 + wm * WM + a * 16 + lane;
-            if (m < G.p[0].M) {
-              const float o = G.x.colsum_out[m] + acc1[a][0];
-              G.x.colsum_out[m] = o;
-              ss = __builtin_fmaf(o, o, ss);
-            }
-          }
-        }
-        wss += (double)ss;
-      }
+      if constexpr (XTR) wss += (double)tile_riders(c, colsum);
     }
     if constexpr (XTR) {
-      static_assert(!XTR || NWC == 4, "riders: four sum-of-squares slots per workgroup");
-      riders_store_ssq(G.x, wss, wave, lane);
+      riders_store_ssq(G.x, wss, wave, lane, NWC);
     }
   } else {
     // ------------------------------------------------------------------ compute waves, v_mfma_f32_32x32x16_bf16 ----
@@ -882,7 +1014,11 @@ int x3_grid(int nwork, int max_wgs) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 8 ? n / 8 * 8 : 256;
   }();
-  const int cap = max_wgs >= 8 ? max_wgs / 8 * 8 : cus;       // one workgroup per CU: it owns the CU's LDS
+  int cap = max_wgs >= 8 ? max_wgs / 8 * 8 : cus;       // one workgroup per CU: it owns the CU's LDS
+  if (g_uniter_cu_reserve > 0) {                          // CUs left to the data-parallel exchange's kernels
+    const int room = (cus - g_uniter_cu_reserve) / 8 * 8;
+    if (room >= 8 && cap > room) cap = room;
+  }
   return grid > cap ? cap : grid;
 }
 
@@ -899,21 +1035,27 @@ int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
 //   1: 8 compute waves of 64 x 32 + 4 loader waves, v_mfma_f32_32x32x16_bf16
 //   2: 4 compute waves of 64 x 64 + 4 loader waves, v_mfma_f32_32x32x16_bf16
 //   3: 4 compute waves of 64 x 64 + 4 loader waves, v_mfma_f32_16x16x32_bf16 (default)
+//   4: 128 x 256 tiles (round 5): 8 compute waves of 64 x 64 + 4 loader waves, TWO stages of 72 KB, v_mfma_f32_16x16x32_bf16 with the
+//      B fragments one piece at a time (168 registers per wave) -- 36 instead of 48 KB staged per 128 x 128 x 32 block of products
 template <bool AKM, bool BKM, int EPI>
 int dispatch_cfg3p(int cfg, const S3Group& G, int max_wgs, hipStream_t st) {
   switch (cfg) {
     case 1: return launch_s3p<128, 128, 64, 32, AKM, BKM, 3, 32, 4, false, EPI>(G, max_wgs, st);
     case 2: return launch_s3p<128, 128, 64, 64, AKM, BKM, 3, 32, 4, false, EPI>(G, max_wgs, st);
     case 3: return launch_s3p<128, 128, 64, 64, AKM, BKM, 3, 32, 4, true, EPI>(G, max_wgs, st);
-    default: uniter_set_error("gemm_x3: bad cfg %d (1..3)", cfg); return UNITER_E_ARG;
+    case 4:
+      if constexpr (!AKM) return launch_s3p<128, 256, 64, 64, AKM, BKM, 2, 32, 4, true, EPI>(G, max_wgs, st);
+      // (weight gradients keep the 128 x 128 whole-K tiles)
+    default: uniter_set_error("gemm_x3: bad cfg %d (1..4)", cfg); return UNITER_E_ARG;
   }
 }
 
 template <bool AKM, bool BKM, int EPI>
 int dispatch_cfg3(int cfg, const S3Args& g, hipStream_t st) {
   S3Group G;
+  memset(&G.x, 0, sizeof(G.x));
   for (int p = 0; p < 4; ++p) G.p[p] = g;
-  plan_tiles3<128>(G.p[0], 128);
+  plan_tiles3<128>(G.p[0], cfg == 4 ? 256 : 128);
   const int total = G.p[0].tiles_m * G.p[0].tiles_n * g.nsplit;
   G.start[0] = 0;
   for (int p = 1; p <= 4; ++p) G.start[p] = total;
@@ -1013,7 +1155,7 @@ bool x3_fits(size_t rows, int rs, int ps, int ext) { return ((rows + 256) * (siz
 }  // namespace
 
 int riders_prepare(uniter_x3_riders_t& x, const char* who) {
-  UCHECK_ARG(x.njobs >= 0 && x.njobs <= 3, "%s: at most 3 column-reduction jobs", who);
+  UCHECK_ARG(x.njobs >= 0 && x.njobs <= 4, "%s: at most 4 column-reduction jobs", who);
   int items = 0;
   for (int j = 0; j < x.njobs; ++j) {
     UCHECK_ARG(x.part[j] && x.nparts[j] > 0 && x.n[j] > 0 && x.seg[j] > 0 && x.stride[j] >= x.n[j], "%s: bad reduction job %d", who, j);
@@ -1024,7 +1166,7 @@ int riders_prepare(uniter_x3_riders_t& x, const char* who) {
     x.first_item[j] = items;
     items += (x.n[j] + 63) / 64;
   }
-  for (int j = x.njobs; j < 4; ++j) x.first_item[j] = items;
+  for (int j = x.njobs; j < 5; ++j) x.first_item[j] = items;
   x.nred = items;
   UCHECK_SHAPE(!x.colsum_out || ((uintptr_t)x.colsum_out & 3) == 0, "%s: colsum_out alignment", who);
   return 0;
@@ -1033,7 +1175,8 @@ int riders_prepare(uniter_x3_riders_t& x, const char* who) {
 // C / Cx = epi(A . B^T) on x3 operands (fp32-accurate, six bf16 MFMA products per block, fp32 accumulate).
 int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, int psa,
                 const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* Cx, int ldcx, int pscx,
-                int epilogue, const float* bias, const float* aux_in, float* aux_out, int ld_aux, void* stream) {
+                int epilogue, const float* bias, const float* aux_in, float* aux_out, int ld_aux, void* stream,
+                float* colsum_part) {
   UCHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && (C || Cx), "gemm_x3: bad argument");
   UCHECK_ARG(!a_kmajor || (b_kmajor && !Cx && (epilogue == UNITER_EPI_NONE || epilogue == UNITER_EPI_ADD)),
              "gemm_x3: A k-major only as the weight-gradient layout (both operands k-major, fp32 output, none / add)");
@@ -1060,9 +1203,25 @@ int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, i
   g.dbg = cfg >> 8; cfg &= 0xff;
   g.stamp = take_stamp_slot();
   g.prio = take_launch_prio();
+  UCHECK_ARG(!colsum_part || (epilogue == UNITER_EPI_MUL && nsplit == 1 && (cfg == 0 || cfg >= 3) && ((uintptr_t)colsum_part & 15) == 0 && N % 4 == 0),
+             "gemm_x3: column partials ride on the x aux epilogue of the 16x16x32 geometries (cfg 0, 3, 4), one k-piece");
+  g.colpart = colsum_part;
   // in the step: 4 x (64 x 64) compute waves + 4 loaders are +1.2 % over cfg 1 (8 x (64 x 32)); the 16x16x32 MFMA shape another
   // +3 % (10.51 -> 10.21 ms, same box): the chip holds a higher clock under it
-  if (cfg == 0) cfg = 3;
+  if (cfg == 0) {
+    cfg = 3;
+    // round 5: 128 x 256 tiles where they take fewer rounds' worth of time.  The k-loop is bound by the LDS-DMA issue rate (one
+    // 1-KiB instruction per ~45 cycles and CU), and a 128 x 256 tile stages 72 KB per k-tile for twice the products of a 128 x 128
+    // one's 48 KB: measured 1.75 x the time per k-tile for 2 x the work (profiles/r05_gemm_x3_lab.txt: QKV forward 61.0 -> 54.9 us,
+    // FFN-up forward 76.7 -> 69.5, FFN-down input gradient 72.9 -> 65.2; the N = hidden products keep two k-pieces of 128 x 128)
+    if (!a_kmajor && nsplit == 1 && N >= 256) {
+      const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t256 = (long)((M + 127) / 128) * ((N + 255) / 256);
+      const int cus = x3_grid(1 << 20, 0);
+      const long r128 = (t128 + cus - 1) / cus, r256 = (t256 + cus - 1) / cus;
+      static const bool on = [] { const char* e = getenv("UNITER_X3_WIDE"); return !(e && e[0] == '0'); }();
+      if (on && 7 * r256 < 4 * r128) cfg = 4;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
   if (a_kmajor) return dispatch_epi3<true, true>(cfg, g, epilogue, st);
   return b_kmajor ? dispatch_epi3<false, true>(cfg, g, epilogue, st) : dispatch_epi3<false, false>(cfg, g, epilogue, st);
@@ -1081,7 +1240,17 @@ extern "C" int uniter_gemm_x3_cfg(int cfg, int nsplit, int a_kmajor, int b_kmajo
                                   void* C_x3, int ldcx, int pscx, int epilogue, const float* bias, const float* aux_in,
                                   float* aux_out, int ld_aux, void* stream) {
   return gemm_x3_run(cfg, nsplit, a_kmajor, b_kmajor, M, N, K, A, lda, psa, B, ldb, psb, C, ldc, c_split_stride, C_x3, ldcx,
-                     pscx, epilogue, bias, aux_in, aux_out, ld_aux, stream);
+                     pscx, epilogue, bias, aux_in, aux_out, ld_aux, stream, nullptr);
+}
+
+// the same product, also leaving partial column sums of its output: colsum_part[(i, n)] = sum of the output rows 64 i .. 64 i + 63
+// of column n ([(M + 63) / 64][N] floats; UNITER_EPI_MUL only: the product that writes dU, whose column sums are intermediate.dense's
+// bias gradient, model/layer.py:140 backward) -- a column-reduction job of the weight-gradient launch's riders finishes them
+extern "C" int uniter_gemm_x3_colpart(int cfg, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, int psa,
+                                      const void* B, int ldb, int psb, float* C, int ldc, void* C_x3, int ldcx, int pscx,
+                                      const float* aux_in, int ld_aux, float* colsum_part, void* stream) {
+  return gemm_x3_run(cfg, 1, a_kmajor, b_kmajor, M, N, K, A, lda, psa, B, ldb, psb, C, ldc, 0, C_x3, ldcx, pscx, UNITER_EPI_MUL,
+                     nullptr, aux_in, nullptr, ld_aux, stream, colsum_part);
 }
 
 extern "C" int uniter_split3(const float* x, int rows, int cols, int ld, void* x3, size_t row_stride, size_t piece_stride,
@@ -1123,9 +1292,23 @@ extern "C" int uniter_colsum_x3_add(const void* x3, int rows, int cols, int ldx,
 
 // dW_p[M_p, N_p] (+)= A_p^T B_p for up to four products of one reduction length K (A_p [K][3][M_p], B_p [K][3][N_p] x3,
 // dW_p fp32 with leading dimension N_p), one launch of whole-K tiles.
+// tile width of the grouped weight-gradient launch: cfg 4 = 128 x 256 tiles (round 5), else 128 x 128
+static int wgrad_bn(int cfg) { return cfg == 4 ? 256 : 128; }
+static int wgrad_tiles(int cfg, int n, const int* Mo, const int* No) {
+  int total = 0;
+  for (int p = 0; p < n; ++p) total += ((Mo[p] + 127) / 128) * ((No[p] + wgrad_bn(cfg) - 1) / wgrad_bn(cfg));
+  return total;
+}
+// the default geometry of the grouped launch (UNITER_X3_WGRAD_CFG = 3 | 4 overrides)
+int gemm_x3_wgrad_default_cfg() {
+  static const int c = [] { const char* e = getenv("UNITER_X3_WGRAD_CFG"); const int v = e ? atoi(e) : 0; return (v == 3 || v == 4) ? v : 4; }();
+  return c;
+}
+
 int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A, const void* const* B,
                         float* const* dW, void* stream, int overwrite, int max_wgs, uniter_x3_riders_t* riders) {
   UCHECK_ARG(n >= 1 && n <= 4 && K > 0 && Mo && No && A && B && dW, "wgrad_x3_group: bad argument");
+  if (cfg == 0) cfg = gemm_x3_wgrad_default_cfg();
   S3Group G;
   memset(&G.x, 0, sizeof(G.x));
   unsigned long long* stamp = take_stamp_slot();
@@ -1143,40 +1326,46 @@ int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, con
     g.C = dW[p]; g.ldc = No[p];
     g.c_split_stride = 0; g.Cx = nullptr; g.ldcx = 0; g.pscx = 0; g.bias = nullptr;
     g.aux_in = overwrite ? nullptr : dW[p]; g.aux_out = nullptr; g.ld_aux = No[p];
-    g.nsplit = 1; g.stamp = stamp; g.prio = 0; g.dbg = 0;
-    plan_tiles3<128>(g, 128);
+    g.nsplit = 1; g.stamp = stamp; g.prio = 0; g.dbg = 0; g.colpart = nullptr;
+    plan_tiles3<128>(g, wgrad_bn(cfg));
     total += g.tiles_m * g.tiles_n;
   }
   G.start[4] = total;
   for (int p = n; p < 4; ++p) G.start[p] = total;
-  if (cfg == 0) cfg = 3;
   hipStream_t st = (hipStream_t)stream;
   if (riders) {
-    // riders ride on the default geometry only (4 compute waves of 64 x 64 on v_mfma_f32_16x16x32_bf16)
-    UCHECK_ARG(cfg == 3, "wgrad_x3_group: riders need cfg 3 (the default)");
+    // riders ride on the v_mfma_f32_16x16x32_bf16 geometries: 4 compute waves of 64 x 64 (cfg 3) or the 128 x 256 tile's 8 (cfg 4)
+    UCHECK_ARG(cfg == 3 || cfg == 4, "wgrad_x3_group: riders need cfg 3 or 4");
     uniter_x3_riders_t& x = *riders;
+    UCHECK_ARG(cfg != 4 || !x.colsum_out, "wgrad_x3_group: colsum_out rides on cfg 3 only (the 128 x 256 geometry has no registers for it: "
+               "take the bias gradient from the producing product's column partials, uniter_gemm_x3_colpart, as a reduction job)");
     x.grid = x3_grid(total, max_wgs);
     UCHECK_RC(riders_prepare(x, "wgrad_x3_group"));
     G.x = x;
+    if (cfg == 4)
+      return overwrite ? launch_s3p<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_NONE, true>(G, max_wgs, st)
+                       : launch_s3p<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_ADD, true>(G, max_wgs, st);
     return overwrite ? launch_s3p<128, 128, 64, 64, true, true, 3, 32, 4, true, S3_NONE, true>(G, max_wgs, st)
                      : launch_s3p<128, 128, 64, 64, true, true, 3, 32, 4, true, S3_ADD, true>(G, max_wgs, st);
   }
+  if (cfg == 4)
+    return overwrite ? launch_s3p<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_NONE>(G, max_wgs, st)
+                     : launch_s3p<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_ADD>(G, max_wgs, st);
   return overwrite ? dispatch_cfg3p<true, true, S3_NONE>(cfg, G, max_wgs, st) : dispatch_cfg3p<true, true, S3_ADD>(cfg, G, max_wgs, st);
 }
 
-// sum-of-squares slots a launch with riders writes (4 per workgroup) for these products
-int gemm_x3_wgrad_group_slots(int n, const int* Mo, const int* No, int max_wgs) {
+// sum-of-squares slots a launch with riders writes (one per compute wave: 4 per workgroup, 8 with 128 x 256 tiles) for these products
+int gemm_x3_wgrad_group_slots(int cfg, int n, const int* Mo, const int* No, int max_wgs) {
   if (!Mo || !No || n < 1 || n > 4) return 0;
-  int total = 0;
-  for (int p = 0; p < n; ++p) total += ((Mo[p] + 127) / 128) * ((No[p] + 127) / 128);
-  return 4 * x3_grid(total, max_wgs);
+  if (cfg == 0) cfg = gemm_x3_wgrad_default_cfg();
+  return (cfg == 4 ? 8 : 4) * x3_grid(wgrad_tiles(cfg, n, Mo, No), max_wgs);
 }
 
 // the smallest grid (a multiple of 8) on which these products' tiles take no more rounds than on one workgroup per CU
-int gemm_x3_wgrad_group_balanced_wgs(int n, const int* Mo, const int* No) {
+int gemm_x3_wgrad_group_balanced_wgs(int cfg, int n, const int* Mo, const int* No) {
   if (!Mo || !No || n < 1 || n > 4) return 0;
-  int total = 0;
-  for (int p = 0; p < n; ++p) total += ((Mo[p] + 127) / 128) * ((No[p] + 127) / 128);
+  if (cfg == 0) cfg = gemm_x3_wgrad_default_cfg();
+  const int total = wgrad_tiles(cfg, n, Mo, No);
   const int full = x3_grid(total, 0);
   const int rounds = (total + full - 1) / full;
   const int wgs = ((total + rounds - 1) / rounds + 7) / 8 * 8;
@@ -1188,8 +1377,8 @@ extern "C" int uniter_wgrad_x3_group_riders(int cfg, int n, const int* M, const 
                                             uniter_x3_riders_t* riders, void* stream) {
   return gemm_x3_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, overwrite, max_wgs, riders);
 }
-extern "C" int uniter_wgrad_x3_group_slots(int n, const int* M, const int* N, int max_wgs) {
-  return gemm_x3_wgrad_group_slots(n, M, N, max_wgs);
+extern "C" int uniter_wgrad_x3_group_slots(int cfg, int n, const int* M, const int* N, int max_wgs) {
+  return gemm_x3_wgrad_group_slots(cfg, n, M, N, max_wgs);
 }
 
 extern "C" int uniter_wgrad_x3_group(int cfg, int n, const int* M, const int* N, int K, const void* const* A,

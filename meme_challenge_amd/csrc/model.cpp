@@ -36,12 +36,14 @@ int gemm_f32_wgrad_group(int n, const int* Mo, const int* No, int K, const float
                          float* const* dW, int overwrite, void* stream);
 int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, int psa,
                 const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* Cx, int ldcx, int pscx,
-                int epilogue, const float* bias, const float* aux_in, float* aux_out, int ld_aux, void* stream);
+                int epilogue, const float* bias, const float* aux_in, float* aux_out, int ld_aux, void* stream,
+                float* colsum_part);
+int gemm_x3_wgrad_default_cfg();
 int gemm_x3_pick_split(int M, int N, int K);
 int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A, const void* const* B,
                         float* const* dW, void* stream, int overwrite, int max_wgs, uniter_x3_riders_t* riders);
-int gemm_x3_wgrad_group_slots(int n, const int* Mo, const int* No, int max_wgs);
-int gemm_x3_wgrad_group_balanced_wgs(int n, const int* Mo, const int* No);
+int gemm_x3_wgrad_group_slots(int cfg, int n, const int* Mo, const int* No, int max_wgs);
+int gemm_x3_wgrad_group_balanced_wgs(int cfg, int n, const int* Mo, const int* No);
 int gemm_bf16v2_pick_split(int M, int N, int K);
 int gemm_bf16v2_wgrad_pieces(int M, int N, int K);
 int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A,
@@ -151,6 +153,7 @@ struct uniter_model {
   uint32_t offset = 0;
   hipStream_t st = nullptr, side = nullptr;
   bool bwd_open = false;
+  int cu_reserve = 0;             // uniter_model_set_cu_reserve: CUs the persistent launches of this model's calls leave free
   hipStream_t aux = nullptr;      // uniter_model_set_aux_stream: launches that depend on nothing the step computes (dropout keep flags)
   hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr;
   double* norm_parts = nullptr;   // uniter_model_set_norm_partials: layer l's clip-norm partial sums at norm_parts + l * norm_stride
@@ -352,13 +355,14 @@ bool attn_b16x(int L, float p_drop, bool keep_flags_ready) {
 // precision 3: A = x3 activations [M][3][K]; W = the piece-major x3 mirror of an encoder weight (row stride ldw, piece stride =
 // the flat parameter buffer's length); outputs fp32 (nsplit slabs) or x3 [M][3][N]; aux operands fp32 (csrc/gemm_split3.hip)
 int gemm_x3(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, int K, const void* A, const unsigned short* W,
-            int ldw, float* C, int nsplit, unsigned short* Cx, int epi, const float* bias, const float* aux_in, float* aux_out) {
+            int ldw, float* C, int nsplit, unsigned short* Cx, int epi, const float* bias, const float* aux_in, float* aux_out,
+            float* colsum_part = nullptr) {
   ProfScope ps(m, kind, st);
   static const int cfg = [] { const char* e = getenv("UNITER_X3_CFG"); return e ? atoi(e) : 0; }();
   static const int main_prio = [] { const char* e = getenv("UNITER_MAIN_PRIO_X3"); return e ? atoi(e) : 0; }();
   g_uniter_launch_prio = main_prio;
   return gemm_x3_run(cfg, nsplit, 0, bkm, M, N, K, A, 3 * K, K, W, ldw, (int)m->mirror_numel, C, N, (long)M * N, Cx, 3 * N, N, epi,
-                     bias, aux_in, aux_out, N, st);
+                     bias, aux_in, aux_out, N, st, colsum_part);
 }
 // precision 3: side work of a layer's backward rides on its grouped weight-gradient launch (default geometry only)
 bool x3_riders_enabled() {
@@ -369,15 +373,26 @@ bool x3_riders_enabled() {
   }();
   return on;
 }
-// precision 2: the same riders on the grouped bf16 weight-gradient launch (UNITER_B16_RIDERS=0: separate launches)
+// precision 3: dU's column sums (the bias gradient of intermediate.dense) as column partials of the product that writes dU + a
+// reduction job of the riders, instead of ones-MFMAs in the weight-gradient launch: whenever that launch runs on 128 x 256 tiles
+bool x3_colpart_on() {
+  static const bool cfg_ok = [] { const char* c = getenv("UNITER_X3_CFG"); return !c || atoi(c) == 0 || atoi(c) >= 3; }();
+  return x3_riders_enabled() && cfg_ok && gemm_x3_wgrad_default_cfg() == 4;
+}
+// precision 2: the same riders on the grouped bf16 weight-gradient launch -- built, parity-tested, and OFF by default
+// (UNITER_B16_RIDERS=1 switches them on): measured 4.42 -> 4.51 ms per step, two same-box pairs.  In this mode the two backward
+// streams really overlap (two 64-KB workgroups share a CU) and the weight-gradient stream idles half of every layer: the separate
+// column-sum / finalize / sum-of-squares launches cost the step nothing there, while the riders lengthen the launch the
+// input-gradient chain shares its CUs with (the fp32x3 mode is the opposite case: its streams serialise, every launch is step time)
 bool b16_riders_enabled() {
-  static const bool on = [] { const char* e = getenv("UNITER_B16_RIDERS"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = getenv("UNITER_B16_RIDERS"); return e && e[0] == '1'; }();
   return on;
 }
 // the side work of layer l's backward as riders of its grouped weight-gradient launch (product 0 must be dW1 = dU^T y1: its A
 // operand's column sums are intermediate.dense's bias gradient)
-void fill_layer_riders(uniter_x3_riders_t& x, const uniter_model* m, int l, const LayerBufs& lb, int M, int B, int H, bool fused_qb) {
-  x.colsum_out = m->LG(l, L_B1);
+void fill_layer_riders(uniter_x3_riders_t& x, const uniter_model* m, int l, const LayerBufs& lb, int M, int B, int H, bool fused_qb,
+                       bool colpart = false) {
+  x.colsum_out = colpart ? nullptr : m->LG(l, L_B1);
   const int lnp = ln_bwd_partial_rows(M);
   x.njobs = fused_qb ? 3 : 2;
   x.part[0] = (const float*)lb.ln_ws2; x.part[1] = (const float*)lb.ln_ws1; x.part[2] = lb.qb_part;
@@ -388,6 +403,14 @@ void fill_layer_riders(uniter_x3_riders_t& x, const uniter_model* m, int l, cons
   x.out[0][0] = m->LG(l, L_LN2_G); x.out[0][1] = m->LG(l, L_LN2_B); x.out[0][2] = m->LG(l, L_B2);
   x.out[1][0] = m->LG(l, L_LN1_G); x.out[1][1] = m->LG(l, L_LN1_B); x.out[1][2] = m->LG(l, L_OB);
   x.out[2][0] = m->LG(l, L_QB);
+  if (!fused_qb) {      // (no per-sample query|key|value partials: the column-partial job, if any, takes slot 2)
+    x.part[2] = nullptr; x.out[2][0] = nullptr;
+  }
+  if (colpart) {
+    const int j = x.njobs++, I = m->cfg.intermediate_size;
+    x.part[j] = lb.du_csum; x.nparts[j] = (M + 63) / 64; x.stride[j] = I; x.n[j] = I; x.seg[j] = I;
+    x.out[j][0] = m->LG(l, L_B1); x.out[j][1] = x.out[j][2] = nullptr;
+  }
 }
 int split_x3(const float* src, unsigned short* dst, int rows, int cols, hipStream_t st) {
   return uniter_split3(src, rows, cols, cols, dst, (size_t)3 * cols, (size_t)cols, st);
@@ -548,6 +571,7 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
                                     int all_layers, int train, uint64_t seed, uint32_t offset, void* ws,
                                     size_t ws_bytes, void* stream) {
   UCHECK_ARG(m && hidden_out && ws, "model_forward: null pointer");
+  g_uniter_cu_reserve = m->cu_reserve;
   UCHECK_ARG(train >= 0 && train <= 2, "model_forward: train must be 0, 1 or 2");
   UCHECK_RC(validate_batch(m, b));
   UCHECK_ARG(((uintptr_t)ws & 255) == 0, "model_forward: workspace must be 256-byte aligned");
@@ -795,6 +819,7 @@ extern "C" int uniter_model_backward_begin(uniter_model_t* m, const uniter_batch
 
 extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   UCHECK_ARG(m, "backward_layer: null model");
+  g_uniter_cu_reserve = m->cu_reserve;
   if (!m->bwd_open) { uniter_set_error("backward_layer: call uniter_model_backward_begin first"); return UNITER_E_STATE; }
   const uniter_config_t& c = m->cfg;
   const int H = c.hidden_size, I = c.intermediate_size, nl = c.num_hidden_layers, nh = c.num_attention_heads;
@@ -866,8 +891,10 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
                       UNITER_EPI_ADD, nullptr, lb.dz2, 0, nullptr, 0, H));
   } else if (x3) {
     // dU = (g2 . W2) * gelu'(u) exists only as x3 pieces: operand of the next product and of intermediate.dense's weight gradient
+    // (with riders on the 128 x 256 weight-gradient geometry the bias gradient of intermediate.dense -- dU's column sums -- starts
+    // here: one row of partial sums per 64 rows of dU, finished by a reduction job of the riders)
     UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, I, H, lb.g2b, m->WB(l, L_W2), I, nullptr, 1, lb.dub, UNITER_EPI_MUL,
-                      nullptr, lb.u, nullptr));
+                      nullptr, lb.u, nullptr, x3_colpart_on() ? lb.du_csum : nullptr));
     UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, I, lb.dub, m->WB(l, L_W1), H, lb.dy1, pl.ns_ki, nullptr, UNITER_EPI_ADD,
                       nullptr, lb.dz2, nullptr));
   } else {
@@ -997,9 +1024,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
       const void* const As[4] = {lb.dub, lb.g2b, lb.dqkvb, lb.g1b};
       const void* const Bs[4] = {lb.y1b, lb.hactb, xb, lb.ctxb};
       float* const dWs[4] = {m->LG(l, L_W1), m->LG(l, L_W2), m->LG(l, L_QW), m->LG(l, L_OW)};
-      // layer 0's launch runs beside the embedding backward's row passes: the smallest grid that takes no more rounds (see precision 3)
-      static const bool wgs_forced = getenv("UNITER_WGRAD_GROUP_WGS") != nullptr;
-      const int b16_wgs = (l == 0 && !wgs_forced) ? gemm_bf16v2_wgrad_group_balanced_wgs(4, Mo, No) : 0;
+      const int b16_wgs = 0;      // (the grid cap of UNITER_WGRAD_GROUP_WGS / its default)
       if (riders_b16) {
         uniter_x3_riders_t x;
         memset(&x, 0, sizeof(x));
@@ -1040,20 +1065,20 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     // smallest grid that needs no more rounds (432 tiles: 216 workgroups walk two tiles each, as 256 would) leaves 40 CUs to
     // those passes -- their 190-register waves find no room on a CU a persistent 144-KB workgroup holds (img_embed_bwd 112 us
     // for 576 rows when it has to wait for one).  UNITER_WGRAD_X3_WGS = n forces a grid for every layer (0 = one per CU)
-    const int x3_wgs = x3_wgs_env >= 0 ? x3_wgs_env : (l == 0 ? gemm_x3_wgrad_group_balanced_wgs(4, Mo, No) : 0);
+    const int x3_wgs = x3_wgs_env >= 0 ? x3_wgs_env : (l == 0 ? gemm_x3_wgrad_group_balanced_wgs(0, 4, Mo, No) : 0);
     if (riders_on) {
       // product 0 is dW1 = dU^T y1: its A operand's column sums are intermediate.dense's bias gradient
       uniter_x3_riders_t x;
       memset(&x, 0, sizeof(x));
-      const int slots = gemm_x3_wgrad_group_slots(4, Mo, No, x3_wgs);
+      const int slots = gemm_x3_wgrad_group_slots(0, 4, Mo, No, x3_wgs);
       if (m->norm_parts) {
         UCHECK_ARG((size_t)slots <= m->norm_stride, "backward_layer: %d clip-norm slots per layer, room for %zu (uniter_model_set_norm_partials)",
                    slots, m->norm_stride);
         x.ssq = m->norm_parts + (size_t)l * m->norm_stride;
       }
-      fill_layer_riders(x, m, l, lb, M, B, H, fused_qb);
+      fill_layer_riders(x, m, l, lb, M, B, H, fused_qb, x3_colpart_on());
       ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-      UCHECK_RC(gemm_x3_wgrad_group(x3_cfg, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, x3_wgs, &x));
+      UCHECK_RC(gemm_x3_wgrad_group(x3_cfg == 3 ? 3 : 0, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, x3_wgs, &x));
     } else {
       {
         ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
@@ -1106,6 +1131,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
 
 extern "C" int uniter_model_backward_embed(uniter_model_t* m) {
   UCHECK_ARG(m, "backward_embed: null model");
+  g_uniter_cu_reserve = m->cu_reserve;
   if (!m->bwd_open) { uniter_set_error("backward_embed: call uniter_model_backward_begin first"); return UNITER_E_STATE; }
   const uniter_config_t& c = m->cfg;
   const int H = c.hidden_size;
@@ -1156,6 +1182,12 @@ extern "C" int uniter_model_backward_embed(uniter_model_t* m) {
   return 0;
 }
 
+extern "C" int uniter_model_set_cu_reserve(uniter_model_t* m, int cus) {
+  UCHECK_ARG(m && cus >= 0 && cus <= 128, "set_cu_reserve: 0 .. 128 CUs");
+  m->cu_reserve = cus;
+  return 0;
+}
+
 extern "C" int uniter_model_set_aux_stream(uniter_model_t* m, void* aux_stream) {
   UCHECK_ARG(m, "set_aux_stream: null model");
   m->aux = (hipStream_t)aux_stream;
@@ -1180,7 +1212,7 @@ extern "C" int uniter_model_norm_partials_per_layer(const uniter_model_t* m) {
   }
   if (m->precision != 3 || !x3_riders_enabled()) return 0;
   static const int x3_wgs = [] { const char* e = getenv("UNITER_WGRAD_X3_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
-  return gemm_x3_wgrad_group_slots(4, Mo, No, x3_wgs);
+  return gemm_x3_wgrad_group_slots(0, 4, Mo, No, x3_wgs);
 }
 
 extern "C" int uniter_model_set_wgrad_overwrite(uniter_model_t* m, int on) {

@@ -45,12 +45,12 @@ __device__ __forceinline__ float riders_reduce_item(const uniter_x3_riders_t& x,
   return ss;
 }
 
-// the wave's sum of squares into its slot: 4 slots per workgroup
-__device__ __forceinline__ void riders_store_ssq(const uniter_x3_riders_t& x, double wss, int wave, int lane) {
+// the wave's sum of squares into its slot: `nw` slots per workgroup (4, or the 8 compute waves of a 128 x 256 tile)
+__device__ __forceinline__ void riders_store_ssq(const uniter_x3_riders_t& x, double wss, int wave, int lane, int nw = 4) {
   if (x.ssq) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wss += __shfl_xor(wss, o, 64);
-    if (lane == 0) x.ssq[(size_t)blockIdx.x * 4 + wave] = wss;
+    if (lane == 0) x.ssq[(size_t)blockIdx.x * nw + wave] = wss;
   }
 }
 #endif

@@ -327,7 +327,25 @@ class GradSync(object):
         self.launched.append((s, e))
 
 
-def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embeddings=None, accum=1):
+DEFAULT_CU_RESERVE = 16      # CUs left to RCCL's kernels beside the backward pass (world > 1); UNITER_DP_CU_RESERVE overrides
+
+
+def cu_reserve_default(world):
+    """CUs the persistent matrix kernels leave free while a gradient exchange is attached: UNITER_DP_CU_RESERVE, else 16 with more
+    than one rank (RCCL runs one workgroup per channel; its kernels -- 256 threads, ~100 registers per lane: they do not fit beside
+    a persistent 144-KB GEMM workgroup on the same CU -- otherwise take CUs as GEMM workgroups exit and strand the launch's last
+    workgroups behind them), 0 on one rank.  NCCL_MAX_NCHANNELS is set to the same number when the caller left it alone (bench.py,
+    the CLI: before the process group exists), so RCCL asks for what was reserved."""
+    e = os.environ.get('UNITER_DP_CU_RESERVE')
+    if e is not None:
+        try:
+            return max(0, min(128, int(e)))
+        except ValueError:
+            return 0
+    return DEFAULT_CU_RESERVE if world > 1 else 0
+
+
+def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embeddings=None, accum=1, cu_reserve=None):
     """Wire a GradSync to a MemeUniter, UniterForPretraining or UniterModel and return it.
     payload None: 'bf16' when the encoder runs in the bf16 precision mode, else 'fp32'.
     accum: the trainer's gradient_accumulation (sizes the sparse exchange for a full window of micro-batches).
@@ -351,6 +369,9 @@ def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embedd
     gs = GradSync(store.flat_grads, store.bucket_ranges, group=group, bucket_bytes=bucket_bytes, payload=payload,
                   word_table=word_table, accum=accum)
     um._grad_hook = gs.hook
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    gs.cu_reserve = cu_reserve_default(world) if cu_reserve is None else int(cu_reserve)
+    um.cu_reserve = gs.cu_reserve
     return gs
 
 

@@ -547,6 +547,7 @@ class _UniterFn(torch.autograd.Function):
         nbytes = lib.uniter_model_ws_bytes(model._handle, B, batch.T if batch.input_ids else 0,
                                            batch.R if batch.img_feat else 0, L, mode)
         ws = model._get_ws(nbytes, mode)
+        check(lib.uniter_model_set_cu_reserve(model._handle, int(getattr(model, 'cu_reserve', 0))), 'uniter_model_set_cu_reserve')
         if mode != 0 and model.use_side_stream and os.environ.get('UNITER_AUX_STREAM') != '0':
             # the dropout keep flags of the attention are drawn beside the head of the forward pass, on a third stream
             aux = _lib.shared_stream(dev, 'aux')
@@ -652,6 +653,8 @@ class UniterModel(UniterPreTrainedModel):
         # (device double buffer, doubles per layer): where the fp32x3 backward leaves each layer's clip-norm partial sums
         # (uniter_model_set_norm_partials; trainer.FusedAdam.attach_norm_hooks); None = nobody asked
         self._norm_parts = None
+        # CUs the persistent matrix kernels leave to the kernels of a data-parallel gradient exchange (dp.attach sets it)
+        self.cu_reserve = 0
         self._side_stream = None
         self.use_side_stream = True
         # 'fp32'; 'bf16': bf16 MFMA GEMMs on bf16-resident operands (weight mirror + bf16 activation copies),

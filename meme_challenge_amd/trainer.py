@@ -162,7 +162,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     NORM_BLOCKS = 256           # workgroups (= partial sums) per layer slice, on the side stream beside the input-gradient chain
     NORM_BLOCKS_LAST = 2048     # the embeddings' slice runs alone behind the backward pass: the whole chip
-    FUSED_SLOTS = 1024          # fp32x3: slots a layer's weight-gradient launch writes itself (4 per workgroup, one workgroup per CU)
+    FUSED_SLOTS = 2048          # fp32x3 / bf16: slots a layer's weight-gradient launch writes itself (one per compute wave: up to 8 x 256)
 
     def attach_norm_hooks(self, encoder):
         """Take the clip norm (clip_grad_norm_, train_template.py:104) slice by slice DURING the backward pass: the

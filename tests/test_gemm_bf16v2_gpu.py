@@ -210,6 +210,80 @@ def test_weight_gradient_group(cfg, shapes, K):
         assert torch.equal(c, c2)
 
 
+@pytest.mark.parametrize('shapes,K,wgs', [([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 2624, 0),
+                                          ([(256, 64), (64, 256), (192, 64), (64, 64)], 1458, 0),
+                                          ([(136, 200), (256, 128), (8, 8)], 200, 0),
+                                          ([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 333, 216)])
+@pytest.mark.parametrize('overwrite', [0, 1])
+def test_weight_gradient_group_riders(shapes, K, wgs, overwrite):
+    """The riders of the grouped bf16 weight-gradient launch (uniter_wgrad_bf16_group_riders; the same block as the fp32x3
+    launch's, tests/test_gemm_x3_gpu.py): dW bit-identical to the plain launch; colsum_out += column sums of product 0's A operand;
+    three column-reduction jobs; the sum of squares of everything written as 4 x grid partial sums; reproducible."""
+    import ctypes
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(len(shapes) * 77 + K)
+    As = [torch.randn(K, M, generator=g).bfloat16().cuda() for M, N in shapes]
+    Bs = [(torch.randn(K, N, generator=g) * 0.05).bfloat16().cuda() for M, N in shapes]
+    C0 = [torch.randn(M, N, generator=g).cuda() for M, N in shapes]
+    Ms, Ns = [m for m, _ in shapes], [n for _, n in shapes]
+    n = len(shapes)
+    H = 192
+    parts = [torch.randn(328, 3 * H, generator=g).cuda(), torch.randn(5, 3 * H, generator=g).cuda(), torch.randn(70, 3 * H, generator=g).cuda()]
+    job_n, job_seg, job_nout = [3 * H, 3 * H, H + 8], [H, 3 * H, H], [3, 1, 2]
+    out0 = [[torch.randn(H, generator=g).cuda() for _ in range(3)], [torch.randn(3 * H, generator=g).cuda()],
+            [torch.randn(H, generator=g).cuda(), torch.randn(H, generator=g).cuda()]]
+    cs0 = torch.randn(Ms[0], generator=g).cuda()
+    IA, PA = ctypes.c_int * n, ctypes.c_void_p * n
+    slots = lib.uniter_wgrad_bf16_group_slots(n, IA(*Ms), IA(*Ns), wgs)
+    assert slots > 0 and slots % 32 == 0
+
+    def run(with_riders):
+        Cs = [c.clone() for c in C0]
+        outs = [[o.clone() for o in job] for job in out0]
+        cs = cs0.clone()
+        ssq = torch.full((slots,), float('nan'), dtype=torch.float64, device='cuda')
+        x = L.X3RidersC()
+        if with_riders:
+            x.ssq, x.colsum_out, x.njobs = ssq.data_ptr(), cs.data_ptr(), 3
+            for j in range(3):
+                x.part[j] = parts[j].data_ptr(); x.nparts[j] = parts[j].shape[0]; x.stride[j] = 3 * H
+                x.n[j] = job_n[j]; x.seg[j] = job_seg[j]
+                for o in range(job_nout[j]):
+                    x.out[j][o] = outs[j][o].data_ptr()
+        L.check(lib.uniter_wgrad_bf16_group_riders(0, n, IA(*Ms), IA(*Ns), K, PA(*[a.data_ptr() for a in As]),
+                                                   PA(*[b.data_ptr() for b in Bs]), PA(*[c.data_ptr() for c in Cs]), overwrite,
+                                                   wgs, ctypes.byref(x) if with_riders else None, L.cur_stream()), 'wgrad_bf16_group_riders')
+        torch.cuda.synchronize()
+        if with_riders:
+            assert x.grid * 4 == slots and x.nred == sum((k + 63) // 64 for k in job_n)
+        return Cs, outs, cs, ssq
+
+    plain = run(False)
+    a, b = run(True), run(True)
+    for c_plain, c_a, c_b in zip(plain[0], a[0], b[0]):
+        assert torch.equal(c_plain, c_a) and torch.equal(c_a, c_b)
+    assert torch.equal(a[3], b[3]) and torch.isfinite(a[3]).all()
+    total = 0.0
+    ref = cs0.double().cpu() + As[0].double().cpu().sum(0)
+    assert (a[2].double().cpu() - ref).abs().max().item() < 2e-6 * math.sqrt(K) * 4 and torch.equal(a[2], b[2])
+    total += float((a[2].double() ** 2).sum())
+    for j in range(3):
+        full = parts[j].double().cpu().sum(0)[:job_n[j]]
+        for o in range(job_nout[j]):
+            seg = full[o * job_seg[j]:(o + 1) * job_seg[j]]
+            exp = out0[j][o].double().cpu().clone()
+            exp[:seg.numel()] += seg
+            assert (a[1][j][o].double().cpu() - exp).abs().max().item() < 1e-5 * math.sqrt(parts[j].shape[0]), (j, o)
+            if seg.numel() < exp.numel():
+                assert torch.equal(a[1][j][o][seg.numel():], out0[j][o][seg.numel():])
+            total += float((a[1][j][o][:seg.numel()].double() ** 2).sum())
+    for c in a[0]:
+        total += float((c.double() ** 2).sum())
+    got = float(a[3].sum())
+    assert abs(got - total) <= 1e-6 * total, (got, total)
+
+
 def test_weight_gradient_group_rejects_bad_arguments():
     from meme_challenge_amd import _lib as L
     lib = L.lib()

@@ -162,10 +162,12 @@ def _run(cfg, akm, bkm, M, N, K, epi, nsplit=1, out='f32', piece_major_b=False, 
         assert (auxo.double().cpu() - aux_ref).abs().max().item() < tol, tag
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 3])
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
 @pytest.mark.parametrize('layout', [(0, 0), (0, 1), (1, 1)], ids=['forward', 'dgrad', 'wgrad'])
 def test_layouts_and_edges(cfg, layout):
     akm, bkm = layout
+    if cfg == 4 and akm:
+        pytest.skip('cfg 4 (128 x 256 tiles) is a forward / input-gradient geometry: weight gradients keep whole-K 128 x 128 tiles')
     _run(cfg, akm, bkm, M=168, N=192, K=128, epi=EPI_NONE)                      # ragged M, N not a tile multiple
     _run(cfg, akm, bkm, M=320, N=264, K=192, epi=EPI_NONE)                      # N % 8 == 0 only
     _run(cfg, akm, bkm, M=64, N=128, K=32, epi=EPI_NONE)                        # one k-tile
@@ -176,18 +178,21 @@ def test_layouts_and_edges(cfg, layout):
         _run(cfg, 1, 1, M=128, N=256, K=1458, epi=EPI_ADD)                      # ragged K, dW += (aux = prior value)
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 3])
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
 def test_epilogues_and_outputs(cfg):
     for epi in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_D):
         for out in ('f32', 'x3', 'both'):
             _run(cfg, 0, 0, M=200, N=256, K=128, epi=epi, out=out)
+            _run(cfg, 0, 0, M=264, N=520, K=96, epi=epi, out=out)
     for epi in (EPI_NONE, EPI_ADD, EPI_MUL):
         for out in ('f32', 'x3', 'both'):
             _run(cfg, 0, 1, M=200, N=256, K=128, epi=epi, out=out)
-    _run(cfg, 1, 1, M=200, N=256, K=128, epi=EPI_ADD)
+            _run(cfg, 0, 1, M=264, N=520, K=96, epi=epi, out=out)
+    if cfg != 4:
+        _run(cfg, 1, 1, M=200, N=256, K=128, epi=EPI_ADD)
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 3])
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
 @pytest.mark.parametrize('nsplit', [2, 3, 4])
 def test_split_k_slabs(cfg, nsplit):
     _run(cfg, 0, 0, M=300, N=256, K=640, epi=EPI_BIAS, nsplit=nsplit)
@@ -218,7 +223,7 @@ def _group_call(cfg, Ms, Ns, K, As, Bs, Cs, overwrite, max_wgs=0):
                                          PA(*[c.data_ptr() for c in Cs]), overwrite, max_wgs, L.cur_stream())
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 3])
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
 @pytest.mark.parametrize('shapes,K', [([(128, 128)], 64), ([(136, 200), (256, 128), (8, 8)], 200),
                                       ([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 2624),
                                       ([(256, 64), (64, 256), (192, 64), (64, 64)], 1458)])
@@ -250,7 +255,8 @@ def test_weight_gradient_group(cfg, shapes, K):
                                           ([(136, 200), (256, 128), (8, 8)], 200, 0),
                                           ([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 333, 64)])
 @pytest.mark.parametrize('overwrite', [0, 1])
-def test_weight_gradient_group_riders(shapes, K, wgs, overwrite):
+@pytest.mark.parametrize('cfg', [3, 4])
+def test_weight_gradient_group_riders(cfg, shapes, K, wgs, overwrite):
     """The riders of the grouped weight-gradient launch (uniter_wgrad_x3_group_riders): the same dW as the plain launch bit for
     bit; colsum_out += the column sums of product 0's A operand (fp64 reference); three column-reduction jobs with one, three
     and two outputs (fp64 reference; columns that are no multiple of 64, more partial rows than slices and fewer); and the sum
@@ -273,8 +279,12 @@ def test_weight_gradient_group_riders(shapes, K, wgs, overwrite):
     out0 = [[torch.randn(H, device='cuda', generator=g) for _ in range(3)], [torch.randn(3 * H, device='cuda', generator=g)],
             [torch.randn(H, device='cuda', generator=g), torch.randn(H, device='cuda', generator=g)]]
     cs0 = torch.randn(Ms[0], device='cuda', generator=g)
+    cpart = Af[0].reshape(-1, Af[0].shape[1])[:(K // 8) * 8].reshape(8, -1, Ms[0]).sum(1) if K >= 8 else Af[0]
+    if K % 8:
+        cpart = torch.cat([cpart, Af[0][(K // 8) * 8:].sum(0, keepdim=True)], 0)
+    cpart = cpart.contiguous()                       # partial rows whose sum is the column sum of product 0's A operand
     IA, PA = ctypes.c_int * n, ctypes.c_void_p * n
-    slots = L.lib().uniter_wgrad_x3_group_slots(n, IA(*Ms), IA(*Ns), wgs)
+    slots = L.lib().uniter_wgrad_x3_group_slots(cfg, n, IA(*Ms), IA(*Ns), wgs)
     assert slots > 0 and slots % 32 == 0
 
     def run(with_riders):
@@ -284,18 +294,25 @@ def test_weight_gradient_group_riders(shapes, K, wgs, overwrite):
         ssq = torch.full((slots,), float('nan'), dtype=torch.float64, device='cuda')
         if with_riders:
             x = L.X3RidersC()
-            x.ssq, x.colsum_out, x.njobs = ssq.data_ptr(), cs.data_ptr(), 3
+            # cfg 3: the column sums by ones-MFMAs; cfg 4 (128 x 256 tiles: no registers for that): a fourth reduction job over
+            # partial rows -- what the producing product's column partials (uniter_gemm_x3_colpart) hand to the riders
+            x.ssq, x.njobs = ssq.data_ptr(), 4 if cfg == 4 else 3
+            if cfg == 3:
+                x.colsum_out = cs.data_ptr()
+            else:
+                x.part[3] = cpart.data_ptr(); x.nparts[3] = cpart.shape[0]; x.stride[3] = Ms[0]; x.n[3] = Ms[0]; x.seg[3] = Ms[0]
+                x.out[3][0] = cs.data_ptr()
             for j in range(3):
                 x.part[j] = parts[j].data_ptr(); x.nparts[j] = parts[j].shape[0]; x.stride[j] = 3 * H
                 x.n[j] = job_n[j]; x.seg[j] = job_seg[j]
                 for o in range(job_nout[j]):
                     x.out[j][o] = outs[j][o].data_ptr()
-            L.check(L.lib().uniter_wgrad_x3_group_riders(0, n, IA(*Ms), IA(*Ns), K, PA(*[a.data_ptr() for a in As]),
+            L.check(L.lib().uniter_wgrad_x3_group_riders(cfg, n, IA(*Ms), IA(*Ns), K, PA(*[a.data_ptr() for a in As]),
                                                          PA(*[b.data_ptr() for b in Bs]), PA(*[c.data_ptr() for c in Cs]), overwrite,
                                                          wgs, ctypes.byref(x), L.cur_stream()), 'wgrad_x3_group_riders')
-            assert x.grid * 4 == slots and x.nred == sum((k + 63) // 64 for k in job_n)
+            assert x.grid * (8 if cfg == 4 else 4) == slots and x.nred == sum((k + 63) // 64 for k in job_n) + ((Ms[0] + 63) // 64 if cfg == 4 else 0)
         else:
-            L.check(_group_call(0, Ms, Ns, K, As, Bs, Cs, overwrite, wgs), 'wgrad_x3_group')
+            L.check(_group_call(cfg, Ms, Ns, K, As, Bs, Cs, overwrite, wgs), 'wgrad_x3_group')
         torch.cuda.synchronize()
         return Cs, outs, cs, ssq
 
@@ -307,7 +324,7 @@ def test_weight_gradient_group_riders(shapes, K, wgs, overwrite):
     total = 0.0
     # column sums of product 0's A operand
     ref = cs0.double().cpu() + Af[0].double().cpu().sum(0)
-    assert (a[2].double().cpu() - ref).abs().max().item() < 2e-6 * math.sqrt(K) * 4 and torch.equal(a[2], b[2])
+    assert (a[2].double().cpu() - ref).abs().max().item() < 2e-6 * math.sqrt(K) * 4 * (4 if cfg == 4 else 1) and torch.equal(a[2], b[2])
     total += float((a[2].double() ** 2).sum())
     for j in range(3):
         full = parts[j].double().cpu().sum(0)[:job_n[j]]
@@ -375,6 +392,34 @@ def test_extreme_operands_are_no_less_accurate_than_the_fp32_mfma_kernel(case, l
     # (an fp32 result below 2^-126 is itself subnormal: both kernels are then compared on what fp32 can hold)
     floor = 2.0 ** -149
     assert e[0] <= 1.5 * e32[0] + floor and e[1] <= 1.5 * e32[1] + floor, (name, layout, e, e32, scale)
+
+
+@pytest.mark.parametrize('cfg', [0, 3, 4])
+@pytest.mark.parametrize('M,N,K', [(2624, 3072, 768), (200, 264, 96), (64, 520, 64)])
+def test_column_partials_of_the_mul_epilogue(cfg, M, N, K):
+    """uniter_gemm_x3_colpart: dU = (A . W) * aux as x3 pieces AND, per 64 output rows, the column sums of those rows: the sum over
+    the partial rows is the column sum of dU (the bias gradient of the layer that produced dU) -- against float64; the product
+    itself unchanged bit for bit."""
+    from meme_challenge_amd import _lib as L
+    A, B = _operands(0, 1, M, N, K, seed=M + K)
+    g = torch.Generator(device='cuda').manual_seed(9)
+    aux = torch.randn(M, N, device='cuda', generator=g)
+    A3, B3 = split3(A), split3(B)
+    Cx = torch.empty(M, 3, N, dtype=torch.bfloat16, device='cuda'); Cx2 = torch.empty_like(Cx)
+    rows = (M + 63) // 64 + 1
+    part = torch.full((rows, N), float('nan'), device='cuda')
+    L.check(L.lib().uniter_gemm_x3_colpart(cfg, 0, 1, M, N, K, L.ptr(A3), 3 * K, K, L.ptr(B3), 3 * N, N, None, N, L.ptr(Cx), 3 * N, N,
+                                           L.ptr(aux), N, L.ptr(part), L.cur_stream()), 'gemm_x3_colpart')
+    L.check(x3_gemm(cfg, 1, 0, 1, M, N, K, A3, B3, None, Cx2, EPI_MUL, None, aux, None), 'gemm_x3')
+    torch.cuda.synchronize()
+    assert torch.equal(Cx, Cx2)
+    dU = join3(Cx).double().cpu()
+    got = part[:(M + 63) // 64].double().cpu()
+    assert torch.isfinite(got).all()
+    for i in range((M + 63) // 64):
+        ref = dU[64 * i:64 * i + 64].sum(0)
+        assert (got[i] - ref).abs().max().item() < 1e-5 * (1 + dU.abs().max().item()) * 8, i
+    assert (got.sum(0) - dU.sum(0)).abs().max().item() < 1e-4 * (1 + dU.abs().max().item()) * math.sqrt(M)
 
 
 def test_below_the_exact_split_range_the_error_grows_gracefully():

@@ -112,7 +112,7 @@ def test_overlapped_optimizer_step_matches_single_launch():
     assert diff <= max(4 * noise, 5e-6), (diff, noise)
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'fp32x3', 'switch'])
+@pytest.mark.parametrize('precision', ['fp32', 'fp32x3', 'bf16', 'switch'])
 def test_clip_norm_taken_during_backward_equals_the_full_pass(precision):
     """(fp32x3: every layer's share of the norm is left by the layer's own weight-gradient launch, its riders -- no reduction
     launch per layer; 'switch': the precision changes between steps, as in bench.py's native-fp32 leg: the slots the other form
@@ -143,11 +143,11 @@ def test_clip_norm_taken_during_backward_equals_the_full_pass(precision):
             m.uniter_model._grad_hook = None
         seen = []
         for it in range(5):
-            m.uniter_model.precision = {'switch': ('fp32x3', 'fp32x3', 'fp32', 'fp32x3', 'fp32x3')[it]}.get(precision, precision)
+            m.uniter_model.precision = {'switch': ('fp32x3', 'bf16', 'fp32', 'fp32x3', 'bf16')[it]}.get(precision, precision)
             step.train_iter(bs[it % 2], iters=it)
             seen.append(opt._sumsq.clone())
         torch.cuda.synchronize()
-        if hooked and precision != 'fp32':
+        if hooked and precision == 'fp32x3':
             assert m.uniter_model.norm_partials_per_layer() > 0          # the riders carried the layers' shares
         finals[hooked], norms[hooked] = m.param_store().flat_params.clone(), torch.cat(seen)
     assert float(norms[True].min()) > 0 and float(norms[True].sqrt().min()) > config['max_grad_norm']     # the clip was active
