@@ -282,6 +282,9 @@ def parse_args(argv=None):
     ap.add_argument('--no_adam_overlap', action='store_true',
                     help='run the optimizer step as one launch on the main stream instead of block by block beside the next forward')
     ap.add_argument('--prof_kind', type=int, default=-1, help='UNITER_K_* kind timed with HIP events inside the timed region (-1 = every kind, 0 = none)')
+    ap.add_argument('--reserve_ab', action='store_true',
+                    help='with a gradient exchange attached: time the step once more with no CUs reserved for its kernels '
+                         '(comm.no_reserve; `value` is the default reserve, comm.cu_reserve)')
     ap.add_argument('--both_exchanges', action='store_true',
                     help='N > 1: time the other form of the word-embedding exchange too (a second timed region, listed in '
                          'comm.other_exchange; `value` is always the requested exchange)')
@@ -357,8 +360,11 @@ def run_rank(args):
         return _run_rank(args, real_stdout, state)
     finally:
         sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        os.close(real_stdout)
+        if not _AS_SCRIPT:
+            # an in-process caller keeps its stdout.  As a script the process ends here and descriptor 1 STAYS on stderr: RCCL
+            # prints its version banner through C stdio when the process exits, and the line on stdout must stay one line
+            os.dup2(real_stdout, 1)
+            os.close(real_stdout)
         if state['rccl_log']:
             try:
                 os.remove(state['rccl_log'])
@@ -396,6 +402,8 @@ def _run_rank(args, real_stdout, state):
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
+        from meme_challenge_amd import dp as _dp0
+        _dp0.prepare_rccl_env(world)         # RCCL asks for no more channels than the CUs the matrix kernels leave it (N > 1)
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -502,10 +510,44 @@ def _run_rank(args, real_stdout, state):
     if sync is not None:
         comm = comm_block(sync, args.steps, rccl_log if rank == 0 else None)
         comm['sparse_embeddings'] = bool(args.dp_sparse_embeddings)
+        # CUs the persistent matrix kernels leave to RCCL's kernels (dp.cu_reserve_default: UNITER_DP_CU_RESERVE, else 16 with more
+        # than one rank) and the channel cap RCCL was started with
+        comm['cu_reserve'] = int(getattr(sync, 'cu_reserve', 0))
+        comm['rccl_max_nchannels_env'] = os.environ.get('NCCL_MAX_NCHANNELS')
         # --both_exchanges (N > 1, finetune): the same timed region once more with the OTHER form of the word-embedding exchange
         # (dense table all-reduce <-> touched rows only).  `value` stays the REQUESTED exchange's; the other one is listed
         # beside it in comm.other_exchange.  Auxiliary: every rank runs it under try / except and the ranks agree on an ok
         # flag before anyone uses a figure of it -- a failure leaves the already-measured line untouched
+        if args.reserve_ab and args.workload == 'finetune':
+            # --reserve_ab: the same timed region with NO CUs reserved (every persistent launch on all 256), listed in
+            # comm.no_reserve; `value` stays the default's.  Guarded like --both_exchanges
+            ok, alt, err, dt3 = 1, None, None, 0.0
+            try:
+                encoder.cu_reserve = 0
+                for _ in range(max(3, args.warmup // 2)):
+                    one_step()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    one_step()
+                barrier()
+                dt3 = time.perf_counter() - t1
+            except Exception as e:                                   # noqa: BLE001
+                ok, err = 0, repr(e)
+            try:
+                flag = torch.tensor([float(ok), dt3], dtype=torch.float64, device=dev)
+                if use_dist:
+                    dist.all_reduce(flag[:1], op=dist.ReduceOp.MIN)
+                    dist.all_reduce(flag[1:], op=dist.ReduceOp.MAX)
+                ok, dt3 = int(flag[0].item()), float(flag[1].item())
+                if ok:
+                    alt = {'cu_reserve': 0, 'ms_per_step': round(dt3 / args.steps * 1e3, 3), 'value': round(B * world * args.steps / dt3, 2)}
+            except Exception as e:                                   # noqa: BLE001
+                alt, err = None, err or repr(e)
+            comm['no_reserve'] = alt if alt is not None else {'error': err or 'failed on another rank'}
+            encoder.cu_reserve = int(getattr(sync, 'cu_reserve', 0))
+            sync.collect_timings()
+            sync.timings = []
         if args.both_exchanges and world > 1 and args.workload == 'finetune':
             ok, alt, err = 1, None, None
             alt_sparse = not args.dp_sparse_embeddings
@@ -809,5 +851,8 @@ def optimizer_alone(out, opt, model):
                         'note': 'adam_kernel alone, 10 launches (after 2 warm-ups) behind the timed region, every chunk on the update path, gradients already zero (no clear stores)%s' % (', + %d B / parameter of weight mirror' % mirror_b if mirror_b else '')}
 
 
+_AS_SCRIPT = False
+
 if __name__ == '__main__':
+    _AS_SCRIPT = True
     sys.exit(main())

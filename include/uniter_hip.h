@@ -203,6 +203,12 @@ int uniter_gemm_x3_cfg(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, i
                        int psa, const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* C_x3,
                        int ldcx, int pscx, int epilogue, const float* bias, const float* aux_in, float* aux_out,
                        int ld_aux, void* stream);
+/* What uniter_gemm_x3_cfg (cfg 0) and the model's plan choose for a forward / input-gradient product on `avail_cus` CUs (0 = the
+ * chip's): tile geometry (3 = 128 x 128 persistent, 4 = 128 x 256) and k-pieces (nsplit_fixed > 0: the caller's; 0: 1..4 compete
+ * where N <= 1024).  Host-only arithmetic (no launch): the cost model of DESIGN.md section 4 -- rounds x k-tiles x time per
+ * k-tile + 4 us per slab.  With a data-parallel exchange holding CUs (uniter_model_set_cu_reserve) the backward pass is planned
+ * with it: 252-item forms that exactly fit 256 CUs would run two rounds on 240. */
+int uniter_gemm_x3_plan(int M, int N, int K, int avail_cus, int nsplit_fixed, int* cfg, int* nsplit);
 /* The weight gradients of one encoder layer in one launch on x3 operands (as uniter_wgrad_bf16_group): for p < n <= 4
  * dW[p] [M[p], N[p]] (fp32) (+)= A[p]^T B[p], A[p] x3 [K][3][M[p]], B[p] x3 [K][3][N[p]]; whole-K 128 x 128 tiles, no
  * atomics, bit-reproducible.  overwrite = 1 stores instead of adding; max_wgs > 0 caps the grid (the persistent

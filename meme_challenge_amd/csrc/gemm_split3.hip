@@ -884,7 +884,7 @@ void gemm_s3p_kernel(const S3Group G) {
         f.a.template tie_piece<2>(); f.b.template tie_piece<2>();
         if (!(dbg & 4)) { mma(f, I0{}, I2{}); mma(f, I2{}, I0{}); }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (XTR && AKM) {
+        if constexpr (XTR && AKM && NWC == 4) {
           if (colsum) {
             static_for<0, MB>([&](auto ac) {
               constexpr int A_ = decltype(ac)::value;
@@ -1003,6 +1003,10 @@ void plan_tiles3(S3Args& g, int BN) {
   const long panel = (long)BM * g.K * 6;
   long bh = (3l << 19) / (panel > 0 ? panel : 1);
   g.band_h = (int)(bh < 1 ? 1 : (bh > 16 ? 16 : bh));
+  // UNITER_X3_BAND_H: tile rows per band of the walk (lab switch: how many row panels an XCD's chunk of the walk spans decides how
+  // often the eight L2s fetch the same operand panels -- VERDICT r04 item 7)
+  static const int band_env = [] { const char* e = getenv("UNITER_X3_BAND_H"); return e ? atoi(e) : 0; }();
+  if (band_env > 0) g.band_h = band_env;
   if (g.band_h > g.tiles_m) g.band_h = g.tiles_m;
 }
 
@@ -1172,6 +1176,8 @@ int riders_prepare(uniter_x3_riders_t& x, const char* who) {
   return 0;
 }
 
+void x3_choose(int M, int N, int K, int avail, int nsplit_fixed, int* cfg_out, int* ns_out);
+
 // C / Cx = epi(A . B^T) on x3 operands (fp32-accurate, six bf16 MFMA products per block, fp32 accumulate).
 int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, int psa,
                 const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* Cx, int ldcx, int pscx,
@@ -1213,18 +1219,56 @@ int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, i
     // round 5: 128 x 256 tiles where they take fewer rounds' worth of time.  The k-loop is bound by the LDS-DMA issue rate (one
     // 1-KiB instruction per ~45 cycles and CU), and a 128 x 256 tile stages 72 KB per k-tile for twice the products of a 128 x 128
     // one's 48 KB: measured 1.75 x the time per k-tile for 2 x the work (profiles/r05_gemm_x3_lab.txt: QKV forward 61.0 -> 54.9 us,
-    // FFN-up forward 76.7 -> 69.5, FFN-down input gradient 72.9 -> 65.2; the N = hidden products keep two k-pieces of 128 x 128)
-    if (!a_kmajor && nsplit == 1 && N >= 256) {
-      const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t256 = (long)((M + 127) / 128) * ((N + 255) / 256);
-      const int cus = x3_grid(1 << 20, 0);
-      const long r128 = (t128 + cus - 1) / cus, r256 = (t256 + cus - 1) / cus;
-      static const bool on = [] { const char* e = getenv("UNITER_X3_WIDE"); return !(e && e[0] == '0'); }();
-      if (on && 7 * r256 < 4 * r128) cfg = 4;
+    // FFN-up forward 76.7 -> 69.5, FFN-down input gradient 72.9 -> 65.2).  x3_choose prices both geometries on the CUs this
+    // launch may use (all of them, or what a data-parallel exchange leaves: g_uniter_cu_reserve)
+    if (!a_kmajor) {
+      int ns_;
+      x3_choose(M, N, K, x3_grid(1 << 20, 0), nsplit, &cfg, &ns_);
     }
   }
   hipStream_t st = (hipStream_t)stream;
   if (a_kmajor) return dispatch_epi3<true, true>(cfg, g, epilogue, st);
   return b_kmajor ? dispatch_epi3<false, true>(cfg, g, epilogue, st) : dispatch_epi3<false, false>(cfg, g, epilogue, st);
+}
+
+// Tile geometry (cfg 3 = 128 x 128 persistent, cfg 4 = 128 x 256 one-round) and k-pieces of a forward / input-gradient product on
+// `avail` CUs: the cost model of profiles/r05_gemm_x3_lab.txt -- rounds x k-tiles per work item x time per k-tile (1.2 us for a
+// 128 x 128 tile, 2.1 us for a 128 x 256 one) plus 4 us per slab (an 8-MB write and an 8-MB read in the consuming row pass at
+// configs[1]).  nsplit_fixed > 0: the caller chose the k-pieces (x3 outputs cannot be split); 0: pieces 1..4 compete (N <= 1024
+// only: more tiles than that fill the chip without them).  Written for `avail` < the chip's CUs too: while a data-parallel
+// exchange holds CUs (uniter_model_set_cu_reserve) the 252-item forms that exactly fit 256 CUs would run two rounds on 240.
+void x3_choose(int M, int N, int K, int avail, int nsplit_fixed, int* cfg_out, int* ns_out) {
+  static const bool wide_on = [] { const char* e = getenv("UNITER_X3_WIDE"); return !(e && e[0] == '0'); }();
+  if (avail < 8) avail = 8;
+  const long tm = (M + 127) / 128, t128 = tm * ((N + 127) / 128), t256 = tm * ((N + 255) / 256);
+  const int nk = (K + 31) / 32;
+  double best = 1e30;
+  int bc = 3, bn = nsplit_fixed > 0 ? nsplit_fixed : 1;
+  const int ns_lo = nsplit_fixed > 0 ? nsplit_fixed : 1, ns_hi = nsplit_fixed > 0 ? nsplit_fixed : ((N <= 1024 && K >= 512) ? 4 : 1);
+  for (int ns = ns_lo; ns <= ns_hi; ++ns) {
+    if (nk / ns < 6 && ns > 1) continue;                     // pieces shorter than six k-tiles do not pay for their prologue
+    for (int c = 3; c <= 4; ++c) {
+      if (c == 4 && (!wide_on || N < 256)) continue;
+      const long items = (c == 4 ? t256 : t128) * ns;
+      const long rounds = (items + avail - 1) / avail;
+      const double t = (double)rounds * ((nk + ns - 1) / ns) * (c == 4 ? 2.1 : 1.2) + 4.0 * ns;
+      if (t < best - 1e-9) { best = t; bc = c; bn = ns; }
+    }
+  }
+  *cfg_out = bc; *ns_out = bn;
+}
+
+extern "C" int uniter_gemm_x3_plan(int M, int N, int K, int avail_cus, int nsplit_fixed, int* cfg, int* nsplit) {
+  UCHECK_ARG(M > 0 && N > 0 && K > 0 && cfg && nsplit && nsplit_fixed >= 0 && nsplit_fixed <= 8, "gemm_x3_plan: bad argument");
+  x3_choose(M, N, K, avail_cus > 0 ? avail_cus : x3_grid(1 << 20, 0), nsplit_fixed, cfg, nsplit);
+  return 0;
+}
+
+// k-pieces of a product whose output goes to fp32 slabs, on `avail` CUs (0 = the chip's)
+int gemm_x3_pick_split_on(int M, int N, int K, int avail) {
+  int c, n;
+  x3_choose(M, N, K, avail > 0 ? avail : x3_grid(1 << 20, 0), 0, &c, &n);
+  return n;
 }
 
 // Pieces for the split-K slab form of the products whose N is the hidden size (126 tiles of 128 x 128 for 256 persistent

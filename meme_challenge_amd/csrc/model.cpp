@@ -40,6 +40,7 @@ int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, i
                 float* colsum_part);
 int gemm_x3_wgrad_default_cfg();
 int gemm_x3_pick_split(int M, int N, int K);
+int gemm_x3_pick_split_on(int M, int N, int K, int avail);
 int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A, const void* const* B,
                         float* const* dW, void* stream, int overwrite, int max_wgs, uniter_x3_riders_t* riders);
 int gemm_x3_wgrad_group_slots(int cfg, int n, const int* Mo, const int* No, int max_wgs);
@@ -109,6 +110,9 @@ struct Plan {
   bool res;               // this plan was carved for precision 2
   bool x3;                // this plan was carved for precision 3: the *b buffers hold x3 pieces [rows][3][cols], embb likewise
   int ns_kh;              // precision 3: k-pieces of the attention-output forward product (N = K = hidden)
+  // precision 3: k-pieces of the BACKWARD pass's N = hidden products (FFN-up / attention-output / QKV input gradients), chosen for the
+  // CUs the backward pass may use: all of them, or what a data-parallel exchange leaves (uniter_model_set_cu_reserve)
+  int ns_ki_b, ns_kh_b, ns_k3h_b;
   // precision 2: k-pieces of the GEMMs whose N is the hidden size (their fp32 outputs are that many slabs, summed by
   // the LayerNorm row pass that consumes them): K = intermediate (FFN-down forward, FFN-up dgrad), K = 3 hidden (QKV dgrad)
   int ns_ki, ns_k3h;
@@ -183,6 +187,8 @@ int check_cfg(const uniter_config_t* c) {
   return 0;
 }
 
+int x3_backward_cus(const uniter_model* m);
+
 void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, int L, bool has_txt,
                bool has_img, bool has_masks, int mode, int Mrows = -1) {
   const uniter_config_t& c = m->cfg;
@@ -207,7 +213,18 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
   pl.ns_ki = pl.res ? gemm_bf16v2_pick_split(pl.M, H, I) : pl.x3 ? gemm_x3_pick_split(pl.M, H, I) : 1;
   pl.ns_k3h = pl.res ? gemm_bf16v2_pick_split(pl.M, H, 3 * H) : pl.x3 ? gemm_x3_pick_split(pl.M, H, 3 * H) : 1;
   pl.ns_kh = pl.x3 ? gemm_x3_pick_split(pl.M, H, H) : 1;
+  pl.ns_ki_b = pl.ns_ki; pl.ns_k3h_b = pl.ns_k3h; pl.ns_kh_b = pl.ns_kh;
+  if (pl.x3) {
+    // (the forward pass runs before any collective of its step: it keeps every CU; the backward pass's products are planned for the
+    // CUs it will have)
+    const int avail_b = x3_backward_cus(m);
+    pl.ns_ki = gemm_x3_pick_split_on(pl.M, H, I, 0); pl.ns_kh = gemm_x3_pick_split_on(pl.M, H, H, 0);
+    pl.ns_ki_b = gemm_x3_pick_split_on(pl.M, H, I, avail_b);
+    pl.ns_kh_b = gemm_x3_pick_split_on(pl.M, H, H, avail_b);
+    pl.ns_k3h_b = pl.ns_k3h = gemm_x3_pick_split_on(pl.M, H, 3 * H, avail_b);
+  }
   const size_t s_ki = (size_t)pl.ns_ki, s_k3h = (size_t)pl.ns_k3h, s_kh = (size_t)pl.ns_kh;
+  const size_t s_ki_b = (size_t)pl.ns_ki_b, s_kh_b = (size_t)pl.ns_kh_b;
   pl.layers.resize(nl);
   const bool save = mode != 0;
   auto alloc_fwd = [&](LayerBufs& b) {
@@ -222,8 +239,8 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
       LayerBufs& b = pl.layers[l];
       b = LayerBufs();
       alloc_fwd(b);
-      b.dz2 = cv.f(M * H); b.g2 = cv.f(M * H); b.du = cv.f(M * I); b.dy1 = cv.f(s_ki * M * H); b.dz1 = cv.f(M * H);
-      b.g1 = cv.f(M * H); b.dctx = cv.f(s_kh * M * H); b.dqkv = cv.f(M * 3 * H); b.delta = cv.f((size_t)B * nh * L);
+      b.dz2 = cv.f(M * H); b.g2 = cv.f(M * H); b.du = cv.f(M * I); b.dy1 = cv.f(s_ki_b * M * H); b.dz1 = cv.f(M * H);
+      b.g1 = cv.f(M * H); b.dctx = cv.f(s_kh_b * M * H); b.dqkv = cv.f(M * 3 * H); b.delta = cv.f((size_t)B * nh * L);
       b.dx = cv.f(s_k3h * M * H);
       b.du_csum = cv.f((size_t)((M + 31) / 32) * I);
       b.qb_part = cv.f((size_t)B * 3 * H);
@@ -363,6 +380,16 @@ int gemm_x3(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, in
   g_uniter_launch_prio = main_prio;
   return gemm_x3_run(cfg, nsplit, 0, bkm, M, N, K, A, 3 * K, K, W, ldw, (int)m->mirror_numel, C, N, (long)M * N, Cx, 3 * N, N, epi,
                      bias, aux_in, aux_out, N, st, colsum_part);
+}
+// CUs the backward pass's persistent launches may use: the chip's minus what the caller reserved for a gradient exchange
+int x3_backward_cus(const uniter_model* m) {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 8 ? n / 8 * 8 : 256;
+  }();
+  const int a = (cus - m->cu_reserve) / 8 * 8;
+  return a >= 8 ? a : 8;
 }
 // precision 3: side work of a layer's backward rides on its grouped weight-gradient launch (default geometry only)
 bool x3_riders_enabled() {
@@ -571,7 +598,7 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
                                     int all_layers, int train, uint64_t seed, uint32_t offset, void* ws,
                                     size_t ws_bytes, void* stream) {
   UCHECK_ARG(m && hidden_out && ws, "model_forward: null pointer");
-  g_uniter_cu_reserve = m->cu_reserve;
+  g_uniter_cu_reserve = 0;      // (no collective of this step is in flight during its forward pass: the reserve is the backward pass's)
   UCHECK_ARG(train >= 0 && train <= 2, "model_forward: train must be 0, 1 or 2");
   UCHECK_RC(validate_batch(m, b));
   UCHECK_ARG(((uintptr_t)ws & 255) == 0, "model_forward: workspace must be 256-byte aligned");
@@ -882,7 +909,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   const bool fused_qb = L <= uniter_attn_varlen_max_len();
   // precision 3 with the x3 attention backward: the attention-output input gradient leaves as k-pieces (the kernel sums them)
   static const bool dctx_split = [] { const char* e = getenv("UNITER_DCTX_SPLIT"); return !(e && e[0] == '0'); }();      // A/B switch
-  const int ns_dctx = (x3 && fused_qb && dctx_split && attn_x3_products(L, pa, pa > 0.f)) ? pl.ns_kh : 1;
+  const int ns_dctx = (x3 && fused_qb && dctx_split && attn_x3_products(L, pa, pa > 0.f)) ? pl.ns_kh_b : 1;
   const int epi_du = pl.gelu_d ? UNITER_EPI_MUL : UNITER_EPI_DGELU;
   if (res) {
     UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, I, H, lb.g2b, H, m->WB(l, L_W2), I, nullptr, I, 1, lb.dub, I,
@@ -895,7 +922,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
     // here: one row of partial sums per 64 rows of dU, finished by a reduction job of the riders)
     UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, I, H, lb.g2b, m->WB(l, L_W2), I, nullptr, 1, lb.dub, UNITER_EPI_MUL,
                       nullptr, lb.u, nullptr, x3_colpart_on() ? lb.du_csum : nullptr));
-    UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, I, lb.dub, m->WB(l, L_W1), H, lb.dy1, pl.ns_ki, nullptr, UNITER_EPI_ADD,
+    UCHECK_RC(gemm_x3(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, I, lb.dub, m->WB(l, L_W1), H, lb.dy1, pl.ns_ki_b, nullptr, UNITER_EPI_ADD,
                       nullptr, lb.dz2, nullptr));
   } else {
     UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, M, I, H, g2, H, m->LP(l, L_W2), I, lb.du, I, epi_du,
@@ -906,7 +933,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   {
     ProfScope ps(m, UNITER_K_LN_BWD, st);
     if (x3)
-      UCHECK_RC(uniter_ln_bwd_rows_slabs_x3(lb.dy1, pl.ns_ki, MH, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1, g1, lb.g1b,
+      UCHECK_RC(uniter_ln_bwd_rows_slabs_x3(lb.dy1, pl.ns_ki_b, MH, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1, g1, lb.g1b,
                                             1, M, H, ph, m->seed, m->offset, SITE_ATTN_OUT(l), lb.ln_ws1, pl.ln_ws_bytes, st));
     else
     UCHECK_RC(uniter_ln_bwd_rows_slabs(lb.dy1, res ? pl.ns_ki : 1, MH, lb.z1, lb.mean1, lb.rstd1, m->LP(l, L_LN1_G), lb.dz1,

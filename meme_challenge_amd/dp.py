@@ -345,6 +345,16 @@ def cu_reserve_default(world):
     return DEFAULT_CU_RESERVE if world > 1 else 0
 
 
+def prepare_rccl_env(world, env=None):
+    """Before the process group exists: tell RCCL to ask for no more channels (one workgroup each) than the CUs the persistent
+    matrix kernels will leave it (NCCL_MAX_NCHANNELS, only when the caller left it alone).  Returns the reserve."""
+    env = os.environ if env is None else env
+    r = cu_reserve_default(world)
+    if r > 0:
+        env.setdefault('NCCL_MAX_NCHANNELS', str(r))
+    return r
+
+
 def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embeddings=None, accum=1, cu_reserve=None):
     """Wire a GradSync to a MemeUniter, UniterForPretraining or UniterModel and return it.
     payload None: 'bf16' when the encoder runs in the bf16 precision mode, else 'fp32'.

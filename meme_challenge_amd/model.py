@@ -544,10 +544,11 @@ class _UniterFn(torch.autograd.Function):
         dev = anchor.device
         shape = (nl, B, L, H) if all_layers else (B, L, H)
         hidden = torch.empty(shape, dtype=torch.float32, device=dev)
+        # (before the workspace is sized: the backward pass's k-pieces are planned for the CUs a gradient exchange leaves it)
+        check(lib.uniter_model_set_cu_reserve(model._handle, int(getattr(model, 'cu_reserve', 0))), 'uniter_model_set_cu_reserve')
         nbytes = lib.uniter_model_ws_bytes(model._handle, B, batch.T if batch.input_ids else 0,
                                            batch.R if batch.img_feat else 0, L, mode)
         ws = model._get_ws(nbytes, mode)
-        check(lib.uniter_model_set_cu_reserve(model._handle, int(getattr(model, 'cu_reserve', 0))), 'uniter_model_set_cu_reserve')
         if mode != 0 and model.use_side_stream and os.environ.get('UNITER_AUX_STREAM') != '0':
             # the dropout keep flags of the attention are drawn beside the head of the forward pass, on a third stream
             aux = _lib.shared_stream(dev, 'aux')

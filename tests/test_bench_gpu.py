@@ -52,8 +52,15 @@ def test_bench_default_contract():
     assert d['optimizer']['bound'] == 'hbm' and 0.05 < d['optimizer']['frac'] < 1.0
     # both gradient GEMM families over the time either of them ran: above each family's own in-situ rate, below the peak
     t = d['backward_gemms_together']
-    assert min(fams['gemm_dgrad']['frac'], fams['gemm_wgrad']['frac']) < t['frac'] < 1.0
-    assert t['ms_per_step'] <= fams['gemm_dgrad']['ms_per_step'] + fams['gemm_wgrad']['ms_per_step'] + 1e-6
+    dg, wg = fams['gemm_dgrad'], fams['gemm_wgrad']
+    assert min(dg['frac'], wg['frac']) < t['frac'] < 1.0
+    # The invariant of the two backward streams: the union of both families' launch intervals is shorter than their sum (they DO
+    # run beside each other) and no shorter than the longer family.  (The stronger `max(frac) < together` of round 3 is a property
+    # of the native fp32 mode, whose 64-KB workgroups share CUs: in the fp32x3 mode two persistent 144-KB workgroups cannot, the
+    # streams time-slice at workgroup granularity, and a family stamped from its first workgroup's start to its last one's end
+    # contains the other one's slices -- its own fraction can then exceed the union's by a hair.  ADVICE r04.)
+    assert max(dg['ms_per_step'], wg['ms_per_step']) - 1e-6 <= t['ms_per_step'] <= 0.98 * (dg['ms_per_step'] + wg['ms_per_step'])
+    assert t['frac'] > 0.9 * max(dg['frac'], wg['frac'])
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'samples/s' and c['value'] > 0 and c['cores'] >= 1 and c['sample']
     assert c['single_thread']['value'] > 0 and c['gflops'] > 0 and c['cpu_model'] and c['os_cpu_count'] >= c['cores']
@@ -109,6 +116,7 @@ def test_bench_starts_its_own_ranks(extra):
     assert c['world'] == 2 and c['payload'] == ('bf16' if 'bf16' in extra else 'fp32') and c['sparse_embeddings'] == bool('--dp_sparse_embeddings' in extra)
     assert c['collectives'] and all(k['bytes'] > 0 and k['issue_to_done_ms'] >= k['exposed_ms'] >= 0 for k in c['collectives'])
     assert c['bytes_per_step'] > 0 and c['exposed_ms_per_step'] >= 0 and c['headline_exchange'] in ('dense', 'sparse word-embedding rows')
+    assert c['cu_reserve'] == 16 and c['rccl_max_nchannels_env'] == '16'          # two ranks: the persistent launches leave 16 CUs
 
 
 def test_graft_entry_smoke():

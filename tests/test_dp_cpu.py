@@ -236,3 +236,24 @@ def test_bucketed_allreduce_equals_big_batch_gradients(tmp_path):
         o = r['offs'][n]
         got = r['reduced'][o:o + t.numel()].view(t.shape) / world      # grad_scale = 1/world
         assert (got - t).abs().max().item() <= 1e-6 + 1e-4 * t.abs().max().item(), n
+
+
+def test_cu_reserve_default_and_rccl_env(monkeypatch):
+    """CUs the persistent matrix kernels leave to the exchange's kernels: 16 with more than one rank, none on one rank,
+    UNITER_DP_CU_RESERVE overrides; RCCL's channel cap follows the reserve unless the caller set one."""
+    from meme_challenge_amd import dp
+    monkeypatch.delenv('UNITER_DP_CU_RESERVE', raising=False)
+    assert dp.cu_reserve_default(1) == 0 and dp.cu_reserve_default(8) == dp.DEFAULT_CU_RESERVE == 16
+    monkeypatch.setenv('UNITER_DP_CU_RESERVE', '24')
+    assert dp.cu_reserve_default(1) == 24 and dp.cu_reserve_default(8) == 24
+    monkeypatch.setenv('UNITER_DP_CU_RESERVE', '0')
+    assert dp.cu_reserve_default(8) == 0
+    monkeypatch.setenv('UNITER_DP_CU_RESERVE', 'junk')
+    assert dp.cu_reserve_default(8) == 0
+    monkeypatch.delenv('UNITER_DP_CU_RESERVE', raising=False)
+    env = {}
+    assert dp.prepare_rccl_env(8, env) == 16 and env == {'NCCL_MAX_NCHANNELS': '16'}
+    env = {'NCCL_MAX_NCHANNELS': '32'}
+    assert dp.prepare_rccl_env(8, env) == 16 and env['NCCL_MAX_NCHANNELS'] == '32'       # the caller's choice stands
+    env = {}
+    assert dp.prepare_rccl_env(1, env) == 0 and env == {}

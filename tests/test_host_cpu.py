@@ -253,3 +253,28 @@ def test_adamax_and_sgd_take_the_reference_arguments():
     src = inspect.getsource(trainer.get_optimizer)
     assert "torch.optim.Adamax(groups, lr=config['lr'])" in src
     assert "torch.optim.SGD(groups, lr=config['lr'], momentum=config['beta1'])" in src
+
+
+def test_x3_plan_fits_the_cus_it_is_given():
+    """uniter_gemm_x3_plan (host arithmetic, no launch): geometry and k-pieces of the fp32x3 forward / input-gradient products.  On the
+    whole chip the choices measured in profiles/r05_gemm_x3_lab.txt (two k-pieces of 128 x 128 tiles for the N = hidden products,
+    128 x 256 tiles for the wide ones); on the 240 CUs a data-parallel exchange leaves, no form of 252 work items (two rounds there)."""
+    import ctypes as C
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+
+    def plan(M, N, K, avail, fixed=0):
+        c, n = C.c_int(), C.c_int()
+        assert lib.uniter_gemm_x3_plan(M, N, K, avail, fixed, C.byref(c), C.byref(n)) == 0
+        return c.value, n.value
+    M, H, I = 2624, 768, 3072
+    assert plan(M, H, I, 256) == (3, 2) and plan(M, H, H, 256) == (3, 2) and plan(M, H, 3 * H, 256) == (3, 2)
+    assert plan(M, I, H, 256, 1) == (4, 1) and plan(M, 3 * H, H, 256, 1) == (4, 1)
+    for shape in ((M, H, I), (M, H, H), (M, H, 3 * H)):
+        cfg, ns = plan(*shape, 240)
+        tiles = ((shape[0] + 127) // 128) * ((shape[1] + (255 if cfg == 4 else 127)) // (256 if cfg == 4 else 128))
+        assert tiles * ns <= 240, (shape, cfg, ns)                      # one round on what is left
+    assert plan(M, I, H, 240, 1)[0] == 3                                 # 252 tiles of 128 x 256 would take two rounds: 504 persistent ones
+    assert plan(M, 3 * H, H, 240, 1) == (4, 1)                           # 189 tiles: still one round
+    assert plan(64, 8, 64, 256) == (3, 1)                                # tiny: nothing to choose
+    assert lib.uniter_gemm_x3_plan(0, 8, 64, 256, 0, None, None) != 0

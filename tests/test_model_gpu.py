@@ -342,3 +342,43 @@ def test_launch_stamps_put_the_gemms_on_one_clock(tiny):
     assert sum(1 for s in spans if s[0] == 7) >= 1                               # weight gradients (grouped or one by one)
     assert spans[0][1] == 0.0 and all(0.0 <= a < e < 1e6 for _, a, e in spans)
     assert all(x[2] <= y[1] for x, y in zip(fwd, fwd[1:]))
+
+
+@pytest.mark.parametrize('precision', ['fp32x3', 'bf16'])
+def test_cu_reserve_for_a_gradient_exchange_changes_no_result(precision):
+    """uniter_model_set_cu_reserve (dp.attach sets UniterModel.cu_reserve): with 16 CUs left to a gradient exchange's kernels the
+    backward pass plans its k-pieces and tile geometry for 240 CUs (uniter_gemm_x3_plan) -- different slabs, a workspace sized
+    for them, the same gradients to fp32 round-off; the forward pass keeps every CU and its output bit for bit."""
+    from meme_challenge_amd.model import UniterConfig, UniterModel
+    from meme_challenge_amd.meme_uniter import MemeUniter
+    from meme_challenge_amd.utils import make_synthetic_batch
+    from meme_challenge_amd.trainer import bce_with_logits_loss
+    cfg = UniterConfig.from_dict(BASE)
+    torch.manual_seed(0)
+    m = MemeUniter(UniterModel(cfg, img_dim=2048), cfg.hidden_size, 1).cuda().train()
+    m.uniter_model.precision = precision
+    b = make_synthetic_batch(16, 128, 36, seed=7, device='cuda')
+    kw = dict(img_feat=b['img_feat'], img_pos_feat=b['img_pos_feat'], input_ids=b['input_ids'], position_ids=b['position_ids'],
+              attention_mask=b['attn_mask'], gather_index=b['gather_index'], output_all_encoded_layers=False)
+    names = ['uniter_model.encoder.layer.11.output.dense.weight', 'uniter_model.encoder.layer.5.attention.self.query.weight',
+             'uniter_model.encoder.layer.0.intermediate.dense.bias', 'uniter_model.encoder.layer.0.attention.output.LayerNorm.weight',
+             'uniter_model.embeddings.position_embeddings.weight']
+    res = {}
+    for reserve in (0, 16, 0):
+        m.uniter_model.cu_reserve = reserve
+        m.uniter_model.set_dropout_seed(11, 0)
+        m.zero_grad(set_to_none=False)
+        st = m.param_store(); st.zero_grads()
+        logits = m(**kw)
+        bce_with_logits_loss(logits.squeeze(1), b['labels'], 1.8).backward()
+        torch.cuda.synchronize()
+        params = dict(m.named_parameters())
+        res.setdefault(reserve, []).append((logits.detach().clone(), {n: params[n].grad.detach().clone() for n in names}))
+    (l0, g0), (l0b, g0b) = res[0]
+    l16, g16 = res[16][0]
+    assert torch.equal(l0, l16) and torch.equal(l0, l0b)
+    for n in names:
+        ref = g0[n]
+        noise = (g0b[n] - ref).abs().max().item()          # two identical runs (float atomics in the embedding gradients)
+        tol = (3e-3 if precision == 'bf16' else 2e-5) * ref.abs().max().item() + 4 * noise
+        assert (g16[n] - ref).abs().max().item() <= tol, (n, (g16[n] - ref).abs().max().item(), tol)
