@@ -695,10 +695,12 @@ def _run_rank(args, real_stdout, state):
                5: ('attention_fwd', 'mfma', nl * att), 6: ('gemm_dgrad', 'mfma', nl * (g_qkv + g_o + 2 * g_ffn)),
                7: ('gemm_wgrad', 'mfma', nl * (g_qkv + g_o + 2 * g_ffn)), 8: ('attention_bwd', 'mfma', nl * 2 * att),
                9: ('layernorm_fwd', 'hbm', nl * 2 * 16.0 * M_eff * H), 10: ('layernorm_bwd', 'hbm', nl * 2 * 16.0 * M_eff * H)}
-        x3k = 'gemm_s3p_kernel<128,128,..> (csrc/gemm_split3.hip: x3 operands, six v_mfma_f32_16x16x32_bf16 per block, persistent, loader + compute waves)'
+        x3k = ('gemm_s3p_kernel (csrc/gemm_split3.hip: x3 operands, six v_mfma_f32_16x16x32_bf16 per block, loader + compute waves; 128 x 256 tiles '
+               'for the wide products and the grouped weight gradients, persistent 128 x 128 tiles elsewhere: uniter_gemm_x3_plan)')
         kernel_of = {'f32x3': {1: x3k + ', bias + GELU epilogue, activation out as x3 pieces + gelu\' fp32', 2: x3k + ', two k-pieces (slabs summed by the LayerNorm pass)',
                                3: x3k, 4: x3k + ', two k-pieces', 6: x3k + ' (weights k-major: ds_read_b64_tr_b16)',
-                               7: x3k + ': the four weight gradients of a layer in ONE launch of whole-K tiles (both operands k-major)'},
+                               7: x3k + ': the four weight gradients of a layer in ONE launch of whole-K tiles (both operands k-major) that also carries the '
+                                        'layer\'s bias / LayerNorm column reductions and clip-norm partial sums (riders)'},
                      'f32': {1: 'gemm_f32_v3_kernel<64,64,false,false,TAG=1>', 6: 'gemm_f32_v3_kernel<64,64,false,true,...>',
                              7: 'gemm_f32_v3_kernel<64,64,true,true,0,false> (whole-K 64x64 tiles; UNITER_WGRAD_WHOLE=0: the stream-K form); layer 0: '
                                 'gemm_f32_wgrad_group_kernel (its four products as one launch)'},
