@@ -122,13 +122,15 @@ struct Dma3 {
   int voff[NI];
   // rs: row stride of the operand (elements)
   static __device__ __forceinline__ int kstep(int rs) { return (KM ? KT * rs : KT) * 2; }
-  __device__ __forceinline__ void offsets(int rs, int rc0, int wave, int lane) {
+  // paired (k-contiguous operands): rows 2 q and 2 q + 1 of the operand interleaved in 64-byte units -- the 32-deep k-tile u of the
+  // pair is ONE 128-byte line at (q * 2 rs + u * 64) elements: the eight lanes of a row pair fetch a whole line instead of two halves
+  __device__ __forceinline__ void offsets(int rs, int rc0, int wave, int lane, bool paired = false) {
 #pragma unroll
     for (int t = 0; t < NI; ++t) {
       const int j = wave + NW * t;
       if constexpr (!KM) {
         const int row = 16 * j + (lane >> 2), c = (lane & 3) ^ chunk_swz<M16>((lane >> 4) & 3);
-        voff[t] = (rc0 + row) * rs * 2 + c * 16;
+        voff[t] = paired ? ((rc0 + row) >> 1) * rs * 4 + ((rc0 + row) & 1) * 64 + c * 16 : (rc0 + row) * rs * 2 + c * 16;
       } else if constexpr (R == 128) {
         const int k = 4 * j + (lane >> 4);
         const int c = (lane & 15) ^ (((lane >> 4) << 2) | (j & 3));
@@ -683,9 +685,14 @@ void gemm_s3p_kernel(const S3Group G) {
                                               (((AKM ? g.K : g.M) - 1) * g.lda + 2 * g.psa + (AKM ? g.M : g.K)) * 2, 0x00020000);
       rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0,
                                               (((BKM ? g.K : g.N) - 1) * g.ldb + 2 * g.psb + (BKM ? g.N : g.K)) * 2, 0x00020000);
-      da.offsets(g.lda, it.m0, lw, lane);
-      db.offsets(g.ldb, it.n0, lw, lane);
-      kstepA = DA::kstep(g.lda); kstepB = DB::kstep(g.ldb);
+#ifdef UNITER_X3_LAB
+      const bool pair_a = !AKM && (G.p[0].dbg & 128), pair_b = !BKM && (G.p[0].dbg & 32);      // timing experiments (wrong data, the real footprint)
+#else
+      constexpr bool pair_a = false, pair_b = false;
+#endif
+      da.offsets(g.lda, it.m0, lw, lane, pair_a);
+      db.offsets(g.ldb, it.n0, lw, lane, pair_b);
+      kstepA = pair_a ? 128 : DA::kstep(g.lda); kstepB = pair_b ? 128 : DB::kstep(g.ldb);
       pstepA = g.psa * 2; pstepB = g.psb * 2;
     };
     bind();

@@ -94,3 +94,12 @@ def test_comm_block_schema_and_rccl_log_parse(tmp_path):
     # physical cores of the CPU baseline: at least one, never more than the logical count
     n = bench._physical_cores()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_round5_flags_parse_and_defaults():
+    """The second timed regions are opt-in: by default `value` is ONE region, the requested exchange with the default CU reserve."""
+    import bench
+    a = bench.parse_args([])
+    assert not a.both_exchanges and not a.reserve_ab and not a.no_bf16_leg and not a.cpu_all_cores and a.precision == 'fp32x3'
+    a = bench.parse_args(['--both_exchanges', '--reserve_ab', '--no_bf16_leg', '--cpu_all_cores', '--gpus', '8'])
+    assert a.both_exchanges and a.reserve_ab and a.no_bf16_leg and a.cpu_all_cores and a.gpus == 8
