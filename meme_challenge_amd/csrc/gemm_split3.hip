@@ -1007,9 +1007,15 @@ template <int BM>
 void plan_tiles3(S3Args& g, int BN) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
-  const long panel = (long)BM * g.K * 6;
-  long bh = (3l << 19) / (panel > 0 ? panel : 1);
-  g.band_h = (int)(bh < 1 ? 1 : (bh > 16 ? 16 : bh));
+  // Band height of the walk (round 5): an XCD's workgroups run ~32 tiles of its chunk of the walk at a time -- a band_h x (32 / band_h)
+  // rectangle of the tile grid -- and its L2 fetches band_h row panels and 32 / band_h column panels for them: least for
+  // band_h = sqrt(32 BN / BM).  (Round 4 sized the band for L2 capacity, 1.5 MB of row panels: 2 rows at K = 768, every XCD then
+  // fetched EVERY weight panel -- 7.1 x the operand bytes on FFN-up forward.  The panels' k-tiles are consumed k-synchronously, so
+  // capacity is not the constraint.  Time is unchanged either way -- the re-fetches are Infinity-Cache hits -- but the fabric moves
+  // a third less: profiles/r05_pmc_traffic.json.)
+  long bh = 1;
+  while ((bh + 1) * (bh + 1) * (long)BM <= 32l * BN) ++bh;
+  g.band_h = (int)(bh > 16 ? 16 : bh);
   // UNITER_X3_BAND_H: tile rows per band of the walk (lab switch: how many row panels an XCD's chunk of the walk spans decides how
   // often the eight L2s fetch the same operand panels -- VERDICT r04 item 7)
   static const int band_env = [] { const char* e = getenv("UNITER_X3_BAND_H"); return e ? atoi(e) : 0; }();
