@@ -650,6 +650,17 @@ size_t uniter_model_ws_bytes(const uniter_model_t* m, int B, int T, int R, int L
 int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* batch, float* hidden_out,
                          int all_layers, int train, uint64_t seed, uint32_t offset,
                          void* ws, size_t ws_bytes, void* stream);
+/* Hidden-dropout keep flags drawn ahead (round 5; the dropout of model/layer.py:113,154 inside the fused dropout + residual +
+ * LayerNorm passes): uniter_hidden_keep_bits_gen draws the flags of `nsites` sites of `elements` values each -- site of even
+ * s = 2 k: site_a0 + k * site_step, of odd s: site_b0 + k * site_step (the two sites of encoder layer k) -- in one launch, as
+ * one nibble per 4-element group (uniter_hidden_keep_bits_bytes per site); uniter_ln_set_next_keep_bits hands ONE site's flags to
+ * the next LayerNorm row pass (forward or backward) launched by this host thread, which then reads them instead of running
+ * Philox (same flags bit for bit; NULL / not called: the pass draws them itself).  uniter_model_forward does both by itself with
+ * UNITER_HIDDEN_PREGEN=1 and an auxiliary stream (off by default: measured no gain inside the step). */
+size_t uniter_hidden_keep_bits_bytes(size_t elements);
+int uniter_hidden_keep_bits_gen(void* bits, size_t site_stride_bytes, int nsites, uint32_t site_a0, uint32_t site_b0,
+                                uint32_t site_step, size_t elements, float p_drop, uint64_t seed, uint32_t offset, void* stream);
+int uniter_ln_set_next_keep_bits(const void* site_bits);
 /* Precision 3: the clip norm's share of the encoder layers (train_template.py:104: clip_grad_norm_ over ALL parameters) taken
  * by the layers' own weight-gradient launches.  With `parts` set, uniter_model_backward_layer(l) leaves the sum of squares of
  * EVERY gradient of layer l's bucket (4 weights, 12 vectors) as uniter_model_norm_partials_per_layer() unreduced partial sums

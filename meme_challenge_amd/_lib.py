@@ -86,6 +86,9 @@ _SIGS = {
     'uniter_wgrad_x3_group_slots': (_I, [_I, _I, _P, _P, _I]),
     'uniter_wgrad_bf16_group_riders': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     'uniter_wgrad_bf16_group_slots': (_I, [_I, _P, _P, _I]),
+    'uniter_hidden_keep_bits_bytes': (_SZ, [_SZ]),
+    'uniter_hidden_keep_bits_gen': (_I, [_P, _SZ, _I, _U32, _U32, _U32, _SZ, _F, _U64, _U32, _P]),
+    'uniter_ln_set_next_keep_bits': (_I, [_P]),
     'uniter_model_set_norm_partials': (_I, [_P, _P, _SZ]),
     'uniter_model_set_aux_stream': (_I, [_P, _P]),
     'uniter_model_set_cu_reserve': (_I, [_P, _I]),

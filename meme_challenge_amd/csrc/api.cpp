@@ -23,3 +23,4 @@ extern "C" const char* uniter_build_info(void) {
 thread_local unsigned long long* g_uniter_stamp_slot = nullptr;
 thread_local int g_uniter_launch_prio = 0;
 thread_local int g_uniter_cu_reserve = 0;
+thread_local const unsigned char* g_uniter_drop_bits = nullptr;

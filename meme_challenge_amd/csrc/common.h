@@ -54,6 +54,15 @@ static inline int take_launch_prio() {
   return p;
 }
 
+// Dropout keep flags drawn ahead for the NEXT LayerNorm row pass (model.cpp sets it, the launch that reads it resets it): see
+// DropCfg::bits.  thread_local, as the channels above.
+extern thread_local const unsigned char* g_uniter_drop_bits;
+static inline const unsigned char* take_drop_bits() {
+  const unsigned char* p = g_uniter_drop_bits;
+  g_uniter_drop_bits = nullptr;
+  return p;
+}
+
 // CUs the persistent matrix kernels leave free (uniter_model_set_cu_reserve: the collectives of a data-parallel exchange run beside the
 // backward pass and need CUs of their own -- a persistent launch that counts on all of them leaves its last workgroups queued behind
 // the collective's and their whole share of the tiles late).  Set by every model call from its handle; thread_local as the channels above.

@@ -422,7 +422,9 @@ static int ln_fwd_run(const float* x, int nslab, size_t slab_stride, const float
   UCHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "ln_fwd: bad dropout p");
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  const DropCfg drop = make_drop(p_drop, seed, offset, site);
+  DropCfg drop = make_drop(p_drop, seed, offset, site);
+  drop.bits = take_drop_bits();
+  if (!drop.active) drop.bits = nullptr;
   const int nv = (H / 4 + 63) / 64;
   LN_DISPATCH(nv, ln_fwd_kernel, dim3((M + 3) / 4), x, res, gamma, beta, z_out, y, mean, rstd, M, H, drop,
               (unsigned short*)y_bf16, nslab, slab_stride, pieces);
@@ -489,7 +491,9 @@ static int ln_bwd_rows_run(const float* dy, int nslab, size_t slab_stride, const
   UCHECK_ARG(ws_bytes >= uniter_ln_bwd_ws_bytes(M, H), "ln_bwd: workspace too small");
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  const DropCfg drop = make_drop(p_drop, seed, offset, site);
+  DropCfg drop = make_drop(p_drop, seed, offset, site);
+  drop.bits = take_drop_bits();
+  if (!drop.active) drop.bits = nullptr;
   const int nv = (H / 4 + 63) / 64;
   const int nblk = ln_bwd_blocks(M);
   float* part = (float*)ws;
@@ -543,4 +547,46 @@ extern "C" int uniter_ln_bwd_finalize(const void* ws, size_t ws_bytes, int M, in
   float* outs[3] = {dgamma, dbeta, dbias};
   return finalize_partials_multi((const float*)ws, ln_bwd_blocks(M), (size_t)3 * H, outs, dbias ? 3 : 2, H,
                                  (hipStream_t)stream);
+}
+
+// ---- hidden-dropout keep flags drawn ahead (round 5) ----------------------------------------------------------------------
+// The row passes draw their dropout flags with ten Philox rounds per 4-element group (1.5 us of a 9-us forward pass, 1.8 of an
+// 11-us backward pass, twice each per layer): a function of (seed, offset, site, index) alone, so all of a step's sites are drawn in ONE
+// launch on the auxiliary stream beside the head of the forward pass, as nibbles -- bits[s][g >> 1] >> 4 (g & 1) = the keep flags
+// of group g of site s -- and the passes read 3 bytes per lane and row instead (DropCfg::bits, through g_uniter_drop_bits).
+// Same flags bit for bit (tests/test_layernorm_gpu.py::test_keep_flags_drawn_ahead_are_the_row_passes_own).
+__global__ __launch_bounds__(256) void hidden_keep_bits_kernel(unsigned* __restrict__ bits, size_t site_words, int nsites, uint32_t site_a0,
+                                                               uint32_t site_b0, uint32_t site_step, size_t words, DropCfg d) {
+  const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int s = blockIdx.y;
+  if (w >= words || s >= nsites) return;
+  d.site = ((s & 1) ? site_b0 : site_a0) + (uint32_t)(s >> 1) * site_step;
+  unsigned word = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) word |= drop_bits4(d, (uint64_t)w * 8 + j) << (4 * j);
+  bits[(size_t)s * site_words + w] = word;
+}
+
+extern "C" size_t uniter_hidden_keep_bits_bytes(size_t elements) { return ((elements / 4 + 7) / 8) * 4; }
+
+// sites site_a0 + k * site_step (even s = 2 k) and site_b0 + k * site_step (odd s = 2 k + 1), `elements` values each
+extern "C" int uniter_hidden_keep_bits_gen(void* bits, size_t site_stride_bytes, int nsites, uint32_t site_a0, uint32_t site_b0,
+                                           uint32_t site_step, size_t elements, float p_drop, uint64_t seed, uint32_t offset,
+                                           void* stream) {
+  UCHECK_ARG(bits && nsites >= 1 && elements > 0 && p_drop > 0.f && p_drop < 1.f, "hidden_keep_bits_gen: bad argument");
+  const size_t words = (elements / 4 + 7) / 8;
+  UCHECK_SHAPE(elements % 4 == 0 && site_stride_bytes % 4 == 0 && site_stride_bytes >= words * 4 && ((uintptr_t)bits & 3) == 0,
+               "hidden_keep_bits_gen: elements %% 4, a 4-byte aligned buffer and site stride >= uniter_hidden_keep_bits_bytes");
+  const DropCfg d = make_drop(p_drop, seed, offset, 0);
+  hipLaunchKernelGGL(hidden_keep_bits_kernel, dim3((unsigned)((words + 255) / 256), nsites), dim3(256), 0, (hipStream_t)stream,
+                     (unsigned*)bits, site_stride_bytes / 4, nsites, site_a0, site_b0, site_step, words, d);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+// the keep flags the NEXT LayerNorm row pass of this host thread reads instead of drawing them (NULL = draw); tests and callers
+// that drive the row passes themselves
+extern "C" int uniter_ln_set_next_keep_bits(const void* site_bits) {
+  g_uniter_drop_bits = (const unsigned char*)site_bits;
+  return 0;
 }

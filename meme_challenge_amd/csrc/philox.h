@@ -18,6 +18,9 @@ struct DropCfg {
   uint32_t thresh;       // keep iff r >= thresh
   float scale;           // 1/(1-p)
   int active;
+  // keep flags drawn ahead (round 5: uniter_hidden_keep_bits_gen): one nibble per 4-element group of the site's index space, two groups
+  // per byte; NULL = draw them here (ten Philox rounds per group)
+  const unsigned char* bits;
 };
 
 static inline DropCfg make_drop(float p, uint64_t seed, uint32_t offset, uint32_t site) {
@@ -30,6 +33,7 @@ static inline DropCfg make_drop(float p, uint64_t seed, uint32_t offset, uint32_
   double t = (double)p * 4294967296.0;
   d.thresh = t >= 4294967295.0 ? 0xffffffffu : (t <= 0.0 ? 0u : (uint32_t)t);
   d.scale = d.active ? 1.0f / (1.0f - p) : 1.0f;
+  d.bits = nullptr;
   return d;
 }
 
@@ -54,6 +58,14 @@ __device__ __forceinline__ u32x4 drop_words(const DropCfg& d, uint64_t group) {
 }
 // multipliers (0 or scale) for the 4 elements of a group
 __device__ __forceinline__ void drop_mult4(const DropCfg& d, uint64_t group, float m[4]) {
+  if (d.bits) {      // (uniform per launch)
+    const unsigned nib = (unsigned)d.bits[group >> 1] >> (4u * (unsigned)(group & 1));
+    m[0] = (nib & 1u) ? d.scale : 0.0f;
+    m[1] = (nib & 2u) ? d.scale : 0.0f;
+    m[2] = (nib & 4u) ? d.scale : 0.0f;
+    m[3] = (nib & 8u) ? d.scale : 0.0f;
+    return;
+  }
   const u32x4 r = drop_words(d, group);
   m[0] = r.x >= d.thresh ? d.scale : 0.0f;
   m[1] = r.y >= d.thresh ? d.scale : 0.0f;

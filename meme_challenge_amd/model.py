@@ -544,6 +544,11 @@ class _UniterFn(torch.autograd.Function):
         dev = anchor.device
         shape = (nl, B, L, H) if all_layers else (B, L, H)
         hidden = torch.empty(shape, dtype=torch.float32, device=dev)
+        if model.precision == 'fp32x3' and L > lib.uniter_attn_x3_max_len() and not getattr(model, '_warned_long_attn', False):
+            # (thin spot ii: say it once instead of silently running at the older kernels' speed)
+            logger.warning('precision fp32x3: joint length %d > %d -- the attention\'s own products run on the fp32 MFMA kernels '
+                           '(attention_f32.hip) for this batch; the dense products stay x3 products', L, lib.uniter_attn_x3_max_len())
+            model._warned_long_attn = True
         # (before the workspace is sized: the backward pass's k-pieces are planned for the CUs a gradient exchange leaves it)
         check(lib.uniter_model_set_cu_reserve(model._handle, int(getattr(model, 'cu_reserve', 0))), 'uniter_model_set_cu_reserve')
         nbytes = lib.uniter_model_ws_bytes(model._handle, B, batch.T if batch.input_ids else 0,

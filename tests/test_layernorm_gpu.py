@@ -138,3 +138,51 @@ def test_ln_x3_copies_are_the_exact_pieces_of_the_fp32_outputs(M, H, p, nslab):
     L.check(lib.uniter_ln_bwd_rows_slabs_x3(L.ptr(dys), nslab, M * H, L.ptr(z), L.ptr(mu), L.ptr(rstd), L.ptr(g), L.ptr(dz), None,
                                             L.ptr(dxx2), 1, M, H, p, seed, offset, site, L.ptr(ws), ws_n, L.cur_stream()))
     assert torch.equal(dxx2, dxx)
+
+
+@pytest.mark.parametrize('M,H,p', [(37, 768, 0.1), (2624, 768, 0.1), (50, 1024, 0.3), (9, 128, 0.1)])
+def test_keep_flags_drawn_ahead_are_the_row_passes_own(M, H, p):
+    """uniter_hidden_keep_bits_gen + uniter_ln_set_next_keep_bits: the forward and backward row passes that READ the keep flags
+    (one nibble per 4-element group, drawn ahead for several sites in one launch) give the outputs of the passes that draw them
+    with Philox themselves, bit for bit; the flags are the oracle's (oracle/philox.py); the hand-over holds for ONE launch."""
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    gen = torch.Generator().manual_seed(M * 3 + H)
+    x, res, dy = (torch.randn(M, H, generator=gen).cuda() for _ in range(3))
+    g = (1 + 0.1 * torch.randn(H, generator=gen)).cuda(); b = (0.1 * torch.randn(H, generator=gen)).cuda()
+    seed, offset = 0x1234567890AB, 7
+    nsites, site_a0, site_b0, step = 6, 3, 4, 4            # the sites of three encoder layers: 3, 4, 7, 8, 11, 12
+    stride = (lib.uniter_hidden_keep_bits_bytes(M * H) + 255) // 256 * 256
+    bits = torch.zeros(nsites * stride, dtype=torch.uint8, device='cuda')
+    L.check(lib.uniter_hidden_keep_bits_gen(L.ptr(bits), stride, nsites, site_a0, site_b0, step, M * H, p, seed, offset, L.cur_stream()))
+    torch.cuda.synchronize()
+    for s in (0, 3, 5):
+        site = (site_b0 if s & 1 else site_a0) + (s >> 1) * step
+        # the flags themselves: the oracle's mask
+        keep = philox.keep_mask(M * H, p, seed, offset, site).astype(np.uint8)
+        nib = bits[s * stride:s * stride + (M * H // 4 + 1) // 2].cpu().numpy()
+        got = np.stack([(nib >> sh) & 1 for sh in range(8)], 1).reshape(-1)[:M * H]         # byte -> 8 flags: low nibble first
+        assert np.array_equal(got, keep), site
+        site_ptr = bits.data_ptr() + s * stride
+        outs = []
+        for ahead in (False, True, False):
+            z, y = torch.empty(M, H, device='cuda'), torch.empty(M, H, device='cuda')
+            mu, rstd = torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
+            if ahead:
+                L.check(lib.uniter_ln_set_next_keep_bits(site_ptr))
+            L.check(lib.uniter_ln_fwd(L.ptr(x), L.ptr(res), L.ptr(g), L.ptr(b), L.ptr(z), L.ptr(y), L.ptr(mu), L.ptr(rstd), M, H, p,
+                                      seed, offset, site, L.cur_stream()))
+            dz, dx = torch.empty(M, H, device='cuda'), torch.empty(M, H, device='cuda')
+            dgam, dbet, dbias = (torch.zeros(H, device='cuda') for _ in range(3))
+            ws_n = lib.uniter_ln_bwd_ws_bytes(M, H)
+            ws = torch.empty(ws_n, dtype=torch.uint8, device='cuda')
+            if ahead:
+                L.check(lib.uniter_ln_set_next_keep_bits(site_ptr))
+            L.check(lib.uniter_ln_bwd(L.ptr(dy), L.ptr(z), L.ptr(mu), L.ptr(rstd), L.ptr(g), L.ptr(dz), L.ptr(dx), L.ptr(dgam),
+                                      L.ptr(dbet), L.ptr(dbias), M, H, p, seed, offset, site, L.ptr(ws), ws_n, L.cur_stream()))
+            torch.cuda.synchronize()
+            outs.append((z, y, dz, dx, dbias))
+        for a, c in zip(outs[0], outs[1]):
+            assert torch.equal(a, c)
+        for a, c in zip(outs[0], outs[2]):          # (the third run drew its own flags again: the hand-over was for one launch)
+            assert torch.equal(a, c)
