@@ -285,6 +285,9 @@ def parse_args(argv=None):
     ap.add_argument('--reserve_ab', action='store_true',
                     help='with a gradient exchange attached: time the step once more with no CUs reserved for its kernels '
                          '(comm.no_reserve; `value` is the default reserve, comm.cu_reserve)')
+    ap.add_argument('--no_reserve_pick', action='store_true',
+                    help='N > 1: keep the attach-time CU reserve (dp.cu_reserve_default) instead of timing a few untimed steps with and '
+                         'without it before the warm-up and keeping the faster (comm.reserve_pick)')
     ap.add_argument('--both_exchanges', action='store_true',
                     help='N > 1: time the other form of the word-embedding exchange too (a second timed region, listed in '
                          'comm.other_exchange; `value` is always the requested exchange)')
@@ -488,6 +491,12 @@ def _run_rank(args, real_stdout, state):
         for _ in range(5):
             one_step()
         torch.cuda.synchronize()
+    # N > 1: how many CUs the persistent matrix kernels should leave to RCCL is a property of the node (channels RCCL opens on its
+    # links, how long its kernels run beside the backward pass): time a few untimed steps with the default reserve and with none,
+    # keep the faster on every rank (dp.pick_cu_reserve; UNITER_DP_CU_RESERVE or --no_reserve_pick fix it instead)
+    reserve_pick = None
+    if sync is not None and world > 1 and not args.no_reserve_pick and 'UNITER_DP_CU_RESERVE' not in os.environ:
+        reserve_pick = dp.pick_cu_reserve(sync, encoder, one_step, steps=max(1, min(6, args.steps)), warm=max(1, min(2, args.warmup)))
     for _ in range(args.warmup):
         one_step()
     lib = _lib.lib()
@@ -514,6 +523,8 @@ def _run_rank(args, real_stdout, state):
         # than one rank) and the channel cap RCCL was started with
         comm['cu_reserve'] = int(getattr(sync, 'cu_reserve', 0))
         comm['rccl_max_nchannels_env'] = os.environ.get('NCCL_MAX_NCHANNELS')
+        if reserve_pick is not None:
+            comm['reserve_pick'] = reserve_pick
         # --both_exchanges (N > 1, finetune): the same timed region once more with the OTHER form of the word-embedding exchange
         # (dense table all-reduce <-> touched rows only).  `value` stays the REQUESTED exchange's; the other one is listed
         # beside it in comm.other_exchange.  Auxiliary: every rank runs it under try / except and the ranks agree on an ok

@@ -160,6 +160,47 @@ struct Stage {
   }
 };
 
+#ifdef UNITER_X3_LAB
+// Measurement build only (LAB & 8: "what if Q, K, V arrived as pieces"): the operand is read as [rows][3][ld] bf16 -- three 8-byte
+// words per four values, no vector work on the way into the images.  Run over a buffer 1.5 x the fp32 one (tests/tools/attn_x3_lab.py);
+// the values are meaningless, the instruction and byte counts are those of the real thing.
+struct StagePieces {
+  u32x2 w[4][3];
+  __device__ __forceinline__ void load(const u16* __restrict__ base, int ld, int L, int Lr, int tid, int nthr) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        w[it][p] = u32x2{0u, 0u};
+        if (idx < Lr * 16 && r < L) w[it][p] = *reinterpret_cast<const u32x2*>(base + ((size_t)r * 3 + p) * ld + c4 * 4);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(u8* img, int Lr, int tid, int nthr) const {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * nthr, r = idx >> 4, c4 = idx & 15;
+      if (idx < Lr * 16) {
+        u8* q = img + r * ROWB + 16 * ((c4 >> 1) ^ swz(r)) + 8 * (c4 & 1);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(q + p * IMG) = w[it][p];
+      }
+    }
+  }
+};
+__device__ __forceinline__ void row_frags_pieces(bf16x8 (&f)[2][3], const u16* __restrict__ row, int ld, bool valid, int g) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (valid) x = *reinterpret_cast<const f32x4*>(row + (size_t)p * ld + 32 * s + 8 * g);
+      f[s][p] = __builtin_bit_cast(bf16x8, x);
+    }
+}
+#endif
+
 // B operand of a product that sums over d, from the lane's own row: step s, lane group g -> d = 32 s + 8 g .. + 7
 template <int NP, bool B16>
 __device__ __forceinline__ void row_frags(bf16x8 (&f)[2][NP], const void* __restrict__ row_, bool valid, int g) {
@@ -452,7 +493,8 @@ __global__ __launch_bounds__(768) void attn_x3_fwd_kernel(const Args a, int Lr) 
 
 // --------------------------------------------------------------- backward ---
 // LDS: operand pieces 1 | operand pieces 2 | mask bias | lse | delta | column sums | keep words
-// LAB (measurement builds, -DUNITER_X3_LAB + UNITER_ATTN_X3_LAB=bits): 1 = no pass-1 loop, 2 = no pass-2 loop, 4 = no MFMAs
+// LAB (measurement builds, -DUNITER_X3_LAB + UNITER_ATTN_X3_LAB=bits): 1 = no pass-1 loop, 2 = no pass-2 loop, 4 = no MFMAs,
+// 8 = Q, K, V read as pieces (StagePieces)
 template <int NP, bool QB16, int LAB>
 __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) {
   set_wave_prio(a.prio);
@@ -484,10 +526,25 @@ __global__ __launch_bounds__(768) void attn_x3_bwd_kernel(const Args a, int Lr) 
   {
     float delta = 0.f;
     {
+#ifdef UNITER_X3_LAB
+      typedef typename std::conditional<(LAB & 8) != 0, StagePieces, Stage<NP, QB16>>::type stage_t;
+      stage_t sk, sv;
+      if constexpr (LAB & 8) {
+        const u16* b16 = static_cast<const u16*>(a.qkv) + (size_t)sp.row0 * 3 * ld + head * D;
+        sk.load(b16 + a.H, ld, Lb, Lr, tid, nthr);
+        sv.load(b16 + 2 * a.H, ld, Lb, Lr, tid, nthr);
+        row_frags_pieces(qf, b16 + (size_t)rw * 3 * ld, ld, vr, g);
+      } else {
+        sk.load(base + a.H, ld, Lb, Lr, tid, nthr);
+        sv.load(base + 2 * a.H, ld, Lb, Lr, tid, nthr);
+        row_frags<NP, QB16>(qf, base + (size_t)rw * ld, vr, g);
+      }
+#else
       Stage<NP, QB16> sk, sv;
       sk.load(base + a.H, ld, Lb, Lr, tid, nthr);
       sv.load(base + 2 * a.H, ld, Lb, Lr, tid, nthr);
       row_frags<NP, QB16>(qf, base + (size_t)rw * ld, vr, g);
+#endif
       // this lane's 16 of the 64 values of its dO and O rows (d = 32 s + 8 g + 0..7): the k-slots of the dO operand
       const float* dorow = dobase + (size_t)rw * a.H;
       const float* orow = a.ctx + ((size_t)sp.row0 + rw) * a.H + head * D;
@@ -733,7 +790,7 @@ int launch_bwd(const Args& a, hipStream_t st) {
       UCHECK_LAUNCH();                                                                                                   \
       return 0;                                                                                                          \
     }
-    X3A_LAB_CASE(1) X3A_LAB_CASE(2) X3A_LAB_CASE(3) X3A_LAB_CASE(4) X3A_LAB_CASE(5) X3A_LAB_CASE(6)
+    X3A_LAB_CASE(1) X3A_LAB_CASE(2) X3A_LAB_CASE(3) X3A_LAB_CASE(4) X3A_LAB_CASE(5) X3A_LAB_CASE(6) X3A_LAB_CASE(8) X3A_LAB_CASE(11)
 #undef X3A_LAB_CASE
   }
 #endif

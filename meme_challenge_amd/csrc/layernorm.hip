@@ -415,6 +415,7 @@ extern "C" int uniter_ln_fwd_b16(const float* x, const float* res, const float* 
 static int ln_fwd_run(const float* x, int nslab, size_t slab_stride, const float* res, const float* gamma,
                       const float* beta, float* z_out, float* y, void* y_bf16, int pieces, float* mean, float* rstd,
                       int M, int H, float p_drop, uint64_t seed, uint32_t offset, uint32_t site, void* stream) {
+  const unsigned char* ahead = take_drop_bits();      // (first thing: a call that fails below must not leave the pointer to the next one)
   UCHECK_ARG(x && gamma && beta && y, "ln_fwd: null pointer");
   UCHECK_ARG(nslab >= 1 && (nslab == 1 || slab_stride >= (size_t)M * H), "ln_fwd: bad slab count / stride");
   UCHECK_ARG((mean == nullptr) == (rstd == nullptr), "ln_fwd: mean/rstd must both be given or NULL");
@@ -423,8 +424,7 @@ static int ln_fwd_run(const float* x, int nslab, size_t slab_stride, const float
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   DropCfg drop = make_drop(p_drop, seed, offset, site);
-  drop.bits = take_drop_bits();
-  if (!drop.active) drop.bits = nullptr;
+  drop.bits = drop.active ? ahead : nullptr;
   const int nv = (H / 4 + 63) / 64;
   LN_DISPATCH(nv, ln_fwd_kernel, dim3((M + 3) / 4), x, res, gamma, beta, z_out, y, mean, rstd, M, H, drop,
               (unsigned short*)y_bf16, nslab, slab_stride, pieces);
@@ -484,6 +484,7 @@ static int ln_bwd_rows_run(const float* dy, int nslab, size_t slab_stride, const
                            const float* rstd, const float* gamma, float* dz, float* dx, void* dx_bf16, int pieces,
                            int want_dbias, int M, int H, float p_drop, uint64_t seed, uint32_t offset,
                            uint32_t site, void* ws, size_t ws_bytes, void* stream) {
+  const unsigned char* ahead = take_drop_bits();      // (first thing, as in the forward pass)
   UCHECK_ARG(dy && z && mean && rstd && gamma && ws, "ln_bwd: null pointer");
   UCHECK_ARG(nslab >= 1 && (nslab == 1 || slab_stride >= (size_t)M * H), "ln_bwd: bad slab count / stride");
   UCHECK_ARG(dz || dx || dx_bf16, "ln_bwd: need dz or dx");
@@ -492,8 +493,7 @@ static int ln_bwd_rows_run(const float* dy, int nslab, size_t slab_stride, const
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   DropCfg drop = make_drop(p_drop, seed, offset, site);
-  drop.bits = take_drop_bits();
-  if (!drop.active) drop.bits = nullptr;
+  drop.bits = drop.active ? ahead : nullptr;
   const int nv = (H / 4 + 63) / 64;
   const int nblk = ln_bwd_blocks(M);
   float* part = (float*)ws;

@@ -355,6 +355,66 @@ def prepare_rccl_env(world, env=None):
     return r
 
 
+def pick_cu_reserve(sync, encoder, one_step, candidates=None, steps=6, warm=2):
+    """Measure instead of believing: run `warm` + `steps` training steps (``one_step()``: forward, backward with the exchange, update)
+    with each candidate number of reserved CUs, take the slowest rank's time for each, keep the fastest candidate on every rank
+    (ties: the earlier one) and return {'picked': r, 'candidates': [{'cu_reserve': r, 'ms_per_step': t}, ...]}.  What the right
+    reserve is depends on how many channels RCCL opens on the node's topology and on how long its kernels sit beside the matrix
+    kernels -- neither can be known before the first exchange has run on the real links.  The steps are ordinary steps (their
+    updates count); results do not depend on the reserve (tests/test_model_gpu.py::test_cu_reserve_for_a_gradient_exchange...).
+    A failure on any rank leaves the attach-time reserve in place on all of them ('error' in the result).  One rank: no-op, None."""
+    import time
+    world = sync.world if sync is not None else 1
+    if sync is None or world <= 1:
+        return None
+    start = int(getattr(sync, 'cu_reserve', 0))
+    if candidates is None:
+        candidates = [start] + ([0] if start != 0 else [DEFAULT_CU_RESERVE])
+    dev = sync.flat.device
+    use_cuda = dev.type == 'cuda'
+
+    def fence():
+        dist.barrier(group=sync.group)
+        if use_cuda:
+            torch.cuda.synchronize(dev)
+
+    times, ok, err = [], 1, None
+    try:
+        for c in candidates:
+            encoder.cu_reserve = int(c)
+            for _ in range(warm):
+                one_step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one_step()
+            fence()
+            times.append((time.perf_counter() - t0) / steps * 1e3)
+    except Exception as e:                                       # noqa: BLE001
+        ok, err = 0, repr(e)
+    res = {'picked': start, 'candidates': []}
+    try:
+        buf = torch.zeros(1 + len(candidates), dtype=torch.float64, device=dev if use_cuda else 'cpu')
+        buf[0] = -float(ok)                                      # MAX over ranks of -ok: 0 as soon as one rank failed
+        for i, t in enumerate(times):
+            buf[1 + i] = t
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=sync.group)
+        if buf[0].item() < 0:
+            ts = [float(x) for x in buf[1:].tolist()]
+            best = min(range(len(ts)), key=lambda i: (ts[i], i))
+            res['picked'] = int(candidates[best])
+            res['candidates'] = [{'cu_reserve': int(c), 'ms_per_step': round(t, 3)} for c, t in zip(candidates, ts)]
+        else:
+            res['error'] = err or 'failed on another rank'
+    except Exception as e:                                       # noqa: BLE001
+        res['error'] = err or repr(e)
+    sync.cu_reserve = res['picked']
+    encoder.cu_reserve = res['picked']
+    sync.collect_timings()
+    sync.timings = []
+    return res
+
+
 def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embeddings=None, accum=1, cu_reserve=None):
     """Wire a GradSync to a MemeUniter, UniterForPretraining or UniterModel and return it.
     payload None: 'bf16' when the encoder runs in the bf16 precision mode, else 'fp32'.

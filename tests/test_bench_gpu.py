@@ -99,8 +99,8 @@ def test_bench_starts_its_own_ranks(extra):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     env.update(UNITER_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-                          '--prewarm_s', '0', '--prof_kind', '0', '--no_cpu_baseline', *extra], cwd=ROOT, env=env, capture_output=True, text=True,
-                         timeout=900)
+                          '--prewarm_s', '0', '--prof_kind', '0', '--no_cpu_baseline', *(extra or ()), *(('--no_reserve_pick',) if extra else ())],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out.stdout
@@ -116,7 +116,14 @@ def test_bench_starts_its_own_ranks(extra):
     assert c['world'] == 2 and c['payload'] == ('bf16' if 'bf16' in extra else 'fp32') and c['sparse_embeddings'] == bool('--dp_sparse_embeddings' in extra)
     assert c['collectives'] and all(k['bytes'] > 0 and k['issue_to_done_ms'] >= k['exposed_ms'] >= 0 for k in c['collectives'])
     assert c['bytes_per_step'] > 0 and c['exposed_ms_per_step'] >= 0 and c['headline_exchange'] in ('dense', 'sparse word-embedding rows')
-    assert c['cu_reserve'] == 16 and c['rccl_max_nchannels_env'] == '16'          # two ranks: the persistent launches leave 16 CUs
+    assert c['rccl_max_nchannels_env'] == '16'
+    if extra:
+        assert c['cu_reserve'] == 16 and 'reserve_pick' not in c           # two ranks: the persistent launches leave 16 CUs
+    else:
+        # the default: a few untimed steps with the reserve and without it, the faster kept on every rank (dp.pick_cu_reserve)
+        rp = c['reserve_pick']
+        assert [k['cu_reserve'] for k in rp['candidates']] == [16, 0] and all(k['ms_per_step'] > 0 for k in rp['candidates'])
+        assert rp['picked'] in (16, 0) and c['cu_reserve'] == rp['picked']
 
 
 def test_graft_entry_smoke():

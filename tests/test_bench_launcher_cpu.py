@@ -101,5 +101,6 @@ def test_round5_flags_parse_and_defaults():
     import bench
     a = bench.parse_args([])
     assert not a.both_exchanges and not a.reserve_ab and not a.no_bf16_leg and not a.cpu_all_cores and a.precision == 'fp32x3'
+    assert not a.no_reserve_pick            # N > 1 measures the CU reserve before the warm-up unless told not to
     a = bench.parse_args(['--both_exchanges', '--reserve_ab', '--no_bf16_leg', '--cpu_all_cores', '--gpus', '8'])
     assert a.both_exchanges and a.reserve_ab and a.no_bf16_leg and a.cpu_all_cores and a.gpus == 8

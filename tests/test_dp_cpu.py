@@ -257,3 +257,55 @@ def test_cu_reserve_default_and_rccl_env(monkeypatch):
     assert dp.prepare_rccl_env(8, env) == 16 and env['NCCL_MAX_NCHANNELS'] == '32'       # the caller's choice stands
     env = {}
     assert dp.prepare_rccl_env(1, env) == 0 and env == {}
+
+
+def _pick_worker(rank, world, port, out):
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from meme_challenge_amd import dp
+
+    class Enc(object):
+        cu_reserve = 16
+    flat = torch.zeros(256)
+    gs = dp.GradSync(flat, [(0, 128), (128, 256)])
+    gs.cu_reserve = 16
+    enc = Enc()
+    seen = []
+
+    def step():                       # reserve 0 is the faster setting on rank 0 but far slower on rank 1: the slowest rank decides
+        seen.append(enc.cu_reserve)
+        time.sleep({16: 0.004, 0: 0.001 if rank == 0 else 0.012}[enc.cu_reserve])
+    r1 = dp.pick_cu_reserve(gs, enc, step, steps=3, warm=1)
+    after1 = (enc.cu_reserve, gs.cu_reserve, list(seen))
+
+    def step2():                      # the other way round on every rank
+        time.sleep({16: 0.008, 0: 0.001}[enc.cu_reserve])
+    r2 = dp.pick_cu_reserve(gs, enc, step2, steps=3, warm=1)
+    after2 = (enc.cu_reserve, gs.cu_reserve)
+
+    def step3():                      # a failure every rank meets alike: the reserve in force stays, the result says why
+        if enc.cu_reserve == 16:
+            raise RuntimeError('workspace too small')
+    r3 = dp.pick_cu_reserve(gs, enc, step3, steps=2, warm=1)
+    after3 = (enc.cu_reserve, gs.cu_reserve)
+    torch.save(dict(r1=r1, after1=after1, r2=r2, after2=after2, r3=r3, after3=after3), out + str(rank))
+    dist.destroy_process_group()
+
+
+def test_cu_reserve_is_picked_by_the_slowest_rank(tmp_path):
+    """dp.pick_cu_reserve: every rank times the same candidates, the maximum over ranks decides, all ranks end with the same
+    reserve; a failure leaves the reserve as it was.  One rank (or no exchange): no-op."""
+    from meme_challenge_amd import dp
+    assert dp.pick_cu_reserve(None, None, lambda: None) is None
+    world, port, out = 2, _free_port(), str(tmp_path / 'pick')
+    mp.spawn(_pick_worker, args=(world, port, out), nprocs=world, join=True)
+    rs = [torch.load(out + str(r)) for r in range(world)]
+    for r in rs:
+        assert r['r1']['picked'] == 16 and [c['cu_reserve'] for c in r['r1']['candidates']] == [16, 0]
+        assert r['after1'][:2] == (16, 16) and r['after1'][2] == [16] * 4 + [0] * 4
+        assert r['r1']['candidates'][1]['ms_per_step'] > r['r1']['candidates'][0]['ms_per_step']
+        assert r['r2']['picked'] == 0 and r['after2'] == (0, 0) and [c['cu_reserve'] for c in r['r2']['candidates']] == [16, 0]
+        # (the third call starts from reserve 0: its candidates are 0, then the default 16, which raises)
+        assert r['r3']['picked'] == 0 and 'workspace too small' in r['r3']['error'] and r['after3'] == (0, 0)
+    assert rs[0]['r1'] == rs[1]['r1'] and rs[0]['r2'] == rs[1]['r2']
