@@ -246,6 +246,27 @@ int uniter_wgrad_x3_group_riders(int cfg, int n, const int* M, const int* N, int
                                  const void* const* B, float* const* dW, int overwrite, int max_wgs,
                                  uniter_x3_riders_t* riders, void* stream);
 int uniter_wgrad_x3_group_slots(int cfg, int n, const int* M, const int* N, int max_wgs);
+/* The BALANCED WALK of the 128 x 256-tile launches (round 5).  A persistent launch whose tiles do not fill whole rounds of the chip
+ * (216 weight-gradient tiles or the QKV product's 189 on 256 CUs) leaves CUs idle for the length of a tile; given a workspace these
+ * entry points cut the k-tiles of all tiles, in tile order, into one equal run per workgroup instead: a tile whose k-range is cut is
+ * finished by the workgroup that holds its first part, which adds the partial sums the following workgroups stored (fixed order:
+ * reproducible run to run; the sum differs from the whole-tile walk's by fp32 rounding of the regrouped additions).
+ * Workspace: uniter_gemm_x3_balanced_ws_bytes() bytes, 256-byte aligned; its first 16 KB (flag words) ZERO before the first launch --
+ * every launch leaves them zero; launches that may run at the same time (two streams) need a workspace each.  ws = NULL, a
+ * geometry other than 128 x 256 or rounds that are full anyway: the classic walk.  (The model passes a workspace only under
+ * UNITER_X3_BALANCED: in the training step the balanced walk loses -- DESIGN.md section 9.)
+ *  - uniter_gemm_x3_cfg_ws: uniter_gemm_x3_cfg + workspace (balanced: forward layout, UNITER_EPI_BIAS, one k-piece, cfg 0 / 4);
+ *  - uniter_wgrad_x3_group_ws: uniter_wgrad_x3_group_riders + workspace (riders may be NULL); a balanced launch runs on every CU it
+ *    may use, so it writes more sum-of-squares slots: uniter_wgrad_x3_group_slots_ws(…, K, max_wgs, ws_bytes) counts them. */
+size_t uniter_gemm_x3_balanced_ws_bytes(void);
+int uniter_gemm_x3_cfg_ws(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda,
+                          int psa, const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* C_x3,
+                          int ldcx, int pscx, int epilogue, const float* bias, const float* aux_in, float* aux_out,
+                          int ld_aux, void* ws, size_t ws_bytes, void* stream);
+int uniter_wgrad_x3_group_ws(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
+                             const void* const* B, float* const* dW, int overwrite, int max_wgs,
+                             uniter_x3_riders_t* riders, void* ws, size_t ws_bytes, void* stream);
+int uniter_wgrad_x3_group_slots_ws(int cfg, int n, const int* M, const int* N, int K, int max_wgs, size_t ws_bytes);
 /* The same riders on the grouped bf16 weight-gradient launch (uniter_wgrad_bf16_group; precision bf16): overwrite = 1 stores
  * instead of adding, max_wgs > 0 caps the grid; cfg must be 0 or 1 (two LDS stages). */
 int uniter_wgrad_bf16_group_riders(int cfg, int n, const int* M, const int* N, int K, const void* const* A,

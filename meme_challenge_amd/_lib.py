@@ -84,6 +84,10 @@ _SIGS = {
     'uniter_gemm_x3_colpart': (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P]),
     'uniter_wgrad_x3_group_riders': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     'uniter_wgrad_x3_group_slots': (_I, [_I, _I, _P, _P, _I]),
+    'uniter_gemm_x3_balanced_ws_bytes': (_SZ, []),
+    'uniter_gemm_x3_cfg_ws': (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, C.c_long, _P, _I, _I, _I, _P, _P, _P, _I, _P, _SZ, _P]),
+    'uniter_wgrad_x3_group_ws': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
+    'uniter_wgrad_x3_group_slots_ws': (_I, [_I, _I, _P, _P, _I, _I, _SZ]),
     'uniter_wgrad_bf16_group_riders': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     'uniter_wgrad_bf16_group_slots': (_I, [_I, _P, _P, _I]),
     'uniter_hidden_keep_bits_bytes': (_SZ, [_SZ]),

@@ -600,6 +600,12 @@ struct S3Group {
   S3Args p[4];
   int start[5];
   uniter_x3_riders_t x;     // side work of a grouped weight-gradient launch (kernels instantiated with XTR only)
+  // balanced walk (kernels instantiated with SK only): the k-tiles of ALL tiles form one sequence of sk_units = tiles x sk_nk units
+  // dealt evenly over the grid; a tile whose k-range is cut hands its later parts over through sk_part (one BM x BN fp32 slot per
+  // workgroup) and sk_flag (one word per workgroup and compute wave; zero before the first launch, left zero by every launch)
+  float* sk_part;
+  unsigned* sk_flag;
+  int sk_units, sk_nk;
 };
 
 // ---- persistent form with loader waves ------------------------------------------------------------------------------------
@@ -616,7 +622,17 @@ struct S3Group {
 //   compute:                            for u: { barrier B_u;  read stage u % ST, MFMAs;  (last k-tile of an item: epilogue) }
 // B_u orders k-tile u's LDS-DMA before its reads (every loader waited for its own instructions) and the reads of k-tile u - 1
 // (each compute wave waits lgkmcnt(0) before its last MFMAs) before the LDS-DMA that overwrites their stage.
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, bool M16, int EPI, bool XTR = false>
+//
+// Balanced walk (SK, round 5): a launch whose tiles do not fill a whole number of rounds -- 216 weight-gradient tiles of 128 x 256 on
+// 256 CUs, 189 tiles of the QKV product -- leaves CUs idle for the length of a tile.  With SK the unit of work is the K-TILE: the
+// k-tiles of all tiles, in tile order, are cut into gridDim.x equal runs (workgroup l, in XCD-chunked order, takes units
+// [l U / G, (l + 1) U / G)), so a workgroup's run is: the LAST k-tiles of a tile another workgroup began (it stores its accumulators
+// as a partial sum, write-through, and raises its waves' flags), whole tiles, and the FIRST k-tiles of a tile it owns (it waits for the
+// flags of the workgroups that hold the rest -- l + 1, l + 2, ..., which stored theirs at the START of their runs -- adds their
+// partial sums in that order and runs the epilogue).  The order of the additions is fixed by the grid: results are reproducible
+// run to run.  A wave waits only for the same wave of another workgroup (each reads exactly what its namesake stored): no
+// workgroup-wide hand-shake beside the k-tile barrier.  No deadlock: a partial sum is stored before its workgroup waits for anything.
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, bool M16, int EPI, bool XTR = false, bool SK = false>
 __global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + NWL), ((BM / WM) * (BN / WN) + NWL + 3) / 4)
 void gemm_s3p_kernel(const S3Group G) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -625,7 +641,7 @@ void gemm_s3p_kernel(const S3Group G) {
   constexpr int KS = KT / 16;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[ST * STAGE];
   const int nwork = G.start[4];
-  if (!XTR && xcd_work_item3(nwork, 0) < 0) return;        // (with riders every workgroup stays: it owns sum-of-squares slots)
+  if (!XTR && !SK && xcd_work_item3(nwork, 0) < 0) return;        // (with riders every workgroup stays: it owns sum-of-squares slots)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   stamp_begin(G.p[0].stamp);
@@ -638,9 +654,22 @@ void gemm_s3p_kernel(const S3Group G) {
 
   // work item number `round` of this workgroup: product, tile origin, k-tile range
   struct Item { int p, piece, m0, n0, kb, ke; bool valid; };
+  // SK: this workgroup's run of units (XCD-chunked order: consecutive runs share an L2; the grid is a multiple of 8)
+  const int sk_l = SK ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : 0;
+  auto sk_first = [&](int l) -> int { return (int)((long)G.sk_units * l / (long)gridDim.x); };
+  const int sk_u0 = SK ? sk_first(sk_l) : 0, sk_u1 = SK ? sk_first(sk_l + 1) : 0;
+  const int sk_t0 = SK ? sk_u0 / G.sk_nk : 0;
   auto item = [&](int round) -> Item {
     Item it;
-    const int w = xcd_work_item3(nwork, round);
+    int w, skb = 0, ske = 0;
+    if constexpr (SK) {
+      const int ustart = round == 0 ? sk_u0 : (sk_t0 + round) * G.sk_nk;
+      w = ustart < sk_u1 ? sk_t0 + round : -1;
+      skb = round == 0 ? sk_u0 - sk_t0 * G.sk_nk : 0;
+      ske = min(G.sk_nk, skb + (sk_u1 - ustart));
+    } else {
+      w = xcd_work_item3(nwork, round);
+    }
     it.valid = w >= 0;
     if (!it.valid) { it.p = 0; it.piece = it.m0 = it.n0 = it.kb = it.ke = 0; return it; }
     it.p = (w >= G.start[1]) + (w >= G.start[2]) + (w >= G.start[3]);
@@ -654,6 +683,7 @@ void gemm_s3p_kernel(const S3Group G) {
     const int nk = (g.K + KT - 1) / KT;
     it.kb = (int)((long)nk * it.piece / g.nsplit);
     it.ke = (int)((long)nk * (it.piece + 1) / g.nsplit);
+    if constexpr (SK) { it.kb = skb; it.ke = ske; }        // (nsplit == 1, every product has sk_nk k-tiles: the launcher checks)
     return it;
   };
 #ifdef UNITER_X3_LAB
@@ -864,10 +894,58 @@ void gemm_s3p_kernel(const S3Group G) {
           __builtin_amdgcn_sched_barrier(0);
           stg = stg == ST - 1 ? 0 : stg + 1;
         }
+        if constexpr (SK) {
+          // a 16 x 16 block of a wave is 1 KiB: [workgroup][wave][block][lane] x 16 bytes, stored and loaded device-coherently (sc1)
+          constexpr int AUX_SC1 = 16;
+          constexpr int SLOT = BM * BN * 4, WSLOT = MB * NB * 1024;
+          if (c.kb > 0) {                 // the later part of a tile another workgroup owns: hand the partial sum over
+            const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<unsigned char*>(G.sk_part) + (size_t)sk_l * SLOT + (size_t)wave * WSLOT, 0, WSLOT, 0x00020000);
+#pragma unroll
+            for (int a = 0; a < MB; ++a)
+#pragma unroll
+              for (int b = 0; b < NB; ++b)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[a][b]), rsP, ((a * NB + b) * 64 + lane) * 16, 0, AUX_SC1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(G.sk_flag + sk_l * NWC + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+          }
+          if (c.ke < G.sk_nk) {           // the first part of a tile this workgroup owns: add the parts the next workgroups hold
+            int cover = c.ke;
+            for (int j = sk_l + 1; cover < G.sk_nk; ++j) {
+              unsigned* fl = G.sk_flag + j * NWC + wave;
+              // (a relaxed device-scope poll: an ACQUIRE would invalidate the XCD's L2 on every turn, under the operand panels of every
+              // workgroup of the XCD; the partial sums themselves are loaded device-coherently below)
+              while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+              asm volatile("" ::: "memory");
+              const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
+                  reinterpret_cast<unsigned char*>(G.sk_part) + (size_t)j * SLOT + (size_t)wave * WSLOT, 0, WSLOT, 0x00020000);
+              // (two row blocks at a time: 32 registers beside the 64 accumulators -- all 64 at once spill)
+#pragma unroll
+              for (int a0 = 0; a0 < MB; a0 += 2) {
+                f32x4 part[2][NB];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                  for (int b = 0; b < NB; ++b)
+                    part[a][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, (((a0 + a) * NB + b) * 64 + lane) * 16, 0, AUX_SC1));
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                  for (int b = 0; b < NB; ++b) acc[a0 + a][b] += part[a][b];
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              if (lane == 0) __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (left zero for the next launch)
+              cover += min(G.sk_nk - cover, sk_first(j + 1) - sk_first(j));
+            }
+          }
+        }
         s3_epilogue16<WM, WN, EPI>(G.p[c.p], c.piece, c.m0, c.n0, wm, wn, lane, acc);
         if constexpr (XTR) wss += (double)tile_riders(c, false);
         continue;
       }
+      static_assert(!SK || NWC > 4, "the balanced walk is built for the 128 x 256 geometry");
       Frs f;
       for (int kt = c.kb; kt < c.ke; ++kt) {
         if (!(dbg & 64)) __builtin_amdgcn_s_barrier();
@@ -1024,13 +1102,17 @@ void plan_tiles3(S3Args& g, int BN) {
 }
 
 // workgroups of a persistent launch over `nwork` items: a multiple of 8 (one chunk of the work per XCD), one per CU at most
-int x3_grid(int nwork, int max_wgs) {
-  int grid = (nwork + 7) / 8 * 8;
+int x3_chip_cus() {
   static const int cus = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 8 ? n / 8 * 8 : 256;
   }();
+  return cus;
+}
+int x3_grid(int nwork, int max_wgs) {
+  int grid = (nwork + 7) / 8 * 8;
+  const int cus = x3_chip_cus();
   int cap = max_wgs >= 8 ? max_wgs / 8 * 8 : cus;       // one workgroup per CU: it owns the CU's LDS
   if (g_uniter_cu_reserve > 0) {                          // CUs left to the data-parallel exchange's kernels
     const int room = (cus - g_uniter_cu_reserve) / 8 * 8;
@@ -1043,6 +1125,37 @@ template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, in
 int launch_s3p(const S3Group& G, int max_wgs, hipStream_t st) {
   const int grid = x3_grid(G.start[4], max_wgs);
   hipLaunchKernelGGL((gemm_s3p_kernel<BM, BN, WM, WN, AKM, BKM, ST, KT, NWL, M16, EPI, XTR>), dim3(grid),
+                     dim3(64 * ((BM / WM) * (BN / WN) + NWL)), 0, st, G);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+// ---- balanced walk (SK kernels: 128 x 256 tiles) ------------------------------------------------------------------------------
+// workspace: [flags: one word per workgroup and compute wave, ZERO before the first launch -- every launch leaves them zero]
+//            [partial sums: one 128 x 256 fp32 tile per workgroup]
+constexpr size_t SK_FLAG_BYTES = 16384;           // 512 workgroups x 8 compute waves x 4 bytes
+constexpr size_t SK_SLOT_BYTES = 128 * 256 * 4;
+size_t sk_ws_bytes_() { return SK_FLAG_BYTES + (size_t)x3_chip_cus() * SK_SLOT_BYTES; }
+// grid of the balanced walk for `tiles` tiles of `nk` k-tiles each: every CU the launch may use -- or 0: the classic walk is as
+// good (its rounds are full), or the workspace is missing.  The hand-over (a 128-KB partial sum stored, flagged and added) is
+// priced at four k-tiles
+int x3_sk_grid(int tiles, int nk, int max_wgs, const void* ws, size_t ws_bytes) {
+  if (!ws || ws_bytes < sk_ws_bytes_() || ((uintptr_t)ws & 255) != 0 || tiles <= 0 || nk <= 0) return 0;
+  const int cap = x3_grid(1 << 20, max_wgs);
+  const long units = (long)tiles * nk;
+  if (cap > 512 || units >= (1l << 30) || units < 8l * cap) return 0;
+  const int g0 = x3_grid(tiles, max_wgs);
+  const long classic = (long)((tiles + g0 - 1) / g0) * nk, balanced = (units + cap - 1) / cap + 4;
+  return classic > balanced ? cap : 0;
+}
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int ST, int KT, int NWL, bool M16, int EPI, bool XTR>
+int launch_s3p_sk(S3Group& G, int grid, void* ws, hipStream_t st) {
+  static_assert(BM == 128 && BN == 256, "the partial-sum slots are 128 x 256 tiles");
+  G.sk_flag = (unsigned*)ws;
+  G.sk_part = (float*)((char*)ws + SK_FLAG_BYTES);
+  G.sk_nk = (G.p[0].K + KT - 1) / KT;
+  G.sk_units = G.start[4] * G.sk_nk;
+  hipLaunchKernelGGL((gemm_s3p_kernel<BM, BN, WM, WN, AKM, BKM, ST, KT, NWL, M16, EPI, XTR, true>), dim3(grid),
                      dim3(64 * ((BM / WM) * (BN / WN) + NWL)), 0, st, G);
   UCHECK_LAUNCH();
   return 0;
@@ -1067,30 +1180,40 @@ int dispatch_cfg3p(int cfg, const S3Group& G, int max_wgs, hipStream_t st) {
   }
 }
 
+struct SkWs { void* p; size_t bytes; };
+
 template <bool AKM, bool BKM, int EPI>
-int dispatch_cfg3(int cfg, const S3Args& g, hipStream_t st) {
+int dispatch_cfg3(int cfg, const S3Args& g, hipStream_t st, SkWs sk) {
   S3Group G;
   memset(&G.x, 0, sizeof(G.x));
+  G.sk_part = nullptr; G.sk_flag = nullptr; G.sk_units = G.sk_nk = 0;
   for (int p = 0; p < 4; ++p) G.p[p] = g;
   plan_tiles3<128>(G.p[0], cfg == 4 ? 256 : 128);
   const int total = G.p[0].tiles_m * G.p[0].tiles_n * g.nsplit;
   G.start[0] = 0;
   for (int p = 1; p <= 4; ++p) G.start[p] = total;
+  // the balanced walk: built for the forward products with a bias epilogue (the QKV product: 189 tiles of 128 x 256 at configs[1])
+  if constexpr (!AKM && !BKM && EPI == S3_BIAS) {
+    if (cfg == 4 && g.nsplit == 1) {
+      const int grid = x3_sk_grid(total, (g.K + 31) / 32, 0, sk.p, sk.bytes);
+      if (grid > 0) return launch_s3p_sk<128, 256, 64, 64, AKM, BKM, 2, 32, 4, true, EPI, false>(G, grid, sk.p, st);
+    }
+  }
   return dispatch_cfg3p<AKM, BKM, EPI>(cfg, G, 0, st);
 }
 
 template <bool AKM, bool BKM>
-int dispatch_epi3(int cfg, const S3Args& g, int epi, hipStream_t st) {
+int dispatch_epi3(int cfg, const S3Args& g, int epi, hipStream_t st, SkWs sk) {
   // forward products (weights k-contiguous): none / bias / bias + GELU; input gradients (weights k-major): none / add / mul;
   // weight gradients (both k-major): none / add
-  if (epi == UNITER_EPI_NONE) return dispatch_cfg3<AKM, BKM, S3_NONE>(cfg, g, st);
+  if (epi == UNITER_EPI_NONE) return dispatch_cfg3<AKM, BKM, S3_NONE>(cfg, g, st, sk);
   if constexpr (!AKM && !BKM) {
-    if (epi == UNITER_EPI_BIAS) return dispatch_cfg3<AKM, BKM, S3_BIAS>(cfg, g, st);
-    if (epi == UNITER_EPI_BIAS_GELU_D) return dispatch_cfg3<AKM, BKM, S3_BIAS_GELU_D>(cfg, g, st);
+    if (epi == UNITER_EPI_BIAS) return dispatch_cfg3<AKM, BKM, S3_BIAS>(cfg, g, st, sk);
+    if (epi == UNITER_EPI_BIAS_GELU_D) return dispatch_cfg3<AKM, BKM, S3_BIAS_GELU_D>(cfg, g, st, sk);
   } else {
-    if (epi == UNITER_EPI_ADD) return dispatch_cfg3<AKM, BKM, S3_ADD>(cfg, g, st);
+    if (epi == UNITER_EPI_ADD) return dispatch_cfg3<AKM, BKM, S3_ADD>(cfg, g, st, sk);
     if constexpr (!AKM) {
-      if (epi == UNITER_EPI_MUL) return dispatch_cfg3<AKM, BKM, S3_MUL>(cfg, g, st);
+      if (epi == UNITER_EPI_MUL) return dispatch_cfg3<AKM, BKM, S3_MUL>(cfg, g, st, sk);
     }
   }
   uniter_set_error("gemm_x3: epilogue %d is not built for this operand layout", epi);
@@ -1171,6 +1294,8 @@ bool x3_fits(size_t rows, int rs, int ps, int ext) { return ((rows + 256) * (siz
 
 }  // namespace
 
+size_t gemm_x3_sk_ws_bytes() { return sk_ws_bytes_(); }
+
 int riders_prepare(uniter_x3_riders_t& x, const char* who) {
   UCHECK_ARG(x.njobs >= 0 && x.njobs <= 4, "%s: at most 4 column-reduction jobs", who);
   int items = 0;
@@ -1195,7 +1320,7 @@ void x3_choose(int M, int N, int K, int avail, int nsplit_fixed, int* cfg_out, i
 int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, int psa,
                 const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* Cx, int ldcx, int pscx,
                 int epilogue, const float* bias, const float* aux_in, float* aux_out, int ld_aux, void* stream,
-                float* colsum_part) {
+                float* colsum_part, void* sk_ws, size_t sk_ws_bytes) {
   UCHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && (C || Cx), "gemm_x3: bad argument");
   UCHECK_ARG(!a_kmajor || (b_kmajor && !Cx && (epilogue == UNITER_EPI_NONE || epilogue == UNITER_EPI_ADD)),
              "gemm_x3: A k-major only as the weight-gradient layout (both operands k-major, fp32 output, none / add)");
@@ -1240,8 +1365,9 @@ int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, i
     }
   }
   hipStream_t st = (hipStream_t)stream;
-  if (a_kmajor) return dispatch_epi3<true, true>(cfg, g, epilogue, st);
-  return b_kmajor ? dispatch_epi3<false, true>(cfg, g, epilogue, st) : dispatch_epi3<false, false>(cfg, g, epilogue, st);
+  const SkWs sk = {sk_ws, sk_ws_bytes};
+  if (a_kmajor) return dispatch_epi3<true, true>(cfg, g, epilogue, st, sk);
+  return b_kmajor ? dispatch_epi3<false, true>(cfg, g, epilogue, st, sk) : dispatch_epi3<false, false>(cfg, g, epilogue, st, sk);
 }
 
 // Tile geometry (cfg 3 = 128 x 128 persistent, cfg 4 = 128 x 256 one-round) and k-pieces of a forward / input-gradient product on
@@ -1297,7 +1423,19 @@ extern "C" int uniter_gemm_x3_cfg(int cfg, int nsplit, int a_kmajor, int b_kmajo
                                   void* C_x3, int ldcx, int pscx, int epilogue, const float* bias, const float* aux_in,
                                   float* aux_out, int ld_aux, void* stream) {
   return gemm_x3_run(cfg, nsplit, a_kmajor, b_kmajor, M, N, K, A, lda, psa, B, ldb, psb, C, ldc, c_split_stride, C_x3, ldcx,
-                     pscx, epilogue, bias, aux_in, aux_out, ld_aux, stream, nullptr);
+                     pscx, epilogue, bias, aux_in, aux_out, ld_aux, stream, nullptr, nullptr, 0);
+}
+
+// the same, with the workspace of the balanced walk (uniter_gemm_x3_balanced_ws_bytes; its first 16 KB zero before the first launch,
+// every launch leaves them zero; one workspace per stream that launches concurrently): a 128 x 256-tile forward product with a bias
+// epilogue whose tiles do not fill whole rounds of the chip is cut into equal runs of k-tiles instead (gemm_s3p_kernel, "balanced walk")
+extern "C" size_t uniter_gemm_x3_balanced_ws_bytes(void) { return gemm_x3_sk_ws_bytes(); }
+extern "C" int uniter_gemm_x3_cfg_ws(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A,
+                                     int lda, int psa, const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride,
+                                     void* C_x3, int ldcx, int pscx, int epilogue, const float* bias, const float* aux_in,
+                                     float* aux_out, int ld_aux, void* ws, size_t ws_bytes, void* stream) {
+  return gemm_x3_run(cfg, nsplit, a_kmajor, b_kmajor, M, N, K, A, lda, psa, B, ldb, psb, C, ldc, c_split_stride, C_x3, ldcx,
+                     pscx, epilogue, bias, aux_in, aux_out, ld_aux, stream, nullptr, ws, ws_bytes);
 }
 
 // the same product, also leaving partial column sums of its output: colsum_part[(i, n)] = sum of the output rows 64 i .. 64 i + 63
@@ -1307,7 +1445,7 @@ extern "C" int uniter_gemm_x3_colpart(int cfg, int a_kmajor, int b_kmajor, int M
                                       const void* B, int ldb, int psb, float* C, int ldc, void* C_x3, int ldcx, int pscx,
                                       const float* aux_in, int ld_aux, float* colsum_part, void* stream) {
   return gemm_x3_run(cfg, 1, a_kmajor, b_kmajor, M, N, K, A, lda, psa, B, ldb, psb, C, ldc, 0, C_x3, ldcx, pscx, UNITER_EPI_MUL,
-                     nullptr, aux_in, nullptr, ld_aux, stream, colsum_part);
+                     nullptr, aux_in, nullptr, ld_aux, stream, colsum_part, nullptr, 0);
 }
 
 extern "C" int uniter_split3(const float* x, int rows, int cols, int ld, void* x3, size_t row_stride, size_t piece_stride,
@@ -1363,11 +1501,13 @@ int gemm_x3_wgrad_default_cfg() {
 }
 
 int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A, const void* const* B,
-                        float* const* dW, void* stream, int overwrite, int max_wgs, uniter_x3_riders_t* riders) {
+                        float* const* dW, void* stream, int overwrite, int max_wgs, uniter_x3_riders_t* riders,
+                        void* sk_ws, size_t sk_ws_bytes) {
   UCHECK_ARG(n >= 1 && n <= 4 && K > 0 && Mo && No && A && B && dW, "wgrad_x3_group: bad argument");
   if (cfg == 0) cfg = gemm_x3_wgrad_default_cfg();
   S3Group G;
   memset(&G.x, 0, sizeof(G.x));
+  G.sk_part = nullptr; G.sk_flag = nullptr; G.sk_units = G.sk_nk = 0;
   unsigned long long* stamp = take_stamp_slot();
   int total = 0;
   for (int p = 0; p < 4; ++p) {
@@ -1390,32 +1530,44 @@ int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, con
   G.start[4] = total;
   for (int p = n; p < 4; ++p) G.start[p] = total;
   hipStream_t st = (hipStream_t)stream;
+  // the balanced walk (128 x 256 tiles, a workspace given): 216 tiles for UNITER-base on 256 CUs -- 82 k-tiles per workgroup become 70
+  const int sk_grid = cfg == 4 ? x3_sk_grid(total, (K + 31) / 32, max_wgs, sk_ws, sk_ws_bytes) : 0;
   if (riders) {
     // riders ride on the v_mfma_f32_16x16x32_bf16 geometries: 4 compute waves of 64 x 64 (cfg 3) or the 128 x 256 tile's 8 (cfg 4)
     UCHECK_ARG(cfg == 3 || cfg == 4, "wgrad_x3_group: riders need cfg 3 or 4");
     uniter_x3_riders_t& x = *riders;
     UCHECK_ARG(cfg != 4 || !x.colsum_out, "wgrad_x3_group: colsum_out rides on cfg 3 only (the 128 x 256 geometry has no registers for it: "
                "take the bias gradient from the producing product's column partials, uniter_gemm_x3_colpart, as a reduction job)");
-    x.grid = x3_grid(total, max_wgs);
+    x.grid = sk_grid > 0 ? sk_grid : x3_grid(total, max_wgs);
     UCHECK_RC(riders_prepare(x, "wgrad_x3_group"));
     G.x = x;
+    if (sk_grid > 0)
+      return overwrite ? launch_s3p_sk<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_NONE, true>(G, sk_grid, sk_ws, st)
+                       : launch_s3p_sk<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_ADD, true>(G, sk_grid, sk_ws, st);
     if (cfg == 4)
       return overwrite ? launch_s3p<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_NONE, true>(G, max_wgs, st)
                        : launch_s3p<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_ADD, true>(G, max_wgs, st);
     return overwrite ? launch_s3p<128, 128, 64, 64, true, true, 3, 32, 4, true, S3_NONE, true>(G, max_wgs, st)
                      : launch_s3p<128, 128, 64, 64, true, true, 3, 32, 4, true, S3_ADD, true>(G, max_wgs, st);
   }
+  if (sk_grid > 0)
+    return overwrite ? launch_s3p_sk<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_NONE, false>(G, sk_grid, sk_ws, st)
+                     : launch_s3p_sk<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_ADD, false>(G, sk_grid, sk_ws, st);
   if (cfg == 4)
     return overwrite ? launch_s3p<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_NONE>(G, max_wgs, st)
                      : launch_s3p<128, 256, 64, 64, true, true, 2, 32, 4, true, S3_ADD>(G, max_wgs, st);
   return overwrite ? dispatch_cfg3p<true, true, S3_NONE>(cfg, G, max_wgs, st) : dispatch_cfg3p<true, true, S3_ADD>(cfg, G, max_wgs, st);
 }
 
-// sum-of-squares slots a launch with riders writes (one per compute wave: 4 per workgroup, 8 with 128 x 256 tiles) for these products
-int gemm_x3_wgrad_group_slots(int cfg, int n, const int* Mo, const int* No, int max_wgs) {
+// sum-of-squares slots a launch with riders writes (one per compute wave: 4 per workgroup, 8 with 128 x 256 tiles) for these products;
+// K > 0 and a workspace size: the launch is given the balanced walk's workspace (it then runs on every CU it may use)
+int gemm_x3_wgrad_group_slots(int cfg, int n, const int* Mo, const int* No, int max_wgs, int K, size_t sk_ws_bytes) {
   if (!Mo || !No || n < 1 || n > 4) return 0;
   if (cfg == 0) cfg = gemm_x3_wgrad_default_cfg();
-  return (cfg == 4 ? 8 : 4) * x3_grid(wgrad_tiles(cfg, n, Mo, No), max_wgs);
+  const int total = wgrad_tiles(cfg, n, Mo, No);
+  // (x3_sk_grid checks the pointer's alignment only: any aligned non-null value stands for the workspace here)
+  const int sk_grid = (cfg == 4 && K > 0) ? x3_sk_grid(total, (K + 31) / 32, max_wgs, (const void*)256, sk_ws_bytes) : 0;
+  return (cfg == 4 ? 8 : 4) * (sk_grid > 0 ? sk_grid : x3_grid(total, max_wgs));
 }
 
 // the smallest grid (a multiple of 8) on which these products' tiles take no more rounds than on one workgroup per CU
@@ -1432,13 +1584,24 @@ int gemm_x3_wgrad_group_balanced_wgs(int cfg, int n, const int* Mo, const int* N
 extern "C" int uniter_wgrad_x3_group_riders(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
                                             const void* const* B, float* const* dW, int overwrite, int max_wgs,
                                             uniter_x3_riders_t* riders, void* stream) {
-  return gemm_x3_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, overwrite, max_wgs, riders);
+  return gemm_x3_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, overwrite, max_wgs, riders, nullptr, 0);
 }
 extern "C" int uniter_wgrad_x3_group_slots(int cfg, int n, const int* M, const int* N, int max_wgs) {
-  return gemm_x3_wgrad_group_slots(cfg, n, M, N, max_wgs);
+  return gemm_x3_wgrad_group_slots(cfg, n, M, N, max_wgs, 0, 0);
+}
+// the same two with the workspace of the balanced walk (uniter_gemm_x3_balanced_ws_bytes, rules as uniter_gemm_x3_cfg_ws; riders may
+// be NULL): with 128 x 256 tiles that do not fill whole rounds the launch is cut into equal runs of k-tiles and runs on every CU it
+// may use -- the slot count follows (K = the reduction length, ws_bytes = the size of the workspace the launch will be given)
+extern "C" int uniter_wgrad_x3_group_ws(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
+                                        const void* const* B, float* const* dW, int overwrite, int max_wgs,
+                                        uniter_x3_riders_t* riders, void* ws, size_t ws_bytes, void* stream) {
+  return gemm_x3_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, overwrite, max_wgs, riders, ws, ws_bytes);
+}
+extern "C" int uniter_wgrad_x3_group_slots_ws(int cfg, int n, const int* M, const int* N, int K, int max_wgs, size_t ws_bytes) {
+  return gemm_x3_wgrad_group_slots(cfg, n, M, N, max_wgs, K, ws_bytes);
 }
 
 extern "C" int uniter_wgrad_x3_group(int cfg, int n, const int* M, const int* N, int K, const void* const* A,
                                      const void* const* B, float* const* dW, int overwrite, int max_wgs, void* stream) {
-  return gemm_x3_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, overwrite, max_wgs, nullptr);
+  return gemm_x3_wgrad_group(cfg, n, M, N, K, A, B, dW, stream, overwrite, max_wgs, nullptr, nullptr, 0);
 }

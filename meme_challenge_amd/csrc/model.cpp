@@ -37,13 +37,15 @@ int gemm_f32_wgrad_group(int n, const int* Mo, const int* No, int K, const float
 int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, int psa,
                 const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* Cx, int ldcx, int pscx,
                 int epilogue, const float* bias, const float* aux_in, float* aux_out, int ld_aux, void* stream,
-                float* colsum_part);
+                float* colsum_part, void* sk_ws, size_t sk_ws_bytes);
+size_t gemm_x3_sk_ws_bytes();
 int gemm_x3_wgrad_default_cfg();
 int gemm_x3_pick_split(int M, int N, int K);
 int gemm_x3_pick_split_on(int M, int N, int K, int avail);
 int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A, const void* const* B,
-                        float* const* dW, void* stream, int overwrite, int max_wgs, uniter_x3_riders_t* riders);
-int gemm_x3_wgrad_group_slots(int cfg, int n, const int* Mo, const int* No, int max_wgs);
+                        float* const* dW, void* stream, int overwrite, int max_wgs, uniter_x3_riders_t* riders,
+                        void* sk_ws, size_t sk_ws_bytes);
+int gemm_x3_wgrad_group_slots(int cfg, int n, const int* Mo, const int* No, int max_wgs, int K, size_t sk_ws_bytes);
 int gemm_x3_wgrad_group_balanced_wgs(int cfg, int n, const int* Mo, const int* No);
 int gemm_bf16v2_pick_split(int M, int N, int K);
 int gemm_bf16v2_wgrad_pieces(int M, int N, int K);
@@ -124,6 +126,10 @@ struct Plan {
   bool hid_on;                // the forward pass drew them (this plan's row passes read them, forward and backward)
   void *ln_ws, *col_ws, *emb_ws, *attn_ws;
   size_t ln_ws_bytes, col_ws_bytes, emb_ws_bytes, attn_ws_bytes;
+  // precision 3: workspaces of the balanced walk of the 128 x 256-tile products (gemm_split3.hip): one for the main stream's
+  // launches, one for the weight-gradient stream's (they run at the same time); their flag words are cleared by every forward pass
+  void *sk_main, *sk_side;
+  size_t sk_bytes;
   size_t total;
 };
 
@@ -263,6 +269,15 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
       if (l & 1) pl.layers[l].y2 = yB;
     }
   }
+  // UNITER_X3_BALANCED (default 0: off; bit 0 = the grouped weight gradients, bit 1 = the forward products with a bias epilogue): the
+  // balanced walk is built and parity-tested, and LOSES in the step -- 9.40 -> 9.81 ms (bit 0), 9.40 -> 9.52 (bit 1) at configs[1],
+  // +0.8 % only for UNITER-large's weight gradients (384 tiles: two rounds): the CUs a 216-tile launch leaves idle are not idle in the
+  // step (the other stream's input-gradient kernels take them), the hand-over costs ~4 k-tiles per workgroup, and a workgroup
+  // that waits for a partial sum holds its CU (profiles/r05_balanced_walk_ab.txt)
+  static const int sk_env = [] { const char* e = getenv("UNITER_X3_BALANCED"); return e ? atoi(e) : 0; }();
+  pl.sk_bytes = gemm_x3_sk_ws_bytes();
+  pl.sk_main = (pl.x3 && (sk_env & 2)) ? cv.raw(pl.sk_bytes) : nullptr;
+  pl.sk_side = (pl.x3 && save && (sk_env & 1)) ? cv.raw(pl.sk_bytes) : nullptr;
   if (save) {
     pl.hid_stride = align_up(uniter_hidden_keep_bits_bytes(M * H), 256);
     pl.hid_keepb = (unsigned char*)cv.raw(pl.hid_stride * 2 * nl);
@@ -384,8 +399,9 @@ int gemm_x3(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, in
   static const int cfg = [] { const char* e = getenv("UNITER_X3_CFG"); return e ? atoi(e) : 0; }();
   static const int main_prio = [] { const char* e = getenv("UNITER_MAIN_PRIO_X3"); return e ? atoi(e) : 0; }();
   g_uniter_launch_prio = main_prio;
+  // (every product of this helper runs on the main stream: the balanced walk's main-stream workspace)
   return gemm_x3_run(cfg, nsplit, 0, bkm, M, N, K, A, 3 * K, K, W, ldw, (int)m->mirror_numel, C, N, (long)M * N, Cx, 3 * N, N, epi,
-                     bias, aux_in, aux_out, N, st, colsum_part);
+                     bias, aux_in, aux_out, N, st, colsum_part, m->plan.sk_main, m->plan.sk_main ? m->plan.sk_bytes : 0);
 }
 // CUs the backward pass's persistent launches may use: the chip's minus what the caller reserved for a gradient exchange
 int x3_backward_cus(const uniter_model* m) {
@@ -641,6 +657,11 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
   const bool res = pl.res, x3 = pl.x3;
   // L <= 192: attention on the bf16 pipe (attention_bf16.hip), which also writes the bf16 copies of its outputs
   const bool attn_b16 = res && L <= uniter_attn_varlen_max_len();
+
+  // the flag words of the balanced walk's two workspaces (16 KB each): zero before the first launch that uses them -- the launches
+  // leave them zero, but the workspace is the caller's and may be a new one
+  if (pl.sk_main) UCHECK_HIP(hipMemsetAsync(pl.sk_main, 0, 16384, st));
+  if (pl.sk_side) UCHECK_HIP(hipMemsetAsync(pl.sk_side, 0, 16384, st));
 
   // dropout keep flags of the attention probabilities of ALL layers, drawn in one elementwise launch ahead of everything --
   // a function of (seed, offset) alone, so it runs while the optimizer still streams the word table the text branch waits for
@@ -1128,7 +1149,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
       // product 0 is dW1 = dU^T y1: its A operand's column sums are intermediate.dense's bias gradient
       uniter_x3_riders_t x;
       memset(&x, 0, sizeof(x));
-      const int slots = gemm_x3_wgrad_group_slots(0, 4, Mo, No, x3_wgs);
+      const int slots = gemm_x3_wgrad_group_slots(0, 4, Mo, No, x3_wgs, M, pl.sk_side ? pl.sk_bytes : 0);
       if (m->norm_parts) {
         UCHECK_ARG((size_t)slots <= m->norm_stride, "backward_layer: %d clip-norm slots per layer, room for %zu (uniter_model_set_norm_partials)",
                    slots, m->norm_stride);
@@ -1136,11 +1157,13 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
       }
       fill_layer_riders(x, m, l, lb, M, B, H, fused_qb, x3_colpart_on());
       ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-      UCHECK_RC(gemm_x3_wgrad_group(x3_cfg == 3 ? 3 : 0, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, x3_wgs, &x));
+      UCHECK_RC(gemm_x3_wgrad_group(x3_cfg == 3 ? 3 : 0, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, x3_wgs, &x,
+                                    pl.sk_side, pl.sk_side ? pl.sk_bytes : 0));
     } else {
       {
         ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-        UCHECK_RC(gemm_x3_wgrad_group(x3_cfg, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, x3_wgs, nullptr));
+        UCHECK_RC(gemm_x3_wgrad_group(x3_cfg, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, x3_wgs, nullptr,
+                                      pl.sk_side, pl.sk_side ? pl.sk_bytes : 0));
       }
       UCHECK_RC(uniter_colsum_x3_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
     }
@@ -1270,7 +1293,8 @@ extern "C" int uniter_model_norm_partials_per_layer(const uniter_model_t* m) {
   }
   if (m->precision != 3 || !x3_riders_enabled()) return 0;
   static const int x3_wgs = [] { const char* e = getenv("UNITER_WGRAD_X3_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
-  return gemm_x3_wgrad_group_slots(0, 4, Mo, No, x3_wgs);
+  // (the plan of the LAST forward: its row count is the reduction length, its workspace the balanced walk's)
+  return gemm_x3_wgrad_group_slots(0, 4, Mo, No, x3_wgs, m->plan.M, m->plan.sk_side ? m->plan.sk_bytes : 0);
 }
 
 extern "C" int uniter_model_set_wgrad_overwrite(uniter_model_t* m, int on) {

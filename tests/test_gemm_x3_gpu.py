@@ -343,6 +343,96 @@ def test_weight_gradient_group_riders(cfg, shapes, K, wgs, overwrite):
     assert abs(got - total) <= 1e-6 * total, (got, total)
 
 
+def _sk_ws():
+    from meme_challenge_amd import _lib as L
+    nb = L.lib().uniter_gemm_x3_balanced_ws_bytes()
+    assert nb >= 16384 + 128 * 256 * 4 * 8
+    return torch.zeros(nb // 4, dtype=torch.int32, device='cuda'), nb
+
+
+@pytest.mark.parametrize('shapes,K,wgs', [([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 2624, 0),     # a layer of UNITER-base: 216 tiles
+                                          ([(520, 696), (264, 264)], 4000, 0),          # 21 ragged tiles for 256 workgroups: a dozen parts per tile
+                                          ([(3072, 768), (768, 3072), (2304, 768), (768, 768)], 2624, 240),   # a CU reserve of 16
+                                          ([(1024, 1024), (1024, 4096), (3072, 1024), (4096, 1024)], 1312, 0)])  # UNITER-large
+@pytest.mark.parametrize('overwrite', [0, 1])
+def test_balanced_walk_of_the_weight_gradient_group(shapes, K, wgs, overwrite):
+    """uniter_wgrad_x3_group_ws: the k-tiles of all 128 x 256 tiles cut into one equal run per workgroup, a cut tile finished by the
+    owner of its first part from the partial sums the following workgroups stored.  Against fp64 at the plain launch's bar, equal to
+    the plain launch to fp32 rounding of the regrouped sums, bit-identical when repeated, every flag word left zero, the riders'
+    sum of squares complete (one slot per compute wave of EVERY workgroup of the larger grid)."""
+    from meme_challenge_amd import _lib as L
+    g = torch.Generator(device='cuda').manual_seed(len(shapes) * 31 + K)
+    Af = [torch.randn(K, M, device='cuda', generator=g) for M, N in shapes]
+    Bf = [torch.randn(K, N, device='cuda', generator=g) * 0.05 for M, N in shapes]
+    C0 = [torch.randn(M, N, device='cuda', generator=g) for M, N in shapes]
+    As, Bs = [split3(a) for a in Af], [split3(b) for b in Bf]
+    Ms, Ns = [m for m, _ in shapes], [n for _, n in shapes]
+    n = len(shapes)
+    IA, PA = ctypes.c_int * n, ctypes.c_void_p * n
+    ws, nb = _sk_ws()
+    slots_plain = L.lib().uniter_wgrad_x3_group_slots(4, n, IA(*Ms), IA(*Ns), wgs)
+    slots = L.lib().uniter_wgrad_x3_group_slots_ws(4, n, IA(*Ms), IA(*Ns), K, wgs, nb)
+    assert L.lib().uniter_wgrad_x3_group_slots_ws(4, n, IA(*Ms), IA(*Ns), K, wgs, 0) == slots_plain
+    assert slots == 8 * (wgs if wgs else 256) and slots >= slots_plain       # the balanced launch runs on every CU it may use
+    parts = torch.randn(40, 192, device='cuda', generator=g)
+    red0 = torch.randn(192, device='cuda', generator=g)
+
+    def run(balanced, riders):
+        Cs = [c.clone() for c in C0]
+        red = red0.clone()
+        ssq = torch.full((slots,), float('nan'), dtype=torch.float64, device='cuda')
+        x = None
+        if riders:
+            x = L.X3RidersC()
+            x.ssq, x.njobs = ssq.data_ptr(), 1
+            x.part[0] = parts.data_ptr(); x.nparts[0] = 40; x.stride[0] = 192; x.n[0] = 192; x.seg[0] = 192; x.out[0][0] = red.data_ptr()
+        L.check(L.lib().uniter_wgrad_x3_group_ws(4, n, IA(*Ms), IA(*Ns), K, PA(*[a.data_ptr() for a in As]), PA(*[b.data_ptr() for b in Bs]),
+                                                 PA(*[c.data_ptr() for c in Cs]), overwrite, wgs, ctypes.byref(x) if riders else None,
+                                                 L.ptr(ws) if balanced else None, nb if balanced else 0, L.cur_stream()), 'wgrad_x3_group_ws')
+        torch.cuda.synchronize()
+        if riders:
+            assert x.grid * 8 == (slots if balanced else slots_plain)
+        return Cs, red, ssq
+
+    plain = run(False, False)
+    a, b, c = run(True, False), run(True, True), run(True, True)
+    assert int(ws[:4096].abs().max()) == 0                                  # the flag words: left zero by every launch
+    for (M, N), af, bf, c0, cp, ca, cb, cc in zip(shapes, Af, Bf, C0, plain[0], a[0], b[0], c[0]):
+        ref = af.double().cpu().t() @ bf.double().cpu() + (0 if overwrite else c0.double().cpu())
+        bar = 3e-6 * math.sqrt(K) * (1 + 0.05 * ref.abs().max().item())
+        assert (ca.double().cpu() - ref).abs().max().item() < bar, (M, N, K)
+        assert (ca - cp).abs().max().item() < bar                            # the same sum, regrouped
+        assert torch.equal(ca, cb) and torch.equal(cb, cc)                   # reproducible; the riders change nothing
+    assert torch.equal(b[2], c[2]) and torch.isfinite(b[2]).all() and torch.equal(b[1], c[1])
+    total = float((b[1].double() ** 2).sum()) + sum(float((t.double() ** 2).sum()) for t in b[0])
+    assert abs(float(b[2].sum()) - total) <= 1e-6 * total
+    assert (b[1].double().cpu() - (red0.double().cpu() + parts.double().cpu().sum(0))).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize('M,N,K', [(2624, 2304, 768), (2624, 4096, 1024), (200, 520, 2048)])
+def test_balanced_walk_of_a_forward_product(M, N, K):
+    """uniter_gemm_x3_cfg_ws: a forward product with a bias epilogue on 128 x 256 tiles that do not fill whole rounds (the QKV
+    product: 189 tiles) as equal runs of k-tiles.  fp64 bar of the plain launch, equal to it to fp32 rounding, reproducible."""
+    from meme_challenge_amd import _lib as L
+    A, B = _operands(0, 0, M, N, K, 5)
+    bias = torch.randn(N, device='cuda')
+    A3, B3 = split3(A), split3(B)
+    ws, nb = _sk_ws()
+    ref = _ref(0, 0, A, B) + bias.double().cpu()
+
+    def run(balanced):
+        C = torch.full((M, N), float('nan'), device='cuda')
+        L.check(L.lib().uniter_gemm_x3_cfg_ws(4, 1, 0, 0, M, N, K, L.ptr(A3), 3 * K, K, L.ptr(B3), 3 * K, K, L.ptr(C), N, M * N, None, 3 * N, N,
+                                              EPI_BIAS, L.ptr(bias), None, None, N, L.ptr(ws) if balanced else None, nb if balanced else 0,
+                                              L.cur_stream()), 'gemm_x3_cfg_ws')
+        torch.cuda.synchronize()
+        return C
+    p, a, b = run(False), run(True), run(True)
+    assert int(ws[:4096].abs().max()) == 0
+    bar = 3e-6 * math.sqrt(K) * (1 + 0.05 * ref.abs().max().item())
+    assert _errs(a, ref)[0] < bar and (a - p).abs().max().item() < bar and torch.equal(a, b)
+
+
 ROBUST = [  # name, scale of A, scale of B, binade spread of A's rows, zero column
     ('tiny_2^-105', 2.0 ** -105, 1.0, 0, False), ('huge_2^100', 2.0 ** 100, 1.0, 0, False),
     ('both_small_2^-60', 2.0 ** -60, 2.0 ** -60, 0, False), ('rows_over_20_binades', 1.0, 1.0, 20, False),

@@ -282,12 +282,14 @@ def test_backward_of_a_stale_forward_fails_loudly(tiny, train):
 @pytest.mark.parametrize('env', [{'UNITER_WGRAD_GROUP_F32': '1'}, {'UNITER_WGRAD_WHOLE': '0', 'UNITER_LAZY_ZERO': '0'},
                                  {'UNITER_KEEP_PREGEN': '0', 'UNITER_ADAM_WORD_SPLIT': '0', 'UNITER_WGRAD_GROUP_F32': '0', 'UNITER_ATTN_BWD_FUSED': '0',
                                   'UNITER_ADAM_EMB_MAIN': '0'},
-                                 {'UNITER_ATTN_X3': '0', 'UNITER_X3_CFG': '2'}, {'UNITER_DCTX_SPLIT': '0', 'UNITER_X3_CFG': '1'}])
+                                 {'UNITER_ATTN_X3': '0', 'UNITER_X3_CFG': '2'}, {'UNITER_DCTX_SPLIT': '0', 'UNITER_X3_CFG': '1'},
+                                 {'UNITER_X3_BALANCED': '3'}])
 def test_alternative_schedules_keep_the_golden_gradients(env):
     """The switches that select another form of the same arithmetic (the layer's weight gradients as one grouped whole-K
     launch; the stream-K form with a clearing zero_grad; dropout flags drawn inside the attention kernels, the embeddings'
     optimizer block in one launch on the side stream, the attention backward as two launches; in the fp32x3 form: attention on the
-    fp32 MFMAs, the other wave geometries / MFMA shape of the x3 products, the attention-output input gradient as one tensor) are read once per process: the reference-golden gradient, dropout-replay and trainer-step
+    fp32 MFMAs, the other wave geometries / MFMA shape of the x3 products, the attention-output input gradient as one tensor, the balanced walk of the
+    128 x 256-tile launches) are read once per process: the reference-golden gradient, dropout-replay and trainer-step
     tests run again in a child process with the switch set."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
