@@ -43,7 +43,9 @@ for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
     if pct < 0.3:
         continue
     f = fetch.get(k); w = write.get(k); mm = mfma.get(k)
-    if f and ref_ratio and abs(calls / f[0] / ref_ratio - 1) > 0.02:
+    # (5 %: a kernel that skips the first step -- the accumulating form of the weight-gradient launch -- is a few launches short in
+    # a 4-step counter pass; the optimizer is excluded by name: the counter passes have no "optimizer alone" leg)
+    if f and ref_ratio and (abs(calls / f[0] / ref_ratio - 1) > 0.05 or k.startswith('adam_kernel')):
         f = w = mm = None
     rd = 2 * f[1] * 1024 / 1e6 if f else None           # KiB -> MB, x2: gfx950 FETCH_SIZE tallies 128-B requests at 64 B
     wr = w[1] * 1024 / 1e6 if w else None

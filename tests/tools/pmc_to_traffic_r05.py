@@ -23,8 +23,8 @@ def pick_all(rs, pred, counter):
 
 
 def x3(akm, bkm, epi):
-    # gemm_s3p_kernel<BM, BN, WM, WN, AKM, BKM, ST, KT, NWL, M16, EPI, XTR>
-    pat = re.compile(r'gemm_s3p_kernel<\d+, \d+, \d+, \d+, %s, %s, \d+, \d+, \d+, (?:true|false), %d, (?:true|false)>' % (akm, bkm, epi))
+    # gemm_s3p_kernel<BM, BN, WM, WN, AKM, BKM, ST, KT, NWL, M16, EPI, XTR, SK>
+    pat = re.compile(r'gemm_s3p_kernel<\d+, \d+, \d+, \d+, %s, %s, \d+, \d+, \d+, (?:true|false), %d, (?:true|false)(?:, (?:true|false))?>' % (akm, bkm, epi))
     return lambda name: bool(pat.search(name))
 
 
