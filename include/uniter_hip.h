@@ -197,7 +197,8 @@ int uniter_join3(const void* x3, int rows, int cols, size_t row_stride, size_t p
  * (aux_out = gelu'(u) fp32, outputs = gelu(u)); input gradient (b_kmajor = 1): NONE, ADD, MUL (aux_in fp32 [M, ld_aux]);
  * weight gradient (both 1, any K; operands [K][3][.]): NONE, ADD.  K % 32 == 0 unless both operands are k-major;
  * N % 8 == 0.  Rows beyond an operand's row count read as zeros only in the [rows][3][ld] form (what a k-major
- * operand with a ragged K needs).  cfg: 0 = choose, 1..3 = wave geometry and MFMA shape (gemm_split3.hip).  nsplit > 1: fp32 slabs only;
+ * operand with a ragged K needs).  cfg: 0 = choose, 1..3 = wave geometry and MFMA shape of 128 x 128 tiles, 4 = 128 x 256 tiles (not for weight
+ * gradients), 5 = 128 x 192 tiles (forward layout, fp32 output only) (gemm_split3.hip).  nsplit > 1: fp32 slabs only;
  * piece 0 applies the epilogue, the consumer adds the slabs. */
 int uniter_gemm_x3_cfg(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda,
                        int psa, const void* B, int ldb, int psb, float* C, int ldc, long c_split_stride, void* C_x3,

@@ -489,7 +489,7 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, int piece, int m0
                                               f32x4 (&acc)[WM / 16][WN / 16]) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int MB = WM / 16, NB = WN / 16;
-  static_assert(NB % 2 == 0, "x3 outputs leave in pairs of column blocks");
+  // (x3 outputs leave in pairs of column blocks: a geometry with an odd number of blocks per wave -- 128 x 192 tiles -- has fp32 outputs only)
   const int r = lane & 15, gq = lane >> 4;
   float* Cp = g.C ? g.C + (size_t)piece * g.c_split_stride : nullptr;
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(Cp, 0, Cp ? g.M * g.ldc * 4 : 0, 0x00020000);
@@ -555,7 +555,7 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, int piece, int m0
     }
     // x3 output: two column blocks at a time -- v_permlane16_swap hands the odd 16-lane rows of block b to the even rows and the
     // even rows of block b + 1 to the odd ones, so every lane ends with 8 consecutive columns: one 16-byte store per piece
-    if (g.Cx) {
+    if constexpr (NB % 2 == 0) if (g.Cx) {
 #pragma unroll
       for (int b = 0; b < NB; b += 2) {
         unsigned wa[3][2], wb[3][2];
@@ -1167,6 +1167,8 @@ int launch_s3p_sk(S3Group& G, int grid, void* ws, hipStream_t st) {
 //   3: 4 compute waves of 64 x 64 + 4 loader waves, v_mfma_f32_16x16x32_bf16 (default)
 //   4: 128 x 256 tiles (round 5): 8 compute waves of 64 x 64 + 4 loader waves, TWO stages of 72 KB, v_mfma_f32_16x16x32_bf16 with the
 //      B fragments one piece at a time (168 registers per wave) -- 36 instead of 48 KB staged per 128 x 128 x 32 block of products
+//   5: 128 x 192 tiles (forward layout, fp32 output): 8 compute waves of 64 x 48, two stages of 60 KB -- for products whose N is a
+//      multiple of 192 and whose 128 x 256 tiles leave CUs idle (the QKV product at configs[1]: 189 tiles of 128 x 256, 252 of 128 x 192)
 template <bool AKM, bool BKM, int EPI>
 int dispatch_cfg3p(int cfg, const S3Group& G, int max_wgs, hipStream_t st) {
   switch (cfg) {
@@ -1176,7 +1178,10 @@ int dispatch_cfg3p(int cfg, const S3Group& G, int max_wgs, hipStream_t st) {
     case 4:
       if constexpr (!AKM) return launch_s3p<128, 256, 64, 64, AKM, BKM, 2, 32, 4, true, EPI>(G, max_wgs, st);
       // (weight gradients keep the 128 x 128 whole-K tiles)
-    default: uniter_set_error("gemm_x3: bad cfg %d (1..4)", cfg); return UNITER_E_ARG;
+    case 5:
+      if constexpr (!AKM && !BKM) return launch_s3p<128, 192, 64, 48, AKM, BKM, 2, 32, 4, true, EPI>(G, max_wgs, st);
+      // (forward layout only)
+    default: uniter_set_error("gemm_x3: bad cfg %d (1..5; 4 not for weight gradients, 5 for the forward layout only)", cfg); return UNITER_E_ARG;
   }
 }
 
@@ -1188,7 +1193,7 @@ int dispatch_cfg3(int cfg, const S3Args& g, hipStream_t st, SkWs sk) {
   memset(&G.x, 0, sizeof(G.x));
   G.sk_part = nullptr; G.sk_flag = nullptr; G.sk_units = G.sk_nk = 0;
   for (int p = 0; p < 4; ++p) G.p[p] = g;
-  plan_tiles3<128>(G.p[0], cfg == 4 ? 256 : 128);
+  plan_tiles3<128>(G.p[0], cfg == 4 ? 256 : cfg == 5 ? 192 : 128);
   const int total = G.p[0].tiles_m * G.p[0].tiles_n * g.nsplit;
   G.start[0] = 0;
   for (int p = 1; p <= 4; ++p) G.start[p] = total;
@@ -1314,7 +1319,7 @@ int riders_prepare(uniter_x3_riders_t& x, const char* who) {
   return 0;
 }
 
-void x3_choose(int M, int N, int K, int avail, int nsplit_fixed, int* cfg_out, int* ns_out);
+void x3_choose(int M, int N, int K, int avail, int nsplit_fixed, int* cfg_out, int* ns_out, bool allow192 = false);
 
 // C / Cx = epi(A . B^T) on x3 operands (fp32-accurate, six bf16 MFMA products per block, fp32 accumulate).
 int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda, int psa,
@@ -1347,6 +1352,7 @@ int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, i
   g.dbg = cfg >> 8; cfg &= 0xff;
   g.stamp = take_stamp_slot();
   g.prio = take_launch_prio();
+  UCHECK_ARG((cfg & 0xff) != 5 || (!a_kmajor && !b_kmajor && !Cx), "gemm_x3: cfg 5 (128 x 192 tiles) is built for the forward layout with an fp32 output");
   UCHECK_ARG(!colsum_part || (epilogue == UNITER_EPI_MUL && nsplit == 1 && (cfg == 0 || cfg >= 3) && ((uintptr_t)colsum_part & 15) == 0 && N % 4 == 0),
              "gemm_x3: column partials ride on the x aux epilogue of the 16x16x32 geometries (cfg 0, 3, 4), one k-piece");
   g.colpart = colsum_part;
@@ -1361,7 +1367,7 @@ int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, i
     // launch may use (all of them, or what a data-parallel exchange leaves: g_uniter_cu_reserve)
     if (!a_kmajor) {
       int ns_;
-      x3_choose(M, N, K, x3_grid(1 << 20, 0), nsplit, &cfg, &ns_);
+      x3_choose(M, N, K, x3_grid(1 << 20, 0), nsplit, &cfg, &ns_, !b_kmajor && !Cx);
     }
   }
   hipStream_t st = (hipStream_t)stream;
@@ -1376,21 +1382,24 @@ int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, i
 // configs[1]).  nsplit_fixed > 0: the caller chose the k-pieces (x3 outputs cannot be split); 0: pieces 1..4 compete (N <= 1024
 // only: more tiles than that fill the chip without them).  Written for `avail` < the chip's CUs too: while a data-parallel
 // exchange holds CUs (uniter_model_set_cu_reserve) the 252-item forms that exactly fit 256 CUs would run two rounds on 240.
-void x3_choose(int M, int N, int K, int avail, int nsplit_fixed, int* cfg_out, int* ns_out) {
+void x3_choose(int M, int N, int K, int avail, int nsplit_fixed, int* cfg_out, int* ns_out, bool allow192) {
   static const bool wide_on = [] { const char* e = getenv("UNITER_X3_WIDE"); return !(e && e[0] == '0'); }();
+  static const bool on192 = [] { const char* e = getenv("UNITER_X3_192"); return !(e && e[0] == '0'); }();
   if (avail < 8) avail = 8;
-  const long tm = (M + 127) / 128, t128 = tm * ((N + 127) / 128), t256 = tm * ((N + 255) / 256);
+  const long tm = (M + 127) / 128, t128 = tm * ((N + 127) / 128), t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
   const int nk = (K + 31) / 32;
   double best = 1e30;
   int bc = 3, bn = nsplit_fixed > 0 ? nsplit_fixed : 1;
   const int ns_lo = nsplit_fixed > 0 ? nsplit_fixed : 1, ns_hi = nsplit_fixed > 0 ? nsplit_fixed : ((N <= 1024 && K >= 512) ? 4 : 1);
   for (int ns = ns_lo; ns <= ns_hi; ++ns) {
     if (nk / ns < 6 && ns > 1) continue;                     // pieces shorter than six k-tiles do not pay for their prologue
-    for (int c = 3; c <= 4; ++c) {
+    for (int c = 3; c <= 5; ++c) {
       if (c == 4 && (!wide_on || N < 256)) continue;
-      const long items = (c == 4 ? t256 : t128) * ns;
+      // 128 x 192 tiles (forward layout, fp32 output): 60 KB staged per k-tile against the 128 x 256 tile's 72 -- 1.75 us
+      if (c == 5 && (!allow192 || !on192 || !wide_on || N % 192 != 0)) continue;
+      const long items = (c == 4 ? t256 : c == 5 ? t192 : t128) * ns;
       const long rounds = (items + avail - 1) / avail;
-      const double t = (double)rounds * ((nk + ns - 1) / ns) * (c == 4 ? 2.1 : 1.2) + 4.0 * ns;
+      const double t = (double)rounds * ((nk + ns - 1) / ns) * (c == 4 ? 2.1 : c == 5 ? 1.75 : 1.2) + 4.0 * ns;
       if (t < best - 1e-9) { best = t; bc = c; bn = ns; }
     }
   }

@@ -798,6 +798,8 @@ class UniterModel(UniterPreTrainedModel):
             check(lib.uniter_model_set_wgrad_overwrite(self._handle, 1), 'uniter_model_set_wgrad_overwrite')
             st.wgrad_stale = False
         np_ = self._norm_parts
+        if np_ is not None and not 0 < self.norm_partials_per_layer() <= np_[1]:
+            np_ = None           # (more slots than the trainer made room for -- a chip with more CUs: it reduces the buckets itself, as it decided)
         check(lib.uniter_model_set_norm_partials(self._handle, np_[0].data_ptr() if np_ is not None else None,
                                                  np_[1] if np_ is not None else 0), 'uniter_model_set_norm_partials')
         check(lib.uniter_model_backward_begin(self._handle, C.byref(batch), ptr(d_hidden),

@@ -192,6 +192,28 @@ def test_epilogues_and_outputs(cfg):
         _run(cfg, 1, 1, M=200, N=256, K=128, epi=EPI_ADD)
 
 
+def test_128x192_tiles_of_the_forward_layout():
+    """cfg 5 (128 x 192 tiles, eight 64 x 48 compute waves; forward layout, fp32 output): every epilogue of that layout, ragged M and N,
+    one k-tile, k-pieces, the QKV product of UNITER-base (where cfg 0 chooses it: 252 tiles for 256 CUs) -- and what it is not built
+    for is refused, not skipped."""
+    from meme_challenge_amd import _lib as L
+    for epi in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_D):
+        _run(5, 0, 0, M=200, N=192, K=128, epi=epi)
+        _run(5, 0, 0, M=264, N=520, K=96, epi=epi)                       # N % 192 != 0: the last tile column is ragged
+        _run(5, 0, 0, M=520, N=776, K=320, epi=epi)
+    _run(5, 0, 0, M=64, N=384, K=32, epi=EPI_BIAS)
+    _run(5, 0, 0, M=8, N=8, K=64, epi=EPI_NONE)
+    _run(5, 0, 0, M=300, N=384, K=640, epi=EPI_BIAS, nsplit=3)
+    _run(5, 0, 0, M=2624, N=2304, K=768, epi=EPI_BIAS)
+    _run(0, 0, 0, M=2624, N=2304, K=768, epi=EPI_BIAS)
+    c, n = ctypes.c_int(0), ctypes.c_int(0)
+    A3 = torch.zeros(128, 3, 64, dtype=torch.bfloat16, device='cuda'); C = torch.zeros(128, 192, device='cuda')
+    Cx = torch.zeros(128, 3, 192, dtype=torch.bfloat16, device='cuda'); B3 = torch.zeros(192, 3, 64, dtype=torch.bfloat16, device='cuda')
+    assert x3_gemm(5, 1, 0, 0, 128, 192, 64, A3, B3, C, Cx, EPI_NONE, None, None, None) != 0            # no x3 output from this geometry
+    Bk = torch.zeros(64, 3, 192, dtype=torch.bfloat16, device='cuda')
+    assert x3_gemm(5, 1, 0, 1, 128, 192, 64, A3, Bk, C, None, EPI_NONE, None, None, None) != 0          # forward layout only
+
+
 @pytest.mark.parametrize('cfg', [1, 2, 3, 4])
 @pytest.mark.parametrize('nsplit', [2, 3, 4])
 def test_split_k_slabs(cfg, nsplit):
