@@ -278,3 +278,24 @@ def test_x3_plan_fits_the_cus_it_is_given():
     assert plan(M, 3 * H, H, 240, 1) == (4, 1)                           # 189 tiles: still one round
     assert plan(64, 8, 64, 256) == (3, 1)                                # tiny: nothing to choose
     assert lib.uniter_gemm_x3_plan(0, 8, 64, 256, 0, None, None) != 0
+
+
+def test_balanced_walk_slot_counts_are_host_arithmetic():
+    """uniter_wgrad_x3_group_slots_ws / uniter_gemm_x3_balanced_ws_bytes (no launch): a layer of UNITER-base is 216 tiles of 128 x 256 --
+    the classic walk writes 8 x 216 sum-of-squares slots, the balanced walk (a workspace of the advertised size) one per compute wave
+    of every CU it may use; a grid capped to the tile count, a workspace too small, or no reduction length: the classic count."""
+    import ctypes as C
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    nb = lib.uniter_gemm_x3_balanced_ws_bytes()
+    assert nb == 16384 + 256 * 128 * 256 * 4                              # flag words + one partial-sum tile per CU (no device: 256)
+    IA = C.c_int * 4
+    Ms, Ns = IA(3072, 768, 2304, 768), IA(768, 3072, 768, 768)
+    plain = lib.uniter_wgrad_x3_group_slots(4, 4, Ms, Ns, 0)
+    assert plain == 8 * 216
+    assert lib.uniter_wgrad_x3_group_slots_ws(4, 4, Ms, Ns, 2624, 0, nb) == 8 * 256
+    assert lib.uniter_wgrad_x3_group_slots_ws(4, 4, Ms, Ns, 2624, 240, nb) == 8 * 240
+    assert lib.uniter_wgrad_x3_group_slots_ws(4, 4, Ms, Ns, 2624, 216, nb) == plain          # full rounds: nothing to balance
+    assert lib.uniter_wgrad_x3_group_slots_ws(4, 4, Ms, Ns, 2624, 0, nb - 1) == plain         # workspace too small
+    assert lib.uniter_wgrad_x3_group_slots_ws(4, 4, Ms, Ns, 0, 0, nb) == plain
+    assert lib.uniter_wgrad_x3_group_slots_ws(3, 4, Ms, Ns, 2624, 0, nb) == lib.uniter_wgrad_x3_group_slots(3, 4, Ms, Ns, 0)   # 128 x 128 tiles: classic
