@@ -286,8 +286,8 @@ def parse_args(argv=None):
                     help='with a gradient exchange attached: time the step once more with no CUs reserved for its kernels '
                          '(comm.no_reserve; `value` is the default reserve, comm.cu_reserve)')
     ap.add_argument('--no_reserve_pick', action='store_true',
-                    help='N > 1: keep the attach-time CU reserve (dp.cu_reserve_default) instead of timing a few untimed steps with and '
-                         'without it before the warm-up and keeping the faster (comm.reserve_pick)')
+                    help='N > 1: keep the attach-time CU reserve (dp.cu_reserve_default) instead of timing a few untimed steps with a reserve '
+                         'of 16, 0 and 48 CUs before the warm-up and keeping the fastest (comm.reserve_pick)')
     ap.add_argument('--both_exchanges', action='store_true',
                     help='N > 1: time the other form of the word-embedding exchange too (a second timed region, listed in '
                          'comm.other_exchange; `value` is always the requested exchange)')
@@ -406,7 +406,7 @@ def _run_rank(args, real_stdout, state):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         from meme_challenge_amd import dp as _dp0
-        _dp0.prepare_rccl_env(world)         # RCCL asks for no more channels than the CUs the matrix kernels leave it (N > 1)
+        _dp0.prepare_rccl_env(world)         # (caps RCCL's channels at the CU reserve only under UNITER_DP_CAP_CHANNELS=1)
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -492,8 +492,8 @@ def _run_rank(args, real_stdout, state):
             one_step()
         torch.cuda.synchronize()
     # N > 1: how many CUs the persistent matrix kernels should leave to RCCL is a property of the node (channels RCCL opens on its
-    # links, how long its kernels run beside the backward pass): time a few untimed steps with the default reserve and with none,
-    # keep the faster on every rank (dp.pick_cu_reserve; UNITER_DP_CU_RESERVE or --no_reserve_pick fix it instead)
+    # links, how long its kernels run beside the backward pass): time a few untimed steps with a reserve of 16, 0 and 48 CUs,
+    # keep the fastest on every rank (dp.pick_cu_reserve; UNITER_DP_CU_RESERVE or --no_reserve_pick fix it instead)
     reserve_pick = None
     if sync is not None and world > 1 and not args.no_reserve_pick and 'UNITER_DP_CU_RESERVE' not in os.environ:
         reserve_pick = dp.pick_cu_reserve(sync, encoder, one_step, steps=max(1, min(6, args.steps)), warm=max(1, min(2, args.warmup)))

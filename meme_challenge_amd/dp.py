@@ -334,8 +334,7 @@ def cu_reserve_default(world):
     """CUs the persistent matrix kernels leave free while a gradient exchange is attached: UNITER_DP_CU_RESERVE, else 16 with more
     than one rank (RCCL runs one workgroup per channel; its kernels -- 256 threads, ~100 registers per lane: they do not fit beside
     a persistent 144-KB GEMM workgroup on the same CU -- otherwise take CUs as GEMM workgroups exit and strand the launch's last
-    workgroups behind them), 0 on one rank.  NCCL_MAX_NCHANNELS is set to the same number when the caller left it alone (bench.py,
-    the CLI: before the process group exists), so RCCL asks for what was reserved."""
+    workgroups behind them), 0 on one rank.  A starting point, not a finding: ``pick_cu_reserve`` measures it on the node."""
     e = os.environ.get('UNITER_DP_CU_RESERVE')
     if e is not None:
         try:
@@ -346,19 +345,23 @@ def cu_reserve_default(world):
 
 
 def prepare_rccl_env(world, env=None):
-    """Before the process group exists: tell RCCL to ask for no more channels (one workgroup each) than the CUs the persistent
-    matrix kernels will leave it (NCCL_MAX_NCHANNELS, only when the caller left it alone).  Returns the reserve."""
+    """Before the process group exists.  RCCL's channel count is RCCL's by default: how many workgroups it needs to fill seven xGMI
+    links is tuned per topology by its authors, a gradient exchange that is starved of channels is exposed at the end of every
+    backward pass (the whole job's scaling), while an exchange that takes CUs from the matrix kernels costs them a few per cent --
+    and the reserve is measured against whatever RCCL opens (``pick_cu_reserve``).  UNITER_DP_CAP_CHANNELS=1 caps the channels at
+    the reserve instead (NCCL_MAX_NCHANNELS, only when the caller left it alone): RCCL then asks for exactly the CUs that were left
+    to it -- the configuration to try when ``comm.collectives`` show the exchange hidden with room to spare.  Returns the reserve."""
     env = os.environ if env is None else env
     r = cu_reserve_default(world)
-    if r > 0:
+    if r > 0 and env.get('UNITER_DP_CAP_CHANNELS') == '1':
         env.setdefault('NCCL_MAX_NCHANNELS', str(r))
     return r
 
 
 def pick_cu_reserve(sync, encoder, one_step, candidates=None, steps=6, warm=2):
     """Measure instead of believing: run `warm` + `steps` training steps (``one_step()``: forward, backward with the exchange, update)
-    with each candidate number of reserved CUs, take the slowest rank's time for each, keep the fastest candidate on every rank
-    (ties: the earlier one) and return {'picked': r, 'candidates': [{'cu_reserve': r, 'ms_per_step': t}, ...]}.  What the right
+    with each candidate number of reserved CUs (default: the reserve in force, 0, 16, 48), take the slowest rank's time for each,
+    keep the fastest candidate on every rank (ties: the earlier one) and return {'picked': r, 'candidates': [{'cu_reserve': r, 'ms_per_step': t}, ...]}.  What the right
     reserve is depends on how many channels RCCL opens on the node's topology and on how long its kernels sit beside the matrix
     kernels -- neither can be known before the first exchange has run on the real links.  The steps are ordinary steps (their
     updates count); results do not depend on the reserve (tests/test_model_gpu.py::test_cu_reserve_for_a_gradient_exchange...).
@@ -369,7 +372,8 @@ def pick_cu_reserve(sync, encoder, one_step, candidates=None, steps=6, warm=2):
         return None
     start = int(getattr(sync, 'cu_reserve', 0))
     if candidates is None:
-        candidates = [start] + ([0] if start != 0 else [DEFAULT_CU_RESERVE])
+        # the reserve in force, none, and three times the default (RCCL's own channel count on eight GPUs is several dozen)
+        candidates = [start] + [c for c in (0, DEFAULT_CU_RESERVE, 3 * DEFAULT_CU_RESERVE) if c != start]
     dev = sync.flat.device
     use_cuda = dev.type == 'cuda'
 

@@ -116,14 +116,14 @@ def test_bench_starts_its_own_ranks(extra):
     assert c['world'] == 2 and c['payload'] == ('bf16' if 'bf16' in extra else 'fp32') and c['sparse_embeddings'] == bool('--dp_sparse_embeddings' in extra)
     assert c['collectives'] and all(k['bytes'] > 0 and k['issue_to_done_ms'] >= k['exposed_ms'] >= 0 for k in c['collectives'])
     assert c['bytes_per_step'] > 0 and c['exposed_ms_per_step'] >= 0 and c['headline_exchange'] in ('dense', 'sparse word-embedding rows')
-    assert c['rccl_max_nchannels_env'] == '16'
+    assert c['rccl_max_nchannels_env'] is None                 # RCCL's channel count is RCCL's (UNITER_DP_CAP_CHANNELS=1 caps it at the reserve)
     if extra:
         assert c['cu_reserve'] == 16 and 'reserve_pick' not in c           # two ranks: the persistent launches leave 16 CUs
     else:
         # the default: a few untimed steps with the reserve and without it, the faster kept on every rank (dp.pick_cu_reserve)
         rp = c['reserve_pick']
-        assert [k['cu_reserve'] for k in rp['candidates']] == [16, 0] and all(k['ms_per_step'] > 0 for k in rp['candidates'])
-        assert rp['picked'] in (16, 0) and c['cu_reserve'] == rp['picked']
+        assert [k['cu_reserve'] for k in rp['candidates']] == [16, 0, 48] and all(k['ms_per_step'] > 0 for k in rp['candidates'])
+        assert rp['picked'] in (16, 0, 48) and c['cu_reserve'] == rp['picked']
 
 
 def test_graft_entry_smoke():

@@ -240,7 +240,8 @@ def test_bucketed_allreduce_equals_big_batch_gradients(tmp_path):
 
 def test_cu_reserve_default_and_rccl_env(monkeypatch):
     """CUs the persistent matrix kernels leave to the exchange's kernels: 16 with more than one rank, none on one rank,
-    UNITER_DP_CU_RESERVE overrides; RCCL's channel cap follows the reserve unless the caller set one."""
+    UNITER_DP_CU_RESERVE overrides; RCCL's channels are capped at the reserve only on request (UNITER_DP_CAP_CHANNELS=1) and never
+    against the caller's own NCCL_MAX_NCHANNELS."""
     from meme_challenge_amd import dp
     monkeypatch.delenv('UNITER_DP_CU_RESERVE', raising=False)
     assert dp.cu_reserve_default(1) == 0 and dp.cu_reserve_default(8) == dp.DEFAULT_CU_RESERVE == 16
@@ -252,8 +253,10 @@ def test_cu_reserve_default_and_rccl_env(monkeypatch):
     assert dp.cu_reserve_default(8) == 0
     monkeypatch.delenv('UNITER_DP_CU_RESERVE', raising=False)
     env = {}
-    assert dp.prepare_rccl_env(8, env) == 16 and env == {'NCCL_MAX_NCHANNELS': '16'}
-    env = {'NCCL_MAX_NCHANNELS': '32'}
+    assert dp.prepare_rccl_env(8, env) == 16 and env == {}                                # RCCL's channel count is RCCL's by default
+    env = {'UNITER_DP_CAP_CHANNELS': '1'}
+    assert dp.prepare_rccl_env(8, env) == 16 and env['NCCL_MAX_NCHANNELS'] == '16'       # on request: no more channels than reserved CUs
+    env = {'UNITER_DP_CAP_CHANNELS': '1', 'NCCL_MAX_NCHANNELS': '32'}
     assert dp.prepare_rccl_env(8, env) == 16 and env['NCCL_MAX_NCHANNELS'] == '32'       # the caller's choice stands
     env = {}
     assert dp.prepare_rccl_env(1, env) == 0 and env == {}
@@ -276,18 +279,18 @@ def _pick_worker(rank, world, port, out):
     def step():                       # reserve 0 is the faster setting on rank 0 but far slower on rank 1: the slowest rank decides
         seen.append(enc.cu_reserve)
         time.sleep({16: 0.004, 0: 0.001 if rank == 0 else 0.012}[enc.cu_reserve])
-    r1 = dp.pick_cu_reserve(gs, enc, step, steps=3, warm=1)
+    r1 = dp.pick_cu_reserve(gs, enc, step, candidates=[16, 0], steps=3, warm=1)
     after1 = (enc.cu_reserve, gs.cu_reserve, list(seen))
 
-    def step2():                      # the other way round on every rank
-        time.sleep({16: 0.008, 0: 0.001}[enc.cu_reserve])
+    def step2():                      # the default candidates: the reserve in force, none, the default, three times the default
+        time.sleep({16: 0.008, 0: 0.001, 48: 0.004}[enc.cu_reserve])
     r2 = dp.pick_cu_reserve(gs, enc, step2, steps=3, warm=1)
     after2 = (enc.cu_reserve, gs.cu_reserve)
 
     def step3():                      # a failure every rank meets alike: the reserve in force stays, the result says why
         if enc.cu_reserve == 16:
             raise RuntimeError('workspace too small')
-    r3 = dp.pick_cu_reserve(gs, enc, step3, steps=2, warm=1)
+    r3 = dp.pick_cu_reserve(gs, enc, step3, candidates=[0, 16], steps=2, warm=1)
     after3 = (enc.cu_reserve, gs.cu_reserve)
     torch.save(dict(r1=r1, after1=after1, r2=r2, after2=after2, r3=r3, after3=after3), out + str(rank))
     dist.destroy_process_group()
@@ -305,7 +308,7 @@ def test_cu_reserve_is_picked_by_the_slowest_rank(tmp_path):
         assert r['r1']['picked'] == 16 and [c['cu_reserve'] for c in r['r1']['candidates']] == [16, 0]
         assert r['after1'][:2] == (16, 16) and r['after1'][2] == [16] * 4 + [0] * 4
         assert r['r1']['candidates'][1]['ms_per_step'] > r['r1']['candidates'][0]['ms_per_step']
-        assert r['r2']['picked'] == 0 and r['after2'] == (0, 0) and [c['cu_reserve'] for c in r['r2']['candidates']] == [16, 0]
-        # (the third call starts from reserve 0: its candidates are 0, then the default 16, which raises)
+        assert r['r2']['picked'] == 0 and r['after2'] == (0, 0) and [c['cu_reserve'] for c in r['r2']['candidates']] == [16, 0, 48]
+        # (the third call starts from reserve 0: candidates 0, then 16, which raises)
         assert r['r3']['picked'] == 0 and 'workspace too small' in r['r3']['error'] and r['after3'] == (0, 0)
     assert rs[0]['r1'] == rs[1]['r1'] and rs[0]['r2'] == rs[1]['r2']

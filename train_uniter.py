@@ -156,7 +156,7 @@ def _main(argv=None):
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         # RCCL; UNITER_DIST_BACKEND=gloo lets several ranks share one GPU (tests: RCCL wants one device per rank)
         from meme_challenge_amd import dp as _dp
-        _dp.prepare_rccl_env(int(os.environ.get('WORLD_SIZE', '1')))       # channels <= the CUs the matrix kernels leave free
+        _dp.prepare_rccl_env(int(os.environ.get('WORLD_SIZE', '1')))       # (UNITER_DP_CAP_CHANNELS=1: RCCL's channels <= the CUs the matrix kernels leave free)
         torch.distributed.init_process_group(os.environ.get('UNITER_DIST_BACKEND', 'nccl'))
     ddp = torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
     rank = torch.distributed.get_rank() if ddp else 0
