@@ -51,6 +51,104 @@ def flops_per_step(cfg, B, T, R, L=None, lens=None):
     return 3 * fwd, 3 * nl * 2 * ffn_up_fwd, ffn_up_fwd
 
 
+INTAKE_GBS_PER_CU = 70.0      # MI355X_MICROARCH.md: L2 -> CU ceiling of any 16-byte-per-lane path (LDS-DMA rings: 68-90 GB/s per CU)
+HBM_TBS = 8.0
+
+
+def gemm_floor(M, N, K, BM, BN, KT, pieces, nsplit, cus, hbm_bytes, flops, peak_tflops, staged=True):
+    """The bound that applies to ONE launch of a tiled product: the largest of
+      mfma_us   = algorithmic FLOPs / the pipe's peak,
+      intake_us = bytes staged through LDS / (70 GB/s x CUs the launch can use): tiles x k-tiles x (BM + BN) x KT x 2 B x pieces
+                  (pieces = 3 for x3 operands); CUs used = min(CUs, work items = tiles x k-pieces),
+      hbm_us    = algorithmic operand + output bytes / 8 TB/s.
+    staged=False (the native fp32 kernels stage through registers, not LDS-DMA): no intake term."""
+    tiles = -(-M // BM) * -(-N // BN)
+    items = tiles * max(1, nsplit)
+    nk = -(-K // KT)
+    staged_bytes = tiles * nk * (BM + BN) * KT * 2 * pieces if staged else 0
+    used = max(1, min(cus, items))
+    mfma_us = flops / (peak_tflops * 1e12) * 1e6
+    intake_us = staged_bytes / (INTAKE_GBS_PER_CU * 1e9 * used) * 1e6
+    hbm_us = hbm_bytes / (HBM_TBS * 1e12) * 1e6
+    return {'mfma_us': round(mfma_us, 2), 'intake_us': round(intake_us, 2), 'hbm_us': round(hbm_us, 2),
+            'floor_us': round(max(mfma_us, intake_us, hbm_us), 2), 'tiles': tiles, 'items': items, 'tile': '%dx%d' % (BM, BN),
+            'staged_mb': round(staged_bytes / 1e6, 1), 'cus_used': used}
+
+
+def _sum_floors(parts):
+    out = {k: round(sum(p[k] for p in parts), 2) for k in ('mfma_us', 'intake_us', 'hbm_us', 'floor_us')}
+    out['launches'] = [{k: p[k] for k in ('name', 'tile', 'items', 'cus_used', 'staged_mb', 'mfma_us', 'intake_us', 'hbm_us', 'floor_us')} for p in parts]
+    return out
+
+
+def family_floors(precision, M, H, I, B, L, nh, cus=256, plan=None, sq=None):
+    """Per LAYER and family: the floor of each launch (gemm_floor) summed over the family's launches of one layer.
+    precision: 'fp32x3' (x3 operands: 6 bytes per value staged, geometry from uniter_gemm_x3_plan), 'bf16' (one piece, 64-deep
+    k-tiles) or 'fp32' (native fp32 MFMA kernels: no LDS-DMA staging term).  plan(M, N, K, nsplit_fixed, fwd32) -> (BM, BN, nsplit)
+    answers the geometry of a forward / input-gradient product; None = 128 x 128 tiles, the nsplit given."""
+    pk = {'fp32x3': 2500.0 / 6.0, 'bf16': 2500.0, 'fp32': 157.3}[precision]
+    pieces = 3 if precision == 'fp32x3' else 1
+    eb = 2 * pieces if precision != 'fp32' else 4                # bytes per operand value in memory
+    KT = 32 if precision == 'fp32x3' else 64
+    staged = precision != 'fp32'
+    sq = B * L * L if sq is None else sq
+
+    def prod(name, m, n, k, fixed, out_bytes, extra_in=0, fwd32=False):
+        BM, BN, ns = plan(m, n, k, fixed, fwd32) if plan is not None else (128, 128, max(1, fixed))
+        hb = m * k * eb + n * k * eb + extra_in + (out_bytes if ns == 1 or out_bytes == 0 else m * n * 4 * ns)
+        f = gemm_floor(m, n, k, BM, BN, KT, pieces, ns, cus, hb, 2.0 * m * n * k, pk, staged)
+        f['name'] = name
+        return f
+
+    fam = {}
+    # forward (model/layer.py:76-78, :112, :140, :153)
+    fam['gemm_qkv_fwd'] = _sum_floors([prod('qkv', M, 3 * H, H, 1, M * 3 * H * (4 if precision != 'bf16' else 2), fwd32=True)])
+    fam['gemm_attn_out_fwd'] = _sum_floors([prod('attn_out', M, H, H, 0, M * H * 4)])
+    fam['gemm_ffn_up_fwd'] = _sum_floors([prod('ffn_up', M, I, H, 1, M * I * (eb + (4 if precision != 'bf16' else 2)))])
+    fam['gemm_ffn_down_fwd'] = _sum_floors([prod('ffn_down', M, H, I, 0, M * H * 4)])
+    # input gradients: dU = (g2 W2) * gelu'(u); dy1 = dU W1 + dz2; dctx = g1 Wo; dx = dqkv Wqkv + dz1
+    gd = 4 if precision != 'bf16' else 2
+    fam['gemm_dgrad'] = _sum_floors([
+        prod('d_ffn_down', M, I, H, 1, M * I * eb, extra_in=M * I * gd),
+        prod('d_ffn_up', M, H, I, 0, M * H * 4, extra_in=M * H * 4),
+        prod('d_attn_out', M, H, H, 0, M * H * 4),
+        prod('d_qkv', M, H, 3 * H, 0, M * H * 4, extra_in=M * H * 4)])
+    # weight gradients: one grouped launch of whole-K tiles, both operands k-major (fp32x3: 128 x 256 tiles; bf16: 128 x 128)
+    wbn = 256 if precision == 'fp32x3' else 128
+    shapes = [(I, H), (H, I), (3 * H, H), (H, H)]
+    tiles = sum(-(-mo // 128) * -(-no // wbn) for mo, no in shapes)
+    nk = -(-M // KT)
+    st_bytes = tiles * nk * (128 + wbn) * KT * 2 * pieces if staged else 0
+    fl = sum(2.0 * mo * no * M for mo, no in shapes)
+    hb = sum(M * (mo + no) * eb + mo * no * 4 for mo, no in shapes)
+    used = max(1, min(cus, tiles))
+    w = {'name': 'wgrad_group', 'tile': '128x%d' % wbn, 'items': tiles, 'cus_used': used, 'staged_mb': round(st_bytes / 1e6, 1),
+         'mfma_us': round(fl / (pk * 1e12) * 1e6, 2), 'intake_us': round(st_bytes / (INTAKE_GBS_PER_CU * 1e9 * used) * 1e6, 2),
+         'hbm_us': round(hb / (HBM_TBS * 1e12) * 1e6, 2)}
+    w['floor_us'] = max(w['mfma_us'], w['intake_us'], w['hbm_us'])
+    fam['gemm_wgrad'] = _sum_floors([w])
+    # attention (model/layer.py:85-100): one workgroup per (sample, head); Q, K, V (backward: + dO, O) staged once per workgroup
+    pa = pk if precision != 'fp32' else 157.3
+    wgs = max(1, min(cus, B * nh))
+    qb = 4 if precision != 'bf16' else 2
+    a_f = {'name': 'attn_fwd', 'tile': 'head', 'items': B * nh, 'cus_used': wgs, 'staged_mb': round(3 * M * H * qb / 1e6, 1),
+           'mfma_us': round(4.0 * sq * H / (pa * 1e12) * 1e6, 2), 'intake_us': round(3 * M * H * qb / (INTAKE_GBS_PER_CU * 1e9 * wgs) * 1e6, 2),
+           'hbm_us': round((3 * M * H * qb + M * H * (4 + eb)) / (HBM_TBS * 1e12) * 1e6, 2)}
+    a_f['floor_us'] = max(a_f['mfma_us'], a_f['intake_us'], a_f['hbm_us'])
+    a_b = {'name': 'attn_bwd', 'tile': 'head', 'items': B * nh, 'cus_used': wgs, 'staged_mb': round((3 * M * H * qb + 2 * M * H * 4) / 1e6, 1),
+           'mfma_us': round(8.0 * sq * H / (pa * 1e12) * 1e6, 2),
+           'intake_us': round((3 * M * H * qb + 2 * M * H * 4) / (INTAKE_GBS_PER_CU * 1e9 * wgs) * 1e6, 2),
+           'hbm_us': round((3 * M * H * qb + 2 * M * H * 4 + 3 * M * H * eb) / (HBM_TBS * 1e12) * 1e6, 2)}
+    a_b['floor_us'] = max(a_b['mfma_us'], a_b['intake_us'], a_b['hbm_us'])
+    fam['attention_fwd'] = _sum_floors([a_f])
+    fam['attention_bwd'] = _sum_floors([a_b])
+    # the two dropout + residual + LayerNorm passes of a layer: 16 bytes per element each way
+    for name in ('layernorm_fwd', 'layernorm_bwd'):
+        us = 2 * 16.0 * M * H / (HBM_TBS * 1e12) * 1e6
+        fam[name] = {'mfma_us': 0.0, 'intake_us': 0.0, 'hbm_us': round(us, 2), 'floor_us': round(us, 2), 'launches': []}
+    return fam
+
+
 def _lscpu_model():
     try:
         import subprocess
@@ -124,11 +222,16 @@ def cpu_baseline(seconds_budget=30.0, all_cores=False):
     # --cpu_all_cores asks for it: 12 s of the driver's time for a number that is noise
     nts = sorted({phys, min(phys, 32)}, reverse=True)
     for nt in nts:
+        if nt > 64 and not all_cores and 'EPYC 9575F' not in _lscpu_model():
+            #  the recorded figure belongs to ONE CPU model: anywhere else the leg is not run and says so
+            legs.append({'cores': nt, 'value': None, 'gflops': None, 'steps': 0, 's_per_step': None,
+                         'note': 'not run (about 12 s per step on 128 threads of the pool\'s hosts; --cpu_all_cores runs it); no recorded figure for this CPU model'})
+            continue
         if nt > 64 and not all_cores:
             legs.append({'cores': nt, 'value': 0.325, 'gflops': round(0.325 * gf_per_sample, 1), 'steps': 0, 's_per_step': 12.3,
                          'note': 'not run: recorded in round 4 on this CPU model (BENCH_r04.json, one step on 128 threads); --cpu_all_cores runs it'})
             continue
-        warm, most = (0, 1) if (nt > 32 and not all_cores) else (2, 8)
+        warm, most = (1, 1) if (nt > 32 and not all_cores) else (2, 8)      # (never time the first call)
         dt, n = timed(nt, warm, most, seconds_budget * 0.3)
         legs.append({'cores': nt, 'value': round(4.0 / dt, 3), 'gflops': round(4.0 / dt * gf_per_sample, 1), 'steps': n, 's_per_step': round(dt, 3)})
     dt1, n1 = timed(1, 1, 2, seconds_budget * 0.3)
@@ -141,7 +244,7 @@ def cpu_baseline(seconds_budget=30.0, all_cores=False):
             'sample': 'config 1: UNITER-base B=4 T=64 R=36 fwd+bwd: %s; %d steps after 1 warm-up on 1 '
                       'thread (%.2f s/step); oracle/uniter_oracle.py (torch CPU fp32, dropout on)'
                       % ('; '.join(('%d steps on %d threads (%.3f s/step)' % (l['steps'], l['cores'], l['s_per_step'])) if l['steps'] else
-                                   ('%d threads: not run (recorded %.3f samples/s)' % (l['cores'], l['value'])) for l in legs),
+                                   ('%d threads: not run%s' % (l['cores'], (' (recorded %.3f samples/s)' % l['value']) if l['value'] else '')) for l in legs),
                          n1, dt1)}
 
 
@@ -244,6 +347,15 @@ def comm_block(sync, steps, rccl_log):
            'sparse_rows_per_rank': getattr(sync, 'last_sparse_rows', None),
            'note': 'dense all-reduces only are timed (issue: event on the issuing stream in front of the collective; done: event behind '
                    'the consumer stream\'s wait); the sparse row exchange is summed in place on its issuing stream'}
+    # the design's arithmetic beside the measurement: the last dense collective of a step has no backward
+    # compute left to hide behind -- a ring all-reduce moves 2 (N - 1) / N of its bytes per rank, at one link's rate or at all seven
+    if cols:
+        from meme_challenge_amd import dp as _dp
+        last = cols[-1]          # (sorted by offset in the flat buffer: the embeddings close it, and they are issued last)
+        out['predicted_exposed_ms'] = {'last_collective_bytes': last['bytes'],
+                                       'one_link_ring': round(_dp.predicted_exposed_ms(last['bytes'], sync.world, 1), 4),
+                                       'all_links': round(_dp.predicted_exposed_ms(last['bytes'], sync.world, 7), 4),
+                                       'note': '2 (N - 1) / N x bytes / (153 GB/s x links): arithmetic for the collective issued last (the embeddings\' bucket), not a measurement'}
     if rccl_log:
         out['rccl'] = parse_rccl_log(rccl_log)
     sync.timings = []
@@ -288,6 +400,9 @@ def parse_args(argv=None):
     ap.add_argument('--no_reserve_pick', action='store_true',
                     help='N > 1: keep the attach-time CU reserve (dp.cu_reserve_default) instead of timing a few untimed steps with a reserve '
                          'of 16, 0 and 48 CUs before the warm-up and keeping the fastest (comm.reserve_pick)')
+    ap.add_argument('--reserve_pick_budget_s', type=float, default=20.0,
+                    help='N > 1: wall-time budget of the CU-reserve measurement in front of the warm-up (candidates that do not fit are '
+                         'skipped on every rank alike; comm.reserve_pick.wall_s says what it took)')
     ap.add_argument('--both_exchanges', action='store_true',
                     help='N > 1: time the other form of the word-embedding exchange too (a second timed region, listed in '
                          'comm.other_exchange; `value` is always the requested exchange)')
@@ -295,6 +410,15 @@ def parse_args(argv=None):
                     help='N > 1: exchange the touched word-embedding gradient rows (all-gather of ids + rows) instead of '
                          'all-reducing the whole 28996 x 768 table')
     return ap.parse_args(argv)
+
+
+def rank_host_threads(world):
+    """CPU threads a rank's host-side pools get: the cores it may use divided by the ranks of the node, 8 at most, 1 at least."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(8, cores // max(1, world)))
 
 
 def launch_ranks(n, cmd, env=None, poll_s=0.2):
@@ -309,6 +433,11 @@ def launch_ranks(n, cmd, env=None, poll_s=0.2):
         port = s.getsockname()[1]
     base = dict(os.environ if env is None else env)
     base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: the only form this pool's driver supports
+    # host threads per rank: N ranks x an uncapped OpenMP / torch pool each (256 hardware threads on the pool's hosts) cost the small
+    # host-side ops 16 x (the CLI trainer's own finding); the caller's setting stands
+    per_rank = str(rank_host_threads(n))
+    for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS'):
+        base.setdefault(var, per_rank)
     base['UNITER_BENCH_LAUNCHER'] = 'self'
     procs = []
     for r in range(n):
@@ -395,6 +524,9 @@ def _run_rank(args, real_stdout, state):
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
     use_dist = world > 1 or 'RANK' in os.environ
+    if world > 1:
+        # (a rank started by torch.distributed.run has no launcher of ours that set OMP_NUM_THREADS: cap the pools here as well)
+        torch.set_num_threads(int(os.environ.get('OMP_NUM_THREADS') or rank_host_threads(world)))
     rccl_log = None
     if use_dist and rank == 0 and backend == 'nccl' and 'NCCL_DEBUG' not in os.environ:
         # RCCL's own account of what it built (rings / trees, channels) for the `comm` block of the line: rank 0's INFO log
@@ -456,7 +588,7 @@ def _run_rank(args, real_stdout, state):
     sync = None
     if use_dist:
         dp.broadcast_parameters(model)
-        sync = dp.attach(model, sparse_embeddings=args.dp_sparse_embeddings, accum=config['gradient_accumulation'])
+        sync = dp.attach(model, sparse_embeddings=args.dp_sparse_embeddings, accum=config['gradient_accumulation'], token_capacity=B * T)
         sync.timing = True
     if args.workload == 'finetune':
         step = TrainStep(model, opt, sched, config, grad_sync=sync)
@@ -496,7 +628,8 @@ def _run_rank(args, real_stdout, state):
     # keep the fastest on every rank (dp.pick_cu_reserve; UNITER_DP_CU_RESERVE or --no_reserve_pick fix it instead)
     reserve_pick = None
     if sync is not None and world > 1 and not args.no_reserve_pick and 'UNITER_DP_CU_RESERVE' not in os.environ:
-        reserve_pick = dp.pick_cu_reserve(sync, encoder, one_step, steps=max(1, min(6, args.steps)), warm=max(1, min(2, args.warmup)))
+        reserve_pick = dp.pick_cu_reserve(sync, encoder, one_step, steps=max(1, min(6, args.steps)), warm=max(1, min(2, args.warmup)),
+                                          budget_s=args.reserve_pick_budget_s)
     for _ in range(args.warmup):
         one_step()
     lib = _lib.lib()
@@ -675,6 +808,10 @@ def _run_rank(args, real_stdout, state):
         except Exception as e:                               # noqa: BLE001
             bf16_leg = {'error': repr(e)}
             encoder.precision = 'fp32x3'
+            try:      #  the later legs must not run on weight pieces the failed leg left stale
+                model.param_store().mirror_dirty = True
+            except Exception:                                # noqa: BLE001
+                pass
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -717,6 +854,25 @@ def _run_rank(args, real_stdout, state):
                                 'gemm_f32_wgrad_group_kernel (its four products as one launch)'},
                      'bf16': {1: 'gemm_dma_kernel<128,128,false,false,SWAP,2,EPI=5> (bias + GELU + gelu\' bf16)',
                               6: 'gemm_dma_kernel<128,128,false,true,SWAP,2,EPI>', 7: 'gemm_dma_wgrad_group_kernel<2> (the four weight gradients of a layer in one launch of whole-K 128x128 tiles)'}}
+        # the bound that applies, per family: floor = max(MFMA time at peak, LDS-staged bytes / (70 GB/s x CUs
+        # used), algorithmic HBM bytes / 8 TB/s) of every launch, summed over a layer's launches of the family, x layers
+        def _plan_x3(m_, n_, k_, fixed, fwd32):
+            c_, n2 = C.c_int(0), C.c_int(0)
+            fn = lib.uniter_gemm_x3_plan_fwd32 if fwd32 else lib.uniter_gemm_x3_plan
+            _lib.check(fn(m_, n_, k_, 0, fixed, C.byref(c_), C.byref(n2)))
+            return (128, {3: 128, 4: 256, 5: 192}.get(c_.value, 128), n2.value)
+
+        def _plan_b16(m_, n_, k_, fixed, fwd32):
+            # gemm_bf16_dma.hip: 128 x 128 tiles (64 x 128 for the few-tile one-piece products), k-pieces by gemm_bf16v2_pick_split
+            tiles, nk = -(-m_ // 128) * -(-n_ // 128), -(-k_ // 64)
+            ns = fixed if fixed > 0 else (4 if (tiles <= 128 and nk >= 48) else 2 if (tiles <= 320 and nk >= 24) else 1)
+            return (64 if (ns == 1 and tiles <= 160) else 128, 128, ns)
+        floors = None
+        try:
+            floors = family_floors(args.precision, M_eff, H, I, B, L_eff, cfgd['num_attention_heads'],
+                                   plan={'fp32x3': _plan_x3, 'bf16': _plan_b16}.get(args.precision), sq=sq)
+        except Exception as e:                                   # noqa: BLE001 -- auxiliary: reported, never fatal
+            prof_error = (prof_error or '') + ' floors: ' + repr(e)
         families = []
         for k, (name, bound, work) in fam.items():
             in_run = k_n[k] > 0
@@ -732,6 +888,13 @@ def _run_rank(args, real_stdout, state):
                              'frac': round(work / sec / pk, 4), 'peak': round(pk / 1e12, 1) if bound == 'mfma' else 8.0, 'kernel': kernel_of[pk_name].get(k),
                              'measured': 'in-kernel stamps inside the timed region' if in_run else
                                          'HIP events, separate %d-step pass after the timed region (%.2f ms/step under events)' % (EV_STEPS, ev_ms)})
+            if floors is not None and name in floors:
+                fl = floors[name]
+                fl_ms = fl['floor_us'] * nl * 1e-3
+                families[-1]['floor'] = {'mfma_us': fl['mfma_us'], 'intake_us': fl['intake_us'], 'hbm_us': fl['hbm_us'], 'floor_us': fl['floor_us'],
+                                         'per': 'layer (sum over the family\'s launches of one layer)', 'launches': fl['launches']}
+                families[-1]['floor_ms_per_step'] = round(fl_ms, 4)
+                families[-1]['over_floor'] = round(sec * 1e3 / fl_ms, 3) if fl_ms > 0 else None
             if ev_us is not None:
                 # the same family under HIP events (the separate pass): from the moment the launch could start on its stream to
                 # its end -- the time a dispatch sits queued behind the other stream's workgroups is IN this one, not in the stamps
@@ -827,6 +990,37 @@ def _run_rank(args, real_stdout, state):
                 out['cpu_baseline'] = cpu_baseline(all_cores=args.cpu_all_cores)
             except Exception as e:                               # noqa: BLE001
                 out['cpu_baseline_error'] = repr(e)
+        # step-level floor: sum of the families' floors (the two backward streams overlap: a serial sum is an upper bound of the true floor)
+        if families and any('floor_ms_per_step' in f for f in families):
+            out['step_floor_ms'] = round(sum(f.get('floor_ms_per_step', 0.0) for f in families), 4)
+            out['step_over_floor'] = round(ms / out['step_floor_ms'], 3) if out['step_floor_ms'] > 0 else None
+        out['attention_kernel'] = ('attn_x3_fwd_kernel / attn_x3_bwd_kernel (csrc/attention_x3.hip: the attention products as x3 products on the bf16 pipe)' if attn_x3 else
+                                   'attn_b16x kernels (csrc/attention_x3.hip, one piece)' if args.precision == 'bf16' and L_eff <= 192 else
+                                   'attn_fwd_split / attn_bwd_* (csrc/attention_f32.hip: fp32 MFMAs%s)' %
+                                   ('; the x3 attention kernels hold L <= %d, this batch has L = %d' % (lib.uniter_attn_x3_max_len(), L_eff)
+                                    if args.precision == 'fp32x3' else ''))
+        # Order of the line: the long blocks first, the short figures a reader wants LAST -- a record that keeps
+        # only the tail of the line still holds them; `summary` repeats them in a few hundred bytes at the very end
+        order_last = ['roofline', 'cpu_baseline', 'optimizer', 'native_fp32', 'bf16', 'step_mfma_frac', 'ffn_roofline_frac',
+                      'step_floor_ms', 'step_over_floor', 'attention_kernel', 'final_loss']
+        for k_ in order_last:
+            if k_ in out:
+                out[k_] = out.pop(k_)
+        summ = {'value': out['value'], 'ms_per_step': out['ms_per_step'], 'precision': args.precision,
+                'step_mfma_frac': out.get('step_mfma_frac'), 'ffn_roofline_frac': out.get('ffn_roofline_frac'),
+                'step_floor_ms': out.get('step_floor_ms'), 'step_over_floor': out.get('step_over_floor')}
+        if isinstance(out.get('roofline'), dict):
+            summ['roofline'] = {k_: out['roofline'].get(k_) for k_ in ('frac', 'achieved', 'peak', 'unit', 'traffic')}
+            summ['roofline']['family'] = (out['roofline'].get('kernel') or '').split(':')[0]
+        summ['over_floor'] = {f['family']: f.get('over_floor') for f in (out.get('roofline_families') or []) if 'over_floor' in f}
+        for k_ in ('native_fp32', 'bf16'):
+            if isinstance(out.get(k_), dict):
+                summ[k_] = {a: out[k_].get(a) for a in ('value', 'ms_per_step', 'step_mfma_frac', 'error') if a in out[k_]}
+        if isinstance(out.get('optimizer'), dict):
+            summ['optimizer'] = {a: out['optimizer'].get(a) for a in ('ms', 'achieved', 'unit', 'frac')}
+        if isinstance(out.get('cpu_baseline'), dict):
+            summ['cpu_baseline'] = {a: out['cpu_baseline'].get(a) for a in ('value', 'unit', 'cores', 'kind')}
+        out['summary'] = summ
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if use_dist:

@@ -210,6 +210,9 @@ int uniter_gemm_x3_cfg(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, i
  * k-tile + 4 us per slab.  With a data-parallel exchange holding CUs (uniter_model_set_cu_reserve) the backward pass is planned
  * with it: 252-item forms that exactly fit 256 CUs would run two rounds on 240. */
 int uniter_gemm_x3_plan(int M, int N, int K, int avail_cus, int nsplit_fixed, int* cfg, int* nsplit);
+/* The same for a forward product (weights k-contiguous) with an fp32 output -- the query|key|value projection of model/layer.py:76-78:
+ * 128 x 192 tiles (cfg 5) compete too (what uniter_gemm_x3_cfg's cfg 0 picks there); bench.py prices the launch's staging floor from it. */
+int uniter_gemm_x3_plan_fwd32(int M, int N, int K, int avail_cus, int nsplit_fixed, int* cfg, int* nsplit);
 /* The weight gradients of one encoder layer in one launch on x3 operands (as uniter_wgrad_bf16_group): for p < n <= 4
  * dW[p] [M[p], N[p]] (fp32) (+)= A[p]^T B[p], A[p] x3 [K][3][M[p]], B[p] x3 [K][3][N[p]]; whole-K 128 x 128 tiles, no
  * atomics, bit-reproducible.  overwrite = 1 stores instead of adding; max_wgs > 0 caps the grid (the persistent

@@ -81,6 +81,7 @@ _SIGS = {
     'uniter_ln_bwd_rows_slabs_x3': (_I, [_P, _I, _SZ, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U32, _U32, _P, _SZ, _P]),
     'uniter_wgrad_x3_group': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
     'uniter_gemm_x3_plan': (_I, [_I, _I, _I, _I, _I, _P, _P]),
+    'uniter_gemm_x3_plan_fwd32': (_I, [_I, _I, _I, _I, _I, _P, _P]),
     'uniter_gemm_x3_colpart': (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P]),
     'uniter_wgrad_x3_group_riders': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     'uniter_wgrad_x3_group_slots': (_I, [_I, _I, _P, _P, _I]),

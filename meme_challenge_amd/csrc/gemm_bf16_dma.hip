@@ -715,6 +715,7 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
 // dW_p fp32 with leading dimension N_p), one launch; cfg 1 = two LDS stages (two workgroups per CU), 4 = three.
 // workgroups of the grouped launch over `total` tiles: a multiple of 8, capped (max_wgs > 0: by the caller; else
 // UNITER_WGRAD_GROUP_WGS, default 256 = one workgroup per CU walking its tiles)
+int gemm_chip_cus();
 static int wgrad_group_grid(int total, int max_wgs) {
   int grid = (total + 7) / 8 * 8;
   // UNITER_WGRAD_GROUP_WGS: cap of the grid (a multiple of 8; 0 = one workgroup per tile).  Default 256 = one workgroup of this
@@ -725,7 +726,7 @@ static int wgrad_group_grid(int total, int max_wgs) {
   static const int cap_env = [] { const char* e = getenv("UNITER_WGRAD_GROUP_WGS"); return e ? atoi(e) / 8 * 8 : 256; }();
   int cap = max_wgs >= 8 ? max_wgs / 8 * 8 : cap_env;
   if (g_uniter_cu_reserve > 0 && cap >= 8) {              // CUs left to the data-parallel exchange's kernels (common.h)
-    const int room = (256 - g_uniter_cu_reserve) / 8 * 8;
+    const int room = (gemm_chip_cus() - g_uniter_cu_reserve) / 8 * 8;      // (the device's CU count: gemm_split3.hip)
     if (room >= 8 && cap > room) cap = room;
   }
   if (cap >= 8 && grid > cap) grid = cap;

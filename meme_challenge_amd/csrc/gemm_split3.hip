@@ -588,7 +588,7 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, int piece, int m0
 #pragma unroll
         for (int e = 0; e < 4; ++e) t[e] += __shfl_xor(t[e], o, 64);
       const int n = n0 + wn * WN + b * 16 + 4 * gq;
-      if (r == 0 && n < g.N) *reinterpret_cast<f32x4*>(prow + n) = t;
+      if (r == 0 && n < g.N && m0 + wm * 64 < g.M) *reinterpret_cast<f32x4*>(prow + n) = t;      // (no row of partials beyond ceil(M / 64))
     }
   }
 #endif
@@ -1300,6 +1300,7 @@ bool x3_fits(size_t rows, int rs, int ps, int ext) { return ((rows + 256) * (siz
 }  // namespace
 
 size_t gemm_x3_sk_ws_bytes() { return sk_ws_bytes_(); }
+int gemm_chip_cus() { return x3_chip_cus(); }      // CUs of the current device, a multiple of 8 (shared with gemm_bf16_dma.hip)
 
 int riders_prepare(uniter_x3_riders_t& x, const char* who) {
   UCHECK_ARG(x.njobs >= 0 && x.njobs <= 4, "%s: at most 4 column-reduction jobs", who);
@@ -1409,6 +1410,13 @@ void x3_choose(int M, int N, int K, int avail, int nsplit_fixed, int* cfg_out, i
 extern "C" int uniter_gemm_x3_plan(int M, int N, int K, int avail_cus, int nsplit_fixed, int* cfg, int* nsplit) {
   UCHECK_ARG(M > 0 && N > 0 && K > 0 && cfg && nsplit && nsplit_fixed >= 0 && nsplit_fixed <= 8, "gemm_x3_plan: bad argument");
   x3_choose(M, N, K, avail_cus > 0 ? avail_cus : x3_grid(1 << 20, 0), nsplit_fixed, cfg, nsplit);
+  return 0;
+}
+
+// the same for a forward product (both operands k-contiguous) with an fp32 output: 128 x 192 tiles (cfg 5) compete too
+extern "C" int uniter_gemm_x3_plan_fwd32(int M, int N, int K, int avail_cus, int nsplit_fixed, int* cfg, int* nsplit) {
+  UCHECK_ARG(M > 0 && N > 0 && K > 0 && cfg && nsplit && nsplit_fixed >= 0 && nsplit_fixed <= 8, "gemm_x3_plan_fwd32: bad argument");
+  x3_choose(M, N, K, avail_cus > 0 ? avail_cus : x3_grid(1 << 20, 0), nsplit_fixed, cfg, nsplit, true);
   return 0;
 }
 

@@ -728,9 +728,10 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     // with K = 2048 -- as a stream-K accumulation on top of the bias rows it fills the chip (fp32: 58 -> 25 us)
     const long t64 = (long)((B * R + 63) / 64) * ((H + 63) / 64);
     static const bool img_sk = [] { const char* e = getenv("UNITER_IMG_SK"); return !e || e[0] != '0'; }();
-    // (fp32 only: the float atomics make the sum's order vary from run to run -- 1e-7 in fp32, but the bf16 mode amplifies any
-    // such difference through its rounding stages, DESIGN.md section 2, and its forward is otherwise deterministic)
-    if (img_sk && m->precision == 0 && t64 >= 8 && t64 <= 600 && c.img_dim >= 1024 && c.img_dim % 64 == 0 && H % 4 == 0) {
+    // (the fp32 modes only -- native and, round 6, fp32x3, whose forward took 76.7 us for this product on 108 whole-K tiles: the float
+    // atomics make the sum's order vary from run to run -- 1e-7 in fp32, but the bf16 mode amplifies any such difference through its
+    // rounding stages, DESIGN.md section 2, and its forward is otherwise deterministic)
+    if (img_sk && (m->precision == 0 || m->precision == 3) && t64 >= 8 && t64 <= 600 && c.img_dim >= 1024 && c.img_dim % 64 == 0 && H % 4 == 0) {
       UCHECK_RC(uniter_bias_rows(m->P(P_IMG_B), pl.imgfc, B * R, H, st));
       UCHECK_RC(gemm(m, 0, st, 0, 0, B * R, H, c.img_dim, feat, c.img_dim, m->P(P_IMG_W), c.img_dim, pl.imgfc, H,
                      UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
@@ -1292,6 +1293,10 @@ extern "C" int uniter_model_norm_partials_per_layer(const uniter_model_t* m) {
     return (m->plan.res && m->plan.mode != 0 && m->plan.wg_group == 1 && b16_riders_enabled()) ? gemm_bf16v2_wgrad_group_slots(4, Mo, No, 0) : 0;
   }
   if (m->precision != 3 || !x3_riders_enabled()) return 0;
+  //  a plan whose joint length is beyond the fused query|key|value bias partials (L > uniter_attn_varlen_max_len(), or
+  // UNITER_ATTN_SPLIT=0) writes that bias gradient by a separate column-sum launch BEHIND the riders' launch: its squares would reach
+  // no slot.  Such a plan announces no slots at all -- the caller reduces the layer's bucket itself, as in the other precisions
+  if (m->plan.mode != 0 && m->plan.L > uniter_attn_varlen_max_len()) return 0;
   static const int x3_wgs = [] { const char* e = getenv("UNITER_WGRAD_X3_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
   // (the plan of the LAST forward: its row count is the reduction length, its workspace the balanced walk's)
   return gemm_x3_wgrad_group_slots(0, 4, Mo, No, x3_wgs, m->plan.M, m->plan.sk_side ? m->plan.sk_bytes : 0);

@@ -56,12 +56,16 @@ import torch.distributed as dist
 
 class GradSync(object):
     def __init__(self, flat_grads, bucket_ranges, group=None, bucket_bytes=32 << 20, payload='fp32', word_table=None,
-                 accum=1):
+                 accum=1, token_capacity=None):
         """word_table: (start, rows, row_len) of the word-embedding gradient inside the LAST bucket (it must open that
         bucket) -- enables the sparse exchange for steps that announce their token ids to ``prepare``.
         accum: micro-batches per optimizer step (gradient_accumulation): the sparse exchange carries the ids of ALL of them,
         so its agreed capacity is sized for a full window (the first exchange of an epoch comes after ONE micro-batch:
-        the reference's iteration-0 quirk, train_template.py:95-109)."""
+        the reference's iteration-0 quirk, train_template.py:95-109).
+        token_capacity: token ids ONE micro-batch can hold at most (batch_size x max_txt_len: the reference truncates and pads every
+        caption to --max_txt_len, train_uniter.py:98, data/meme_dataset.py:170-177) -- the sparse exchange's capacity is then
+        token_capacity x accum from the start, the same on every rank by construction: no agreement collective, no host
+        synchronisation, and a later batch that holds more ids than the first cannot exceed it.  None: agreed at the first step."""
         if payload not in ('fp32', 'bf16'):
             raise ValueError("payload must be 'fp32' or 'bf16'")
         self.flat = flat_grads
@@ -79,8 +83,10 @@ class GradSync(object):
             self.ranges[-1:] = [(ws, we)] + ([(we, le)] if we < le else [])
         self._tokens = []                         # token ids of the micro-batches accumulated since the last exchange
         self._tokens_dense = False                # one of them had a dense word-embedding gradient
-        self._cap = None                          # ids per rank and exchange, agreed over the ranks at the first sparse step
         self.accum = max(1, int(accum))
+        # ids per rank and exchange: static (token_capacity x accum), or agreed over the ranks at the first sparse step
+        self._cap = int(token_capacity) * self.accum if token_capacity else None
+        self.cap_source = 'static' if token_capacity else 'agreed at the first step'
         self._micro = 0                           # micro-batches recorded since the last exchange
         # timing of the collectives (bench.py --gpus N: the `comm` block): events on the issuing / waiting streams
         self.timing = False
@@ -134,9 +140,9 @@ class GradSync(object):
                         dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=self.group)
                     self._cap = int(cap.item())
                 if ids.numel() > self._cap:
-                    raise ValueError('sparse embedding exchange: %d token ids in a step, capacity agreed at the first '
-                                     'step is %d (same batch shape on every rank and step, gradient_accumulation = %d '
-                                     'passed to dp.attach)' % (ids.numel(), self._cap, self.accum))
+                    raise ValueError('sparse embedding exchange: %d token ids in a step, capacity (%s) is %d (gradient_accumulation '
+                                     '= %d passed to dp.attach; pass token_capacity = batch_size x max_txt_len to dp.attach to size it '
+                                     'for the largest batch up front)' % (ids.numel(), self.cap_source, self._cap, self.accum))
                 srt = ids.sort().values
                 first = torch.ones_like(srt, dtype=torch.bool)
                 first[1:] = srt[1:] != srt[:-1]
@@ -358,14 +364,17 @@ def prepare_rccl_env(world, env=None):
     return r
 
 
-def pick_cu_reserve(sync, encoder, one_step, candidates=None, steps=6, warm=2):
+def pick_cu_reserve(sync, encoder, one_step, candidates=None, steps=6, warm=2, budget_s=None):
     """Measure instead of believing: run `warm` + `steps` training steps (``one_step()``: forward, backward with the exchange, update)
     with each candidate number of reserved CUs (default: the reserve in force, 0, 16, 48), take the slowest rank's time for each,
     keep the fastest candidate on every rank (ties: the earlier one) and return {'picked': r, 'candidates': [{'cu_reserve': r, 'ms_per_step': t}, ...]}.  What the right
     reserve is depends on how many channels RCCL opens on the node's topology and on how long its kernels sit beside the matrix
     kernels -- neither can be known before the first exchange has run on the real links.  The steps are ordinary steps (their
     updates count); results do not depend on the reserve (tests/test_model_gpu.py::test_cu_reserve_for_a_gradient_exchange...).
-    A failure on any rank leaves the attach-time reserve in place on all of them ('error' in the result).  One rank: no-op, None."""
+    A failure on any rank leaves the attach-time reserve in place on all of them ('error' in the result).  One rank: no-op, None.
+    budget_s: wall-time budget -- after every candidate the ranks agree (one 8-byte MAX all-reduce) on the time spent so far, and
+    the candidates that do not fit are skipped on every rank alike ('skipped' in the result; the first candidate always runs).  The
+    result carries 'wall_s', the slowest rank's time inside this function."""
     import time
     world = sync.world if sync is not None else 1
     if sync is None or world <= 1:
@@ -383,8 +392,10 @@ def pick_cu_reserve(sync, encoder, one_step, candidates=None, steps=6, warm=2):
             torch.cuda.synchronize(dev)
 
     times, ok, err = [], 1, None
+    t_in = time.perf_counter()
+    tried = list(candidates)
     try:
-        for c in candidates:
+        for i, c in enumerate(candidates):
             encoder.cu_reserve = int(c)
             for _ in range(warm):
                 one_step()
@@ -394,9 +405,20 @@ def pick_cu_reserve(sync, encoder, one_step, candidates=None, steps=6, warm=2):
                 one_step()
             fence()
             times.append((time.perf_counter() - t0) / steps * 1e3)
+            if budget_s is not None and i + 1 < len(candidates):
+                # every rank must stop at the same candidate: the slowest rank's clock decides
+                el = torch.tensor([time.perf_counter() - t_in], dtype=torch.float64, device=dev if use_cuda else 'cpu')
+                dist.all_reduce(el, op=dist.ReduceOp.MAX, group=sync.group)
+                if float(el.item()) * (i + 2) / (i + 1) > float(budget_s):      # (the next candidate would not fit)
+                    tried = list(candidates[:i + 1])
+                    break
     except Exception as e:                                       # noqa: BLE001
         ok, err = 0, repr(e)
+    skipped = [int(c) for c in candidates[len(tried):]]
+    candidates = tried
     res = {'picked': start, 'candidates': []}
+    if skipped:
+        res['skipped'] = skipped
     try:
         buf = torch.zeros(1 + len(candidates), dtype=torch.float64, device=dev if use_cuda else 'cpu')
         buf[0] = -float(ok)                                      # MAX over ranks of -ok: 0 as soon as one rank failed
@@ -416,15 +438,38 @@ def pick_cu_reserve(sync, encoder, one_step, candidates=None, steps=6, warm=2):
     encoder.cu_reserve = res['picked']
     sync.collect_timings()
     sync.timings = []
+    try:
+        w = torch.tensor([time.perf_counter() - t_in], dtype=torch.float64, device=dev if use_cuda else 'cpu')
+        dist.all_reduce(w, op=dist.ReduceOp.MAX, group=sync.group)
+        res['wall_s'] = round(float(w.item()), 3)
+    except Exception:                                            # noqa: BLE001
+        res['wall_s'] = round(time.perf_counter() - t_in, 3)
+    if budget_s is not None:
+        res['budget_s'] = float(budget_s)
     return res
 
 
-def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embeddings=None, accum=1, cu_reserve=None):
+XGMI_LINK_GBS = 153.0        # one xGMI link, one direction (MI355X: 7 links per GPU to its 7 peers)
+
+
+def predicted_exposed_ms(last_bytes, world, links=1):
+    """What the LAST collective of a step (the embeddings': the one no backward compute is left to hide) costs on the wire if it
+    runs as a ring all-reduce: every rank sends and receives 2 (N - 1) / N of the payload, at the rate of `links` xGMI links
+    (1 = one ring on one link per hop, the pessimistic case; 7 = all links of the fully connected node).  Arithmetic, to read the
+    measured ``exposed_ms_per_step`` against -- not a measurement."""
+    if world <= 1 or last_bytes <= 0:
+        return 0.0
+    return 2.0 * (world - 1) / world * last_bytes / (XGMI_LINK_GBS * 1e9 * max(1, links)) * 1e3
+
+
+def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embeddings=None, accum=1, cu_reserve=None,
+           token_capacity=None):
     """Wire a GradSync to a MemeUniter, UniterForPretraining or UniterModel and return it.
     payload None: 'bf16' when the encoder runs in the bf16 precision mode, else 'fp32'.
     accum: the trainer's gradient_accumulation (sizes the sparse exchange for a full window of micro-batches).
     sparse_embeddings (None: UNITER_DP_SPARSE_EMB=1): exchange the touched rows of the word-embedding gradient instead
-    of the table (GradSync docstring); the trainer then passes each micro-batch's token ids to ``prepare``."""
+    of the table (GradSync docstring); the trainer then passes each micro-batch's token ids to ``prepare``.
+    token_capacity: batch_size x max_txt_len -- sizes the sparse exchange statically (GradSync docstring)."""
     store = model.param_store() if hasattr(model, 'param_store') else None
     if store is None:
         from .model import ensure_store
@@ -441,7 +486,7 @@ def attach(model, group=None, bucket_bytes=32 << 20, payload=None, sparse_embedd
             V, H = store.params[name].shape
             word_table = (store.offsets[name], int(V), int(H))
     gs = GradSync(store.flat_grads, store.bucket_ranges, group=group, bucket_bytes=bucket_bytes, payload=payload,
-                  word_table=word_table, accum=accum)
+                  word_table=word_table, accum=accum, token_capacity=token_capacity)
     um._grad_hook = gs.hook
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     gs.cu_reserve = cu_reserve_default(world) if cu_reserve is None else int(cu_reserve)

@@ -194,7 +194,11 @@ class TrainerTemplate(object):
         self.model_saver = ModelSaver(self.model_file)
         if self.config.get('parallel_computing') and _distributed() and dist.get_world_size() > 1:
             dp.broadcast_parameters(self.model)
-            self.grad_sync = dp.attach(self.model, accum=int(self.config.get('gradient_accumulation', 1) or 1))
+            # the sparse word-row exchange (opt-in: UNITER_DP_SPARSE_EMB=1) is sized statically -- every caption is truncated and
+            # padded to --max_txt_len (train_uniter.py:98, data/meme_dataset.py:170-177): batch_size x max_txt_len ids at most
+            bs, tl = int(self.config.get('batch_size', 0) or 0), int(self.config.get('max_txt_len', 0) or 0)
+            self.grad_sync = dp.attach(self.model, accum=int(self.config.get('gradient_accumulation', 1) or 1),
+                                       token_capacity=(bs * tl) if (bs > 0 and tl > 0) else None)
             enc = getattr(self.model, 'uniter_model', None)
             if enc is not None:          # different dropout masks on every rank (the batches differ as well)
                 enc.set_dropout_seed(int(self.config.get('seed', 0)) + 7919 * dist.get_rank())

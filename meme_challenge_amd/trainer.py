@@ -188,7 +188,7 @@ class FusedAdam(torch.optim.Optimizer):
         layers_view = self._np_buf[head_n:head_n + nl * lstride]
         self._np_blocks, self._np_seen = 0, set()
         lib = _lib.lib()
-        state = {'fused': False}
+        state = {'fused': False, 'per_layer': 0}
 
         def region(k):
             """(offset in doubles, slots) of bucket k's partial sums"""
@@ -216,9 +216,12 @@ class FusedAdam(torch.optim.Optimizer):
                 # two backward passes (bench.py's native-fp32 leg) changes which slots are written: clear the stale ones
                 per_layer = encoder.norm_partials_per_layer()
                 fused = 0 < per_layer <= lstride
-                if fused != state['fused']:
+                #  the slot COUNT matters too: uniter_sumsq_combine joins the whole buffer, and a launch on a smaller
+                # grid (a CU reserve, a capped grid, another batch shape) leaves the larger grid's tail slots behind
+                if fused != state['fused'] or (fused and per_layer != state['per_layer']):
                     layers_view.zero_()
                     state['fused'] = fused
+                state['per_layer'] = per_layer
                 if first_layer == 1:
                     reduce_bucket(0, stream)                 # head / pooler: final before the encoder's backward starts
             elif kind == 'layer':

@@ -16,6 +16,7 @@ import json, os, sys, time
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 assert os.environ['LOCAL_RANK'] == os.environ['RANK'] and os.environ['MASTER_ADDR'] == '127.0.0.1'
 assert int(os.environ['MASTER_PORT']) > 0 and os.environ['UNITER_BENCH_LAUNCHER'] == 'self'
+assert 1 <= int(os.environ['OMP_NUM_THREADS']) <= 8 and os.environ['MKL_NUM_THREADS'] == os.environ['OMP_NUM_THREADS']      # (round 6: host pools capped per rank)
 mode = sys.argv[1]
 if mode == 'fail' and rank == 1:
     sys.exit(7)
@@ -88,6 +89,9 @@ def test_comm_block_schema_and_rccl_log_parse(tmp_path):
     assert a['bytes'] == 2000 and a['per_step'] == 1.0 and a['issue_to_done_ms'] == 2.0 and a['exposed_ms'] == 0.25
     assert b['elements'] == 4000 and b['issue_to_done_ms'] == 1.0 and b['exposed_ms'] == 0.5
     assert c['bytes_per_step'] == 10000 and c['exposed_ms_per_step'] == 0.75
+    # round 6: the design's arithmetic for the collective issued last, beside the measurement
+    pe = c['predicted_exposed_ms']
+    assert pe['last_collective_bytes'] == 8000 and pe['one_link_ring'] == round(2 * 7 / 8 * 8000 / 153e9 * 1e3, 4) and pe['all_links'] <= pe['one_link_ring']
     r = c['rccl']
     assert r['channels'] == 8 and r['algorithm'] == 'RING' and r['protocol'] == 'SIMPLE' and r['log_lines'] == 5
     assert bench.parse_rccl_log(str(tmp_path / 'missing.log'))['channels'] is None
@@ -104,3 +108,28 @@ def test_round5_flags_parse_and_defaults():
     assert not a.no_reserve_pick            # N > 1 measures the CU reserve before the warm-up unless told not to
     a = bench.parse_args(['--both_exchanges', '--reserve_ab', '--no_bf16_leg', '--cpu_all_cores', '--gpus', '8'])
     assert a.both_exchanges and a.reserve_ab and a.no_bf16_leg and a.cpu_all_cores and a.gpus == 8
+
+
+def test_rank_host_threads_and_floor_arithmetic():
+    """Round 6: (i) host threads per rank of a self-launched N-rank run; (ii) the floor bench.py prints per family,
+    recomputed by hand for one launch: FFN-up forward of configs[1] on 128 x 256 x3 tiles."""
+    import bench
+    assert bench.rank_host_threads(1) >= 1 and bench.rank_host_threads(10 ** 6) == 1 and bench.rank_host_threads(8) <= 8
+    a = bench.parse_args([])
+    assert a.reserve_pick_budget_s == 20.0
+    M, N, K = 2624, 3072, 768
+    f = bench.gemm_floor(M, N, K, 128, 256, 32, 3, 1, 256, hbm_bytes=M * K * 6 + N * K * 6 + M * N * 10, flops=2.0 * M * N * K, peak_tflops=2500.0 / 6.0)
+    tiles = 21 * 12
+    assert f['tiles'] == tiles and f['items'] == tiles and f['cus_used'] == 252
+    staged = tiles * 24 * (128 + 256) * 32 * 2 * 3
+    assert abs(f['intake_us'] - staged / (70e9 * 252) * 1e6) < 0.01 and abs(f['mfma_us'] - 2.0 * M * N * K / (2500e12 / 6) * 1e6) < 0.01
+    assert abs(f['hbm_us'] - (M * K * 6 + N * K * 6 + M * N * 10) / 8e12 * 1e6) < 0.01
+    assert f['floor_us'] == max(f['mfma_us'], f['intake_us'], f['hbm_us'])
+    # k-pieces: the same staged bytes over twice the work items (more CUs used)
+    g1 = bench.gemm_floor(M, 768, 3072, 128, 128, 32, 3, 1, 256, 0, 1.0, 1.0)
+    g2 = bench.gemm_floor(M, 768, 3072, 128, 128, 32, 3, 2, 256, 0, 1.0, 1.0)
+    assert g1['cus_used'] == 126 and g2['cus_used'] == 252 and abs(g1['intake_us'] - 2 * g2['intake_us']) < 0.02
+    fam = bench.family_floors('fp32x3', M, 768, 3072, 16, 164, 12)
+    assert set(fam) >= {'gemm_ffn_up_fwd', 'gemm_dgrad', 'gemm_wgrad', 'attention_bwd', 'layernorm_fwd'}
+    assert len(fam['gemm_dgrad']['launches']) == 4 and fam['gemm_dgrad']['floor_us'] >= fam['gemm_dgrad']['mfma_us']
+    assert bench.family_floors('fp32', M, 768, 3072, 16, 164, 12)['gemm_ffn_up_fwd']['intake_us'] == 0.0      # no LDS-DMA staging there

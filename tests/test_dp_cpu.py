@@ -292,7 +292,31 @@ def _pick_worker(rank, world, port, out):
             raise RuntimeError('workspace too small')
     r3 = dp.pick_cu_reserve(gs, enc, step3, candidates=[0, 16], steps=2, warm=1)
     after3 = (enc.cu_reserve, gs.cu_reserve)
-    torch.save(dict(r1=r1, after1=after1, r2=r2, after2=after2, r3=r3, after3=after3), out + str(rank))
+    # round 6: a wall-time budget -- the slowest rank's clock decides, every rank skips the same candidates
+    enc.cu_reserve = gs.cu_reserve = 16
+
+    def step4():
+        time.sleep(0.02 if rank == 1 else 0.001)
+    r4 = dp.pick_cu_reserve(gs, enc, step4, candidates=[16, 0, 48], steps=2, warm=1, budget_s=0.1)
+    # round 6: the sparse exchange sized statically (batch_size x max_txt_len x accumulation): no agreement collective, and a later
+    # batch with more ids than the first fits
+    flat2 = torch.zeros(64 + 16 * 8 + 64)
+    gss = dp.GradSync(flat2, [(0, 64), (64, 64 + 16 * 8 + 64)], word_table=(64, 16, 8), accum=2, token_capacity=6)
+    cap0 = (gss._cap, gss.cap_source)
+    gss.prepare(True, token_ids=torch.tensor([1, 2, 3]))               # the first exchange: 3 ids
+    n1 = gss._sorted[0].numel()
+    gss.flush_all()
+    gss.prepare(False, token_ids=torch.tensor([4, 5, 6, 7, 8, 9]))     # a later window: 6 + 5 = 11 ids <= 12
+    gss.prepare(True, token_ids=torch.tensor([1, 1, 2, 3, 5]))
+    n2 = gss._sorted[0].numel()
+    gss.flush_all()
+    try:
+        gss.prepare(True, token_ids=torch.arange(13))
+        too_many = None
+    except ValueError as e:
+        too_many = str(e)
+    torch.save(dict(r1=r1, after1=after1, r2=r2, after2=after2, r3=r3, after3=after3, r4=r4, cap0=cap0, n1=n1, n2=n2, too_many=too_many),
+               out + str(rank))
     dist.destroy_process_group()
 
 
@@ -311,4 +335,16 @@ def test_cu_reserve_is_picked_by_the_slowest_rank(tmp_path):
         assert r['r2']['picked'] == 0 and r['after2'] == (0, 0) and [c['cu_reserve'] for c in r['r2']['candidates']] == [16, 0, 48]
         # (the third call starts from reserve 0: candidates 0, then 16, which raises)
         assert r['r3']['picked'] == 0 and 'workspace too small' in r['r3']['error'] and r['after3'] == (0, 0)
-    assert rs[0]['r1'] == rs[1]['r1'] and rs[0]['r2'] == rs[1]['r2']
+        # budget 0.1 s: the first candidate takes rank 1 0.06 s (3 steps of 20 ms) -- the second would not fit: skipped everywhere
+        assert [c['cu_reserve'] for c in r['r4']['candidates']] == [16] and r['r4']['skipped'] == [0, 48] and r['r4']['picked'] == 16
+        assert r['r4']['wall_s'] >= 0.05 and r['r4']['budget_s'] == 0.1 and 'wall_s' in r['r1'] and 'skipped' not in r['r1']
+        assert r['cap0'] == (12, 'static') and r['n1'] == 12 and r['n2'] == 12
+        assert r['too_many'] and 'token_capacity' in r['too_many']
+    assert rs[0]['r4']['wall_s'] == rs[1]['r4']['wall_s']
+    rs0 = {k: v for k, v in rs[0]['r1'].items() if k != 'wall_s'}
+    assert rs0 == {k: v for k, v in rs[1]['r1'].items() if k != 'wall_s'}
+    assert {k: v for k, v in rs[0]['r2'].items() if k != 'wall_s'} == {k: v for k, v in rs[1]['r2'].items() if k != 'wall_s'}
+    # the design's arithmetic for the exposed collective: 98 MB fp32 at 8 ranks on one link / on seven
+    assert abs(dp.predicted_exposed_ms(97.6e6, 8, 1) - 2 * 7 / 8 * 97.6e6 / 153e9 * 1e3) < 1e-9
+    assert abs(dp.predicted_exposed_ms(97.6e6, 8, 7) * 7 - dp.predicted_exposed_ms(97.6e6, 8, 1)) < 1e-9
+    assert dp.predicted_exposed_ms(97.6e6, 1) == 0.0
