@@ -142,9 +142,12 @@ def family_floors(precision, M, H, I, B, L, nh, cus=256, plan=None, sq=None):
     a_b['floor_us'] = max(a_b['mfma_us'], a_b['intake_us'], a_b['hbm_us'])
     fam['attention_fwd'] = _sum_floors([a_f])
     fam['attention_bwd'] = _sum_floors([a_b])
-    # the two dropout + residual + LayerNorm passes of a layer: 16 bytes per element each way
+    # the two dropout + residual + LayerNorm passes of a layer: 16 bytes per element each way (x, residual in; z, y out / dy, z in;
+    # dz, dx out) + what the mode adds: the second k-piece slab of the product in front (4 B) and the operand copy of the product
+    # behind (x3 pieces 6 B, bf16 2 B)
+    extra = {'fp32x3': 4.0 + 6.0, 'bf16': 4.0 + 2.0, 'fp32': 0.0}[precision]
     for name in ('layernorm_fwd', 'layernorm_bwd'):
-        us = 2 * 16.0 * M * H / (HBM_TBS * 1e12) * 1e6
+        us = 2 * (16.0 + extra) * M * H / (HBM_TBS * 1e12) * 1e6
         fam[name] = {'mfma_us': 0.0, 'intake_us': 0.0, 'hbm_us': round(us, 2), 'floor_us': round(us, 2), 'launches': []}
     return fam
 

@@ -277,6 +277,19 @@ int uniter_wgrad_bf16_group_riders(int cfg, int n, const int* M, const int* N, i
                                    const void* const* B, float* const* dW, int overwrite, int max_wgs,
                                    uniter_x3_riders_t* riders, void* stream);
 int uniter_wgrad_bf16_group_slots(int n, const int* M, const int* N, int max_wgs);
+/* Round 6: the PERSISTENT loader / compute form of the bf16-resident products (csrc/gemm_bf16_p.hip: the structure of the x3 kernels
+ * for one-piece operands -- 4 loader waves run LDS-DMA two 64-deep k-tiles ahead of 4 or 8 compute waves across the work items of a
+ * persistent workgroup, v_mfma_f32_16x16x32_bf16, XCD-chunked banded tile walk).  Reached through the entry points above:
+ *  - uniter_gemm_bf16v2_cfg with cfg 6 (128 x 128 tiles), 7 (128 x 256: 48 instead of 64 KB staged per k-tile and pair of 128 x 128
+ *    products) or 8 (128 x 192, k-contiguous weights only: the query|key|value projection's 252 tiles); epilogues none / bias /
+ *    + aux / bias + GELU + gelu' / x aux, no accumulate (beta = 0), forward and input-gradient layouts;
+ *  - uniter_wgrad_bf16_group(_riders) with cfg 7: a layer's four weight gradients as 216 whole-K tiles of 128 x 256 (one round of
+ *    the chip); riders without colsum_out (the bias gradient of intermediate.dense comes from the producing product's column
+ *    partials as a reduction job), 8 sum-of-squares slots per workgroup: uniter_wgrad_bf16_group_slots_cfg.
+ * uniter_gemm_bf16p_plan: the geometry (6 / 7 / 8) and k-pieces the model's plan picks for a product on `avail_cus` CUs (0 = the
+ * chip's; nsplit_fixed > 0: the caller's k-pieces) -- host arithmetic; bench.py prices the launch's staging floor from it. */
+int uniter_wgrad_bf16_group_slots_cfg(int cfg, int n, const int* M, const int* N, int max_wgs);
+int uniter_gemm_bf16p_plan(int M, int N, int K, int avail_cus, int nsplit_fixed, int b_kmajor, int* cfg, int* nsplit);
 /* out[c] += sum_r X[r, c] for an x3 tensor X [rows][3][ldx] (bias gradient of intermediate.dense from dU). */
 int uniter_colsum_x3_add(const void* x3, int rows, int cols, int ldx, float* out, void* stream);
 /* uniter_ln_fwd_slabs / uniter_ln_bwd_rows_slabs whose operand copy for the next GEMM is x3 [M][3][H] instead of bf16 */

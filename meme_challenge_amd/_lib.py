@@ -91,6 +91,8 @@ _SIGS = {
     'uniter_wgrad_x3_group_slots_ws': (_I, [_I, _I, _P, _P, _I, _I, _SZ]),
     'uniter_wgrad_bf16_group_riders': (_I, [_I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     'uniter_wgrad_bf16_group_slots': (_I, [_I, _P, _P, _I]),
+    'uniter_wgrad_bf16_group_slots_cfg': (_I, [_I, _I, _P, _P, _I]),
+    'uniter_gemm_bf16p_plan': (_I, [_I, _I, _I, _I, _I, _I, _P, _P]),
     'uniter_hidden_keep_bits_bytes': (_SZ, [_SZ]),
     'uniter_hidden_keep_bits_gen': (_I, [_P, _SZ, _I, _U32, _U32, _U32, _SZ, _F, _U64, _U32, _P]),
     'uniter_ln_set_next_keep_bits': (_I, [_P]),

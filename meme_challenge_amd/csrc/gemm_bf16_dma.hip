@@ -669,7 +669,16 @@ int dispatch_epi(int cfg, const GArgsD& g, hipStream_t st) {
 
 }  // namespace
 
-// cfg: 1 = 128x128 (2 stages), 2 = 128x256, 3 = 256x128, 4 = 128x128 (3 stages), 5 = 64x128 (2 waves); 0 = choose.
+// the persistent loader / compute kernels (gemm_bf16_p.hip, round 6): cfg 6 = 128 x 128 tiles, 7 = 128 x 256, 8 = 128 x 192
+int gemm_b1p_run(int cfg, int nsplit, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                 float* C, int ldc, long c_split_stride, void* Cb, int ldcb, int epilogue, const float* bias,
+                 const void* aux_in, int aux_in_bf16, void* aux_out, int aux_out_bf16, int ld_aux, float* colpart, void* stream);
+int gemm_b1p_wgrad_group(int n, const int* Mo, const int* No, int K, const void* const* A, const void* const* B, float* const* dW,
+                         void* stream, int overwrite, int max_wgs, uniter_x3_riders_t* riders);
+int gemm_b1p_wgrad_group_slots(int n, const int* Mo, const int* No, int max_wgs);
+
+// cfg: 1 = 128x128 (2 stages), 2 = 128x256, 3 = 256x128, 4 = 128x128 (3 stages), 5 = 64x128 (2 waves); 0 = choose;
+// 6 / 7 / 8 = the persistent loader / compute kernels of gemm_bf16_p.hip (128 x 128 / 128 x 256 / 128 x 192 tiles).
 // beta = 1: C += A.B through fp32 atomics (lane = column orientation; no epilogue, no bf16 output).
 int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int lda,
                     const void* B, int ldb, float* C, int ldc, long c_split_stride, void* Cb, int ldcb, int epilogue,
@@ -691,6 +700,12 @@ int gemm_bf16v2_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int 
   UCHECK_SHAPE((size_t)(a_kmajor ? K : M + 256) * lda * 2 < (1ull << 31) && (size_t)(b_kmajor ? K + 64 : N + 256) * ldb * 2 < (1ull << 31) &&
                ((size_t)M + 256) * (ldc > 0 ? ldc : 1) * 4 < (1ull << 31) &&
                ((size_t)M + 256) * (ld_aux > 0 ? ld_aux : 1) * 4 < (1ull << 31), "gemm_bf16v2: operand beyond 31-bit offsets");
+  if ((cfg & 0xff) >= 6) {
+    UCHECK_ARG(!a_kmajor && !beta, "gemm_bf16v2: cfg %d (persistent kernels) runs forward / input-gradient layouts without accumulate "
+               "(weight gradients: uniter_wgrad_bf16_group, cfg 7)", cfg & 0xff);
+    return gemm_b1p_run(cfg & 0xff, nsplit, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, c_split_stride, Cb, ldcb, epilogue, bias, aux_in,
+                        aux_in_bf16, aux_out, aux_out_bf16, ld_aux, nullptr, stream);
+  }
   GArgsD g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.c_split_stride = c_split_stride; g.Cb = (unsigned short*)Cb; g.ldcb = ldcb; g.epi = epilogue; g.bias = bias;
@@ -756,6 +771,7 @@ int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K,
                             const void* const* B, float* const* dW, void* stream, int overwrite, int max_wgs,
                             uniter_x3_riders_t* riders) {
   UCHECK_ARG(n >= 1 && n <= 4 && K > 0 && Mo && No && A && B && dW, "wgrad_group: bad argument");
+  if (cfg == 7) return gemm_b1p_wgrad_group(n, Mo, No, K, A, B, dW, stream, overwrite, max_wgs, riders);      // 128 x 256 tiles, persistent
   GGroupD G;
   memset(&G.x, 0, sizeof(G.x));
   unsigned long long* stamp = take_stamp_slot();
@@ -813,6 +829,10 @@ extern "C" int uniter_wgrad_bf16_group_riders(int cfg, int n, const int* M, cons
 }
 extern "C" int uniter_wgrad_bf16_group_slots(int n, const int* M, const int* N, int max_wgs) {
   return gemm_bf16v2_wgrad_group_slots(n, M, N, max_wgs);
+}
+// the same for a given geometry of the grouped launch: cfg 7 (persistent 128 x 256 tiles, gemm_bf16_p.hip) writes 8 slots per workgroup
+extern "C" int uniter_wgrad_bf16_group_slots_cfg(int cfg, int n, const int* M, const int* N, int max_wgs) {
+  return cfg == 7 ? gemm_b1p_wgrad_group_slots(n, M, N, max_wgs) : gemm_bf16v2_wgrad_group_slots(n, M, N, max_wgs);
 }
 
 // Split-K choice for the GEMMs whose N is the hidden size (measured on MI355X, tests/tools/gemm_v2_lab.py,

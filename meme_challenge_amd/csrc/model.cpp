@@ -48,6 +48,11 @@ int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, con
 int gemm_x3_wgrad_group_slots(int cfg, int n, const int* Mo, const int* No, int max_wgs, int K, size_t sk_ws_bytes);
 int gemm_x3_wgrad_group_balanced_wgs(int cfg, int n, const int* Mo, const int* No);
 int gemm_bf16v2_pick_split(int M, int N, int K);
+int gemm_b1p_pick_split(int M, int N, int K, int avail);
+int gemm_b1p_run(int cfg, int nsplit, int b_kmajor, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                 float* C, int ldc, long c_split_stride, void* Cb, int ldcb, int epilogue, const float* bias,
+                 const void* aux_in, int aux_in_bf16, void* aux_out, int aux_out_bf16, int ld_aux, float* colpart, void* stream);
+int gemm_b1p_wgrad_group_slots(int n, const int* Mo, const int* No, int max_wgs);
 int gemm_bf16v2_wgrad_pieces(int M, int N, int K);
 int gemm_bf16v2_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, const void* const* A,
                             const void* const* B, float* const* dW, void* stream, int overwrite, int max_wgs,
@@ -197,6 +202,14 @@ int check_cfg(const uniter_config_t* c) {
 }
 
 int x3_backward_cus(const uniter_model* m);
+// precision 2, round 6: which products run on the persistent kernels of gemm_bf16_p.hip (bit mask, see gemm_v2 / backward_layer)
+int b16_persist_mask() {
+  // default 0: built, parity-tested through the C ABI, faster isolated -- and the STEP is slower with every subset of them (same-box A/B,
+  // profiles/r06_b16_persist_ab.txt: 4.39 ms with none, 4.43-4.75 with bits 1 / 2 / 4 / 7 / 12 / 15): their 96-144 KB workgroups own a
+  // CU, where two 64-KB workgroups of gemm_dma_kernel let the two backward streams and the kernel boundaries of the forward pass overlap
+  static const int m = [] { const char* e = getenv("UNITER_B16_PERSIST"); return e ? atoi(e) : 0; }();
+  return m;
+}
 
 void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, int L, bool has_txt,
                bool has_img, bool has_masks, int mode, int Mrows = -1) {
@@ -222,6 +235,13 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
   pl.embb = (pl.res || pl.x3) ? cv.h(pc * M * H) : nullptr;
   pl.ns_ki = pl.res ? gemm_bf16v2_pick_split(pl.M, H, I) : pl.x3 ? gemm_x3_pick_split(pl.M, H, I) : 1;
   pl.ns_k3h = pl.res ? gemm_bf16v2_pick_split(pl.M, H, 3 * H) : pl.x3 ? gemm_x3_pick_split(pl.M, H, 3 * H) : 1;
+  if (pl.res && (b16_persist_mask() & 2)) {
+    // round 6: the N = hidden products on the persistent kernels are planned by their own cost model (one workgroup per CU: two
+    // k-pieces fill the chip where gemm_dma_kernel's two workgroups per CU wanted four -- two slabs less for the row pass behind)
+    const int a = gemm_b1p_pick_split(pl.M, H, I, 0), b = gemm_b1p_pick_split(pl.M, H, 3 * H, 0);
+    if (a > 1) pl.ns_ki = a;
+    if (b > 1) pl.ns_k3h = b;
+  }
   pl.ns_kh = pl.x3 ? gemm_x3_pick_split(pl.M, H, H) : 1;
   pl.ns_ki_b = pl.ns_ki; pl.ns_k3h_b = pl.ns_k3h; pl.ns_kh_b = pl.ns_kh;
   if (pl.x3) {
@@ -371,11 +391,31 @@ int gemm(uniter_model* m, int kind, hipStream_t st, int akm, int bkm, int M, int
 // (gemm_bf16_dma.hip); aux operands (gelu' in, gelu' out) are bf16 there, residual gradients fp32.
 int gemm_v2(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, int K, const void* A, int lda,
             const void* B, int ldb, float* C, int ldc, int nsplit, unsigned short* Cb, int ldcb, int epi,
-            const float* bias, const void* aux_in, int aux_in_b16, void* aux_out, int aux_out_b16, int ld_aux) {
+            const float* bias, const void* aux_in, int aux_in_b16, void* aux_out, int aux_out_b16, int ld_aux,
+            float* colpart = nullptr) {
   ProfScope ps(m, kind, st);
   static const int main_prio = [] { const char* e = getenv("UNITER_MAIN_PRIO_BF16"); return e ? atoi(e) : 2; }();
   g_uniter_launch_prio = main_prio;
-  return gemm_bf16v2_run(0, nsplit, 0, bkm, M, N, K, A, lda, B, ldb, C, ldc, (long)M * ldc, Cb, ldcb, epi, bias, aux_in,
+  // round 6: the persistent loader / compute kernels (csrc/gemm_bf16_p.hip) where they win isolated (profiles/r06_b1p_lab.txt):
+  // the query|key|value projection on 128 x 192 tiles (252 for 256 CUs: 15.4 against 16.9 us), the N = hidden products with k-pieces
+  // on persistent 128 x 128 tiles (FFN-down forward 20.4 against 22.6 us, FFN-up / QKV input gradients 22.1 / 19.1 against
+  // 24.1 / 20.5).  The N = intermediate products tie (128 x 256 tiles stage a quarter less per k-tile -- 0.75 against 0.93 us, the
+  // vendor library's slope -- and pay 2 us more fixed cost on a 12-k-tile loop): they keep gemm_dma_kernel.  UNITER_B16_PERSIST is a
+  // bit mask: 1 = QKV forward, 2 = N = hidden products, 8 = the wide products as well (4: the grouped weight gradients, below)
+  int cfg = 0;
+  const int mask = b16_persist_mask();
+  const bool epi_ok = epi == UNITER_EPI_NONE || epi == UNITER_EPI_BIAS || epi == UNITER_EPI_ADD || epi == UNITER_EPI_BIAS_GELU_D || epi == UNITER_EPI_MUL;
+  if (epi_ok && K % 64 == 0) {
+    if ((mask & 1) && kind == UNITER_K_GEMM_QKV_FWD && !bkm && N % 192 == 0) cfg = 8;
+    else if ((mask & 2) && nsplit > 1 && N <= 1024) cfg = 6;
+    else if ((mask & 8) && nsplit == 1 && N >= 2048) cfg = 7;
+  }
+  if (colpart) {      // (the product that writes dU also leaves its column partials: the persistent 128 x 256 kernel's epilogue)
+    UCHECK_ARG(epi_ok && K % 64 == 0 && nsplit == 1, "gemm_v2: column partials ride on the persistent kernels");
+    return gemm_b1p_run(7, 1, bkm, M, N, K, A, lda, B, ldb, C, ldc, (long)M * ldc, Cb, ldcb, epi, bias, aux_in, aux_in_b16, aux_out,
+                        aux_out_b16, ld_aux, colpart, st);
+  }
+  return gemm_bf16v2_run(cfg, nsplit, 0, bkm, M, N, K, A, lda, B, ldb, C, ldc, (long)M * ldc, Cb, ldcb, epi, bias, aux_in,
                          aux_in_b16, aux_out, aux_out_b16, ld_aux, 0, st);
 }
 // precision 3: the attention's products on the bf16 pipe too (csrc/attention_x3.hip) -- L <= 192 and, with dropout, keep flags drawn
@@ -437,6 +477,20 @@ bool b16_riders_enabled() {
   static const bool on = [] { const char* e = getenv("UNITER_B16_RIDERS"); return e && e[0] == '1'; }();
   return on;
 }
+// round 6: with the grouped launch on the persistent 128 x 256-tile kernel (UNITER_B16_PERSIST bit 4) a workgroup of it owns its CU, the
+// two backward streams time-slice as in the fp32x3 mode, and every side launch is step time: there the riders are ON unless
+// UNITER_B16_RIDERS=0
+bool b16_p7() { return (b16_persist_mask() & 4) != 0; }
+bool b16_riders_on(const Plan& pl) {
+  static const bool off = [] { const char* e = getenv("UNITER_B16_RIDERS"); return e && e[0] == '0'; }();
+  // (on the 128 x 256 geometry the bias gradient of intermediate.dense must come from column partials -- bit 8 and the gelu' form of the
+  // forward epilogue: a separate pass over dU would write it outside the launch, and its squares would reach no clip-norm slot)
+  if (b16_p7()) return pl.res && pl.wg_group == 1 && !off && (b16_persist_mask() & 8) && pl.gelu_d;
+  return pl.res && pl.wg_group == 1 && b16_riders_enabled();
+}
+// ... and dU's column sums (the bias gradient of intermediate.dense) start in the epilogue of the product that writes dU when that product
+// runs on the persistent 128 x 256 kernel (bit 8), finished by a fourth reduction job of the riders
+bool b16_colpart_on(const Plan& pl) { return b16_p7() && b16_riders_on(pl); }
 // the side work of layer l's backward as riders of its grouped weight-gradient launch (product 0 must be dW1 = dU^T y1: its A
 // operand's column sums are intermediate.dense's bias gradient)
 void fill_layer_riders(uniter_x3_riders_t& x, const uniter_model* m, int l, const LayerBufs& lb, int M, int B, int H, bool fused_qb,
@@ -728,10 +782,11 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
     // with K = 2048 -- as a stream-K accumulation on top of the bias rows it fills the chip (fp32: 58 -> 25 us)
     const long t64 = (long)((B * R + 63) / 64) * ((H + 63) / 64);
     static const bool img_sk = [] { const char* e = getenv("UNITER_IMG_SK"); return !e || e[0] != '0'; }();
-    // (the fp32 modes only -- native and, round 6, fp32x3, whose forward took 76.7 us for this product on 108 whole-K tiles: the float
-    // atomics make the sum's order vary from run to run -- 1e-7 in fp32, but the bf16 mode amplifies any such difference through its
-    // rounding stages, DESIGN.md section 2, and its forward is otherwise deterministic)
-    if (img_sk && (m->precision == 0 || m->precision == 3) && t64 >= 8 && t64 <= 600 && c.img_dim >= 1024 && c.img_dim % 64 == 0 && H % 4 == 0) {
+    // (native fp32 only: the float atomics make the sum's order vary from run to run -- 1e-7 in fp32, but the bf16 mode amplifies any
+    // such difference through its rounding stages, DESIGN.md section 2, and the fp32x3 mode's forward and backward are bit-reproducible
+    // run to run, which tests/test_model_gpu.py::test_cu_reserve_for_a_gradient_exchange_changes_no_result relies on -- round 6 tried
+    // the stream-K form there and took it out again for that reason)
+    if (img_sk && m->precision == 0 && t64 >= 8 && t64 <= 600 && c.img_dim >= 1024 && c.img_dim % 64 == 0 && H % 4 == 0) {
       UCHECK_RC(uniter_bias_rows(m->P(P_IMG_B), pl.imgfc, B * R, H, st));
       UCHECK_RC(gemm(m, 0, st, 0, 0, B * R, H, c.img_dim, feat, c.img_dim, m->P(P_IMG_W), c.img_dim, pl.imgfc, H,
                      UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
@@ -965,7 +1020,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   const int epi_du = pl.gelu_d ? UNITER_EPI_MUL : UNITER_EPI_DGELU;
   if (res) {
     UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, I, H, lb.g2b, H, m->WB(l, L_W2), I, nullptr, I, 1, lb.dub, I,
-                      epi_du, nullptr, lb.u, 1, nullptr, 0, I));
+                      epi_du, nullptr, lb.u, 1, nullptr, 0, I, b16_colpart_on(pl) ? lb.du_csum : nullptr));
     UCHECK_RC(gemm_v2(m, UNITER_K_GEMM_DGRAD, st, 1, M, H, I, lb.dub, I, m->WB(l, L_W1), H, lb.dy1, H, pl.ns_ki, nullptr, 0,
                       UNITER_EPI_ADD, nullptr, lb.dz2, 0, nullptr, 0, H));
   } else if (x3) {
@@ -1071,7 +1126,7 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
   // precision 3 (round 5): the column reductions below, the bias gradient of intermediate.dense and the layer's share of the clip
   // norm RIDE on the grouped weight-gradient launch (uniter_wgrad_x3_group_riders) -- no finalize / column-sum / sum-of-squares
   // launches on this stream.  UNITER_X3_RIDERS=0 keeps the separate launches (A/B measurements)
-  const bool riders_b16 = res && pl.wg_group == 1 && b16_riders_enabled();
+  const bool riders_b16 = b16_riders_on(pl);
   const bool riders_on = (x3 && x3_riders_enabled()) || riders_b16;
   // LayerNorm / dense-bias gradients: the column reductions of the two row passes above, the attention backward's
   // per-sample query|key|value bias partials and (fp32 mode) the dU column partials -- ONE launch for all of them
@@ -1108,19 +1163,22 @@ extern "C" int uniter_model_backward_layer(uniter_model_t* m, int l) {
       if (riders_b16) {
         uniter_x3_riders_t x;
         memset(&x, 0, sizeof(x));
-        const int slots = gemm_bf16v2_wgrad_group_slots(4, Mo, No, b16_wgs);
+        const bool p7 = b16_p7(), colpart = b16_colpart_on(pl);
+        const int slots = p7 ? gemm_b1p_wgrad_group_slots(4, Mo, No, b16_wgs) : gemm_bf16v2_wgrad_group_slots(4, Mo, No, b16_wgs);
         if (m->norm_parts) {
           UCHECK_ARG((size_t)slots <= m->norm_stride, "backward_layer: %d clip-norm slots per layer, room for %zu (uniter_model_set_norm_partials)",
                      slots, m->norm_stride);
           x.ssq = m->norm_parts + (size_t)l * m->norm_stride;
         }
-        fill_layer_riders(x, m, l, lb, M, B, H, fused_qb);
+        fill_layer_riders(x, m, l, lb, M, B, H, fused_qb, colpart);
         ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-        UCHECK_RC(gemm_bf16v2_wgrad_group(1, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, b16_wgs, &x));
+        UCHECK_RC(gemm_bf16v2_wgrad_group(p7 ? 7 : 1, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, b16_wgs, &x));
       } else {
         {
           ProfScope ps(m, UNITER_K_GEMM_WGRAD, sd);
-          UCHECK_RC(gemm_bf16v2_wgrad_group(pl.wg_group == 4 ? 4 : 1, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, b16_wgs, nullptr));
+          // (round 6: 216 whole-K tiles of 128 x 256 on the persistent kernel -- 47 against 61 us alone, UNITER_B16_PERSIST bit 4)
+          const int wcfg = pl.wg_group == 4 ? 4 : ((b16_persist_mask() & 4) ? 7 : 1);
+          UCHECK_RC(gemm_bf16v2_wgrad_group(wcfg, 4, Mo, No, M, As, Bs, dWs, sd, m->wg_overwrite ? 1 : 0, b16_wgs, nullptr));
         }
         UCHECK_RC(uniter_colsum_bf16_add(lb.dub, M, I, I, m->LG(l, L_B1), sd));      // intermediate.dense bias gradient
       }
@@ -1290,7 +1348,10 @@ extern "C" int uniter_model_norm_partials_per_layer(const uniter_model_t* m) {
   if (m->precision == 2) {
     // (the grouped launch is the default form of this precision: UNITER_WGRAD_GROUP unset or 1; very long batches fall back)
     // (answers for the plan of the LAST forward: the grouped launch is that plan's choice -- very long batches keep stream-K)
-    return (m->plan.res && m->plan.mode != 0 && m->plan.wg_group == 1 && b16_riders_enabled()) ? gemm_bf16v2_wgrad_group_slots(4, Mo, No, 0) : 0;
+    if (!(m->plan.mode != 0 && b16_riders_on(m->plan))) return 0;
+    // (as in the fp32x3 mode: a plan beyond the fused query|key|value bias partials announces no slots -- ADVICE r05)
+    if (m->plan.L > uniter_attn_varlen_max_len()) return 0;
+    return b16_p7() ? gemm_b1p_wgrad_group_slots(4, Mo, No, 0) : gemm_bf16v2_wgrad_group_slots(4, Mo, No, 0);
   }
   if (m->precision != 3 || !x3_riders_enabled()) return 0;
   //  a plan whose joint length is beyond the fused query|key|value bias partials (L > uniter_attn_varlen_max_len(), or

@@ -114,7 +114,8 @@ if not only or 'wgroup' in only:
             lib.uniter_gemm_bf16res_cfg(0, 1, 1, m, n, K, L.ptr(a), m, L.ptr(b), n, L.ptr(c), n, None, 0, 0, None, None, None, 0, 1, L.cur_stream())
     runs = {'v1_4launches': sep,
             'group_c1': lambda: L.check(lib.uniter_wgrad_bf16_group(1, 4, Ms, Ns, K, pa, pb, pc, L.cur_stream())),
-            'group_c4': lambda: L.check(lib.uniter_wgrad_bf16_group(4, 4, Ms, Ns, K, pa, pb, pc, L.cur_stream()))}
+            'group_c4': lambda: L.check(lib.uniter_wgrad_bf16_group(4, 4, Ms, Ns, K, pa, pb, pc, L.cur_stream())),
+            'group_c7_persistent_128x256': lambda: L.check(lib.uniter_wgrad_bf16_group(7, 4, Ms, Ns, K, pa, pb, pc, L.cur_stream()))}
     for r in runs.values(): r()
     torch.cuda.synchronize()
     graphs = {k: make_graph(r) for k, r in runs.items()}
