@@ -607,6 +607,18 @@ int uniter_adam_step_x3(float* params, float* grads, const void* grads_bf16, flo
                         const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale, float max_norm,
                         float lr, float beta1, float beta2, float eps, float weight_decay, int step, int adamw,
                         int zero_grads, void* mirror, size_t mirror_piece_stride, int max_workgroups, void* stream);
+/* The update of ONE table split by rows (round 6; utils/optim_utils.py:33-40 + train_template.py:104-107 for
+ * model/model.py:220-221's word-embedding table).  torch.optim.Adam with weight_decay updates every row of the table (g += wd p),
+ * 0.62 of the step's 3.18 GB, and the next forward's text branch waits for it; but a row WITHOUT a gradient is updated from g = 0,
+ * which no clip coefficient changes -- its update depends on nothing this step's backward pass computes.  So: rows_touched = 0 updates
+ * the rows whose row_mask byte is 0, g taken as zero (never read, never cleared; sumsq / max_norm ignored), at any point after the
+ * previous step's update -- e.g. beside the backward pass; rows_touched = 1 updates the masked rows with their gradients, clipped,
+ * behind the backward pass.  Per-element arithmetic unchanged: the parameters are bit-identical to one launch over the table.
+ * params / grads / exp_avg / exp_avg_sq / chunk_flags point at the table; n = rows x row_len, row_len % 64 == 0. */
+int uniter_adam_step_rows(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* chunk_flags, size_t n,
+                          const double* sumsq, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, int adamw, int zero_grads, const uint8_t* row_mask, int row_len,
+                          int rows_touched, int max_workgroups, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Whole-model schedule: the library owns the kernel sequence of

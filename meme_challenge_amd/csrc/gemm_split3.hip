@@ -60,6 +60,12 @@ struct S3Args {
 };
 
 #define OOB 0x7ffffff0        /* buffer offset beyond every descriptor: load returns 0, store is dropped */
+// cache policy of the 16x16x32 epilogue's output stores (lab switch, -DX3_ST_AUX=2: nt, =16: sc1 write-through, =18: both).  A
+// one-round launch of 252 workgroups ends in one store burst (80 MB for FFN-up forward) and the kernel boundary behind it writes the
+// L2s' dirty lines back: round 6 measured whether stores that leave the L2 as they are issued shorten that
+#ifndef X3_ST_AUX
+#define X3_ST_AUX 0
+#endif
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -544,8 +550,8 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, int piece, int m0
         }
       }
       const int n = n0 + wn * WN + b * 16 + 4 * gq;
-      if (Cp) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsC, n < g.N ? (m * g.ldc + n) * 4 : OOB, 0, 0);
-      if (TWO) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x2[b]), rsX, n < g.N ? (m * g.ld_aux + n) * 4 : OOB, 0, 0);
+      if (Cp) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsC, n < g.N ? (m * g.ldc + n) * 4 : OOB, 0, X3_ST_AUX);
+      if (TWO) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x2[b]), rsX, n < g.N ? (m * g.ld_aux + n) * 4 : OOB, 0, X3_ST_AUX);
     }
     if constexpr (EPI == S3_MUL) {      // (the one epilogue whose output is a dY with a bias gradient: dU)
       if (g.colpart && first) {
@@ -570,7 +576,7 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, int piece, int m0
           const auto r0 = __builtin_amdgcn_permlane16_swap(wa[p][0], wb[p][0], false, false);
           const auto r1 = __builtin_amdgcn_permlane16_swap(wa[p][1], wb[p][1], false, false);
           const u32x4_t o = {r0[0], r1[0], r0[1], r1[1]};
-          __builtin_amdgcn_raw_buffer_store_b128(o, rsCx, ok ? (m * g.ldcx + p * g.pscx + n8) * 2 : OOB, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o, rsCx, ok ? (m * g.ldcx + p * g.pscx + n8) * 2 : OOB, 0, X3_ST_AUX);
         }
       }
     }

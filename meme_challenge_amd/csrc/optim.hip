@@ -84,6 +84,11 @@ struct AdamArgs {
   unsigned short* mirror;     // optional bf16 copy of the updated parameters (precision 'bf16' weight mirror)
   size_t mirror_ps;           // > 0: the mirror holds the THREE bf16 pieces of every parameter, piece p at mirror + p * mirror_ps (precision 'fp32x3')
   const unsigned short* g16;  // optional: read the gradient from this bf16 buffer (reduced data-parallel payload); g is still zeroed
+  // row split of a table (round 6, uniter_adam_step_rows): chunk c belongs to row c / row_chunks; only the rows whose mask byte is
+  // (!= 0) == (rows_want != 0) are updated.  rows_want == 0 also means "these rows received no gradient": g is taken as zero
+  // without being read (and is not cleared)
+  const uint8_t* rowmask;
+  int row_chunks, rows_want;
 };
 
 #define NT_LOAD(base, idx) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base) + (idx))
@@ -138,22 +143,27 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += 2 * stride) {
     const size_t j = i + stride;
     const bool two = j < a.n4;
-    const uint8_t f0 = a.flags[(i * 4) / CHUNK];
-    const uint8_t f1 = two ? a.flags[(j * 4) / CHUNK] : 0;
-    f32x4 p0, g0, m0, v0, p1, g1, m1, v1;
+    uint8_t f0 = a.flags[(i * 4) / CHUNK];
+    uint8_t f1 = two ? a.flags[(j * 4) / CHUNK] : 0;
+    if (a.rowmask) {      // (one table, split by rows: this launch takes the rows on its side of the mask)
+      if (f0 && (a.rowmask[((i * 4) / CHUNK) / a.row_chunks] != 0) != (a.rows_want != 0)) f0 = 0;
+      if (f1 && (a.rowmask[((j * 4) / CHUNK) / a.row_chunks] != 0) != (a.rows_want != 0)) f1 = 0;
+    }
+    const bool no_g = a.rowmask && a.rows_want == 0;      // rows without a gradient this step: g == 0, unread
+    f32x4 p0, g0 = {0.f, 0.f, 0.f, 0.f}, m0, v0, p1, g1 = g0, m1, v1;
     if (f0) {
-      p0 = NT_LOAD(a.p, i); g0 = a.g16 ? widen4(a.g16, i) : NT_LOAD(a.g, i); m0 = NT_LOAD(a.m, i); v0 = NT_LOAD(a.v, i);
+      p0 = NT_LOAD(a.p, i); if (!no_g) g0 = a.g16 ? widen4(a.g16, i) : NT_LOAD(a.g, i); m0 = NT_LOAD(a.m, i); v0 = NT_LOAD(a.v, i);
     }
     if (f1) {
-      p1 = NT_LOAD(a.p, j); g1 = a.g16 ? widen4(a.g16, j) : NT_LOAD(a.g, j); m1 = NT_LOAD(a.m, j); v1 = NT_LOAD(a.v, j);
+      p1 = NT_LOAD(a.p, j); if (!no_g) g1 = a.g16 ? widen4(a.g16, j) : NT_LOAD(a.g, j); m1 = NT_LOAD(a.m, j); v1 = NT_LOAD(a.v, j);
     }
     // (gradients read from the bf16 payload: the fp32 buffer holds this rank's own sums, cleared whatever the payload says)
     if (f0) {
-      const bool c0 = a.zero_grads && !(f0 & 4) && (a.g16 != nullptr || any_nonzero(g0));
+      const bool c0 = !no_g && a.zero_grads && !(f0 & 4) && (a.g16 != nullptr || any_nonzero(g0));
       adam_update4(a, coef, (f0 & 3) == 2 ? a.wd : 0.f, p0, g0, m0, v0); adam_store4(a, i, p0, m0, v0, c0);
     }
     if (f1) {
-      const bool c1 = a.zero_grads && !(f1 & 4) && (a.g16 != nullptr || any_nonzero(g1));
+      const bool c1 = !no_g && a.zero_grads && !(f1 & 4) && (a.g16 != nullptr || any_nonzero(g1));
       adam_update4(a, coef, (f1 & 3) == 2 ? a.wd : 0.f, p1, g1, m1, v1); adam_store4(a, j, p1, m1, v1, c1);
     }
   }
@@ -252,11 +262,46 @@ extern "C" int uniter_adam_step_g16(float* params, float* grads, const void* gra
                              beta1, beta2, eps, weight_decay, step, adamw, zero_grads, mirror_bf16, 0, max_workgroups, stream);
 }
 
+static int adam_step_impl(float* params, float* grads, const void* grads_bf16, float* exp_avg,
+                          float* exp_avg_sq, const uint8_t* chunk_flags, size_t n, const double* sumsq,
+                          float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
+                          size_t mirror_piece_stride, int max_workgroups, const uint8_t* row_mask, int row_chunks, int rows_want,
+                          void* stream);
+
 extern "C" int uniter_adam_step_x3(float* params, float* grads, const void* grads_bf16, float* exp_avg,
                                    float* exp_avg_sq, const uint8_t* chunk_flags, size_t n, const double* sumsq,
                                    float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                                    float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
                                    size_t mirror_piece_stride, int max_workgroups, void* stream) {
+  return adam_step_impl(params, grads, grads_bf16, exp_avg, exp_avg_sq, chunk_flags, n, sumsq, grad_scale, max_norm, lr, beta1, beta2,
+                        eps, weight_decay, step, adamw, zero_grads, mirror_bf16, mirror_piece_stride, max_workgroups, nullptr, 0, 0, stream);
+}
+
+// The update of ONE table split by rows (round 6): a fine-tuning step touches at most B x T of the word-embedding table's 28996 rows
+// (model/model.py:220-221), yet torch.optim.Adam with weight_decay updates every row (utils/optim_utils.py:33-40: g += wd p) -- 0.62 of
+// the step's 3.18 GB -- and the next forward's text branch waits for all of it.  A row WITHOUT a gradient is updated from g = 0, which
+// neither the clip coefficient nor the gradient exchange can change (0 x c = 0): its update does not depend on this step's backward
+// pass at all.  So the table's launch is two: rows_touched = 0 -- the rows whose mask byte is 0, g taken as zero (never read), any
+// time after the previous step's update, e.g. beside the backward pass; rows_touched = 1 -- the masked rows with their gradients,
+// clipped, behind the backward pass as before (a few per cent of the table).  Same arithmetic per element: bit-identical parameters.
+// params .. chunk_flags point at the TABLE (row 0); n = rows x row_len with row_len % 64 == 0; row_mask one byte per row.
+extern "C" int uniter_adam_step_rows(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* chunk_flags,
+                                     size_t n, const double* sumsq, float grad_scale, float max_norm, float lr, float beta1,
+                                     float beta2, float eps, float weight_decay, int step, int adamw, int zero_grads,
+                                     const uint8_t* row_mask, int row_len, int rows_touched, int max_workgroups, void* stream) {
+  UCHECK_ARG(row_mask && row_len > 0 && row_len % CHUNK == 0 && n % (size_t)row_len == 0, "adam_step_rows: row_len must be a multiple of 64 dividing n");
+  return adam_step_impl(params, grads, nullptr, exp_avg, exp_avg_sq, chunk_flags, n, rows_touched ? sumsq : nullptr, grad_scale,
+                        rows_touched ? max_norm : 0.f, lr, beta1, beta2, eps, weight_decay, step, adamw, zero_grads, nullptr, 0,
+                        max_workgroups, row_mask, row_len / CHUNK, rows_touched ? 1 : 0, stream);
+}
+
+static int adam_step_impl(float* params, float* grads, const void* grads_bf16, float* exp_avg,
+                          float* exp_avg_sq, const uint8_t* chunk_flags, size_t n, const double* sumsq,
+                          float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
+                          size_t mirror_piece_stride, int max_workgroups, const uint8_t* row_mask, int row_chunks, int rows_want,
+                          void* stream) {
   UCHECK_SHAPE(mirror_piece_stride % 4 == 0 && (mirror_piece_stride == 0 || mirror_bf16), "adam_step: bad mirror piece stride");
   UCHECK_ARG(params && grads && exp_avg && exp_avg_sq && chunk_flags, "adam_step: null pointer");
   UCHECK_SHAPE(((uintptr_t)grads_bf16 & 7) == 0, "adam_step: bf16 gradients must be 8-byte aligned");
@@ -270,6 +315,7 @@ extern "C" int uniter_adam_step_x3(float* params, float* grads, const void* grad
   a.mirror = (unsigned short*)mirror_bf16;
   a.mirror_ps = mirror_piece_stride;
   a.g16 = (const unsigned short*)grads_bf16;
+  a.rowmask = row_mask; a.row_chunks = row_chunks > 0 ? row_chunks : 1; a.rows_want = rows_want;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   a.step_size = (float)((double)lr / bc1);

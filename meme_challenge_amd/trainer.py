@@ -137,6 +137,17 @@ class FusedAdam(torch.optim.Optimizer):
         self.overlap_workgroups = int(os.environ.get('UNITER_ADAM_OVERLAP_WGS', '256'))
         self._pending = None
         self._plan_cache = None
+        # the word-embedding table's update split by rows (round 6, uniter_adam_step_rows): note_tokens / early_word_update / step
+        # (built, bit-identical, and OFF by default: same-box A/B 9.53 ms with and without in fp32x3, 4.39 -> 4.44 ms in bf16 --
+        # profiles/r06_word_rows_ab.txt: the 100 us the head of the next forward pass no longer waits for are CU-time the ahead-of-time
+        # launch takes from the forward pass it runs beside, and behind the table the next forward's own first kernels bound the head)
+        self.split_word_rows = os.environ.get('UNITER_ADAM_WORD_ROWS', '0') == '1'
+        self._rowmask = None        # one byte per row of the table: 1 = a token of the micro-batches since the last step looks it up
+        self._rows_noted = False    # every micro-batch since the last step announced its ids (none had a dense table gradient)
+        self._early = None          # the rows without a gradient were updated ahead: (step_count, lr, betas, eps, wd, adamw, event)
+        self._word_cache = None
+        self._rowmask_clear = None  # event behind the mask's clearing (side stream)
+        self._rowmask_ready = None  # event behind the mask's last fill (the stream note_tokens ran on)
 
     def _overlap_plan(self, enc):
         """(head ranges, [embeddings, layer 0, ..] ranges) in flat-buffer elements, or None when the
@@ -238,6 +249,97 @@ class FusedAdam(torch.optim.Optimizer):
         encoder._norm_parts = (layers_view, lstride)
         self._norm_hook = hook
         return True
+
+    # -- the word-embedding table, row by row ---------------------------------------------------------------------------
+    def _word_table(self):
+        """(offset, rows, row length) of the word-embedding table in the flat buffers, or None (no such tensor, a row length
+        that is no multiple of the optimizer's 64-element chunks, or the split switched off)."""
+        if not self.split_word_rows:
+            return None
+        if self._word_cache is None:
+            st = self.store
+            name = next((n for n in st.names if n.endswith('embeddings.word_embeddings.weight')), None)
+            wt = False
+            if name is not None:
+                V, H = st.params[name].shape
+                if int(H) % CHUNK == 0 and st.offsets[name] % CHUNK == 0:
+                    wt = (st.offsets[name], int(V), int(H), name)
+            self._word_cache = wt
+        return self._word_cache or None
+
+    def note_tokens(self, input_ids):
+        """Once per micro-batch, before its backward pass: the token ids it looks up in the word-embedding table -- the only rows its
+        gradient can touch (model/model.py:232-236; padding_idx 0 included: harmless).  None = this micro-batch's table gradient is
+        dense (the MLM task's tied decoder): no split this step."""
+        wt = self._word_table()
+        if wt is None:
+            return
+        if input_ids is None:
+            self._rows_noted = None           # dense until the next step
+            return
+        if self._rows_noted is None:
+            return
+        if self._rowmask is None:
+            self._rowmask = torch.zeros(wt[1], dtype=torch.uint8, device=self.store.device)
+        if self._rowmask_clear is not None:        # (the last step cleared the mask on the side stream, behind its last reader)
+            torch.cuda.current_stream().wait_event(self._rowmask_clear)
+            self._rowmask_clear = None
+        ids = input_ids.reshape(-1)
+        self._rowmask.index_fill_(0, ids.clamp(0, wt[1] - 1), 1)
+        self._rowmask_ready = torch.cuda.Event()
+        self._rowmask_ready.record()
+        self._rows_noted = True
+
+    def early_word_update(self, stream=None):
+        """Before the backward pass of the micro-batch that steps (every micro-batch since the last step called note_tokens): update the
+        rows of the word-embedding table that NO token of them looks up.  Their gradient is zero whatever the backward pass computes, and
+        0 x (clip coefficient) = 0: torch.optim.Adam's update of such a row (g = wd p, utils/optim_utils.py:33-40) depends on the
+        step number and the learning rate alone -- so 93 % of the table (0.58 of the step's 3.18 GB) leaves the head of the NEXT
+        forward pass, whose text branch used to wait for all of it, and streams beside this step's own forward / backward instead.
+        `step()` then updates the looked-up rows only (with their gradients, clipped).  Parameters bit-identical to the one-launch
+        update.  Returns True when the ahead-of-time launch was issued."""
+        wt = self._word_table()
+        if wt is None or self._rows_noted is not True or self._early is not None:
+            return False
+        st = self.store
+        g0, g1 = self.param_groups
+        lr = float(g0['lr'])
+        if float(g1['lr']) != lr:
+            return False
+        off, V, H, name = wt
+        flags = self._row_flags(off, V * H, no_decay(name))
+        side = stream
+        if side is None:
+            enc = self.overlap_encoder
+            side = getattr(enc, '_side_stream', None) if enc is not None else None
+        if side is None:
+            side = _lib.shared_stream(st.device, 'side')
+        # behind the mask's last fill only -- NOT behind everything queued on the current stream: called in front of the forward pass, the
+        # launch then runs beside it like one more of the optimizer's blocks (the side stream holds the previous step's update ahead of it)
+        if self._rowmask_ready is not None:
+            side.wait_event(self._rowmask_ready)
+        b1, b2 = g0['betas']
+        import ctypes as C
+        wgs = int(os.environ.get('UNITER_ADAM_EARLY_WGS', self.overlap_workgroups))
+        check(_lib.lib().uniter_adam_step_rows(st.flat_params.data_ptr() + 4 * off, st.flat_grads.data_ptr() + 4 * off,
+                                               self.exp_avg.data_ptr() + 4 * off, self.exp_avg_sq.data_ptr() + 4 * off,
+                                               flags.data_ptr(), V * H, None, 1.0, 0.0, lr, float(b1), float(b2), float(g0['eps']),
+                                               float(g0['weight_decay']), self.step_count + 1, int(self.adamw), 0,
+                                               self._rowmask.data_ptr(), H, 0, wgs, C.c_void_p(side.cuda_stream)),
+              'uniter_adam_step_rows')
+        ev = torch.cuda.Event()
+        ev.record(side)
+        self._early = (self.step_count + 1, lr, (float(b1), float(b2)), float(g0['eps']), float(g0['weight_decay']), bool(self.adamw), ev)
+        return True
+
+    def _row_flags(self, off, n, nodecay):
+        """chunk flags of the word table for the row-split launches: every chunk on the update path (decay as the tensor's group says)"""
+        key = ('rows', off, n, bool(nodecay))
+        f = self._flags_cache.get(key)
+        if f is None:
+            f = torch.full((n // CHUNK,), 1 if nodecay else 2, dtype=torch.uint8, device=self.store.device)
+            self._flags_cache[key] = f
+        return f
 
     def join(self):
         """Make the current stream wait for an overlapped update still running on the side stream."""
@@ -362,10 +464,41 @@ class FusedAdam(torch.optim.Optimizer):
                                           max_wgs, stream_ptr),
                   'uniter_adam_step')
 
+        # the word-embedding table's rows without a gradient were updated ahead (early_word_update): its launch takes the looked-up rows
+        early, self._early = self._early, None
+        wt = self._word_table() if early is not None else None
+        if early is not None:
+            ok = (wt is not None and early[:6] == (self.step_count, lr, (float(b1), float(b2)), float(g0['eps']), float(g0['weight_decay']),
+                                                  bool(self.adamw)) and grad_bf16 is None)
+            if not ok:
+                raise UniterHipError('FusedAdam.step: the word-embedding rows without a gradient were updated ahead (early_word_update) '
+                                     'for step %d / lr %g, but this step runs with other hyper-parameters or a bf16 gradient payload'
+                                     % (early[0], early[1]))
+
+        def launch_word_rows(stream_ptr, max_wgs):
+            off, V, H, name = wt
+            rf = self._row_flags(off, V * H, no_decay(name))
+            check(lib.uniter_adam_step_rows(st.flat_params.data_ptr() + 4 * off, st.flat_grads.data_ptr() + 4 * off,
+                                            self.exp_avg.data_ptr() + 4 * off, self.exp_avg_sq.data_ptr() + 4 * off, rf.data_ptr(),
+                                            V * H, ptr(self._sumsq), float(grad_scale), float(max_grad_norm or 0.0), lr, float(b1),
+                                            float(b2), float(g0['eps']), float(g0['weight_decay']), self.step_count, int(self.adamw),
+                                            int(bool(zero_grads)), self._rowmask.data_ptr(), H, 1, max_wgs, stream_ptr),
+                  'uniter_adam_step_rows')
+
         if plan is None:
             if grad_ready is not None:
                 grad_ready(0, st.numel)
-            launch(0, st.numel, _lib.cur_stream())
+            if early is None:
+                launch(0, st.numel, _lib.cur_stream())
+            else:
+                off, V, H, _ = wt
+                we = off + V * H
+                torch.cuda.current_stream().wait_event(early[6])
+                if off > 0:
+                    launch(0, off, _lib.cur_stream())
+                launch_word_rows(_lib.cur_stream(), 0)
+                if we < st.numel:
+                    launch(we, st.numel, _lib.cur_stream())
         else:
             # The update is HBM-bound, the next forward MFMA-bound: run the encoder's blocks on the
             # side stream in the order the forward needs them (embeddings, layer 0, 1, ..), one event
@@ -373,6 +506,9 @@ class FusedAdam(torch.optim.Optimizer):
             head, blocks, word = plan
             if os.environ.get('UNITER_ADAM_WORD_SPLIT') == '0':
                 word = None
+            if early is not None and (word is None or word[0] != wt[0]):
+                raise UniterHipError('FusedAdam.step: early_word_update needs the word table as its own optimizer launch '
+                                     '(UNITER_ADAM_WORD_SPLIT=0 or an unexpected parameter layout)')
             main = torch.cuda.current_stream()
             for lo, hi in head:                                  # pooler / heads: tiny, stay on this stream
                 if grad_ready is not None:
@@ -389,7 +525,21 @@ class FusedAdam(torch.optim.Optimizer):
                 if grad_ready is not None:
                     with torch.cuda.stream(side):
                         grad_ready(lo, hi)
-                launch(lo, hi, C.c_void_p(side.cuda_stream), max_wgs)
+                if early is not None and word is not None and (lo, hi) == tuple(word):
+                    # the table's looked-up rows only (the ahead-of-time launch ran on this stream: stream order), then the 64-element
+                    # padding behind the table, if the block has any
+                    we = wt[0] + wt[1] * wt[2]
+                    launch_word_rows(C.c_void_p(side.cuda_stream), max_wgs)
+                    # the row mask belongs to the micro-batches of THIS step: cleared right behind its last reader (NOT behind the layers'
+                    # blocks that follow on this stream: the next step's note_tokens waits for this event in front of its forward pass)
+                    with torch.cuda.stream(side):
+                        self._rowmask.zero_()
+                    self._rowmask_clear = torch.cuda.Event()
+                    self._rowmask_clear.record(side)
+                    if we < hi:
+                        launch(we, hi, C.c_void_p(side.cuda_stream), max_wgs)
+                else:
+                    launch(lo, hi, C.c_void_p(side.cuda_stream), max_wgs)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 return ev
@@ -420,6 +570,12 @@ class FusedAdam(torch.optim.Optimizer):
                 events.append(word_ev)
             enc._set_ready_events(events)
             self._pending = last
+        if early is not None or self._rows_noted is not False:
+            # the row mask belongs to the micro-batches of THIS step: clear it behind its last reader
+            if self._rowmask is not None and not (plan is not None and early is not None):
+                self._rowmask.zero_()          # (the overlapped path cleared it behind the looked-up rows' launch, on the side stream)
+                self._rowmask_clear = None
+            self._rows_noted = False
         if zero_grads:
             st.touched.clear()      # flags stay cached: the same set is touched again next step
             if lazy:
@@ -589,11 +745,18 @@ class TrainStep(object):
         if iters is not None:
             self.iters = iters
         cfg = self.config
+        accum = cfg['gradient_accumulation']
+        stepping = self.iters % accum == 0
+        opt = self.optimizer
+        if self.grad_sync is None and isinstance(opt, FusedAdam):
+            # single process: the rows of the word-embedding table this step cannot touch are updated AHEAD, beside this forward pass
+            # (FusedAdam.early_word_update); with a gradient exchange the other ranks' tokens are not known here
+            opt.note_tokens(batch.get('input_ids'))
+            if stepping:
+                opt.early_word_update()
         preds = self.model(**self.forward_kwargs(batch))
         loss, probs = bce_with_logits_loss(preds.squeeze(1), batch['labels'], cfg['pos_wt'],
                                            return_probs=True)
-        accum = cfg['gradient_accumulation']
-        stepping = self.iters % accum == 0
         if self.grad_sync is not None:
             self.grad_sync.prepare(will_step=stepping, token_ids=batch['input_ids'])
         loss.backward(unit_gradient(loss.device))

@@ -285,3 +285,61 @@ def test_two_host_threads_drive_two_model_handles():
         assert both[k]['counts'] == solo[k]['counts'] and sum(both[k]['counts']) > 0, (k, both[k]['counts'], solo[k]['counts'])
         # (the embedding tables' gradients are summed with float atomics: equal up to their order)
         assert (both[k]['grads'] - solo[k]['grads']).abs().max().item() <= 1e-6 * solo[k]['grads'].abs().max().item(), k
+
+
+@pytest.mark.parametrize('optimizer', ['adam', 'adamw'])
+@pytest.mark.parametrize('overlap', [False, True])
+@pytest.mark.parametrize('precision', ['fp32', 'fp32x3'])
+def test_word_table_rows_updated_ahead_equal_the_one_launch_update(optimizer, overlap, precision):
+    """Round 6 (uniter_adam_step_rows, FusedAdam.early_word_update): the rows of the word-embedding table that no token of the step
+    looks up are updated AHEAD of the backward pass -- their gradient is zero whatever it computes, and 0 x clip coefficient = 0, so
+    torch.optim.Adam's update of such a row (g = wd p; utils/optim_utils.py:33-40) depends on the step number and the learning rate
+    alone -- and the optimizer step then takes the looked-up rows only.  Same arithmetic per element: parameters AND both moment
+    buffers are bit-identical to the one-launch update, with gradient accumulation (the reference's iteration-0 quirk included),
+    clipping on, Adam and AdamW, with and without the update overlapping the next forward."""
+    from meme_challenge_amd.model import UniterConfig, UniterModel
+    from meme_challenge_amd.meme_uniter import MemeUniter
+    from meme_challenge_amd.trainer import FusedAdam, TrainStep, get_scheduler
+    from meme_challenge_amd.utils import make_synthetic_batch
+    cfg = UniterConfig.from_dict(TINY)
+    config = dict(optimizer=optimizer, lr=1e-3, beta1=0.9, beta2=0.999, weight_decay=1e-2, gradient_accumulation=2,
+                  max_grad_norm=0.05, pos_wt=1.8, loss_func='bce_logits', scheduler='warmup_cosine', warmup_steps=2, max_epoch=2)
+    bs = [make_synthetic_batch(4, 16, 6, seed=3 + k, vocab=TINY['vocab_size'], img_dim=TINY_IMG_DIM, device='cuda') for k in range(3)]
+    res = {}
+    for split in (False, True):
+        torch.manual_seed(0)
+        m = MemeUniter(UniterModel(cfg, img_dim=TINY_IMG_DIM), cfg.hidden_size, 1).cuda().train()
+        m.uniter_model.precision = precision
+        m.uniter_model.set_dropout_seed(5, 0)
+        opt = FusedAdam(m, lr=config['lr'], weight_decay=config['weight_decay'], adamw=(optimizer == 'adamw'))
+        opt.split_word_rows = split
+        opt._word_cache = None
+        if overlap:
+            opt.overlap_encoder = m.uniter_model
+        step = TrainStep(m, opt, get_scheduler(opt, config, steps_per_epoch=10), config)
+        early = 0
+        for it in range(7):
+            before = opt._early
+            step.train_iter(bs[it % 3], iters=it)
+            early += int(split and before is None and opt._early is None and it % 2 == 0)
+        opt.join()
+        torch.cuda.synchronize()
+        assert opt._early is None and (opt._rowmask is None or int(opt._rowmask.sum()) == 0)      # nothing pending, the mask is clear
+        res[split] = (m.param_store().flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone())
+    st = m.param_store()
+    name = 'uniter_model.embeddings.word_embeddings.weight'
+    V, H = st.params[name].shape
+    off = st.offsets[name]
+    looked_up = torch.zeros(V, dtype=torch.bool, device='cuda')
+    for b in bs:
+        looked_up[b['input_ids'].reshape(-1)] = True
+    never = ~looked_up
+    assert int(never.sum()) >= 8              # rows of the table that none of these batches looks up
+    for a, b in zip(res[False], res[True]):
+        # the rows updated ahead: their update depends on the step number and the learning rate alone -- bit for bit the one-launch update's
+        ta, tb = a[off:off + V * H].view(V, H), b[off:off + V * H].view(V, H)
+        assert torch.equal(ta[never], tb[never])
+        # everything else: the same arithmetic on gradients that carry the embedding backward's float-atomics order noise
+        assert (a - b).abs().max().item() <= 5e-6
+    # ... and they DID move (weight decay + the moments' decay): not a comparison of two untouched tables
+    assert (res[True][0][off:off + V * H].view(V, H)[never] - st.params[name].detach().new_zeros(1)).abs().max().item() > 0
