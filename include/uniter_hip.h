@@ -615,6 +615,24 @@ int uniter_adam_step_x3(float* params, float* grads, const void* grads_bf16, flo
  * previous step's update -- e.g. beside the backward pass; rows_touched = 1 updates the masked rows with their gradients, clipped,
  * behind the backward pass.  Per-element arithmetic unchanged: the parameters are bit-identical to one launch over the table.
  * params / grads / exp_avg / exp_avg_sq / chunk_flags point at the table; n = rows x row_len, row_len % 64 == 0. */
+/* Round 6: the PAIRED-ROW layout of the x3 weight mirror.  The forward products read a weight [N][K] k-contiguous, 32 elements (64 bytes)
+ * of a row per k-tile: half a cache line per request, and the loaders' cost is per request.  In the paired layout
+ * rows 2 q and 2 q + 1 are interleaved in 64-byte units -- element (n, k) of the tensor at (n >> 1) * 2 K + (k >> 5) * 64 + (n & 1) * 32 +
+ * (k & 31) in every piece -- so a k-tile of a row pair is ONE 128-byte line (forward products -3.5 .. -4.7 %); the input-gradient
+ * products read the same weight k-major and find whole lines too (two rows of a pair per request).  Who knows the layout:
+ *  - the writers: uniter_adam_step_x3p (uniter_adam_step_x3 with a per-64-element-chunk destination table: mirror_dst[c] >= 0 = absolute
+ *    element offset in the mirror of chunk c's first unit, the second at + 64; < 0 = the chunk's own place) and uniter_mirror_refresh_x3
+ *    (the same table, for a refresh from the fp32 parameters);
+ *  - the readers: uniter_gemm_x3_cfg with cfg | 64 (B = the weight, forward or input-gradient layout) and the model once
+ *    uniter_model_set_weight_pairing(m, 1) is set (the caller's mirror must then hold the encoder layers' weights -- query|key|value
+ *    as ONE [3 H][H] tensor, attention.output.dense, intermediate.dense, output.dense -- in this layout). */
+int uniter_adam_step_x3p(float* params, float* grads, const void* grads_bf16, float* exp_avg, float* exp_avg_sq,
+                         const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale, float max_norm,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, int step, int adamw,
+                         int zero_grads, void* mirror, size_t mirror_piece_stride, const int* mirror_dst, void* mirror_base,
+                         int max_workgroups, void* stream);
+int uniter_mirror_refresh_x3(const float* params_base, size_t first, size_t n, void* mirror, size_t piece_stride,
+                             const int* pair_dst, void* stream);
 int uniter_adam_step_rows(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* chunk_flags, size_t n,
                           const double* sumsq, float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int step, int adamw, int zero_grads, const uint8_t* row_mask, int row_len,
@@ -679,6 +697,7 @@ typedef struct {
  * LayerNorm, embeddings, loss and optimizer are those of mode 0.  The weight mirror then holds the three pieces of every
  * parameter, piece p at mirror + p * numel (3 * numel bf16 elements; uniter_adam_step_x3 / uniter_split3 write it). */
 int  uniter_model_set_weight_mirror(uniter_model_t* m, const float* flat_base, const void* mirror_bf16, size_t numel);
+int  uniter_model_set_weight_pairing(uniter_model_t* m, int on);
 int  uniter_model_set_precision(uniter_model_t* m, int precision);
 /* Number of uniter_model_forward calls on this handle so far.  The handle keeps ONE plan (activations of the latest
  * forward): a caller that wants to backpropagate records the value after its forward and must see the same value at

@@ -55,6 +55,8 @@ struct S3Args {
   unsigned long long* stamp;
   int prio;
   int dbg;
+  int b_paired;       // B (the weights) in the PAIRED-ROW layout of the optimizer's mirror (round 6): rows 2 q and 2 q + 1 interleaved in
+                      // 64-byte units, so the 32-deep k-tile u of a row pair is ONE 128-byte line at (q * 2 ldb + u * 64) elements
   float* colpart;     // optional (v_mfma_f32_16x16x32_bf16 geometries): partial column sums of the values the epilogue leaves, one row of N
                       // floats per 64 output rows (row 2 (m0 / 128) + wm): the bias gradient that belongs to a dY this product writes
 };
@@ -140,12 +142,16 @@ struct Dma3 {
       } else if constexpr (R == 128) {
         const int k = 4 * j + (lane >> 4);
         const int c = (lane & 15) ^ (((lane >> 4) << 2) | (j & 3));
-        voff[t] = (k * rs + rc0) * 2 + c * 16;
+        // paired (a k-major read of the paired-row weight mirror: k = row of the weight): element (k, col) sits at
+        // (k >> 1) * 2 rs + (col >> 5) * 64 + (k & 1) * 32 + (col & 31); rc0 is a multiple of 128, a 16-byte chunk never crosses a unit
+        voff[t] = paired ? ((k >> 1) * 2 * rs + ((rc0 >> 5) + (c >> 2)) * 64 + (k & 1) * 32 + 8 * (c & 3)) * 2 : (k * rs + rc0) * 2 + c * 16;
       } else {
         const int k = 2 * j + (lane >> 5);
         const int sw = (((2 * (j & 1) + (lane >> 5)) & 3) << 2) | ((j >> 1) & 3);
         const int c = (lane & 15) ^ sw;
-        voff[t] = (k * rs + rc0) * 2 + ((lane >> 4) & 1) * 256 + c * 16;
+        const int cf = ((lane >> 4) & 1) * 16 + c;          // 16-byte chunk of the 512-byte k-row
+        voff[t] = paired ? ((k >> 1) * 2 * rs + ((rc0 >> 5) + (cf >> 2)) * 64 + (k & 1) * 32 + 8 * (cf & 3)) * 2
+                         : (k * rs + rc0) * 2 + ((lane >> 4) & 1) * 256 + c * 16;
       }
     }
   }
@@ -722,13 +728,16 @@ void gemm_s3p_kernel(const S3Group G) {
       rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0,
                                               (((BKM ? g.K : g.N) - 1) * g.ldb + 2 * g.psb + (BKM ? g.N : g.K)) * 2, 0x00020000);
 #ifdef UNITER_X3_LAB
-      const bool pair_a = !AKM && (G.p[0].dbg & 128), pair_b = !BKM && (G.p[0].dbg & 32);      // timing experiments (wrong data, the real footprint)
+      const bool pair_a = !AKM && (G.p[0].dbg & 128);      // timing experiment (wrong data, the real footprint)
+      const bool pair_b = (!BKM && (G.p[0].dbg & 32)) || g.b_paired != 0;
 #else
-      constexpr bool pair_a = false, pair_b = false;
+      constexpr bool pair_a = false;
+      const bool pair_b = g.b_paired != 0;                 // the weights as the optimizer's paired-row mirror holds them
 #endif
       da.offsets(g.lda, it.m0, lw, lane, pair_a);
       db.offsets(g.ldb, it.n0, lw, lane, pair_b);
-      kstepA = pair_a ? 128 : DA::kstep(g.lda); kstepB = pair_b ? 128 : DB::kstep(g.ldb);
+      // (k-contiguous paired: the next 32-deep k-tile of a row pair is the next 128-byte line; k-major paired: 32 k-rows = 16 pairs on)
+      kstepA = pair_a ? 128 : DA::kstep(g.lda); kstepB = (pair_b && !BKM) ? 128 : DB::kstep(g.ldb);
       pstepA = g.psa * 2; pstepB = g.psb * 2;
     };
     bind();
@@ -1250,6 +1259,27 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     *reinterpret_cast<u32x4_t*>(x3 + (size_t)r * rs + p * ps + c8 * 8) = u32x4_t{w[p][0], w[p][1], w[p][2], w[p][3]};
 }
 
+// fp32 -> the weight mirror (three piece-major copies of the flat parameter buffer) with a per-chunk destination table: chunk c (64
+// consecutive parameters = two 32-element units of one weight row) goes to dst[c] (first unit) and dst[c] + 64 (second unit) -- the
+// paired-row layout of the encoder layers' weights -- or, dst[c] < 0, to its own place
+__global__ __launch_bounds__(256) void split3_mirror_kernel(const float* __restrict__ x, size_t n4, size_t first, unsigned short* __restrict__ mirror,
+                                                            size_t ps, const int* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // one f32x4 per thread
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+  unsigned w[3][2];
+  split3_pair(v[0], v[1], w[0][0], w[1][0], w[2][0]);
+  split3_pair(v[2], v[3], w[0][1], w[1][1], w[2][1]);
+  const size_t e = first + 4 * i;                                 // absolute element
+  size_t o = e;
+  if (dst) {
+    const int d = dst[e >> 6];
+    if (d >= 0) o = (size_t)d + ((e >> 5) & 1) * 64 + (e & 31);
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2_t*>(mirror + p * ps + o) = u32x2_t{w[p][0], w[p][1]};
+}
+
 // x3 -> fp32 (tests, and consumers that want the plain tensor back): the exact sum of the three pieces
 __global__ __launch_bounds__(256) void join3_kernel(const unsigned short* __restrict__ x3, int rows, int cols, size_t rs, size_t ps,
                                                     float* __restrict__ x, int ld) {
@@ -1356,7 +1386,9 @@ int gemm_x3_run(int cfg, int nsplit, int a_kmajor, int b_kmajor, int M, int N, i
   g.c_split_stride = c_split_stride; g.Cx = (unsigned short*)Cx; g.ldcx = ldcx; g.pscx = pscx; g.bias = bias;
   g.aux_in = aux_in; g.aux_out = aux_out; g.ld_aux = ld_aux;
   g.tiles_m = g.tiles_n = 0; g.band_h = 1; g.nsplit = nsplit;
-  g.dbg = cfg >> 8; cfg &= 0xff;
+  g.dbg = cfg >> 8; g.b_paired = (cfg >> 6) & 1; cfg &= 0x3f;      // (cfg | 64: B in the paired-row layout of the weight mirror)
+  UCHECK_ARG(!g.b_paired || (!a_kmajor && N % 2 == 0 && ldb % 32 == 0), "gemm_x3: paired rows are the layout of a weight (B, forward or input-gradient "
+             "product) with an even number of rows and a row length that is a multiple of 32");
   g.stamp = take_stamp_slot();
   g.prio = take_launch_prio();
   UCHECK_ARG((cfg & 0xff) != 5 || (!a_kmajor && !b_kmajor && !Cx), "gemm_x3: cfg 5 (128 x 192 tiles) is built for the forward layout with an fp32 output");
@@ -1482,6 +1514,21 @@ extern "C" int uniter_split3(const float* x, int rows, int cols, int ld, void* x
   return 0;
 }
 
+// Refresh elements [first, first + n) of the x3 weight mirror (piece p of element e at mirror + p * piece_stride + e, or, with a
+// destination table, chunk-wise at pair_dst[e / 64] (+ 64 for the chunk's second 32-element unit): the paired-row layout
+// ParamStore.mirror_pair_dst describes -- what uniter_adam_step_x3p writes and uniter_gemm_x3_cfg (cfg | 64) reads).
+extern "C" int uniter_mirror_refresh_x3(const float* params_base, size_t first, size_t n, void* mirror, size_t piece_stride,
+                                        const int* pair_dst, void* stream) {
+  UCHECK_ARG(params_base && mirror && n > 0, "mirror_refresh_x3: bad argument");
+  UCHECK_SHAPE(first % 64 == 0 && n % 4 == 0 && piece_stride % 4 == 0 && ((uintptr_t)params_base & 15) == 0 && ((uintptr_t)mirror & 7) == 0,
+               "mirror_refresh_x3: first %% 64, n %% 4, 16-byte aligned parameters required");
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(split3_mirror_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params_base + first, n4, first,
+                     (unsigned short*)mirror, piece_stride, pair_dst);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int uniter_join3(const void* x3, int rows, int cols, size_t row_stride, size_t piece_stride, float* x, int ld,
                             void* stream) {
   UCHECK_ARG(x && x3 && rows > 0 && cols > 0, "join3: bad argument");
@@ -1546,7 +1593,7 @@ int gemm_x3_wgrad_group(int cfg, int n, const int* Mo, const int* No, int K, con
     g.C = dW[p]; g.ldc = No[p];
     g.c_split_stride = 0; g.Cx = nullptr; g.ldcx = 0; g.pscx = 0; g.bias = nullptr;
     g.aux_in = overwrite ? nullptr : dW[p]; g.aux_out = nullptr; g.ld_aux = No[p];
-    g.nsplit = 1; g.stamp = stamp; g.prio = 0; g.dbg = 0; g.colpart = nullptr;
+    g.nsplit = 1; g.stamp = stamp; g.prio = 0; g.dbg = 0; g.colpart = nullptr; g.b_paired = 0;
     plan_tiles3<128>(g, wgrad_bn(cfg));
     total += g.tiles_m * g.tiles_n;
   }

@@ -147,6 +147,7 @@ struct uniter_model {
   std::vector<std::string> names;
   std::vector<hipEvent_t> ev_main, ev_side, ev_mid;
   int precision = 0;        // 0 = fp32 MFMA GEMMs, 1 = bf16 MFMA GEMMs (fp32 storage)
+  bool mirror_paired = false;               // precision 3: the encoder layers' weights sit in the mirror in the paired-row layout
   const unsigned short* mirror = nullptr;   // bf16 copy of the flat parameter buffer (precision 2)
   const float* mirror_base = nullptr;
   size_t mirror_numel = 0;
@@ -440,7 +441,8 @@ int gemm_x3(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, in
   static const int main_prio = [] { const char* e = getenv("UNITER_MAIN_PRIO_X3"); return e ? atoi(e) : 0; }();
   g_uniter_launch_prio = main_prio;
   // (every product of this helper runs on the main stream: the balanced walk's main-stream workspace)
-  return gemm_x3_run(cfg, nsplit, 0, bkm, M, N, K, A, 3 * K, K, W, ldw, (int)m->mirror_numel, C, N, (long)M * N, Cx, 3 * N, N, epi,
+  // (cfg | 64: the weight's pieces in the paired-row layout -- full 128-byte source lines for the loaders of the forward products)
+  return gemm_x3_run(cfg | (m->mirror_paired ? 64 : 0), nsplit, 0, bkm, M, N, K, A, 3 * K, K, W, ldw, (int)m->mirror_numel, C, N, (long)M * N, Cx, 3 * N, N, epi,
                      bias, aux_in, aux_out, N, st, colsum_part, m->plan.sk_main, m->plan.sk_main ? m->plan.sk_bytes : 0);
 }
 // CUs the backward pass's persistent launches may use: the chip's minus what the caller reserved for a gradient exchange
@@ -1404,6 +1406,14 @@ extern "C" int uniter_model_set_weight_mirror(uniter_model_t* m, const float* fl
                  "set_weight_mirror: layer %d weight %d is not inside the flat buffer on a 16-byte bf16 boundary", l, k);
     }
   m->mirror = (const unsigned short*)mirror_bf16; m->mirror_base = flat_base; m->mirror_numel = numel;
+  return 0;
+}
+
+extern "C" int uniter_model_set_weight_pairing(uniter_model_t* m, int on) {
+  UCHECK_ARG(m, "set_weight_pairing: null model");
+  UCHECK_SHAPE(!on || (m->cfg.hidden_size % 64 == 0 && m->cfg.intermediate_size % 64 == 0),
+               "set_weight_pairing: hidden and intermediate sizes must be multiples of 64 (a 64-element chunk of the optimizer is two whole 32-element units of one row)");
+  m->mirror_paired = on != 0;
   return 0;
 }
 

@@ -89,6 +89,11 @@ struct AdamArgs {
   // without being read (and is not cleared)
   const uint8_t* rowmask;
   int row_chunks, rows_want;
+  // paired-row weight mirror (round 6, uniter_adam_step_x3p): mirror_dst[c] >= 0 sends chunk c's two 32-element units to
+  // mirror_abs + mirror_dst[c] and + 64 (elements, in every piece); < 0 / no table: the chunk's own place.  The table pointer is that of
+  // this launch's first chunk; the offsets in it are absolute (from mirror_abs)
+  const int* mirror_dst;
+  unsigned short* mirror_abs;
 };
 
 #define NT_LOAD(base, idx) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base) + (idx))
@@ -112,13 +117,18 @@ __device__ __forceinline__ void adam_store4(const AdamArgs& a, size_t i, const f
   if (a.mirror) {
     typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
     const bf16x4_t o = {(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
-    reinterpret_cast<bf16x4_t*>(a.mirror)[i] = o;
+    bf16x4_t* m0 = reinterpret_cast<bf16x4_t*>(a.mirror) + i;
+    if (a.mirror_dst) {      // the paired-row layout of the encoder layers' weights: four elements stay inside one 32-element unit
+      const int d = a.mirror_dst[(i * 4) / CHUNK];
+      if (d >= 0) m0 = reinterpret_cast<bf16x4_t*>(a.mirror_abs + (size_t)d + (((i * 4) >> 5) & 1) * 64 + ((i * 4) & 31));
+    }
+    *m0 = o;
     if (a.mirror_ps) {      // x = x1 + x2 + x3 exactly (round-to-nearest residuals): the operands of csrc/gemm_split3.hip
       f32x4 r = {p[0] - (float)o[0], p[1] - (float)o[1], p[2] - (float)o[2], p[3] - (float)o[3]};
       const bf16x4_t o2 = {(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
-      reinterpret_cast<bf16x4_t*>(a.mirror + a.mirror_ps)[i] = o2;
+      *reinterpret_cast<bf16x4_t*>(reinterpret_cast<unsigned short*>(m0) + a.mirror_ps) = o2;
       r = f32x4{r[0] - (float)o2[0], r[1] - (float)o2[1], r[2] - (float)o2[2], r[3] - (float)o2[3]};
-      reinterpret_cast<bf16x4_t*>(a.mirror + 2 * a.mirror_ps)[i] = bf16x4_t{(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
+      *reinterpret_cast<bf16x4_t*>(reinterpret_cast<unsigned short*>(m0) + 2 * a.mirror_ps) = bf16x4_t{(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
     }
   }
   __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(a.m) + i);
@@ -267,7 +277,7 @@ static int adam_step_impl(float* params, float* grads, const void* grads_bf16, f
                           float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
                           size_t mirror_piece_stride, int max_workgroups, const uint8_t* row_mask, int row_chunks, int rows_want,
-                          void* stream);
+                          const int* mirror_dst, void* mirror_abs, void* stream);
 
 extern "C" int uniter_adam_step_x3(float* params, float* grads, const void* grads_bf16, float* exp_avg,
                                    float* exp_avg_sq, const uint8_t* chunk_flags, size_t n, const double* sumsq,
@@ -275,7 +285,21 @@ extern "C" int uniter_adam_step_x3(float* params, float* grads, const void* grad
                                    float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
                                    size_t mirror_piece_stride, int max_workgroups, void* stream) {
   return adam_step_impl(params, grads, grads_bf16, exp_avg, exp_avg_sq, chunk_flags, n, sumsq, grad_scale, max_norm, lr, beta1, beta2,
-                        eps, weight_decay, step, adamw, zero_grads, mirror_bf16, mirror_piece_stride, max_workgroups, nullptr, 0, 0, stream);
+                        eps, weight_decay, step, adamw, zero_grads, mirror_bf16, mirror_piece_stride, max_workgroups, nullptr, 0, 0, nullptr, nullptr, stream);
+}
+
+// uniter_adam_step_x3 that writes the weight pieces in the PAIRED-ROW layout (round 6): mirror_dst points at the destination table's
+// entry for this launch's first 64-element chunk (absolute element offsets from mirror_base, < 0 = the chunk's own place;
+// ParamStore.mirror_pair_dst); `mirror` stays the block-relative pointer the unpaired chunks use.
+extern "C" int uniter_adam_step_x3p(float* params, float* grads, const void* grads_bf16, float* exp_avg,
+                                    float* exp_avg_sq, const uint8_t* chunk_flags, size_t n, const double* sumsq,
+                                    float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, int step, int adamw, int zero_grads, void* mirror,
+                                    size_t mirror_piece_stride, const int* mirror_dst, void* mirror_base, int max_workgroups, void* stream) {
+  UCHECK_ARG(!mirror_dst || (mirror && mirror_base && mirror_piece_stride > 0), "adam_step_x3p: a destination table needs the x3 mirror and its base");
+  return adam_step_impl(params, grads, grads_bf16, exp_avg, exp_avg_sq, chunk_flags, n, sumsq, grad_scale, max_norm, lr, beta1, beta2,
+                        eps, weight_decay, step, adamw, zero_grads, mirror, mirror_piece_stride, max_workgroups, nullptr, 0, 0, mirror_dst,
+                        mirror_base, stream);
 }
 
 // The update of ONE table split by rows (round 6): a fine-tuning step touches at most B x T of the word-embedding table's 28996 rows
@@ -293,7 +317,7 @@ extern "C" int uniter_adam_step_rows(float* params, float* grads, float* exp_avg
   UCHECK_ARG(row_mask && row_len > 0 && row_len % CHUNK == 0 && n % (size_t)row_len == 0, "adam_step_rows: row_len must be a multiple of 64 dividing n");
   return adam_step_impl(params, grads, nullptr, exp_avg, exp_avg_sq, chunk_flags, n, rows_touched ? sumsq : nullptr, grad_scale,
                         rows_touched ? max_norm : 0.f, lr, beta1, beta2, eps, weight_decay, step, adamw, zero_grads, nullptr, 0,
-                        max_workgroups, row_mask, row_len / CHUNK, rows_touched ? 1 : 0, stream);
+                        max_workgroups, row_mask, row_len / CHUNK, rows_touched ? 1 : 0, nullptr, nullptr, stream);
 }
 
 static int adam_step_impl(float* params, float* grads, const void* grads_bf16, float* exp_avg,
@@ -301,7 +325,7 @@ static int adam_step_impl(float* params, float* grads, const void* grads_bf16, f
                           float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
                           size_t mirror_piece_stride, int max_workgroups, const uint8_t* row_mask, int row_chunks, int rows_want,
-                          void* stream) {
+                          const int* mirror_dst, void* mirror_abs, void* stream) {
   UCHECK_SHAPE(mirror_piece_stride % 4 == 0 && (mirror_piece_stride == 0 || mirror_bf16), "adam_step: bad mirror piece stride");
   UCHECK_ARG(params && grads && exp_avg && exp_avg_sq && chunk_flags, "adam_step: null pointer");
   UCHECK_SHAPE(((uintptr_t)grads_bf16 & 7) == 0, "adam_step: bf16 gradients must be 8-byte aligned");
@@ -316,6 +340,7 @@ static int adam_step_impl(float* params, float* grads, const void* grads_bf16, f
   a.mirror_ps = mirror_piece_stride;
   a.g16 = (const unsigned short*)grads_bf16;
   a.rowmask = row_mask; a.row_chunks = row_chunks > 0 ? row_chunks : 1; a.rows_want = rows_want;
+  a.mirror_dst = mirror_dst; a.mirror_abs = (unsigned short*)mirror_abs;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   a.step_size = (float)((double)lr / bc1);

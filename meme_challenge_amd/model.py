@@ -269,8 +269,44 @@ class ParamStore(object):
             self._mirror_version = version
         return self.mirror
 
+    PAIRED_SUFFIXES = ('attention.self.query.weight', 'attention.self.key.weight', 'attention.self.value.weight',
+                       'attention.output.dense.weight', 'intermediate.dense.weight', 'output.dense.weight')
+
+    def pair_dst(self):
+        """Destination table of the PAIRED-ROW layout of the x3 weight mirror (include/uniter_hip.h, uniter_adam_step_x3p): one int32 per
+        64-element chunk of the flat buffer -- for the encoder layers' dense weights [N][K] the absolute mirror offset of the chunk's
+        first 32-element unit, (n >> 1) * 2 K + (k >> 5) * 64 + (n & 1) * 32 from the tensor's start (rows 2 q, 2 q + 1 interleaved in
+        64-byte units: a 32-deep k-tile of a row pair is one 128-byte line for the forward products' loaders), -1 elsewhere.  None:
+        pairing off (UNITER_X3_PAIRED=0) or a tensor shape it does not fit (odd rows, a row length that is no multiple of 64)."""
+        if not hasattr(self, '_pair_dst'):
+            self._pair_dst = None
+            if os.environ.get('UNITER_X3_PAIRED', '1') != '0':
+                tab = np.full(self.numel // CHUNK, -1, dtype=np.int32)
+                ok, any_ = True, False
+                for n in self.names:
+                    if '.encoder.layer.' not in '.' + n or not n.endswith(self.PAIRED_SUFFIXES):
+                        continue
+                    N, K = (int(x) for x in self.params[n].shape)
+                    off = self.offsets[n]
+                    if N % 2 or K % CHUNK or off % CHUNK:
+                        ok = False
+                        break
+                    cr = np.arange(N * K // CHUNK, dtype=np.int64)
+                    row, kk = cr // (K // CHUNK), (cr % (K // CHUNK)) * CHUNK
+                    tab[off // CHUNK: off // CHUNK + cr.size] = (off + (row >> 1) * 2 * K + (kk >> 5) * 64 + (row & 1) * 32).astype(np.int32)
+                    any_ = True
+                if ok and any_ and self.numel < 2 ** 31:
+                    self._pair_dst = torch.from_numpy(tab).to(self.device)
+        return self._pair_dst
+
+    def mirror_paired(self):
+        return getattr(self, 'mirror_pieces', 1) == 3 and self.pair_dst() is not None
+
     def refresh_mirror(self, lo, hi, stream_ptr):
-        if getattr(self, 'mirror_pieces', 1) == 3:
+        if getattr(self, 'mirror_pieces', 1) == 3 and self.pair_dst() is not None:
+            check(_lib.lib().uniter_mirror_refresh_x3(self.flat_params.data_ptr(), lo, hi - lo, self.mirror.data_ptr(), self.numel,
+                                                      self.pair_dst().data_ptr(), stream_ptr), 'uniter_mirror_refresh_x3')
+        elif getattr(self, 'mirror_pieces', 1) == 3:
             check(_lib.lib().uniter_split3(self.flat_params.data_ptr() + 4 * lo, 1, hi - lo, hi - lo,
                                            self.mirror.data_ptr() + 2 * lo, 0, self.numel, stream_ptr), 'uniter_split3')
         else:
@@ -723,6 +759,9 @@ class UniterModel(UniterPreTrainedModel):
                                                                 st.numel), 'uniter_model_set_weight_mirror')
                 check(_lib.lib().uniter_model_set_precision(self._handle, 3 if self.precision == 'fp32x3' else 2),
                       'uniter_model_set_precision')
+                # fp32x3: the encoder layers' weights sit in the mirror in the paired-row layout (ParamStore.pair_dst)
+                check(_lib.lib().uniter_model_set_weight_pairing(self._handle, int(self.precision == 'fp32x3' and st.mirror_paired())),
+                      'uniter_model_set_weight_pairing')
                 self._applied_precision = (self.precision, mirror.data_ptr())
         elif self._applied_precision != self.precision:
             check(_lib.lib().uniter_model_set_precision(self._handle, 1 if self.precision == 'bf16_hybrid' else 0),

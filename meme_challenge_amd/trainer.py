@@ -452,16 +452,20 @@ class FusedAdam(torch.optim.Optimizer):
                 mirror = None
             # the bf16 weight mirror (precision 'bf16') is written by the same kernel, on the same stream
             # (precision 'fp32x3': its three bf16 pieces, piece p at mirror + p * numel)
-            check(lib.uniter_adam_step_x3(st.flat_params.data_ptr() + off, st.flat_grads.data_ptr() + off,
-                                          (grad_bf16.data_ptr() + lo * 2) if grad_bf16 is not None else None,
-                                          self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
-                                          flags.data_ptr() + lo // CHUNK, hi - lo, ptr(self._sumsq),
-                                          float(grad_scale), float(max_grad_norm or 0.0), lr, float(b1), float(b2),
-                                          float(g0['eps']), float(g0['weight_decay']), self.step_count,
-                                          int(self.adamw), int(bool(zero_grads)),
-                                          (mirror.data_ptr() + lo * 2) if mirror is not None else None,
-                                          st.numel if (mirror is not None and getattr(st, 'mirror_pieces', 1) == 3) else 0,
-                                          max_wgs, stream_ptr),
+            x3 = mirror is not None and getattr(st, 'mirror_pieces', 1) == 3
+            dst = st.pair_dst() if x3 else None       # fp32x3: the layers' weights go to the mirror in the paired-row layout
+            check(lib.uniter_adam_step_x3p(st.flat_params.data_ptr() + off, st.flat_grads.data_ptr() + off,
+                                           (grad_bf16.data_ptr() + lo * 2) if grad_bf16 is not None else None,
+                                           self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
+                                           flags.data_ptr() + lo // CHUNK, hi - lo, ptr(self._sumsq),
+                                           float(grad_scale), float(max_grad_norm or 0.0), lr, float(b1), float(b2),
+                                           float(g0['eps']), float(g0['weight_decay']), self.step_count,
+                                           int(self.adamw), int(bool(zero_grads)),
+                                           (mirror.data_ptr() + lo * 2) if mirror is not None else None,
+                                           st.numel if x3 else 0,
+                                           (dst.data_ptr() + 4 * (lo // CHUNK)) if dst is not None else None,
+                                           mirror.data_ptr() if dst is not None else None,
+                                           max_wgs, stream_ptr),
                   'uniter_adam_step')
 
         # the word-embedding table's rows without a gradient were updated ahead (early_word_update): its launch takes the looked-up rows

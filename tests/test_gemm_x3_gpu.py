@@ -229,6 +229,93 @@ def test_piece_major_weights(bkm):
     _run(1, 0, bkm, M=2624, N=768, K=3072, epi=EPI_BIAS if not bkm else EPI_ADD, nsplit=2, piece_major_b=True)
 
 
+def pair_rows(p3):
+    """piece-major x3 weight [3][N][K] -> the PAIRED-ROW layout of the weight mirror (include/uniter_hip.h): rows 2 q, 2 q + 1
+    interleaved in 32-element units -- element (n, k) at (n >> 1) * 2 K + (k >> 5) * 64 + (n & 1) * 32 + (k & 31)"""
+    P, N, K = p3.shape
+    return p3.view(P, N // 2, 2, K // 32, 32).permute(0, 1, 3, 2, 4).contiguous().view(P, N, K)
+
+
+@pytest.mark.parametrize('cfg', [3, 4, 5])
+@pytest.mark.parametrize('bkm', [0, 1])
+def test_paired_row_weights(cfg, bkm):
+    """Round 6: the weight operand in the paired-row layout (cfg | 64) -- a 32-deep k-tile of a row pair is one 128-byte line for
+    the forward products' loaders; the input-gradient products read the same layout k-major.  Bit-identical to the unpaired weight:
+    the layout changes where the loaders fetch from, not one product or the order of the additions."""
+    from meme_challenge_amd import _lib as L
+    if cfg == 5 and bkm:
+        pytest.skip('128 x 192 tiles: forward layout only')
+    for (M, N, K, epi, ns) in ((300, 256, 384, EPI_NONE, 1), (2624, 768, 3072, EPI_BIAS if not bkm else EPI_ADD, 2),
+                               (264, 520 if cfg != 5 else 576, 96 if not bkm else 128, EPI_NONE, 1), (2624, 2304 if not bkm else 768, 768 if not bkm else 2304, EPI_NONE, 1)):
+        # weight W: [N][K] for the forward layout (rows = N); the input-gradient layout multiplies by a weight stored [K'][N'] = [K][N]
+        A, B = _operands(0, bkm, M, N, K, seed=M + N)
+        wr, wc = B.shape
+        if wr % 2 or wc % 32:
+            continue
+        g = torch.Generator(device='cuda').manual_seed(5)
+        bias = torch.randn(N, device='cuda', generator=g)
+        aux = torch.randn(M, N, device='cuda', generator=g)
+        A3, B3 = split3(A), split3(B, True)
+        Bp = pair_rows(B3)
+        outs = []
+        for paired, Bx in ((0, B3), (64, Bp)):
+            C = torch.full((ns, M, N), float('nan'), device='cuda')
+            L.check(x3_gemm(cfg | paired, ns, 0, bkm, M, N, K, A3, Bx, C, None, epi, bias, aux, None, True), 'gemm_x3 paired=%d' % paired)
+            torch.cuda.synchronize()
+            outs.append(C)
+        assert not torch.isnan(outs[1]).any() and torch.equal(outs[0], outs[1]), (cfg, bkm, M, N, K)
+        ref = _ref(0, bkm, A, B) + (bias.double().cpu() if epi == EPI_BIAS else aux.double().cpu() if epi == EPI_ADD else 0.0)
+        assert (outs[1].double().cpu().sum(0) - ref).abs().max().item() < 3e-6 * math.sqrt(K) * (1.0 + ref.abs().max().item() * 0.05)
+
+
+def test_mirror_refresh_and_optimizer_write_the_paired_layout():
+    """uniter_mirror_refresh_x3 and uniter_adam_step_x3p with a destination table: chunks with an entry land in the paired-row layout, the
+    others in their own place; the pieces are the exact three-piece split of the (updated) parameters either way."""
+    import numpy as np
+    from meme_challenge_amd import _lib as L
+    lib = L.lib()
+    N, K, pre, post = 6, 128, 64, 128                      # [64 plain | a 6 x 128 paired tensor | 128 plain] elements
+    numel = pre + N * K + post
+    g = torch.Generator(device='cuda').manual_seed(3)
+    p = torch.randn(numel, device='cuda', generator=g)
+    tab = np.full(numel // 64, -1, dtype=np.int32)
+    cr = np.arange(N * K // 64)
+    row, kk = cr // (K // 64), (cr % (K // 64)) * 64
+    tab[pre // 64: pre // 64 + cr.size] = pre + (row >> 1) * 2 * K + (kk >> 5) * 64 + (row & 1) * 32
+    dst = torch.from_numpy(tab).cuda()
+
+    def expect(params):
+        flat = split3(params.view(1, -1), True).view(3, numel).clone()
+        t = flat[:, pre:pre + N * K].view(3, N, K)
+        flat[:, pre:pre + N * K] = pair_rows(t).view(3, N * K)
+        return flat
+    mirror = torch.full((3, numel), float('nan'), dtype=torch.bfloat16, device='cuda')
+    L.check(lib.uniter_mirror_refresh_x3(L.ptr(p), 0, numel, L.ptr(mirror), numel, L.ptr(dst), L.cur_stream()), 'mirror_refresh_x3')
+    torch.cuda.synchronize()
+    assert torch.equal(mirror, expect(p))
+    # a refresh of a sub-range (the optimizer's blocks): only that range is written
+    mirror2 = torch.zeros_like(mirror)
+    L.check(lib.uniter_mirror_refresh_x3(L.ptr(p), pre, N * K, L.ptr(mirror2), numel, L.ptr(dst), L.cur_stream()), 'mirror_refresh_x3')
+    torch.cuda.synchronize()
+    e = expect(p)
+    assert torch.equal(mirror2[:, pre:pre + N * K], e[:, pre:pre + N * K]) and float(mirror2[:, :pre].abs().sum()) == 0 and float(mirror2[:, pre + N * K:].abs().sum()) == 0
+    # the optimizer step writes the same layout (a launch over a block that starts inside the buffer: the table pointer is the block's)
+    grads = torch.randn(numel, device='cuda', generator=g)
+    m_, v_ = torch.zeros(numel, device='cuda'), torch.zeros(numel, device='cuda')
+    flags = torch.full((numel // 64,), 2, dtype=torch.uint8, device='cuda')
+    lo = pre
+    mirror3 = torch.zeros_like(mirror)
+    p3 = p.clone()
+    L.check(lib.uniter_adam_step_x3p(p3.data_ptr() + 4 * lo, grads.data_ptr() + 4 * lo, None, m_.data_ptr() + 4 * lo, v_.data_ptr() + 4 * lo,
+                                     flags.data_ptr() + lo // 64, numel - lo, None, 1.0, 0.0, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 1, 0, 1,
+                                     mirror3.data_ptr() + 2 * lo, numel, dst.data_ptr() + 4 * (lo // 64), mirror3.data_ptr(), 0, L.cur_stream()),
+            'adam_step_x3p')
+    torch.cuda.synchronize()
+    assert not torch.equal(p3[lo:], p[lo:]) and torch.equal(p3[:lo], p[:lo])
+    e3 = expect(p3)
+    assert torch.equal(mirror3[:, lo:], e3[:, lo:]) and float(mirror3[:, :lo].abs().sum()) == 0
+
+
 def test_model_shapes_with_their_epilogues():
     _run(1, 0, 0, M=2624, N=3072, K=768, epi=EPI_BIAS_GELU_D, out='x3')           # FFN up: activation as pieces, gelu' fp32
     _run(1, 0, 0, M=2624, N=2304, K=768, epi=EPI_BIAS)                            # QKV

@@ -276,8 +276,19 @@ def test_fused_clip_adam_step_at_base_size_matches_the_adam_oracle(precision, ad
     assert worst < (2e-7 if adamw else 1e-2 * 3e-4), worst
     assert st.flat_grads.abs().max().item() == 0.0
     if precision == 'fp32x3':
+        # the optimizer's three-piece weight mirror sums back to the updated parameters exactly; the encoder layers' weights sit in it in
+        # the paired-row layout (round 6, ParamStore.pair_dst): un-pair them through the same table
         back = torch.empty(st.numel, device='cuda')
         L.check(L.lib().uniter_join3(L.ptr(st.mirror), 1, st.numel, 0, st.numel, L.ptr(back), st.numel, L.cur_stream()))
+        dst = st.pair_dst()
+        if dst is not None:
+            assert st.mirror_paired()
+            src = torch.arange(st.numel, device='cuda', dtype=torch.int64)
+            d = dst.to(torch.int64).repeat_interleave(64)
+            e = src & 63
+            where = torch.where(d >= 0, d + ((e >> 5) & 1) * 64 + (e & 31), src)
+            assert torch.equal(where.sort().values, src)                 # the layout is a permutation of the buffer
+            back = back[where]
         assert torch.equal(back, st.flat_params)
 
 
