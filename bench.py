@@ -253,17 +253,25 @@ def cpu_baseline(seconds_budget=30.0, all_cores=False):
 
 def pmc_traffic(args, M, cfgd, build_info):
     """Memory-side bytes per launch of the GEMM families from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of this command, tests/tools/run_profile_r05.sh -> tests/tools/pmc_to_traffic_r05.py; FETCH_SIZE doubled as
+    WRITE_SIZE runs of this command, tests/tools/run_profile_r06.sh -> tests/tools/pmc_to_traffic_r06.py; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside a timed run, so this is a PROFILE
     ARTEFACT, reported only for the shape AND the library build it was taken on."""
     here = os.path.dirname(os.path.abspath(__file__))
     if args.workload != 'finetune' or args.precision == 'bf16':
         return None
     if args.precision == 'fp32x3':
-        src = 'profiles/r05_pmc_traffic.json'
-        try:
-            allrec = json.load(open(os.path.join(here, src)))
-        except (OSError, ValueError):
+        allrec, src = None, None
+        for cand in ('profiles/r06_pmc_traffic.json', 'profiles/r05_pmc_traffic.json'):      # the newest set taken on THIS library build
+            try:
+                rec_ = json.load(open(os.path.join(here, cand)))
+            except (OSError, ValueError):
+                continue
+            b_ = (rec_.get('gemm_ffn_up_fwd') or {}).get('build')
+            if allrec is None or (b_ and b_ == build_info):
+                allrec, src = rec_, cand
+            if b_ and b_ == build_info:
+                break
+        if allrec is None:
             return None
         rec = allrec.get('gemm_ffn_up_fwd') or {}
         shape = rec.get('shape') or {}
