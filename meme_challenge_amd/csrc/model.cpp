@@ -130,6 +130,8 @@ struct Plan {
   size_t hid_stride;
   bool hid_on;                // the forward pass drew them (this plan's row passes read them, forward and backward)
   void *ln_ws, *col_ws, *emb_ws, *attn_ws;
+  void *emb_ws2, *emb_ws3;   // round 6: the text branch of the embedding backward and the region projection's bias column sums run on
+                             // the auxiliary stream beside the image branch: partial-sum workspaces of their own
   size_t ln_ws_bytes, col_ws_bytes, emb_ws_bytes, attn_ws_bytes;
   // precision 3: workspaces of the balanced walk of the 128 x 256-tile products (gemm_split3.hip): one for the main stream's
   // launches, one for the weight-gradient stream's (they run at the same time); their flag words are cleared by every forward pass
@@ -175,6 +177,7 @@ struct uniter_model {
   int cu_reserve = 0;             // uniter_model_set_cu_reserve: CUs the persistent launches of this model's calls leave free
   hipStream_t aux = nullptr;      // uniter_model_set_aux_stream: launches that depend on nothing the step computes (dropout keep flags)
   hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr;
+  hipEvent_t ev_emb0 = nullptr, ev_emb1 = nullptr, ev_emb2 = nullptr;      // embedding backward: main <-> auxiliary stream
   double* norm_parts = nullptr;   // uniter_model_set_norm_partials: layer l's clip-norm partial sums at norm_parts + l * norm_stride
   size_t norm_stride = 0;
   bool wg_overwrite = false; // the next backward pass overwrites the encoder's weight gradients (uniter_model_set_wgrad_overwrite)
@@ -316,6 +319,8 @@ void make_plan(const uniter_model* m, Plan& pl, void* ws, int B, int T, int R, i
     const int rows = B * (T > R ? T : R);
     pl.emb_ws_bytes = uniter_embed_bwd_ws_bytes(rows, H);
     pl.emb_ws = cv.raw(pl.emb_ws_bytes);
+    pl.emb_ws2 = cv.raw(pl.emb_ws_bytes);
+    pl.emb_ws3 = cv.raw(pl.emb_ws_bytes);
     pl.attn_ws_bytes = uniter_attn_bwd_ws_bytes(B, L, c.num_attention_heads);
     pl.attn_ws = cv.raw(pl.attn_ws_bytes);
     pl.wg_slabs = pl.res ? cv.f((size_t)4 * 3 * H * (I > 3 * H ? I : 3 * H)) : nullptr;
@@ -662,6 +667,9 @@ extern "C" void uniter_model_destroy(uniter_model_t* m) {
   if (m->ev_aux0) hipEventDestroy(m->ev_aux0);
   if (m->ev_aux1) hipEventDestroy(m->ev_aux1);
   if (m->ev_aux2) hipEventDestroy(m->ev_aux2);
+  if (m->ev_emb0) hipEventDestroy(m->ev_emb0);
+  if (m->ev_emb1) hipEventDestroy(m->ev_emb1);
+  if (m->ev_emb2) hipEventDestroy(m->ev_emb2);
   delete m;
 }
 
@@ -1290,12 +1298,29 @@ extern "C" int uniter_model_backward_embed(uniter_model_t* m) {
   } else {
     UCHECK_RC(uniter_gather_rows_bwd(demb, joint ? b.gather_index : nullptr, pl.dcat, B, S, L, H, st));
   }
+  // Round 6: the tail of the step is a chain of latency-bound launches behind the last input gradient (text-embedding backward 55 us,
+  // image-embedding backward 67, the 7-d projection's and the region projection's weight gradients 15 + 52, column sums: 220 us on one
+  // stream, profiles/r06_timeline_f32x3.txt), while layer 0's weight-gradient launch holds most of the chip on the side stream.  The
+  // text branch and the image branch share nothing but dcat: with an auxiliary stream the text branch (and, behind the image rows'
+  // pass, the region projection's bias column sums) runs there, beside the image branch.  Same kernels, same results; the token-type
+  // table's gradient is the one buffer both branches add to (row 0 / the text rows' types there, row 1 / the image rows' types here):
+  // with explicit type ids both scatter by float atomics, without them each finalizes into its own row -- no ordering between them
+  // is needed either way.  UNITER_EMBED_BWD_PAR=0 keeps one stream.
+  static const bool par_env = [] { const char* e = getenv("UNITER_EMBED_BWD_PAR"); return !(e && e[0] == '0'); }();
+  hipStream_t ax = (par_env && m->aux && m->aux != st && m->aux != sd && pl.has_txt && pl.has_img) ? m->aux : nullptr;
+  if (ax) {
+    if (!m->ev_emb0) UCHECK_HIP(hipEventCreateWithFlags(&m->ev_emb0, hipEventDisableTiming));
+    if (!m->ev_emb1) UCHECK_HIP(hipEventCreateWithFlags(&m->ev_emb1, hipEventDisableTiming));
+    if (!m->ev_emb2) UCHECK_HIP(hipEventCreateWithFlags(&m->ev_emb2, hipEventDisableTiming));
+    UCHECK_HIP(hipEventRecord(m->ev_emb0, st));               // dcat is complete
+    UCHECK_HIP(hipStreamWaitEvent(ax, m->ev_emb0, 0));
+  }
   if (pl.has_txt)
     UCHECK_RC(uniter_txt_embed_bwd(pl.dcat, b.input_ids, b.position_ids, b.txt_type_ids, m->P(P_WORD),
                                    m->P(P_POS), m->P(P_TYPE), m->P(P_ELN_G), m->G(P_WORD), m->G(P_POS),
                                    m->G(P_TYPE), m->G(P_ELN_G), m->G(P_ELN_B), B, T, S, H, c.vocab_size,
                                    c.max_position_embeddings, c.type_vocab_size, b.pos_bcast, ph, m->seed,
-                                   m->offset, pl.emb_ws, pl.emb_ws_bytes, st));
+                                   m->offset, ax ? pl.emb_ws2 : pl.emb_ws, pl.emb_ws_bytes, ax ? ax : st));
   if (pl.has_img) {
     UCHECK_RC(uniter_img_embed_bwd(pl.dcat, pl.imgfc, b.img_pos_feat, b.img_type_ids, m->P(P_POSL_W),
                                    m->P(P_POSL_B), m->P(P_TYPE), m->P(P_ILN_G), m->P(P_ILN_B), m->P(P_PLN_G),
@@ -1304,16 +1329,25 @@ extern "C" int uniter_model_backward_embed(uniter_model_t* m) {
                                    m->G(P_PLN_G), m->G(P_PLN_B), m->G(P_FLN_G), m->G(P_FLN_B), B, R, pl.T0, S, H,
                                    c.type_vocab_size, ph, m->seed, m->offset, pl.emb_ws, pl.emb_ws_bytes, st));
     const float* feat = b.img_masks ? pl.feat_eff : b.img_feat;
+    // NOT pl.col_ws: the side stream's bias-gradient reductions of layer 0 may still be using it
+    if (ax) {      // the region projection's bias column sums beside its weight gradient: behind the text branch on the auxiliary stream
+      UCHECK_HIP(hipEventRecord(m->ev_emb1, st));             // d_imgfc is written
+      UCHECK_HIP(hipStreamWaitEvent(ax, m->ev_emb1, 0));
+      UCHECK_RC(uniter_colsum_f32(pl.d_imgfc, B * R, H, H, m->G(P_IMG_B), 1, pl.emb_ws3, pl.emb_ws_bytes, ax));
+    }
     UCHECK_RC(gemm(m, UNITER_K_GEMM_WGRAD, st, 1, 1, H, c.img_dim, B * R, pl.d_imgfc, H, feat, c.img_dim,
                    m->G(P_IMG_W), c.img_dim, UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 1));
-    // NOT pl.col_ws: the side stream's bias-gradient reductions of layer 0 may still be using it
-    UCHECK_RC(uniter_colsum_f32(pl.d_imgfc, B * R, H, H, m->G(P_IMG_B), 1, pl.emb_ws, pl.emb_ws_bytes, st));
+    if (!ax) UCHECK_RC(uniter_colsum_f32(pl.d_imgfc, B * R, H, H, m->G(P_IMG_B), 1, pl.emb_ws, pl.emb_ws_bytes, st));
     if (b.img_masks) {
       // d(img_feat + mask_emb[img_masks]) = d_imgfc @ W_img; row 1 of mask_embedding sums the masked rows
       UCHECK_RC(gemm(m, UNITER_K_GEMM_DGRAD, st, 0, 1, B * R, c.img_dim, H, pl.d_imgfc, H, m->P(P_IMG_W),
                      c.img_dim, pl.d_feat, c.img_dim, UNITER_EPI_NONE, nullptr, nullptr, nullptr, 0, 0));
       UCHECK_RC(launch_masked_rowsum(pl.d_feat, b.img_masks, m->G(P_MASK_EMB) + c.img_dim, B * R, c.img_dim, st));
     }
+  }
+  if (ax) {           // join the auxiliary stream's branch
+    UCHECK_HIP(hipEventRecord(m->ev_emb2, ax));
+    UCHECK_HIP(hipStreamWaitEvent(st, m->ev_emb2, 0));
   }
   if (sd != st) {   // join: everything the caller does next on `stream` sees all gradients
     UCHECK_HIP(hipEventRecord(m->ev_side[c.num_hidden_layers], sd));
