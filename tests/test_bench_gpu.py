@@ -75,6 +75,27 @@ def test_bench_default_contract():
     assert 0.02 < b16['step_mfma_frac'] < 1.0 and b16['peak_tflops'] == 2500.0 and b16['final_loss'] == b16['final_loss']
     # both durations of the dominant family: in-kernel stamps (frac) and HIP events with the queueing included (frac_dispatch)
     assert r['avg_ms'] > 0 and r['avg_ms_dispatch'] > 0 and 0.0 < r['frac_dispatch'] < 1.0 and 'stamps' in r['note']
+    # round 6: the bound that applies, per family -- recomputed here from the shape for one family: FFN-up forward
+    # at configs[1] is M = 2624, N = 3072, K = 768 on 128 x 256 x3 tiles (252 work items, three pieces: 72 KB staged per k-tile)
+    fl = fams['gemm_ffn_up_fwd']['floor']
+    M, N, K = 2624, 3072, 768
+    mfma = 2.0 * M * N * K / (2500e12 / 6) * 1e6
+    staged = 21 * 12 * (K // 32) * (128 + 256) * 32 * 2 * 3
+    intake = staged / (70e9 * 252) * 1e6
+    hbm = (M * K * 6 + N * K * 6 + M * N * 10) / 8e12 * 1e6
+    assert abs(fl['mfma_us'] - mfma) < 0.02 and abs(fl['intake_us'] - intake) < 0.02 and abs(fl['hbm_us'] - hbm) < 0.02
+    assert abs(fl['floor_us'] - max(mfma, intake, hbm)) < 0.02 and fl['launches'][0]['tile'] == '128x256' and fl['launches'][0]['items'] == 252
+    f_up = fams['gemm_ffn_up_fwd']
+    assert abs(f_up['floor_ms_per_step'] - 12 * fl['floor_us'] * 1e-3) < 1e-3 and abs(f_up['over_floor'] - f_up['ms_per_step'] / f_up['floor_ms_per_step']) < 0.01
+    assert all(f.get('over_floor', 2.0) > 1.0 for f in fams.values())                    # nothing runs below its floor
+    assert abs(d['step_floor_ms'] - sum(f['floor_ms_per_step'] for f in fams.values())) < 1e-2 and d['step_over_floor'] > 1.0
+    assert 'attn_x3' in d['attention_kernel']
+    # the short figures close the line: the last key is the summary, and it repeats them
+    assert list(d)[-1] == 'summary' and list(d).index('roofline_families') < list(d).index('roofline') < list(d).index('bf16')
+    sm = d['summary']
+    assert sm['value'] == d['value'] and sm['bf16']['value'] == b16['value'] and sm['native_fp32']['value'] == nat['value']
+    assert sm['over_floor']['gemm_ffn_up_fwd'] == f_up['over_floor'] and sm['roofline']['frac'] == r['frac'] and sm['cpu_baseline']['cores'] == c['cores']
+    assert len(json.dumps(sm)) < 2000
 
 
 def test_bench_native_fp32_mode_keeps_its_roofline():

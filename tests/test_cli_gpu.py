@@ -77,17 +77,40 @@ def test_device_prefetcher_yields_the_loader_batches_on_the_gpu():
                 'seq_lens': [int(s['i']) for s in samples], 'none': None}
 
     loader = data.DataLoader(DS(), batch_size=4, collate_fn=collate, pin_memory=True)
-    pf = DevicePrefetcher(loader, 'cuda')
-    assert len(pf) == len(loader) and pf.dataset.name == 'toy'
-    seen = []
-    for ref, got in zip(loader, pf):
-        assert got['x'].is_cuda and got['i'].is_cuda and got['none'] is None and got['seq_lens'] == ref['seq_lens']
-        y = (got['x'] * 2).sum()                      # consume on the compute stream
-        assert torch.equal(got['x'].cpu(), ref['x']) and torch.equal(got['i'].cpu(), ref['i'])
-        assert y.item() == ref['x'].sum().item() * 2
-        seen.extend(got['i'].tolist())
-    assert seen == list(range(23))
-    assert sum(1 for _ in pf) == len(loader)          # re-iterable
+    for threaded in (True, False):                    # (round 6: the loader's work in a background thread, the default; and inline)
+        pf = DevicePrefetcher(loader, 'cuda', threaded=threaded)
+        assert len(pf) == len(loader) and pf.dataset.name == 'toy' and pf.threaded is threaded
+        seen = []
+        for ref, got in zip(loader, pf):
+            assert got['x'].is_cuda and got['i'].is_cuda and got['none'] is None and got['seq_lens'] == ref['seq_lens']
+            y = (got['x'] * 2).sum()                      # consume on the compute stream
+            assert torch.equal(got['x'].cpu(), ref['x']) and torch.equal(got['i'].cpu(), ref['i'])
+            assert y.item() == ref['x'].sum().item() * 2
+            seen.extend(got['i'].tolist())
+        assert seen == list(range(23))
+        assert sum(1 for _ in pf) == len(loader)          # re-iterable
+        # leaving the loop early stops the background thread (no batch is fetched for nobody)
+        for k, got in enumerate(pf):
+            if k == 1:
+                break
+        import threading
+        import time
+        time.sleep(0.3)
+        assert not any(t.name == 'uniter-prefetch' and t.is_alive() for t in threading.enumerate())
+
+    class Boom(DS):
+        def __getitem__(self, i):
+            if i == 9:
+                raise RuntimeError('broken sample')
+            return super().__getitem__(i)
+    pf = DevicePrefetcher(data.DataLoader(Boom(), batch_size=4, collate_fn=collate), 'cuda', threaded=True)
+    try:
+        for _ in pf:
+            pass
+        raised = False
+    except RuntimeError as e:
+        raised = 'broken sample' in str(e)
+    assert raised                                     # a failure in the loader's thread reaches the trainer
 
 
 def test_cli_with_shards_prefetch_and_packing(tmp_path):
