@@ -620,16 +620,18 @@ int uniter_adam_step_x3(float* params, float* grads, const void* grads_bf16, flo
  * rows 2 q and 2 q + 1 are interleaved in 64-byte units -- element (n, k) of the tensor at (n >> 1) * 2 K + (k >> 5) * 64 + (n & 1) * 32 +
  * (k & 31) in every piece -- so a k-tile of a row pair is ONE 128-byte line (forward products -3.5 .. -4.7 %); the input-gradient
  * products read the same weight k-major and find whole lines too (two rows of a pair per request).  Who knows the layout:
- *  - the writers: uniter_adam_step_x3p (uniter_adam_step_x3 with a per-64-element-chunk destination table: mirror_dst[c] >= 0 = absolute
- *    element offset in the mirror of chunk c's first unit, the second at + 64; < 0 = the chunk's own place) and uniter_mirror_refresh_x3
- *    (the same table, for a refresh from the fp32 parameters);
+ *  - the writers: uniter_adam_step_x3p -- uniter_adam_step_x3 walking the buffer in the MIRROR's order: pair_src holds two int32 per
+ *    64-element chunk of the mirror, the flat-buffer offsets of the parameters behind its two 32-element units (one unit of row 2 q, the
+ *    same unit of row 2 q + 1; first < 0 = the chunk is its own source), so the fp32 streams and the mirror are both read / written in
+ *    whole 128-byte lines -- and uniter_mirror_refresh_x3 (a refresh from the fp32 parameters through the inverse table: pair_dst[c] >= 0 =
+ *    mirror offset of parameter chunk c's first unit, the second at + 64);
  *  - the readers: uniter_gemm_x3_cfg with cfg | 64 (B = the weight, forward or input-gradient layout) and the model once
  *    uniter_model_set_weight_pairing(m, 1) is set (the caller's mirror must then hold the encoder layers' weights -- query|key|value
  *    as ONE [3 H][H] tensor, attention.output.dense, intermediate.dense, output.dense -- in this layout). */
 int uniter_adam_step_x3p(float* params, float* grads, const void* grads_bf16, float* exp_avg, float* exp_avg_sq,
                          const uint8_t* chunk_flags, size_t n, const double* sumsq, float grad_scale, float max_norm,
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step, int adamw,
-                         int zero_grads, void* mirror, size_t mirror_piece_stride, const int* mirror_dst, void* mirror_base,
+                         int zero_grads, void* mirror, size_t mirror_piece_stride, const int* pair_src, size_t first_element,
                          int max_workgroups, void* stream);
 int uniter_mirror_refresh_x3(const float* params_base, size_t first, size_t n, void* mirror, size_t piece_stride,
                              const int* pair_dst, void* stream);

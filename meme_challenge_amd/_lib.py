@@ -156,7 +156,7 @@ _SIGS = {
     'uniter_adam_step_ex': (_I, [_P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _I, _P]),
     'uniter_adam_step_g16': (_I, [_P, _P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _I, _P]),
     'uniter_adam_step_x3': (_I, [_P, _P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _SZ, _I, _P]),
-    'uniter_adam_step_x3p': (_I, [_P, _P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _SZ, _P, _P, _I, _P]),
+    'uniter_adam_step_x3p': (_I, [_P, _P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _SZ, _P, _SZ, _I, _P]),
     'uniter_mirror_refresh_x3': (_I, [_P, _SZ, _SZ, _P, _SZ, _P, _P]),
     'uniter_model_set_weight_pairing': (_I, [_P, _I]),
     'uniter_adam_step_rows': (_I, [_P, _P, _P, _P, _P, _SZ, _P, _F, _F, _F, _F, _F, _F, _F, _I, _I, _I, _P, _I, _I, _I, _P]),

@@ -89,11 +89,14 @@ struct AdamArgs {
   // without being read (and is not cleared)
   const uint8_t* rowmask;
   int row_chunks, rows_want;
-  // paired-row weight mirror (round 6, uniter_adam_step_x3p): mirror_dst[c] >= 0 sends chunk c's two 32-element units to
-  // mirror_abs + mirror_dst[c] and + 64 (elements, in every piece); < 0 / no table: the chunk's own place.  The table pointer is that of
-  // this launch's first chunk; the offsets in it are absolute (from mirror_abs)
-  const int* mirror_dst;
-  unsigned short* mirror_abs;
+  // paired-row weight mirror (round 6, uniter_adam_step_x3p): the launch walks the buffer in the MIRROR's order.  vsrc[c] = {s0, s1}
+  // (elements from the flat buffers' start; s0 < 0 / no table: chunk c is its own source): the two 32-element units of chunk c of the
+  // mirror are the parameters s0 .. s0 + 31 and s1 .. s1 + 31 -- one unit of row 2 q and the same unit of row 2 q + 1.  p, g, m, v are
+  // then read and written in whole 128-byte lines (a unit is 32 floats) and the mirror in whole lines too (two neighbouring 64-byte
+  // units); walking in the parameters' order instead left half-written mirror lines behind every wave (adam_kernel 76 -> 95 us).
+  // The table pointer is that of this launch's first chunk; vsrc_base = the launch's first element (its offsets are absolute)
+  const int2* vsrc;
+  long vsrc_base;
 };
 
 #define NT_LOAD(base, idx) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base) + (idx))
@@ -110,18 +113,14 @@ __device__ __forceinline__ void adam_update4(const AdamArgs& a, float coef, floa
     p[e] = pp - a.step_size * (m[e] / denom);
   }
 }
-__device__ __forceinline__ void adam_store4(const AdamArgs& a, size_t i, const f32x4& p, const f32x4& m, const f32x4& v, bool clear) {
+__device__ __forceinline__ void adam_store4(const AdamArgs& a, size_t i, size_t si, const f32x4& p, const f32x4& m, const f32x4& v, bool clear) {
   // the update streams 34 bytes per parameter once: non-temporal accesses, so that it does not evict the operand panels of
-  // the forward kernels that share the chip with it from the L2s
-  __builtin_nontemporal_store(p, reinterpret_cast<f32x4*>(a.p) + i);
+  // the forward kernels that share the chip with it from the L2s.  si: the item's place in the parameter buffers, i: in the mirror
+  __builtin_nontemporal_store(p, reinterpret_cast<f32x4*>(a.p) + si);
   if (a.mirror) {
     typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
     const bf16x4_t o = {(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
-    bf16x4_t* m0 = reinterpret_cast<bf16x4_t*>(a.mirror) + i;
-    if (a.mirror_dst) {      // the paired-row layout of the encoder layers' weights: four elements stay inside one 32-element unit
-      const int d = a.mirror_dst[(i * 4) / CHUNK];
-      if (d >= 0) m0 = reinterpret_cast<bf16x4_t*>(a.mirror_abs + (size_t)d + (((i * 4) >> 5) & 1) * 64 + ((i * 4) & 31));
-    }
+    bf16x4_t* m0 = reinterpret_cast<bf16x4_t*>(a.mirror) + i;      // (i: the item's place in the mirror's order)
     *m0 = o;
     if (a.mirror_ps) {      // x = x1 + x2 + x3 exactly (round-to-nearest residuals): the operands of csrc/gemm_split3.hip
       f32x4 r = {p[0] - (float)o[0], p[1] - (float)o[1], p[2] - (float)o[2], p[3] - (float)o[3]};
@@ -131,11 +130,11 @@ __device__ __forceinline__ void adam_store4(const AdamArgs& a, size_t i, const f
       *reinterpret_cast<bf16x4_t*>(reinterpret_cast<unsigned short*>(m0) + 2 * a.mirror_ps) = bf16x4_t{(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
     }
   }
-  __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(a.m) + i);
-  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.v) + i);
+  __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(a.m) + si);
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.v) + si);
   // zero_grad: only where something was written -- four of five rows of the embeddings' block (the word table away from
   // the batch's tokens) hold zeros already
-  if (clear) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(a.g) + i);
+  if (clear) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(a.g) + si);
 }
 __device__ __forceinline__ bool any_nonzero(const f32x4& g) { return g[0] != 0.f || g[1] != 0.f || g[2] != 0.f || g[3] != 0.f; }
 
@@ -153,28 +152,39 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += 2 * stride) {
     const size_t j = i + stride;
     const bool two = j < a.n4;
-    uint8_t f0 = a.flags[(i * 4) / CHUNK];
-    uint8_t f1 = two ? a.flags[(j * 4) / CHUNK] : 0;
+    // where the item sits in the parameter buffers: its own place, or -- a chunk of a paired tensor, walked in the mirror's order --
+    // one of the two source units the table names
+    size_t si = i, sj = j;
+    if (a.vsrc) {
+      const int2 vi = a.vsrc[(i * 4) / CHUNK];
+      if (vi.x >= 0) si = (size_t)((long)((((i * 4) >> 5) & 1) ? vi.y : vi.x) - a.vsrc_base + (long)((i * 4) & 31)) / 4;
+      if (two) {
+        const int2 vj = a.vsrc[(j * 4) / CHUNK];
+        if (vj.x >= 0) sj = (size_t)((long)((((j * 4) >> 5) & 1) ? vj.y : vj.x) - a.vsrc_base + (long)((j * 4) & 31)) / 4;
+      }
+    }
+    uint8_t f0 = a.flags[(si * 4) / CHUNK];
+    uint8_t f1 = two ? a.flags[(sj * 4) / CHUNK] : 0;
     if (a.rowmask) {      // (one table, split by rows: this launch takes the rows on its side of the mask)
-      if (f0 && (a.rowmask[((i * 4) / CHUNK) / a.row_chunks] != 0) != (a.rows_want != 0)) f0 = 0;
-      if (f1 && (a.rowmask[((j * 4) / CHUNK) / a.row_chunks] != 0) != (a.rows_want != 0)) f1 = 0;
+      if (f0 && (a.rowmask[((si * 4) / CHUNK) / a.row_chunks] != 0) != (a.rows_want != 0)) f0 = 0;
+      if (f1 && (a.rowmask[((sj * 4) / CHUNK) / a.row_chunks] != 0) != (a.rows_want != 0)) f1 = 0;
     }
     const bool no_g = a.rowmask && a.rows_want == 0;      // rows without a gradient this step: g == 0, unread
     f32x4 p0, g0 = {0.f, 0.f, 0.f, 0.f}, m0, v0, p1, g1 = g0, m1, v1;
     if (f0) {
-      p0 = NT_LOAD(a.p, i); if (!no_g) g0 = a.g16 ? widen4(a.g16, i) : NT_LOAD(a.g, i); m0 = NT_LOAD(a.m, i); v0 = NT_LOAD(a.v, i);
+      p0 = NT_LOAD(a.p, si); if (!no_g) g0 = a.g16 ? widen4(a.g16, si) : NT_LOAD(a.g, si); m0 = NT_LOAD(a.m, si); v0 = NT_LOAD(a.v, si);
     }
     if (f1) {
-      p1 = NT_LOAD(a.p, j); if (!no_g) g1 = a.g16 ? widen4(a.g16, j) : NT_LOAD(a.g, j); m1 = NT_LOAD(a.m, j); v1 = NT_LOAD(a.v, j);
+      p1 = NT_LOAD(a.p, sj); if (!no_g) g1 = a.g16 ? widen4(a.g16, sj) : NT_LOAD(a.g, sj); m1 = NT_LOAD(a.m, sj); v1 = NT_LOAD(a.v, sj);
     }
     // (gradients read from the bf16 payload: the fp32 buffer holds this rank's own sums, cleared whatever the payload says)
     if (f0) {
       const bool c0 = !no_g && a.zero_grads && !(f0 & 4) && (a.g16 != nullptr || any_nonzero(g0));
-      adam_update4(a, coef, (f0 & 3) == 2 ? a.wd : 0.f, p0, g0, m0, v0); adam_store4(a, i, p0, m0, v0, c0);
+      adam_update4(a, coef, (f0 & 3) == 2 ? a.wd : 0.f, p0, g0, m0, v0); adam_store4(a, i, si, p0, m0, v0, c0);
     }
     if (f1) {
       const bool c1 = !no_g && a.zero_grads && !(f1 & 4) && (a.g16 != nullptr || any_nonzero(g1));
-      adam_update4(a, coef, (f1 & 3) == 2 ? a.wd : 0.f, p1, g1, m1, v1); adam_store4(a, j, p1, m1, v1, c1);
+      adam_update4(a, coef, (f1 & 3) == 2 ? a.wd : 0.f, p1, g1, m1, v1); adam_store4(a, j, sj, p1, m1, v1, c1);
     }
   }
 }
@@ -277,7 +287,7 @@ static int adam_step_impl(float* params, float* grads, const void* grads_bf16, f
                           float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
                           size_t mirror_piece_stride, int max_workgroups, const uint8_t* row_mask, int row_chunks, int rows_want,
-                          const int* mirror_dst, void* mirror_abs, void* stream);
+                          const void* vsrc, long vsrc_base, void* stream);
 
 extern "C" int uniter_adam_step_x3(float* params, float* grads, const void* grads_bf16, float* exp_avg,
                                    float* exp_avg_sq, const uint8_t* chunk_flags, size_t n, const double* sumsq,
@@ -285,21 +295,23 @@ extern "C" int uniter_adam_step_x3(float* params, float* grads, const void* grad
                                    float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
                                    size_t mirror_piece_stride, int max_workgroups, void* stream) {
   return adam_step_impl(params, grads, grads_bf16, exp_avg, exp_avg_sq, chunk_flags, n, sumsq, grad_scale, max_norm, lr, beta1, beta2,
-                        eps, weight_decay, step, adamw, zero_grads, mirror_bf16, mirror_piece_stride, max_workgroups, nullptr, 0, 0, nullptr, nullptr, stream);
+                        eps, weight_decay, step, adamw, zero_grads, mirror_bf16, mirror_piece_stride, max_workgroups, nullptr, 0, 0, nullptr, 0, stream);
 }
 
-// uniter_adam_step_x3 that writes the weight pieces in the PAIRED-ROW layout (round 6): mirror_dst points at the destination table's
-// entry for this launch's first 64-element chunk (absolute element offsets from mirror_base, < 0 = the chunk's own place;
-// ParamStore.mirror_pair_dst); `mirror` stays the block-relative pointer the unpaired chunks use.
+// uniter_adam_step_x3 that writes the weight pieces in the PAIRED-ROW layout (round 6) by walking the buffer in the MIRROR's order:
+// pair_src points at the source table's entry for this launch's first 64-element chunk -- two int32 per chunk, the flat-buffer
+// element offsets of the chunk's two 32-element units ({s0 < 0, ..} = the chunk is its own source; ParamStore.pair_src);
+// first_element = the flat-buffer offset of `params` (the table's offsets are absolute).
 extern "C" int uniter_adam_step_x3p(float* params, float* grads, const void* grads_bf16, float* exp_avg,
                                     float* exp_avg_sq, const uint8_t* chunk_flags, size_t n, const double* sumsq,
                                     float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                                     float weight_decay, int step, int adamw, int zero_grads, void* mirror,
-                                    size_t mirror_piece_stride, const int* mirror_dst, void* mirror_base, int max_workgroups, void* stream) {
-  UCHECK_ARG(!mirror_dst || (mirror && mirror_base && mirror_piece_stride > 0), "adam_step_x3p: a destination table needs the x3 mirror and its base");
+                                    size_t mirror_piece_stride, const int* pair_src, size_t first_element, int max_workgroups, void* stream) {
+  UCHECK_ARG(!pair_src || (mirror && mirror_piece_stride > 0 && first_element % CHUNK == 0 && ((uintptr_t)pair_src & 7) == 0),
+             "adam_step_x3p: a source table needs the x3 mirror, a launch that starts on a chunk and an 8-byte aligned table");
   return adam_step_impl(params, grads, grads_bf16, exp_avg, exp_avg_sq, chunk_flags, n, sumsq, grad_scale, max_norm, lr, beta1, beta2,
-                        eps, weight_decay, step, adamw, zero_grads, mirror, mirror_piece_stride, max_workgroups, nullptr, 0, 0, mirror_dst,
-                        mirror_base, stream);
+                        eps, weight_decay, step, adamw, zero_grads, mirror, mirror_piece_stride, max_workgroups, nullptr, 0, 0, pair_src,
+                        (long)first_element, stream);
 }
 
 // The update of ONE table split by rows (round 6): a fine-tuning step touches at most B x T of the word-embedding table's 28996 rows
@@ -317,7 +329,7 @@ extern "C" int uniter_adam_step_rows(float* params, float* grads, float* exp_avg
   UCHECK_ARG(row_mask && row_len > 0 && row_len % CHUNK == 0 && n % (size_t)row_len == 0, "adam_step_rows: row_len must be a multiple of 64 dividing n");
   return adam_step_impl(params, grads, nullptr, exp_avg, exp_avg_sq, chunk_flags, n, rows_touched ? sumsq : nullptr, grad_scale,
                         rows_touched ? max_norm : 0.f, lr, beta1, beta2, eps, weight_decay, step, adamw, zero_grads, nullptr, 0,
-                        max_workgroups, row_mask, row_len / CHUNK, rows_touched ? 1 : 0, nullptr, nullptr, stream);
+                        max_workgroups, row_mask, row_len / CHUNK, rows_touched ? 1 : 0, nullptr, 0, stream);
 }
 
 static int adam_step_impl(float* params, float* grads, const void* grads_bf16, float* exp_avg,
@@ -325,7 +337,7 @@ static int adam_step_impl(float* params, float* grads, const void* grads_bf16, f
                           float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int step, int adamw, int zero_grads, void* mirror_bf16,
                           size_t mirror_piece_stride, int max_workgroups, const uint8_t* row_mask, int row_chunks, int rows_want,
-                          const int* mirror_dst, void* mirror_abs, void* stream) {
+                          const void* vsrc, long vsrc_base, void* stream) {
   UCHECK_SHAPE(mirror_piece_stride % 4 == 0 && (mirror_piece_stride == 0 || mirror_bf16), "adam_step: bad mirror piece stride");
   UCHECK_ARG(params && grads && exp_avg && exp_avg_sq && chunk_flags, "adam_step: null pointer");
   UCHECK_SHAPE(((uintptr_t)grads_bf16 & 7) == 0, "adam_step: bf16 gradients must be 8-byte aligned");
@@ -340,7 +352,7 @@ static int adam_step_impl(float* params, float* grads, const void* grads_bf16, f
   a.mirror_ps = mirror_piece_stride;
   a.g16 = (const unsigned short*)grads_bf16;
   a.rowmask = row_mask; a.row_chunks = row_chunks > 0 ? row_chunks : 1; a.rows_want = rows_want;
-  a.mirror_dst = mirror_dst; a.mirror_abs = (unsigned short*)mirror_abs;
+  a.vsrc = (const int2*)vsrc; a.vsrc_base = vsrc_base;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   a.step_size = (float)((double)lr / bc1);

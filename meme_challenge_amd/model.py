@@ -299,6 +299,27 @@ class ParamStore(object):
                     self._pair_dst = torch.from_numpy(tab).to(self.device)
         return self._pair_dst
 
+    def pair_src(self):
+        """The inverse of pair_dst for the optimizer (uniter_adam_step_x3p walks the buffer in the mirror's order): int32 [numel / 64][2],
+        the flat-buffer offsets of the parameters behind the two 32-element units of every 64-element chunk of the mirror -- unit u of
+        row 2 q and unit u of row 2 q + 1 of a paired tensor; (-1, -1) where a chunk is its own source."""
+        if not hasattr(self, '_pair_src'):
+            self._pair_src = None
+            if self.pair_dst() is not None:
+                tab = np.full((self.numel // CHUNK, 2), -1, dtype=np.int32)
+                for n in self.names:
+                    if '.encoder.layer.' not in '.' + n or not n.endswith(self.PAIRED_SUFFIXES):
+                        continue
+                    N, K = (int(x) for x in self.params[n].shape)
+                    off = self.offsets[n]
+                    d = np.arange(N * K // CHUNK, dtype=np.int64) * CHUNK          # mirror offset of the chunk inside the tensor
+                    q, u = d // (2 * K), (d % (2 * K)) // 64
+                    s0 = off + (2 * q) * K + 32 * u
+                    tab[off // CHUNK: off // CHUNK + d.size, 0] = s0.astype(np.int32)
+                    tab[off // CHUNK: off // CHUNK + d.size, 1] = (s0 + K).astype(np.int32)
+                self._pair_src = torch.from_numpy(tab).to(self.device)
+        return self._pair_src
+
     def mirror_paired(self):
         return getattr(self, 'mirror_pieces', 1) == 3 and self.pair_dst() is not None
 

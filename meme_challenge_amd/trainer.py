@@ -453,7 +453,7 @@ class FusedAdam(torch.optim.Optimizer):
             # the bf16 weight mirror (precision 'bf16') is written by the same kernel, on the same stream
             # (precision 'fp32x3': its three bf16 pieces, piece p at mirror + p * numel)
             x3 = mirror is not None and getattr(st, 'mirror_pieces', 1) == 3
-            dst = st.pair_dst() if x3 else None       # fp32x3: the layers' weights go to the mirror in the paired-row layout
+            dst = st.pair_src() if x3 else None       # fp32x3: the layers' weights go to the mirror in the paired-row layout (the launch walks the mirror's order)
             check(lib.uniter_adam_step_x3p(st.flat_params.data_ptr() + off, st.flat_grads.data_ptr() + off,
                                            (grad_bf16.data_ptr() + lo * 2) if grad_bf16 is not None else None,
                                            self.exp_avg.data_ptr() + off, self.exp_avg_sq.data_ptr() + off,
@@ -463,8 +463,8 @@ class FusedAdam(torch.optim.Optimizer):
                                            int(self.adamw), int(bool(zero_grads)),
                                            (mirror.data_ptr() + lo * 2) if mirror is not None else None,
                                            st.numel if x3 else 0,
-                                           (dst.data_ptr() + 4 * (lo // CHUNK)) if dst is not None else None,
-                                           mirror.data_ptr() if dst is not None else None,
+                                           (dst.data_ptr() + 8 * (lo // CHUNK)) if dst is not None else None,
+                                           lo if dst is not None else 0,
                                            max_wgs, stream_ptr),
                   'uniter_adam_step')
 

@@ -301,19 +301,34 @@ def test_mirror_refresh_and_optimizer_write_the_paired_layout():
     assert torch.equal(mirror2[:, pre:pre + N * K], e[:, pre:pre + N * K]) and float(mirror2[:, :pre].abs().sum()) == 0 and float(mirror2[:, pre + N * K:].abs().sum()) == 0
     # the optimizer step writes the same layout (a launch over a block that starts inside the buffer: the table pointer is the block's)
     grads = torch.randn(numel, device='cuda', generator=g)
+    g4 = grads.clone()                                     # (the launch clears the gradients it applied: keep a copy for the plain launch below)
     m_, v_ = torch.zeros(numel, device='cuda'), torch.zeros(numel, device='cuda')
     flags = torch.full((numel // 64,), 2, dtype=torch.uint8, device='cuda')
     lo = pre
     mirror3 = torch.zeros_like(mirror)
     p3 = p.clone()
+    # (the optimizer walks the buffer in the MIRROR's order: the inverse table -- per mirror chunk the two source units)
+    src = np.full((numel // 64, 2), -1, dtype=np.int32)
+    d = np.arange(N * K // 64) * 64
+    q, u = d // (2 * K), (d % (2 * K)) // 64
+    src[pre // 64: pre // 64 + d.size, 0] = pre + (2 * q) * K + 32 * u
+    src[pre // 64: pre // 64 + d.size, 1] = pre + (2 * q + 1) * K + 32 * u
+    srct = torch.from_numpy(src).cuda()
     L.check(lib.uniter_adam_step_x3p(p3.data_ptr() + 4 * lo, grads.data_ptr() + 4 * lo, None, m_.data_ptr() + 4 * lo, v_.data_ptr() + 4 * lo,
                                      flags.data_ptr() + lo // 64, numel - lo, None, 1.0, 0.0, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 1, 0, 1,
-                                     mirror3.data_ptr() + 2 * lo, numel, dst.data_ptr() + 4 * (lo // 64), mirror3.data_ptr(), 0, L.cur_stream()),
+                                     mirror3.data_ptr() + 2 * lo, numel, srct.data_ptr() + 8 * (lo // 64), lo, 0, L.cur_stream()),
             'adam_step_x3p')
     torch.cuda.synchronize()
     assert not torch.equal(p3[lo:], p[lo:]) and torch.equal(p3[:lo], p[:lo])
     e3 = expect(p3)
     assert torch.equal(mirror3[:, lo:], e3[:, lo:]) and float(mirror3[:, :lo].abs().sum()) == 0
+    # ... and the update itself is the plain launch's, element for element (walking order changes nothing but addresses)
+    p4, m4, v4 = p.clone(), torch.zeros(numel, device='cuda'), torch.zeros(numel, device='cuda')
+    L.check(lib.uniter_adam_step_x3(p4.data_ptr() + 4 * lo, g4.data_ptr() + 4 * lo, None, m4.data_ptr() + 4 * lo, v4.data_ptr() + 4 * lo,
+                                    flags.data_ptr() + lo // 64, numel - lo, None, 1.0, 0.0, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 1, 0, 1, None, 0, 0, L.cur_stream()),
+            'adam_step_x3')
+    torch.cuda.synchronize()
+    assert torch.equal(p4, p3) and torch.equal(m4, m_) and torch.equal(v4, v_) and float(grads[lo:].abs().sum()) == 0 and float(g4[lo:].abs().sum()) == 0
 
 
 def test_model_shapes_with_their_epilogues():
