@@ -134,7 +134,13 @@ class FusedAdam(torch.optim.Optimizer):
         # pass those .grad tensors hold the previous step's values (ParamStore.wgrad_stale); the trainers of this package
         # never read them in between (the reference calls zero_grad right after step, train_template.py:105-107)
         self.lazy_zero_encoder = None
-        self.overlap_workgroups = int(os.environ.get('UNITER_ADAM_OVERLAP_WGS', '256'))
+        # grid of the blocks that share the chip with the next forward pass.  256 (one workgroup per CU) where the forward's kernels
+        # can share a CU with it (fp32, bf16: DESIGN.md section 4 "Streams"); in the fp32x3 mode a persistent 144-KB, 504-of-512-register
+        # GEMM workgroup cannot start on a CU while an optimizer workgroup sits there -- the blocks should be OUT OF THE WAY fast, not
+        # thin: round 6 measured 9.52 ms (256), 9.42 (512), 9.35 (1024), 9.47 (no overlap at all) per step, bf16 unchanged
+        # (profiles/r06_adam_wgs_ab.txt).  UNITER_ADAM_OVERLAP_WGS fixes it for every mode
+        self._overlap_wgs_env = os.environ.get('UNITER_ADAM_OVERLAP_WGS')
+        self._overlap_wgs = int(self._overlap_wgs_env) if self._overlap_wgs_env else None
         self._pending = None
         self._plan_cache = None
         # the word-embedding table's update split by rows (round 6, uniter_adam_step_rows): note_tokens / early_word_update / step
@@ -148,6 +154,17 @@ class FusedAdam(torch.optim.Optimizer):
         self._word_cache = None
         self._rowmask_clear = None  # event behind the mask's clearing (side stream)
         self._rowmask_ready = None  # event behind the mask's last fill (the stream note_tokens ran on)
+
+    @property
+    def overlap_workgroups(self):
+        if self._overlap_wgs is not None:
+            return self._overlap_wgs
+        enc = self.overlap_encoder
+        return 1024 if (enc is not None and getattr(enc, 'precision', 'fp32') == 'fp32x3') else 256
+
+    @overlap_workgroups.setter
+    def overlap_workgroups(self, v):
+        self._overlap_wgs = None if v is None else int(v)
 
     def _overlap_plan(self, enc):
         """(head ranges, [embeddings, layer 0, ..] ranges) in flat-buffer elements, or None when the
