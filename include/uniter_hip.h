@@ -509,6 +509,17 @@ int uniter_linear_small_fwd(const float* x, const float* W, const float* b, floa
                             int B, int H, int C, void* stream);
 int uniter_linear_small_bwd(const float* dy, const float* x, const float* W,
                             float* dx, float* dW, float* db, int B, int H, int C, void* stream);
+/* Pooler + classifier as ONE launch each way (model/layer.py:179-185 followed by model/meme_uniter.py:19-21): results equal
+ * uniter_pooler_fwd + uniter_linear_small_fwd, and uniter_linear_small_bwd + uniter_pooler_bwd.  `ticket`:
+ * UNITER_POOL_HEAD_TICKET_WORDS zero-initialised unsigneds in device memory, left zero by every launch (the workgroups count
+ * themselves there; the last one to finish computes the logits).  Hidden sizes up to 4096.  The backward ACCUMULATES
+ * into dWp, dbp, dWl, dbl; dhidden (optional) gets row 0 of every sample (assigned, or added with beta_dhidden != 0). */
+#define UNITER_POOL_HEAD_TICKET_WORDS (17 * 64)
+int uniter_pool_head_fwd(const float* hidden, const float* Wp, const float* bp, const float* Wl, const float* bl,
+                         float* pooled, float* logits, unsigned* ticket, int B, int L, int H, int C, void* stream);
+int uniter_pool_head_bwd(const float* dlogits, const float* pooled, const float* hidden, const float* Wp, const float* Wl,
+                         float* dWp, float* dbp, float* dWl, float* dbl, float* dhidden,
+                         int B, int L, int H, int C, int beta_dhidden, void* stream);
 /* loss (scalar, mean over B), probs = sigmoid(logits), dlogits = dloss/dlogits * grad_scale */
 int uniter_bce_logits(const float* logits, const int64_t* labels, float pos_weight,
                       float* loss, float* probs, float* dlogits, float grad_scale,

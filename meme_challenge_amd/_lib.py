@@ -139,6 +139,8 @@ _SIGS = {
     'uniter_linear_small_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'uniter_linear_small_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'uniter_bce_logits': (_I, [_P, _P, _F, _P, _P, _P, _F, _I, _P]),
+    'uniter_pool_head_fwd': (_I, [_P] * 8 + [_I] * 4 + [_P]),
+    'uniter_pool_head_bwd': (_I, [_P] * 10 + [_I] * 5 + [_P]),
     'uniter_row_gather': (_I, [_P, _P, _P, _I, _I, _I, _P]),
     'uniter_row_scatter_add': (_I, [_P, _P, _P, _I, _I, _I, _P]),
     'uniter_cross_entropy_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -2,7 +2,7 @@
 (mirror of model/meme_uniter.py:6-21)."""
 from torch import nn
 
-from .model import UniterModel, HipLinear, ensure_store
+from .model import UniterModel, HipLinear, ensure_store, pool_head
 
 
 class MemeUniter(nn.Module):
@@ -22,6 +22,5 @@ class MemeUniter(nn.Module):
     def forward(self, **kwargs):
         ensure_store(self)
         out = self.uniter_model(**kwargs)
-        out = self.uniter_model.pooler(out)
-        out = self.linear(out)
-        return out
+        # pooler -> linear (model/meme_uniter.py:19-21), one launch each way
+        return pool_head(out, self.uniter_model.pooler, self.linear)

@@ -537,6 +537,73 @@ class _LinearSmallFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class _PoolHeadFn(torch.autograd.Function):
+    """Pooler + classifier (model/layer.py:179-185, model/meme_uniter.py:19-21) as ONE launch each way (csrc/head.hip,
+    uniter_pool_head_fwd / _bwd): the stretch between the encoder's forward and backward passes is a chain of launch latencies with
+    nothing beside it.  Same results as BertPooler followed by HipLinear."""
+
+    _tickets = {}       # device -> the zeroed counters the forward launch counts its workgroups on (left zero by every launch)
+    _zero_grads = {}    # (device, shape) -> the encoder output's gradient: zero outside the first row of every sample, kept between steps
+
+    @staticmethod
+    def forward(ctx, hidden, anchor, pooler, linear):
+        _lib.require_gpu_tensor(hidden, torch.float32, 'hidden')
+        hidden = hidden.contiguous()
+        B, L, H = hidden.shape
+        wl = linear.weight
+        Cn = wl.shape[0]
+        dev = hidden.device
+        ticket = _PoolHeadFn._tickets.get(dev)
+        if ticket is None:
+            ticket = _PoolHeadFn._tickets[dev] = torch.zeros(17 * 64, dtype=torch.int32, device=dev)      # UNITER_POOL_HEAD_TICKET_WORDS
+        pooled = torch.empty(B, H, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, Cn, dtype=torch.float32, device=dev)
+        check(_lib.lib().uniter_pool_head_fwd(ptr(hidden), ptr(pooler.dense.weight), ptr(pooler.dense.bias), ptr(wl), ptr(linear.bias),
+                                              ptr(pooled), ptr(logits), ptr(ticket), B, L, H, Cn, _lib.cur_stream()),
+              'uniter_pool_head_fwd')
+        ctx.save_for_backward(hidden, pooled)
+        ctx.pooler, ctx.linear = pooler, linear
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        hidden, pooled = ctx.saved_tensors
+        pooler, linear = ctx.pooler, ctx.linear
+        B, L, H = hidden.shape
+        dlogits = dlogits.contiguous()
+        wp, bp, wl, bl = pooler.dense.weight, pooler.dense.bias, linear.weight, linear.bias
+        for p_ in (wp, bp, wl, bl):
+            _ensure_grad(p_)
+        dhidden = None
+        if ctx.needs_input_grad[0]:
+            # only row 0 of every sample carries a gradient and the launch ASSIGNS it: the zeros around it are written once, not per step
+            # (the encoder's backward pass reads this tensor, it never writes it; the cache's own reference keeps autograd from
+            # accumulating into it in place)
+            key = (hidden.device, tuple(hidden.shape))
+            dhidden = _PoolHeadFn._zero_grads.get(key) if os.environ.get('UNITER_HEAD_ZERO_CACHE', '1') != '0' else torch.zeros_like(hidden)
+            if dhidden is None:
+                if len(_PoolHeadFn._zero_grads) >= 4:
+                    _PoolHeadFn._zero_grads.clear()
+                dhidden = _PoolHeadFn._zero_grads[key] = torch.zeros_like(hidden)
+        check(_lib.lib().uniter_pool_head_bwd(ptr(dlogits), ptr(pooled), ptr(hidden), ptr(wp), ptr(wl), ptr(wp.grad), ptr(bp.grad),
+                                              ptr(wl.grad), ptr(bl.grad), ptr(dhidden), B, L, H, wl.shape[0], 0, _lib.cur_stream()),
+              'uniter_pool_head_bwd')
+        _mark_touched(pooler, (wp, bp))
+        _mark_touched(linear, (wl, bl))
+        return dhidden, None, None, None
+
+
+def pool_head(hidden, pooler, linear):
+    """logits = linear(pooler(hidden)) in one launch; the separate modules when the fused form does not apply (UNITER_FUSED_HEAD=0,
+    another dtype / device, more classes than a wave handles comfortably)."""
+    if (os.environ.get('UNITER_FUSED_HEAD', '1') == '0' or not hidden.is_cuda or hidden.dtype != torch.float32 or hidden.dim() != 3
+            or linear.weight.shape[0] > 16 or hidden.shape[-1] > 4096 or not isinstance(pooler, BertPooler) or not isinstance(linear, HipLinear)):
+        return linear(pooler(hidden))
+    w = pooler.dense.weight
+    anchor = w if torch.is_grad_enabled() else w.detach()
+    return _PoolHeadFn.apply(hidden, anchor, pooler, linear)
+
+
 def _ensure_grad(p):
     if p.grad is None:
         p.grad = torch.zeros_like(p)
