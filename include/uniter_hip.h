@@ -459,6 +459,12 @@ int uniter_img_embed_fwd(const float* imgfc, const float* pos7, const int64_t* i
 /* out[b, j] = cat[b, gather_index[b, j]]   (gather_index NULL = identity copy) */
 int uniter_gather_rows(const float* cat, const int64_t* gather_index, float* out,
                        int B, int S, int Lout, int H, void* stream);
+/* uniter_gather_rows with the gathered rows' operand copy for the first encoder product written by the same launch (the
+ * concatenation + gather of model/model.py:327-334 and the copy the precision modes add): mode 1 = three bf16 pieces per row,
+ * out_b16[row][3][H] (= uniter_split3 with row stride 3 H, piece stride H), mode 2 = one bf16 copy out_b16[row][H]
+ * (= uniter_cast_bf16).  H % 4 == 0, H <= 1024 (UNITER_E_SHAPE beyond: run the two launches). */
+int uniter_gather_rows_ex(const float* cat, const int64_t* gather_index, float* out, void* out_b16, int mode,
+                          int B, int S, int Lout, int H, void* stream);
 /* dcat[b, s] = sum_{j : gather_index[b,j] == s} dout[b, j]   (deterministic) */
 int uniter_gather_rows_bwd(const float* dout, const int64_t* gather_index, float* dcat,
                            int B, int S, int Lout, int H, void* stream);

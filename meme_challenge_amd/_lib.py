@@ -129,6 +129,7 @@ _SIGS = {
     'uniter_img_embed_fwd': (_I, [_P] * 14 + [_I] * 6 + [_F, _U64, _U32, _P]),
     'uniter_gather_rows': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'uniter_gather_rows_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'uniter_gather_rows_ex': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'uniter_img_mask_add': (_I, [_P, _P, _P, _P, _I, _I, _P]),
     'uniter_bias_rows': (_I, [_P, _P, _I, _I, _P]),
     'uniter_txt_embed_bwd': (_I, [_P] * 13 + [_I] * 8 + [_F, _U64, _U32, _P, _SZ, _P]),

@@ -263,6 +263,26 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   for (int c = lane; c < (H >> 2); c += 64) dst[c] = src[c];
 }
 
+// the same gather with the operand copies of layer 0's first product written in the same pass (round 6: the gather and the split were
+// two launches of the chain that keeps the first encoder product waiting behind the optimizer -- 11 + 8 us): MODE 1 = the three bf16
+// pieces of the fp32x3 mode ([row][3][H], what uniter_split3 writes), MODE 2 = the bf16 copy of the bf16 mode (uniter_cast_bf16)
+template <int NV, int MODE>
+__global__ __launch_bounds__(256) void gather_rows_ex_kernel(const float* __restrict__ cat, const int64_t* __restrict__ gi,
+                                                             float* __restrict__ out, unsigned short* __restrict__ outb, int B, int S,
+                                                             int Lout, int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * Lout) return;
+  const int b = row / Lout, j = row - b * Lout;
+  const int s = gi ? clampi(gi[row], S) : j;
+  const int H4 = H >> 2;
+  f32x4 v[NV];
+  row_load<NV>(v, cat + ((size_t)b * S + s) * H, H4, lane);
+  row_store<NV>(v, out + (size_t)row * H, H4, lane);
+  if constexpr (MODE == 1) row_store_x3<NV>(v, outb + (size_t)row * 3 * H, H, H4, lane);
+  else row_store_bf16<NV>(v, outb + (size_t)row * H, H4, lane);
+}
+
 // source-indexed: dcat[b,s] = sum over j with gi[b,j]==s of dout[b,j]  (no atomics, deterministic)
 __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __restrict__ dout,
                                                               const int64_t* __restrict__ gi,
@@ -449,6 +469,27 @@ extern "C" int uniter_gather_rows(const float* cat, const int64_t* gather_index,
   if (B * Lout <= 0) return 0;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((B * Lout + 3) / 4), dim3(256), 0, (hipStream_t)stream, cat,
                      gather_index, out, B, S, Lout, H);
+  UCHECK_LAUNCH();
+  return 0;
+}
+
+// uniter_gather_rows with the joint rows' operand copy in the same launch: mode 1 = three bf16 pieces per row ([row][3][H], as
+// uniter_split3 with row stride 3 H and piece stride H), mode 2 = one bf16 copy ([row][H], as uniter_cast_bf16).  H up to 1024;
+// UNITER_E_SHAPE beyond (the caller then runs the two launches).
+extern "C" int uniter_gather_rows_ex(const float* cat, const int64_t* gather_index, float* out, void* out_b16, int mode, int B, int S,
+                                     int Lout, int H, void* stream) {
+  UCHECK_ARG(cat && out && out_b16 && (mode == 1 || mode == 2), "gather_rows_ex: bad argument");
+  UCHECK_SHAPE(H % 4 == 0 && H <= 1024 && (gather_index || Lout <= S), "gather_rows_ex: bad shape (H %% 4, H <= 1024)");
+  if (B * Lout <= 0) return 0;
+  const dim3 grid((B * Lout + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* ob = (unsigned short*)out_b16;
+  const int nv = (H / 4 + 63) / 64;
+#define UNITER_GRX(NV_)                                                                                                       \
+  if (mode == 1) hipLaunchKernelGGL((gather_rows_ex_kernel<NV_, 1>), grid, block, 0, st, cat, gather_index, out, ob, B, S, Lout, H); \
+  else hipLaunchKernelGGL((gather_rows_ex_kernel<NV_, 2>), grid, block, 0, st, cat, gather_index, out, ob, B, S, Lout, H);
+  if (nv == 1) { UNITER_GRX(1) } else if (nv == 2) { UNITER_GRX(2) } else if (nv == 3) { UNITER_GRX(3) } else { UNITER_GRX(4) }
+#undef UNITER_GRX
   UCHECK_LAUNCH();
   return 0;
 }

@@ -817,10 +817,15 @@ extern "C" int uniter_model_forward(uniter_model_t* m, const uniter_batch_t* b, 
                                    ph, seed, offset, st));
   }
   const bool joint = has_txt && has_img;
+  // (round 6) the joint rows and their operand copy for layer 0's first product in ONE launch: this chain -- text embeddings, gather,
+  // split -- is what the first encoder product waits for behind the optimizer's update of the word table
+  static const bool gather_ex = [] { const char* e = getenv("UNITER_GATHER_EX"); return !(e && e[0] == '0'); }();
+  const bool fuse_copy = gather_ex && !packed && (res || x3) && H <= 1024 && m->mirror != nullptr;
   if (packed) UCHECK_RC(uniter_row_gather(pl.cat, b->pack_src, pl.emb, M, H, B * S, st));
+  else if (fuse_copy) UCHECK_RC(uniter_gather_rows_ex(pl.cat, joint ? b->gather_index : nullptr, pl.emb, pl.embb, x3 ? 1 : 2, B, S, L, H, st));
   else UCHECK_RC(uniter_gather_rows(pl.cat, joint ? b->gather_index : nullptr, pl.emb, B, S, L, H, st));
   const size_t PH = (size_t)B * L * H;          // one layer of the padded output
-  if (res || x3) {
+  if ((res || x3) && !fuse_copy) {
     UCHECK_ARG(m->mirror != nullptr, "model_forward: precision 2 / 3 needs uniter_model_set_weight_mirror");
     if (res) UCHECK_RC(cast_b(pl.emb, pl.embb, (size_t)M * H, st));
     else UCHECK_RC(split_x3(pl.emb, pl.embb, M, H, st));
