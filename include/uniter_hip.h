@@ -589,8 +589,8 @@ int uniter_adam_step_mirror(float* params, float* grads, float* exp_avg, float* 
                             float grad_scale, float max_norm, float lr, float beta1, float beta2,
                             float eps, float weight_decay, int step, int adamw, int zero_grads,
                             void* mirror_bf16, void* stream);
-/* as uniter_adam_step_mirror with the grid capped at max_workgroups (0 = the default, which fills every wave slot of
- * the chip): a launch that shares the GPU with the next forward (trainer.FusedAdam's per-layer blocks on the side
+/* as uniter_adam_step_mirror with the grid set to max_workgroups (0 = the default, at most 2048 workgroups, which fill every
+ * wave slot of the chip; an explicit value may go up to the grid in which each thread takes its two 16-byte items once): a launch that shares the GPU with the next forward (trainer.FusedAdam's per-layer blocks on the side
  * stream) leaves the wave slots the forward's kernels need -- at full occupancy it slows them three-fold. */
 int uniter_adam_step_ex(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                         const uint8_t* chunk_flags, size_t n, const double* sumsq,

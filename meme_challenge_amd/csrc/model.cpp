@@ -442,7 +442,11 @@ int gemm_x3(uniter_model* m, int kind, hipStream_t st, int bkm, int M, int N, in
             int ldw, float* C, int nsplit, unsigned short* Cx, int epi, const float* bias, const float* aux_in, float* aux_out,
             float* colsum_part = nullptr) {
   ProfScope ps(m, kind, st);
-  static const int cfg = [] { const char* e = getenv("UNITER_X3_CFG"); return e ? atoi(e) : 0; }();
+  static const int cfg_all = [] { const char* e = getenv("UNITER_X3_CFG"); return e ? atoi(e) : 0; }();
+  // (lab switch: the FFN-up forward product alone on another tile geometry -- 3 = 128 x 128, whose workgroups leave register room
+  // for a resident optimizer wave, which the 128 x 256 geometry's 504 of 512 registers per SIMD do not)
+  static const int cfg_ffn_up = [] { const char* e = getenv("UNITER_X3_CFG_FFN_UP_FWD"); return e ? atoi(e) : 0; }();
+  const int cfg = (kind == UNITER_K_GEMM_FFN_UP_FWD && cfg_ffn_up) ? cfg_ffn_up : cfg_all;
   static const int main_prio = [] { const char* e = getenv("UNITER_MAIN_PRIO_X3"); return e ? atoi(e) : 0; }();
   g_uniter_launch_prio = main_prio;
   // (every product of this helper runs on the main stream: the balanced walk's main-stream workspace)

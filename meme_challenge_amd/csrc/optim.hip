@@ -358,7 +358,12 @@ static int adam_step_impl(float* params, float* grads, const void* grads_bf16, f
   a.step_size = (float)((double)lr / bc1);
   a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   int nb = sumsq_blocks(n);
-  if (max_workgroups > 0 && nb > max_workgroups) nb = max_workgroups;
+  if (max_workgroups > 0) {
+    // an explicit grid: up to the one in which every thread takes its two items once (short-lived workgroups: what a persistent
+    // product of the forward pass that wants the CU waits for is ONE workgroup's lifetime)
+    const size_t full = (a.n4 + 511) / 512;
+    nb = (int)(full < (size_t)max_workgroups ? (full < 1 ? 1 : full) : (size_t)max_workgroups);
+  }
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
   UCHECK_LAUNCH();
   return 0;

@@ -576,14 +576,14 @@ class FusedAdam(torch.optim.Optimizer):
                     if os.environ.get('UNITER_ADAM_EMB_MAIN', '1') != '0' and grad_ready is None:
                         # ... on the MAIN stream: the next forward's first kernels then follow it in stream order instead of
                         # behind a cross-stream event that an idle queue picks up 40-150 us late
-                        word_ev = block(word[0], word[1], int(os.environ.get('UNITER_ADAM_WORD_WGS', self.overlap_workgroups * 4)))
+                        word_ev = block(word[0], word[1], int(os.environ.get('UNITER_ADAM_WORD_WGS', min(2048, self.overlap_workgroups * 4))))
                         launch(word[1], hi, _lib.cur_stream(), 0)
                         ev = torch.cuda.Event()
                         ev.record(main)
                         events.append(ev)
                     else:
                         events.append(block(word[1], hi, 0))
-                        word_ev = block(word[0], word[1], int(os.environ.get('UNITER_ADAM_WORD_WGS', self.overlap_workgroups * 4)))
+                        word_ev = block(word[0], word[1], int(os.environ.get('UNITER_ADAM_WORD_WGS', min(2048, self.overlap_workgroups * 4))))
                 else:
                     events.append(block(lo, hi, 0 if k == 0 else self.overlap_workgroups))
             last = events[-1]                    # the side stream's last launch: what join() waits for
