@@ -542,8 +542,6 @@ class _PoolHeadFn(torch.autograd.Function):
     uniter_pool_head_fwd / _bwd): the stretch between the encoder's forward and backward passes is a chain of launch latencies with
     nothing beside it.  Same results as BertPooler followed by HipLinear."""
 
-    _tickets = {}       # device -> the zeroed counters the forward launch counts its workgroups on (left zero by every launch)
-    _zero_grads = {}    # (device, shape) -> the encoder output's gradient: zero outside the first row of every sample, kept between steps
 
     @staticmethod
     def forward(ctx, hidden, anchor, pooler, linear):
@@ -553,9 +551,11 @@ class _PoolHeadFn(torch.autograd.Function):
         wl = linear.weight
         Cn = wl.shape[0]
         dev = hidden.device
-        ticket = _PoolHeadFn._tickets.get(dev)
-        if ticket is None:
-            ticket = _PoolHeadFn._tickets[dev] = torch.zeros(17 * 64, dtype=torch.int32, device=dev)      # UNITER_POOL_HEAD_TICKET_WORDS
+        # (one set of counters per head module, not per device: two models' forward launches on two streams must not count on the same words)
+        ticket = linear.__dict__.get('_pool_head_ticket')
+        if ticket is None or ticket.device != dev:
+            ticket = torch.zeros(17 * 64, dtype=torch.int32, device=dev)      # UNITER_POOL_HEAD_TICKET_WORDS
+            object.__setattr__(linear, '_pool_head_ticket', ticket)
         pooled = torch.empty(B, H, dtype=torch.float32, device=dev)
         logits = torch.empty(B, Cn, dtype=torch.float32, device=dev)
         check(_lib.lib().uniter_pool_head_fwd(ptr(hidden), ptr(pooler.dense.weight), ptr(pooler.dense.bias), ptr(wl), ptr(linear.bias),
@@ -580,11 +580,15 @@ class _PoolHeadFn(torch.autograd.Function):
             # (the encoder's backward pass reads this tensor, it never writes it; the cache's own reference keeps autograd from
             # accumulating into it in place)
             key = (hidden.device, tuple(hidden.shape))
-            dhidden = _PoolHeadFn._zero_grads.get(key) if os.environ.get('UNITER_HEAD_ZERO_CACHE', '1') != '0' else torch.zeros_like(hidden)
+            cache = pooler.__dict__.get('_zero_dhidden')         # (per module: two models on two streams do not share the buffer)
+            if cache is None:
+                cache = {}
+                object.__setattr__(pooler, '_zero_dhidden', cache)
+            dhidden = cache.get(key) if os.environ.get('UNITER_HEAD_ZERO_CACHE', '1') != '0' else torch.zeros_like(hidden)
             if dhidden is None:
-                if len(_PoolHeadFn._zero_grads) >= 4:
-                    _PoolHeadFn._zero_grads.clear()
-                dhidden = _PoolHeadFn._zero_grads[key] = torch.zeros_like(hidden)
+                if len(cache) >= 2:
+                    cache.clear()
+                dhidden = cache[key] = torch.zeros_like(hidden)
         check(_lib.lib().uniter_pool_head_bwd(ptr(dlogits), ptr(pooled), ptr(hidden), ptr(wp), ptr(wl), ptr(wp.grad), ptr(bp.grad),
                                               ptr(wl.grad), ptr(bl.grad), ptr(dhidden), B, L, H, wl.shape[0], 0, _lib.cur_stream()),
               'uniter_pool_head_bwd')
